@@ -1,0 +1,217 @@
+/*
+ * mitransient_amd.h — C-ABI of the MI355X-native transient path tracer.
+ *
+ * This is the drop-in boundary for ONE path of diegoroyo/mitransient: the
+ * `transient_path` integrator + `transient_hdr_film` time-binning
+ * (reference: mitransient/integrators/common.py:122-213,
+ *  mitransient/integrators/transientpath.py:88-326,
+ *  mitransient/films/transient_hdr_film.py:210-276,
+ *  mitransient/render/transient_image_block.py:56-151).
+ *
+ * The reference has no FFI of its own: its Python plugins call into Mitsuba 3
+ * (C++) / Dr.Jit through pybind11 objects.  The entry points below are what a
+ * ctypes binding placed at those Python call sites would bind (see
+ * INTEGRATION.md for the stub); each one cites the reference interface it
+ * replaces.
+ *
+ * Conventions: opaque handles; plain pointers and sizes; no C++/torch types;
+ * every function returns 0 on success or a negative mtr_status; the message of
+ * the last failure on a context is available through mtr_last_error().
+ * Pointers documented "device" must be HIP device pointers on the context's
+ * GPU; all launches go to the hipStream_t handed to mtr_ctx_set_stream()
+ * (default: the NULL stream).  A context is not re-entrant; use one per
+ * thread/stream.
+ */
+#ifndef MITRANSIENT_AMD_H
+#define MITRANSIENT_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTR_ABI_VERSION 1
+
+typedef enum mtr_status {
+    MTR_OK = 0,
+    MTR_ERR_INVALID = -1,     /* bad argument / unsupported property            */
+    MTR_ERR_NO_DEVICE = -2,   /* no HIP device: there is NO CPU fallback        */
+    MTR_ERR_HIP = -3,         /* a HIP runtime call failed                      */
+    MTR_ERR_OOM = -4,
+    MTR_ERR_UNSUPPORTED = -5
+} mtr_status;
+
+/* ---- materials: BSDF subset of the north-star path --------------------- */
+enum { MTR_BSDF_DIFFUSE = 0, MTR_BSDF_CONDUCTOR = 1, MTR_BSDF_DIELECTRIC = 2,
+       MTR_BSDF_NULL = 3 /* no BSDF: absorbs */ };
+enum { MTR_MAT_TWOSIDED = 1u };
+
+typedef struct mtr_material {
+    uint32_t type;        /* MTR_BSDF_*                                          */
+    uint32_t flags;       /* MTR_MAT_TWOSIDED                                    */
+    float    a[3];        /* diffuse: reflectance rgb | conductor: eta rgb       */
+    float    b[3];        /* conductor: k rgb                                    */
+    float    c[3];        /* conductor/dielectric: specular_reflectance rgb      */
+    float    int_ior;     /* dielectric                                          */
+    float    ext_ior;     /* dielectric                                          */
+    float    c2[3];       /* dielectric: specular_transmittance rgb              */
+} mtr_material;
+
+/* ---- emitters: `area` emitter attached to a `rectangle` shape ----------- */
+typedef struct mtr_emitter {
+    float center[3];      /* to_world * (0,0,0)                                  */
+    float du[3];          /* to_world * (1,0,0) - center  (half edge)            */
+    float dv[3];          /* to_world * (0,1,0) - center  (half edge)            */
+    float radiance[3];
+} mtr_emitter;
+
+/* ---- sensor: `perspective` (utils.py:92-105 of the reference) ----------- */
+typedef struct mtr_camera {
+    float sample_to_camera[16]; /* row-major 4x4 projective, film sample [0,1]^2 -> camera near plane */
+    float to_world[16];         /* row-major 4x4 camera -> world (rigid)         */
+    float near_clip, far_clip;
+} mtr_camera;
+
+/* ---- film: `transient_hdr_film` (transient_hdr_film.py:114-121) --------- */
+typedef struct mtr_film_desc {
+    uint32_t width, height;               /* full film size (tensor is H x W x T x 4)  */
+    uint32_t crop_width, crop_height;     /* sampled window                            */
+    uint32_t crop_offset_x, crop_offset_y;
+    uint32_t temporal_bins;               /* T  (default 2048)                         */
+    float    start_opl;                   /* default 0                                 */
+    float    bin_width_opl;               /* default 0.003                             */
+} mtr_film_desc;
+
+typedef struct mtr_scene_desc {
+    uint32_t        n_tris;
+    const float    *tri_verts;     /* host, n_tris*9 floats: p0 p1 p2, world space      */
+    const uint32_t *tri_material;  /* host, n_tris: index into materials                */
+    const int32_t  *tri_emitter;   /* host, n_tris: index into emitters or -1           */
+    uint32_t        n_materials;
+    const mtr_material *materials; /* host                                              */
+    uint32_t        n_emitters;
+    const mtr_emitter  *emitters;  /* host                                              */
+    mtr_camera      camera;
+    mtr_film_desc   film;
+} mtr_scene_desc;
+
+/* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */
+enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133-138 */
+       MTR_FLAG_DISCARD_DIRECT_LIGHT = 2u  /* common.py:27, transientpath.py:173-176 */ };
+
+/* which kernel organisation executes the path */
+enum { MTR_MODE_AUTO = 0,
+       MTR_MODE_FUSED = 1,      /* one persistent launch per tile; per-pixel LDS time histogram */
+       MTR_MODE_WAVEFRONT = 2   /* per-bounce launches over SoA path queues in HBM + splat
+                                   records + the stand-alone time-bin scatter-add kernel        */ };
+
+typedef struct mtr_render_params {
+    uint32_t spp_total;     /* samples per pixel of the WHOLE render: sample_scale = 1/spp_total
+                               (common.py:173-175) and lane = pixel*spp_total + s             */
+    uint32_t spp_begin;     /* this call renders samples s in [spp_begin, spp_end) ...         */
+    uint32_t spp_end;
+    uint32_t pixel_begin;   /* ... of crop-window pixels [pixel_begin, pixel_end) (row-major)  */
+    uint32_t pixel_end;
+    uint32_t seed;          /* mi.render(seed=) + sampler base seed (common.py:52)             */
+    int32_t  max_depth;     /* -1 = unbounded                                                   */
+    int32_t  rr_depth;
+    uint32_t flags;         /* MTR_FLAG_*                                                       */
+    uint32_t mode;          /* MTR_MODE_*                                                       */
+    uint32_t reserved[6];
+} mtr_render_params;
+
+/* in-kernel counters */
+typedef struct mtr_counters {
+    uint64_t paths;
+    uint64_t rays_closest;
+    uint64_t rays_shadow;
+    uint64_t splats_issued;   /* in-range, non-zero time-bin contributions                      */
+    uint64_t bounces;         /* loop iterations executed                                       */
+    uint64_t splats_overflow; /* wavefront mode: records that took the global-atomic fallback   */
+    uint64_t reserved[2];
+} mtr_counters;
+
+/* one time-resolved contribution, as consumed by the stand-alone scatter-add */
+typedef struct mtr_splat_soa {
+    const uint32_t *pixel;   /* device, n: y*W + x (film coordinates)                          */
+    const float    *opl;     /* device, n: optical path length                                 */
+    const float    *r, *g, *b; /* device, n: value already multiplied by sample_scale          */
+    uint64_t        n;
+} mtr_splat_soa;
+
+/* per-kernel timing of the last mtr_render (HIP events on the context stream) */
+typedef struct mtr_kernel_times {
+    float    total_ms;        /* whole mtr_render call on the stream                            */
+    float    trace_ms;        /* fused: the path kernel | wavefront: sum of bounce kernels      */
+    float    scatter_ms;      /* wavefront: sum of time-bin scatter-add launches (0 if fused)   */
+    uint32_t trace_launches;
+    uint32_t scatter_launches;
+    uint32_t reserved[3];
+} mtr_kernel_times;
+
+typedef struct mtr_ctx   mtr_ctx;
+typedef struct mtr_scene mtr_scene;
+
+/* ------------------------------------------------------------------------ */
+int  mtr_abi_version(void);
+
+/* Context = one GPU + one stream.  device_ordinal >= 0 is required: this
+ * library has no CPU path (MTR_ERR_NO_DEVICE when HIP sees no device). */
+int  mtr_ctx_create(int device_ordinal, mtr_ctx **out);
+void mtr_ctx_destroy(mtr_ctx *);
+int  mtr_ctx_set_stream(mtr_ctx *, void *hip_stream);
+const char *mtr_last_error(const mtr_ctx *);   /* never NULL; ctx may be NULL for creation errors */
+
+/* Replaces mi.load_dict(scene_dict) for the supported subset (reference
+ * call site: README.md:159, utils.py:78-220).  Copies the arrays, builds the
+ * BVH2 on the host and uploads it. */
+int  mtr_scene_create(mtr_ctx *, const mtr_scene_desc *, mtr_scene **out);
+void mtr_scene_destroy(mtr_scene *);
+/* transient_hdr_film traverse()/parameters_changed (transient_hdr_film.py:295-311):
+ * change T / start / width between renders. */
+int  mtr_scene_set_film(mtr_scene *, const mtr_film_desc *);
+/* BVH statistics for tests: nodes, max depth, leaf count. */
+int  mtr_scene_bvh_info(const mtr_scene *, uint32_t *n_nodes, uint32_t *max_depth, uint32_t *n_leaves);
+
+/* TransientImageBlock.clear (transient_image_block.py:56-70): zero the
+ * (H,W,T,4) f32 accumulator and the (H,W,4) steady accumulator. */
+int  mtr_film_clear(mtr_ctx *, const mtr_film_desc *, float *transient_hwt4 /*device, may be NULL*/,
+                    float *steady_hw4 /*device, may be NULL*/);
+
+/* TransientADIntegrator.render pass (common.py:157-210) + TransientPath.sample
+ * (transientpath.py:88-326) + add_transient_data/put_/accum
+ * (transient_hdr_film.py:250-276, transient_image_block.py:103-151):
+ * ADDS the contributions of the requested lanes into
+ *   transient_hwt4 : device f32 (H, W, T, 4)  channels R,G,B,W (W stays 0)
+ *   steady_hw4     : device f32 (H, W, 4)     sum of L over samples, and the sample count in .w
+ * counters/times may be NULL.  Asynchronous on the context stream unless
+ * counters or times are requested (then it synchronises the stream). */
+int  mtr_render(mtr_scene *, const mtr_render_params *,
+                float *transient_hwt4, float *steady_hw4,
+                mtr_counters *counters_out /*host*/, mtr_kernel_times *times_out /*host*/);
+
+/* TransientHDRFilm.develop / develop_transient_ (transient_hdr_film.py:210-248)
+ * and steady.develop (common.py:206,212):  raw (H,W,T,4) -> (H,W,T,3) with the
+ * weight division (w==0 -> 1), steady (H,W,4) -> (H,W,3) = sum / count. */
+int  mtr_film_develop(mtr_ctx *, const mtr_film_desc *,
+                      const float *transient_hwt4, float *transient_hwt3 /*device, may be NULL*/,
+                      const float *steady_hw4, float *steady_hw3 /*device, may be NULL*/);
+
+/* The time-bin scatter-add alone: add_transient_data + put_ + accum
+ * (transient_hdr_film.py:263-276, transient_image_block.py:131-149) over n
+ * splats.  variant 0 = global f32 atomics (contract form), 1 = sorted-by-pixel
+ * LDS-privatised rows (requires `pixel` non-decreasing). */
+int  mtr_splat_add(mtr_ctx *, const mtr_splat_soa *, const mtr_film_desc *, int variant,
+                   float *transient_hwt4 /*device*/, float *elapsed_ms /*host, may be NULL*/);
+
+/* Debug/test aid: per-lane splat log of one render (records of 8 x u32:
+ * lane, depth|kind<<16, pixel, bin, r,g,b bits, opl bits), capacity in records.
+ * Pass NULL to disable. The count is written to *n_records_device (u64). */
+int  mtr_debug_set_splat_log(mtr_scene *, uint32_t *log_device, uint64_t capacity, uint64_t *n_records_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MITRANSIENT_AMD_H */

@@ -1,0 +1,153 @@
+"""ctypes mirror of ``include/mitransient_amd.h`` and the loader of the HIP library.
+
+There is NO CPU fallback: if ``libmitransient_amd.so`` (the gfx950 HIP build) is
+missing or no HIP device is visible, every product entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmitransient_amd.so")
+
+MTR_ABI_VERSION = 1
+
+MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
+MTR_MAT_TWOSIDED = 1
+MTR_FLAG_CAMERA_UNWARP = 1
+MTR_FLAG_DISCARD_DIRECT_LIGHT = 2
+MTR_MODE_AUTO, MTR_MODE_FUSED, MTR_MODE_WAVEFRONT = 0, 1, 2
+
+_f3 = C.c_float * 3
+_f16 = C.c_float * 16
+
+
+class mtr_material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32),
+                ("a", _f3), ("b", _f3), ("c", _f3),
+                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("c2", _f3)]
+
+
+class mtr_emitter(C.Structure):
+    _fields_ = [("center", _f3), ("du", _f3), ("dv", _f3), ("radiance", _f3)]
+
+
+class mtr_camera(C.Structure):
+    _fields_ = [("sample_to_camera", _f16), ("to_world", _f16),
+                ("near_clip", C.c_float), ("far_clip", C.c_float)]
+
+
+class mtr_film_desc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32),
+                ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
+                ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
+                ("temporal_bins", C.c_uint32),
+                ("start_opl", C.c_float), ("bin_width_opl", C.c_float)]
+
+
+class mtr_scene_desc(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32),
+                ("tri_verts", C.POINTER(C.c_float)),
+                ("tri_material", C.POINTER(C.c_uint32)),
+                ("tri_emitter", C.POINTER(C.c_int32)),
+                ("n_materials", C.c_uint32),
+                ("materials", C.POINTER(mtr_material)),
+                ("n_emitters", C.c_uint32),
+                ("emitters", C.POINTER(mtr_emitter)),
+                ("camera", mtr_camera),
+                ("film", mtr_film_desc)]
+
+
+class mtr_render_params(C.Structure):
+    _fields_ = [("spp_total", C.c_uint32), ("spp_begin", C.c_uint32), ("spp_end", C.c_uint32),
+                ("pixel_begin", C.c_uint32), ("pixel_end", C.c_uint32),
+                ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
+                ("flags", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+
+
+class mtr_counters(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("splats_issued", C.c_uint64), ("bounces", C.c_uint64), ("splats_overflow", C.c_uint64),
+                ("reserved", C.c_uint64 * 2)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k in
+                ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces", "splats_overflow")}
+
+
+class mtr_splat_soa(C.Structure):
+    _fields_ = [("pixel", C.c_void_p), ("opl", C.c_void_p),
+                ("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p), ("n", C.c_uint64)]
+
+
+class mtr_kernel_times(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("trace_ms", C.c_float), ("scatter_ms", C.c_float),
+                ("trace_launches", C.c_uint32), ("scatter_launches", C.c_uint32),
+                ("reserved", C.c_uint32 * 3)]
+
+    def as_dict(self):
+        return {"total_ms": float(self.total_ms), "trace_ms": float(self.trace_ms),
+                "scatter_ms": float(self.scatter_ms), "trace_launches": int(self.trace_launches),
+                "scatter_launches": int(self.scatter_launches)}
+
+
+# Every symbol include/mitransient_amd.h declares (checked by tests/test_abi.py).
+EXPORTS = [
+    "mtr_abi_version", "mtr_ctx_create", "mtr_ctx_destroy", "mtr_ctx_set_stream", "mtr_last_error",
+    "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_bvh_info",
+    "mtr_film_clear", "mtr_render", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
+]
+
+_lib = None
+
+
+class MitransientAMDError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP library (built by ``__graft_entry__.build()``). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MitransientAMDError(
+            f"{LIB_PATH} not found: build the gfx950 HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mtr_abi_version.restype = C.c_int
+    lib.mtr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.mtr_ctx_destroy.argtypes = [vp]
+    lib.mtr_ctx_destroy.restype = None
+    lib.mtr_ctx_set_stream.argtypes = [vp, vp]
+    lib.mtr_last_error.argtypes = [vp]
+    lib.mtr_last_error.restype = C.c_char_p
+    lib.mtr_scene_create.argtypes = [vp, C.POINTER(mtr_scene_desc), C.POINTER(vp)]
+    lib.mtr_scene_destroy.argtypes = [vp]
+    lib.mtr_scene_destroy.restype = None
+    lib.mtr_scene_set_film.argtypes = [vp, C.POINTER(mtr_film_desc)]
+    lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mtr_film_clear.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp]
+    lib.mtr_render.argtypes = [vp, C.POINTER(mtr_render_params), vp, vp,
+                               C.POINTER(mtr_counters), C.POINTER(mtr_kernel_times)]
+    lib.mtr_film_develop.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp, vp, vp]
+    lib.mtr_splat_add.argtypes = [vp, C.POINTER(mtr_splat_soa), C.POINTER(mtr_film_desc), C.c_int, vp,
+                                  C.POINTER(C.c_float)]
+    lib.mtr_debug_set_splat_log.argtypes = [vp, vp, C.c_uint64, vp]
+    if lib.mtr_abi_version() != MTR_ABI_VERSION:
+        raise MitransientAMDError("libmitransient_amd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, ctx=None, what: str = ""):
+    if status == 0:
+        return
+    msg = ""
+    try:
+        msg = (load_library().mtr_last_error(ctx) or b"").decode()
+    except Exception:  # pragma: no cover
+        pass
+    raise MitransientAMDError(f"{what} failed (status {status}): {msg}")

@@ -1,0 +1,160 @@
+// mtr_bvh.cpp — binned-SAH BVH2 over triangles, flattened to "node packets": one record per
+// inner node holding BOTH children's (padded) boxes and references, so a traversal step is one
+// 64-byte fetch (4 x ds_read_b128 from LDS, or one cache line from L2) and two slab tests.
+#include "mtr_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cfloat>
+
+namespace mtr {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; } }
+    void grow(const float *p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    float area() const
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Tmp { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+struct Builder {
+    const float *verts;
+    std::vector<Box> tbox;
+    std::vector<float> cent;       // 3 per triangle
+    std::vector<uint32_t> order;
+    std::vector<Tmp> tmp;
+
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kLeafTarget = 2, kLeafMax = 4;
+
+    int build(uint32_t first, uint32_t count)
+    {
+        int idx = (int)tmp.size();
+        tmp.emplace_back();
+        Box b; b.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            b.grow(tbox[order[i]]);
+            cb.grow(&cent[3 * (size_t)order[i]]);
+        }
+        tmp[idx].box = b; tmp[idx].first = first; tmp[idx].count = count;
+        if (count <= kLeafTarget) return idx;
+
+        // binned SAH over the three axes
+        float best_cost = FLT_MAX; int best_axis = -1, best_split = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            float ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0.0f)) continue;
+            Box bins[kBins]; uint32_t cnt[kBins];
+            for (int k = 0; k < kBins; ++k) { bins[k].reset(); cnt[k] = 0; }
+            float scale = (float)kBins / ext;
+            for (uint32_t i = first; i < first + count; ++i) {
+                uint32_t t = order[i];
+                int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + ax] - cb.lo[ax]) * scale)));
+                bins[k].grow(tbox[t]); cnt[k]++;
+            }
+            float right_area[kBins]; uint32_t right_cnt[kBins];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) { acc.grow(bins[k]); c += cnt[k]; right_area[k] = acc.area(); right_cnt[k] = c; }
+            acc.reset(); c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                acc.grow(bins[k]); c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                float cost = acc.area() * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = k; }
+            }
+        }
+        uint32_t mid = first;
+        if (best_axis >= 0) {
+            float leaf_cost = b.area() * (float)count;
+            if (count <= kLeafMax && best_cost >= leaf_cost) return idx;          // a leaf is cheaper
+            float ext = cb.hi[best_axis] - cb.lo[best_axis];
+            float scale = (float)kBins / ext;
+            auto it = std::stable_partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + best_axis] - cb.lo[best_axis]) * scale)));
+                return k <= best_split;
+            });
+            mid = (uint32_t)(it - order.begin());
+        }
+        if (mid == first || mid == first + count) {
+            if (count <= kLeafMax) return idx;
+            mid = first + count / 2;                                              // degenerate: split by index
+        }
+        int l = build(first, mid - first);
+        int r = build(mid, first + count - mid);
+        tmp[idx].left = l; tmp[idx].right = r; tmp[idx].count = 0;
+        return idx;
+    }
+};
+
+void set_box(float *lo, float *hi, const Box &b)
+{
+    float m = 0.0f;
+    for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    float pad = 2e-5f * (1.0f + m);        // culling must stay conservative under f32 rounding
+    for (int k = 0; k < 3; ++k) { lo[k] = b.lo[k] - pad; hi[k] = b.hi[k] + pad; }
+}
+void set_empty(float *lo, float *hi)
+{
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+}
+
+} // namespace
+
+void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
+{
+    out.nodes.clear(); out.order.clear(); out.max_depth = 0; out.n_leaves = 0;
+    if (n == 0) return;
+    Builder B; B.verts = verts;
+    B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        Box b; b.reset();
+        for (int k = 0; k < 3; ++k) b.grow(verts + 9 * (size_t)i + 3 * k);
+        B.tbox[i] = b;
+        for (int k = 0; k < 3; ++k) B.cent[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+        B.order[i] = i;
+    }
+    B.tmp.reserve(2 * (size_t)n);
+    int root = B.build(0, n);
+
+    // flatten: one packet per inner Tmp node
+    auto leaf_ref = [&](const Tmp &t) -> int32_t {
+        uint32_t code = (t.first << 2) | (t.count - 1u);
+        return (int32_t)~code;
+    };
+    struct Item { int tmp; int packet; uint32_t depth; };
+    std::vector<Item> stack;
+    const Tmp &R = B.tmp[root];
+    if (R.left < 0) {                        // the whole scene is one leaf
+        Node nd{}; set_box(nd.lo0, nd.hi0, R.box); set_empty(nd.lo1, nd.hi1);
+        nd.c0 = leaf_ref(R); nd.c1 = leaf_ref(R);
+        out.nodes.push_back(nd); out.max_depth = 1; out.n_leaves = 1;
+    } else {
+        out.nodes.emplace_back();
+        stack.push_back({ root, 0, 1 });
+        while (!stack.empty()) {
+            Item it = stack.back(); stack.pop_back();
+            out.max_depth = std::max(out.max_depth, it.depth);
+            const Tmp &t = B.tmp[it.tmp];
+            const Tmp &L = B.tmp[t.left], &Rr = B.tmp[t.right];
+            Node nd{};
+            set_box(nd.lo0, nd.hi0, L.box); set_box(nd.lo1, nd.hi1, Rr.box);
+            if (L.left < 0) { nd.c0 = leaf_ref(L); out.n_leaves++; }
+            else { nd.c0 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.left, nd.c0, it.depth + 1 }); }
+            if (Rr.left < 0) { nd.c1 = leaf_ref(Rr); out.n_leaves++; }
+            else { nd.c1 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.right, nd.c1, it.depth + 1 }); }
+            out.nodes[it.packet] = nd;
+        }
+    }
+    out.order = B.order;
+}
+
+} // namespace mtr

@@ -1,0 +1,560 @@
+// mtr_core.h — per-path arithmetic of the transient path tracer (PRODUCT code).
+//
+// Everything a single path does between two queue/LDS accesses lives here as
+// force-inlined functions: PCG32/TEA sampler, perspective ray generation, BVH2
+// traversal over node packets, Moller-Trumbore, shading frame, BSDFs, rectangle
+// area-emitter sampling, MIS, Russian roulette and the OPL -> time-bin mapping.
+// The kernels in mtr_kernels.hip only add the CDNA4 machinery around it (LDS
+// staging, wave64 compaction, queues, histograms).
+//
+// Reference map (mitransient/integrators/transientpath.py):
+//   path_begin()  :118-138 + ADIntegrator.sample_rays (common.py:159)
+//   path_bounce() :140-319, one loop iteration
+//   film_bin()    films/transient_hdr_film.py:263-265 + render/transient_image_block.py:131-146
+//
+// Numerics contract: IEEE f32, compiled with -ffp-contract=off, fmaf only
+// where written, correctly rounded 1/x and sqrtf, polynomial sin/cos.  The file is
+// plain C++ so tests can also compile it for the host (tests/host_harness.cpp).
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+#include "../../include/mitransient_amd.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MTR_HD __host__ __device__ __forceinline__
+#else
+#define MTR_HD inline __attribute__((always_inline))
+#endif
+
+namespace mtr {
+
+struct f3 { float x, y, z; };
+
+MTR_HD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MTR_HD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+MTR_HD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+MTR_HD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+MTR_HD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+MTR_HD float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+MTR_HD f3 cross(f3 a, f3 b)
+{
+    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+MTR_HD f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MTR_HD f3 fma3(f3 a, float s, f3 b) { return mk(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
+MTR_HD float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+MTR_HD bool sign_neg(float s) { return s < 0.0f || (s == 0.0f && signbit(s)); }
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kRayEps = 1500.0f * 5.9604644775390625e-8f;
+constexpr float kShadowEps = kRayEps * 10.0f;
+constexpr float kInf = __builtin_huge_valf();
+
+// ---------------------------------------------------------------- sampler
+struct Rng { uint64_t state, inc; };
+
+MTR_HD uint32_t rng_u32(Rng &r)
+{
+    uint64_t old = r.state;
+    r.state = old * 0x5851f42d4c957f2dULL + r.inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((0u - rot) & 31u));
+}
+MTR_HD float rng_f32(Rng &r)
+{
+    uint32_t u = (rng_u32(r) >> 9) | 0x3f800000u;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f - 1.0f;
+}
+// TEA-scrambled (seed, lane) -> PCG32 stream; `inc` is recomputable from (seed, lane)
+MTR_HD void tea4(uint32_t &v0, uint32_t &v1)
+{
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+}
+MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane)
+{
+    uint32_t v0 = seed, v1 = lane;
+    tea4(v0, v1);
+    return ((uint64_t)v1 << 1u) | 1u;
+}
+MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane)
+{
+    uint32_t v0 = seed, v1 = lane;
+    tea4(v0, v1);
+    Rng r;
+    r.inc = ((uint64_t)v1 << 1u) | 1u;
+    r.state = 0u;
+    rng_u32(r);
+    r.state += (uint64_t)v0;
+    rng_u32(r);
+    return r;
+}
+
+// ---------------------------------------------------------------- warps
+MTR_HD void sincos_quarter(float x, float &s, float &c)   // |x| <= pi/4
+{
+    float z = x * x;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    s = fmaf(x * z, ps, x);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+}
+MTR_HD f3 cosine_hemisphere(float u1, float u2)
+{
+    float x = fmaf(2.0f, u1, -1.0f), y = fmaf(2.0f, u2, -1.0f);
+    bool swap = fabsf(x) < fabsf(y);
+    float r = swap ? y : x, rp = swap ? x : y;
+    float phi = (0.25f * kPi) * rp / r;
+    if (x == 0.0f && y == 0.0f) phi = 0.0f;
+    float s, c;
+    sincos_quarter(phi, s, c);
+    float cs = swap ? s : c, sn = swap ? c : s;
+    float px = r * cs, py = r * sn;
+    float zz = 1.0f - fmaf(px, px, py * py);
+    return mk(px, py, sqrtf(zz > 0.0f ? zz : 0.0f));
+}
+
+// ---------------------------------------------------------------- scene (device layout)
+// BVH2 "node packet": both children's boxes + refs in one 64-byte, 16-byte-aligned record
+// (4 x ds_read_b128 / global_load_dwordx4).  ref >= 0: inner node; ref < 0: leaf,
+// ~ref = (first_tri << 2) | (count - 1), count in 1..4.  An absent child has an inverted box.
+struct alignas(16) Node {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;
+    uint32_t pad[2];
+};
+// triangle, split by use: geometry (intersection) and shading data
+struct alignas(16) TriGeom { float p0[3], p1[3], p2[3]; uint32_t mat_em; uint32_t orig; uint32_t pad; };   // 48 B
+// orig: index of the triangle in the caller's array (ties on t go to the lower ORIGINAL index)
+struct alignas(16) TriShade { float n[3], s[3], t[3]; float pad[3]; };                        // 48 B
+// mat_em: material index | (emitter index + 1) << 16
+struct alignas(16) Emitter { float center[3], du[3], dv[3], n[3], radiance[3], inv_area; };   // 64 B
+
+struct Camera {
+    float s2c[16];
+    float tw[16];
+    float near_clip, far_clip;
+};
+
+struct Film {
+    uint32_t width, height, crop_w, crop_h, crop_x, crop_y, bins;
+    float start_opl, bin_width;
+};
+
+struct SceneView {
+    const Node *nodes;
+    const TriGeom *tgeom;
+    const TriShade *tshade;
+    const mtr_material *mats;
+    const Emitter *ems;
+    uint32_t n_emitters;
+    uint32_t n_tris;
+};
+
+struct RenderConst {
+    uint32_t spp_total;
+    uint32_t seed;
+    uint32_t max_depth;      // 0xffffffff = unbounded
+    uint32_t rr_depth;
+    uint32_t flags;
+    float sample_scale;      // (float)(1.0 / spp_total), computed on the host
+    float inv_crop_w, inv_crop_h, off_x, off_y;   // sample_rays: scale / offset of the film position
+    float n_emitters_f, inv_n_emitters;
+};
+
+MTR_HD f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- intersection
+struct Hit { float t, u, v; int32_t prim; };
+
+MTR_HD bool tri_hit(const TriGeom &g, f3 o, f3 d, float tmax, float &t, float &u, float &v)
+{
+    f3 p0 = ld3(g.p0);
+    f3 e1 = ld3(g.p1) - p0, e2 = ld3(g.p2) - p0;
+    f3 pvec = cross(d, e2);
+    float inv_det = 1.0f / dot(e1, pvec);
+    f3 tvec = o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    f3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    t = dot(e2, qvec) * inv_det;
+    return (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= 0.0f) & (t <= tmax);
+}
+
+// conservative slab test (culling only: hits are decided by tri_hit, ties by primitive index)
+MTR_HD float box_near(const float *lo, const float *hi, f3 id, f3 oid, float tbest)
+{
+    float ax = fmaf(lo[0], id.x, -oid.x), bx = fmaf(hi[0], id.x, -oid.x);
+    float ay = fmaf(lo[1], id.y, -oid.y), by = fmaf(hi[1], id.y, -oid.y);
+    float az = fmaf(lo[2], id.z, -oid.z), bz = fmaf(hi[2], id.z, -oid.z);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tbest));
+    return (tn <= tf) ? tn : kInf;      // +inf = miss
+}
+
+// Stack: any type with push(int)/pop()/empty(); kernels keep it in LDS, the host harness in an array.
+template <bool ANY_HIT, class Stack>
+MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
+{
+    Hit h; h.t = kInf; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    uint32_t best_orig = 0xffffffffu;
+    if (sc.n_tris == 0) return h;
+    f3 id = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 oid = mk(o.x * id.x, o.y * id.y, o.z * id.z);
+    st.reset();
+    int32_t cur = 0;
+    float tbest = tmax;
+    for (;;) {
+        if (cur >= 0) {
+            const Node &n = sc.nodes[cur];
+            float t0 = box_near(n.lo0, n.hi0, id, oid, tbest);
+            float t1 = box_near(n.lo1, n.hi1, id, oid, tbest);
+            int32_t c0 = n.c0, c1 = n.c1;
+            bool h0 = t0 < kInf, h1 = t1 < kInf;
+            if (h0 & h1) {
+                bool near0 = t0 <= t1;
+                st.push(near0 ? c1 : c0);
+                cur = near0 ? c0 : c1;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t code = ~(uint32_t)cur;
+            uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t, u, v;
+                int32_t prim = (int32_t)(first + i);
+                const TriGeom &tg = sc.tgeom[prim];
+                if (tri_hit(tg, o, d, tmax, t, u, v)) {
+                    if (ANY_HIT) { h.t = t; h.prim = prim; return h; }
+                    if (t < h.t || (t == h.t && tg.orig < best_orig)) {
+                        h.t = t; h.u = u; h.v = v; h.prim = prim; best_orig = tg.orig;
+                        tbest = t;
+                    }
+                }
+            }
+        }
+        if (st.empty()) break;
+        cur = st.pop();
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------- sensor
+struct Ray { f3 o, d; float tmax; };
+
+MTR_HD Ray camera_ray(const Camera &c, const RenderConst &rc, uint32_t px, uint32_t py, float j1, float j2)
+{
+    float sx = fmaf((float)px + j1, rc.inv_crop_w, rc.off_x);
+    float sy = fmaf((float)py + j2, rc.inv_crop_h, rc.off_y);
+    const float *M = c.s2c;
+    float nx = fmaf(M[0], sx, fmaf(M[1], sy, M[3]));
+    float ny = fmaf(M[4], sx, fmaf(M[5], sy, M[7]));
+    float nz = fmaf(M[8], sx, fmaf(M[9], sy, M[11]));
+    float nw = fmaf(M[12], sx, fmaf(M[13], sy, M[15]));
+    float iw = 1.0f / nw;
+    f3 dl = normalize(mk(nx * iw, ny * iw, nz * iw));
+    const float *T = c.tw;
+    Ray r;
+    r.d = mk(fmaf(T[0], dl.x, fmaf(T[1], dl.y, T[2] * dl.z)),
+             fmaf(T[4], dl.x, fmaf(T[5], dl.y, T[6] * dl.z)),
+             fmaf(T[8], dl.x, fmaf(T[9], dl.y, T[10] * dl.z)));
+    float inv_z = 1.0f / dl.z;
+    float near_t = c.near_clip * inv_z, far_t = c.far_clip * inv_z;
+    r.o = fma3(r.d, near_t, mk(T[3], T[7], T[11]));
+    r.tmax = far_t - near_t;
+    return r;
+}
+
+// ---------------------------------------------------------------- film
+// returns the time bin or -1 (transient_hdr_film.py:263-265)
+MTR_HD int32_t film_bin(const Film &f, float opl)
+{
+    float pos = (opl - f.start_opl) / f.bin_width;
+    if (!(pos >= 0.0f && pos < (float)f.bins)) return -1;
+    return (int32_t)(uint32_t)floorf(pos);
+}
+
+// ---------------------------------------------------------------- BSDFs
+MTR_HD float fresnel_conductor(float ci, float er, float ei)
+{
+    float c2 = ci * ci, s2 = 1.0f - c2, s4 = s2 * s2;
+    float t1 = er * er - ei * ei - s2;
+    float q = t1 * t1 + 4.0f * ei * ei * er * er;
+    float a2pb2 = sqrtf(q > 0.0f ? q : 0.0f);
+    float hh = 0.5f * (a2pb2 + t1);
+    float a = sqrtf(hh > 0.0f ? hh : 0.0f);
+    float term1 = a2pb2 + c2, term2 = 2.0f * ci * a;
+    float rs = (term1 - term2) / (term1 + term2);
+    float term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+    float rp = rs * (term3 - term4) / (term3 + term4);
+    return 0.5f * (rs + rp);
+}
+MTR_HD void fresnel_dielectric(float ci, float eta, float &r, float &cos_t, float &eta_it, float &eta_ti)
+{
+    bool outside = ci >= 0.0f;
+    float rcp_eta = 1.0f / eta;
+    eta_it = outside ? eta : rcp_eta;
+    eta_ti = outside ? rcp_eta : eta;
+    float ct2 = fmaf(-fmaf(-ci, ci, 1.0f), eta_ti * eta_ti, 1.0f);
+    float cia = fabsf(ci), cta = sqrtf(ct2 > 0.0f ? ct2 : 0.0f);
+    bool matched = eta == 1.0f, special = matched || cia == 0.0f;
+    float as = fmaf(-eta_it, cta, cia) / fmaf(eta_it, cta, cia);
+    float ap = fmaf(-eta_it, cia, cta) / fmaf(eta_it, cia, cta);
+    float rr = 0.5f * (as * as + ap * ap);
+    if (special) rr = matched ? 0.0f : 1.0f;
+    r = rr;
+    cos_t = sign_neg(ci) ? cta : -cta;
+}
+
+struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
+
+MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub)
+{
+    BsdfSample bs;
+    bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
+    bool flip = (m.flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f;
+    if (flip) wi.z = -wi.z;
+    float ci = wi.z;
+    if (m.type == MTR_BSDF_DIFFUSE) {
+        bs.wo = cosine_hemisphere(ua, ub);
+        bs.pdf = kInvPi * bs.wo.z;
+        if (ci > 0.0f && bs.pdf > 0.0f) bs.w = mk(m.a[0], m.a[1], m.a[2]);
+    } else if (m.type == MTR_BSDF_CONDUCTOR) {
+        bs.wo = mk(-wi.x, -wi.y, wi.z); bs.pdf = 1.0f; bs.delta = true;
+        if (ci > 0.0f)
+            bs.w = mk(m.c[0] * fresnel_conductor(ci, m.a[0], m.b[0]),
+                      m.c[1] * fresnel_conductor(ci, m.a[1], m.b[1]),
+                      m.c[2] * fresnel_conductor(ci, m.a[2], m.b[2]));
+    } else if (m.type == MTR_BSDF_DIELECTRIC) {
+        float r, ct, eit, eti;
+        fresnel_dielectric(ci, m.int_ior / m.ext_ior, r, ct, eit, eti);
+        bool refl = u1 <= r;
+        bs.delta = true;
+        bs.pdf = refl ? r : 1.0f - r;
+        if (refl) { bs.wo = mk(-wi.x, -wi.y, wi.z); bs.w = mk(m.c[0], m.c[1], m.c[2]); }
+        else {
+            bs.wo = mk(-eti * wi.x, -eti * wi.y, ct); bs.eta = eit;
+            float f2 = eti * eti;
+            bs.w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
+        }
+    }
+    if (flip) bs.wo.z = -bs.wo.z;
+    return bs;
+}
+
+MTR_HD float mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    return (fabsf(w) <= 3.402823466e+38f) ? w : 0.0f;     // isfinite
+}
+
+// ---------------------------------------------------------------- path state
+struct Path {
+    Ray ray;
+    f3 beta, L, prev_p;
+    float eta, dist, prev_pdf;
+    uint32_t depth;
+    uint32_t prev_delta;     // bool
+    Rng rng;
+    uint32_t px, py;         // film coordinates incl. crop offset (ray generation)
+    uint32_t lane;
+};
+
+struct BounceStats { uint32_t closest, shadow; };
+
+// lane -> pixel, RNG seeding, jitter, camera ray, loop-state init (transientpath.py:118-131);
+// camera_unwarp pre-pass is done by the caller (it needs a traversal).
+MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderConst &rc, uint32_t pixel, uint32_t s)
+{
+    uint32_t lane = pixel * rc.spp_total + s;
+    uint32_t py = pixel / f.crop_w, px = pixel - f.crop_w * py;
+    p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
+    p.rng = rng_seed(rc.seed, lane);
+    float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
+    p.ray = camera_ray(cam, rc, p.px, p.py, j1, j2);
+    p.beta = mk(1, 1, 1); p.L = mk(0, 0, 0); p.prev_p = mk(0, 0, 0);
+    p.eta = 1.0f; p.dist = 0.0f; p.prev_pdf = 1.0f; p.depth = 0; p.prev_delta = 1;
+}
+
+// One iteration of the loop of transientpath.py:140-319.
+// Sink: splat(px_film, py_film, bin, r, g, b, opl, depth, kind) for an in-range non-zero contribution.
+// Returns active_next.
+template <class Stack, class Sink>
+MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
+                        Stack &st, Sink &sink, BounceStats &stats)
+{
+    // 1. closest hit (:148-151)
+    Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);
+    stats.closest++;
+    const bool valid = h.prim >= 0;
+    p.dist += h.t * p.eta;                                   // :154 (inf on a miss)
+
+    bool active_next = ((p.depth + 1u) < rc.max_depth) & valid;     // :185
+    f3 Le = mk(0, 0, 0), Lr = mk(0, 0, 0);
+    const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;   // transient_image_block.py:132
+    const bool in_film = (fx < film.width) & (fy < film.height);
+
+    // RNG draws are unconditional for a live lane (:193, :223-224, :256)
+    float u1 = rng_f32(p.rng), u2 = rng_f32(p.rng);
+    float s1 = rng_f32(p.rng), s2a = rng_f32(p.rng), s2b = rng_f32(p.rng);
+    float rr_u = rng_f32(p.rng);
+
+    f3 sp = mk(0, 0, 0), sn = mk(0, 0, 1), ss = mk(1, 0, 0), stt = mk(0, 1, 0), wi = mk(0, 0, 0);
+    BsdfSample bs;
+    bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
+
+    if (valid) {
+        const TriGeom &g = sc.tgeom[h.prim];
+        const TriShade &tsd = sc.tshade[h.prim];
+        float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
+        sp = mk(fmaf(g.p0[0], b0, fmaf(g.p1[0], b1, g.p2[0] * b2)),
+                fmaf(g.p0[1], b0, fmaf(g.p1[1], b1, g.p2[1] * b2)),
+                fmaf(g.p0[2], b0, fmaf(g.p1[2], b1, g.p2[2] * b2)));
+        sn = ld3(tsd.n); ss = ld3(tsd.s); stt = ld3(tsd.t);
+        f3 md = -p.ray.d;
+        wi = mk(dot(md, ss), dot(md, stt), dot(md, sn));
+        const uint32_t mat_em = g.mat_em;
+        const mtr_material &mat = sc.mats[mat_em & 0xffffu];
+        const int32_t em = (int32_t)(mat_em >> 16) - 1;
+
+        // 2. direct emission (:166-176)
+        if (em >= 0 && !(rc.flags & MTR_FLAG_DISCARD_DIRECT_LIGHT)) {
+            const Emitter &E = sc.ems[em];
+            f3 rel = sp - p.prev_p;
+            float dist = sqrtf(dot(rel, rel));
+            f3 dd = rel / dist;
+            float em_pdf = 0.0f;
+            if (!p.prev_delta) {
+                float dp = dot(dd, sn);
+                if (dp < 0.0f) {
+                    float adp = fabsf(dp);
+                    em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
+                    if (sc.n_emitters > 1) em_pdf *= rc.inv_n_emitters;
+                }
+            }
+            float mis = mis_weight(p.prev_pdf, em_pdf);
+            if (wi.z > 0.0f)
+                Le = mk((p.beta.x * mis) * E.radiance[0], (p.beta.y * mis) * E.radiance[1],
+                        (p.beta.z * mis) * E.radiance[2]);
+        }
+        {   // add_transient(Le, distance) :179-180; common.py:417-421 pre-multiplies the sample scale
+            float vr = Le.x * rc.sample_scale, vg = Le.y * rc.sample_scale, vb = Le.z * rc.sample_scale;
+            if (in_film && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {       // adding +0 is a no-op
+                int32_t bin = film_bin(film, p.dist);
+                if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, p.dist, p.depth, 0u);
+            }
+        }
+
+        // 3. emitter sampling (:188-218); only smooth BSDFs (diffuse) take part
+        if (active_next && mat.type == MTR_BSDF_DIFFUSE && sc.n_emitters > 0) {
+            uint32_t ei = 0;
+            if (sc.n_emitters > 1) {
+                float su = u1 * rc.n_emitters_f;
+                uint32_t i = (uint32_t)su;
+                if (i > sc.n_emitters - 1) i = sc.n_emitters - 1;
+                ei = i; u1 = su - (float)i;
+            }
+            const Emitter &E = sc.ems[ei];
+            float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
+            f3 ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),
+                       fmaf(E.du[1], a, fmaf(E.dv[1], b, E.center[1])),
+                       fmaf(E.du[2], a, fmaf(E.dv[2], b, E.center[2])));
+            f3 en = ld3(E.n);
+            f3 dd = ep - sp;
+            float dist2 = dot(dd, dd), dist = sqrtf(dist2);
+            dd = dd / dist;
+            float dp = dot(dd, en), adp = fabsf(dp);
+            float x = dist2 / adp;
+            float pdf_dir = E.inv_area * ((fabsf(x) <= 3.402823466e+38f) ? x : 0.0f);
+            bool ok = (dp < 0.0f) & (pdf_dir != 0.0f);
+            if (ok) {
+                f3 emw = mk(E.radiance[0] / pdf_dir, E.radiance[1] / pdf_dir, E.radiance[2] / pdf_dir);
+                float pdf = pdf_dir;
+                if (sc.n_emitters > 1) {
+                    pdf = pdf_dir * rc.inv_n_emitters;
+                    emw = emw * rc.n_emitters_f;
+                }
+                if (pdf != 0.0f) {
+                    // shadow ray: spawn_ray_to(ds.p) + ray_test
+                    float m = max3(fabsf(sp.x), fabsf(sp.y), fabsf(sp.z));
+                    float mag = (1.0f + m) * kRayEps;
+                    if (sign_neg(dot(sn, ep - sp))) mag = -mag;
+                    f3 so = fma3(sn, mag, sp);
+                    f3 sd = ep - so;
+                    float sdist = sqrtf(dot(sd, sd));
+                    sd = sd / sdist;
+                    stats.shadow++;
+                    Hit sh = traverse<true>(sc, so, sd, sdist * (1.0f - kShadowEps), st);
+                    if (sh.prim < 0) {
+                        f3 wo = mk(dot(dd, ss), dot(dd, stt), dot(dd, sn));
+                        f3 wi_e = wi;
+                        if ((mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
+                        if (wi_e.z > 0.0f && wo.z > 0.0f) {
+                            float bpdf = kInvPi * wo.z;
+                            float mis_em = mis_weight(pdf, bpdf);
+                            Lr = mk(((p.beta.x * mis_em) * ((mat.a[0] * kInvPi) * wo.z)) * emw.x,
+                                    ((p.beta.y * mis_em) * ((mat.a[1] * kInvPi) * wo.z)) * emw.y,
+                                    ((p.beta.z * mis_em) * ((mat.a[2] * kInvPi) * wo.z)) * emw.z);
+                            float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
+                            if (in_film && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
+                                float opl = p.dist + dist * p.eta;                  // :217
+                                int32_t bin = film_bin(film, opl);
+                                if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, opl, p.depth, 1u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // 4. BSDF sampling (:222-227)
+        if (active_next) bs = bsdf_sample(mat, wi, s1, s2a, s2b);
+    }
+
+    // 5. loop state (:230-240)
+    p.L = mk((p.L.x + Le.x) + Lr.x, (p.L.y + Le.y) + Lr.y, (p.L.z + Le.z) + Lr.z);
+    if (active_next) {
+        f3 wo_w = mk(fmaf(sn.x, bs.wo.z, fmaf(stt.x, bs.wo.y, ss.x * bs.wo.x)),
+                     fmaf(sn.y, bs.wo.z, fmaf(stt.y, bs.wo.y, ss.y * bs.wo.x)),
+                     fmaf(sn.z, bs.wo.z, fmaf(stt.z, bs.wo.y, ss.z * bs.wo.x)));
+        float m = max3(fabsf(sp.x), fabsf(sp.y), fabsf(sp.z));
+        float mag = (1.0f + m) * kRayEps;
+        if (sign_neg(dot(sn, wo_w))) mag = -mag;
+        p.ray.o = fma3(sn, mag, sp);
+        p.ray.d = wo_w;
+        p.ray.tmax = kInf;
+    }
+    p.eta *= bs.eta;
+    p.beta = mk(p.beta.x * bs.w.x, p.beta.y * bs.w.y, p.beta.z * bs.w.z);
+    p.prev_p = sp; p.prev_pdf = bs.pdf; p.prev_delta = bs.delta ? 1u : 0u;
+
+    // 6. stopping criterion (:245-257)
+    float bmax = max3(p.beta.x, p.beta.y, p.beta.z);
+    active_next &= (bmax != 0.0f);
+    float rr_prob = fminf(bmax * (p.eta * p.eta), 0.95f);
+    active_next &= rr_prob > 0.0f;
+    bool rr_active = p.depth >= rc.rr_depth;
+    if (rr_active) {
+        float inv = rr_prob > 0.0f ? 1.0f / rr_prob : 0.0f;
+        p.beta = p.beta * inv;
+    }
+    active_next &= (!rr_active) | (rr_u < rr_prob);
+    if (valid) p.depth += 1;                                 // :318
+    return active_next;
+}
+
+} // namespace mtr

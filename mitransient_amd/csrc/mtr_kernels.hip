@@ -1,0 +1,428 @@
+// mtr_kernels.hip — CDNA4 (gfx950) kernels of the transient path tracer.
+//
+// k_fused        MTR_MODE_FUSED: one workgroup owns a segment of G pixels (all their samples).
+//                The whole scene (BVH2 node packets + triangles + materials) is staged in LDS,
+//                paths are generated, traced and shaded by persistent lanes that refill
+//                themselves from an LDS work counter (no idle lanes while the segment has work),
+//                every OPL -> time-bin contribution is an LDS float atomic into the segment's
+//                private (G, T, 3) histogram, and each film row is added to HBM exactly once,
+//                coalesced, by the owning workgroup: no global atomics, no splat traffic.
+// k_splat_*      the stand-alone time-bin scatter-add (add_transient_data + put_ + accum).
+// k_develop_*    TransientHDRFilm.develop.
+#include "mtr_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace mtr {
+
+// ------------------------------------------------------------------ helpers
+template <int DEPTH>
+struct LdsStack {
+    int32_t *base;     // &stack[tid]; entry k lives at base[k * kBlock]  (one bank column per lane)
+    int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ void push(int32_t v) { if (sp < DEPTH) { base[sp * kBlock] = v; ++sp; } }
+    __device__ __forceinline__ int32_t pop() { --sp; return base[sp * kBlock]; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+__device__ __forceinline__ void lds_add(float *p, float v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void log_splat(const SplatLog &lg, uint32_t lane, uint32_t depth, uint32_t kind,
+                                          uint32_t pixel, uint32_t bin, float r, float g, float b, float opl)
+{
+    unsigned long long i = atomicAdd(lg.count, 1ull);
+    if (i < lg.cap) {
+        uint32_t *R = lg.rec + 8 * i;
+        R[0] = lane; R[1] = depth | (kind << 16); R[2] = pixel; R[3] = bin;
+        R[4] = __float_as_uint(r); R[5] = __float_as_uint(g); R[6] = __float_as_uint(b); R[7] = __float_as_uint(opl);
+    }
+}
+
+// private per-segment histogram in LDS: planes [3][G*T]
+struct LdsHistSink {
+    float *hist; uint32_t plane;       // plane = G * T
+    uint32_t row;                      // (local pixel) * T, set per path
+    uint32_t film_w;
+    uint32_t lane;
+    uint32_t n_splats;
+    SplatLog log;
+    __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
+                                          float opl, uint32_t depth, uint32_t kind)
+    {
+        float *p = hist + row + bin;
+        lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b);
+        ++n_splats;
+        if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
+    }
+};
+
+// contract form: f32 atomics straight into the (H,W,T,4) tensor in HBM
+struct GlobalAtomicSink {
+    float *film; uint32_t film_w, bins;
+    uint32_t lane;
+    uint32_t n_splats;
+    SplatLog log;
+    __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
+                                          float opl, uint32_t depth, uint32_t kind)
+    {
+        size_t idx = (((size_t)fy * film_w + fx) * bins + bin) * 4u;
+        unsafeAtomicAdd(film + idx, r); unsafeAtomicAdd(film + idx + 1, g); unsafeAtomicAdd(film + idx + 2, b);
+        ++n_splats;
+        if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
+    }
+};
+
+__device__ __forceinline__ void copy16(void *dst, const void *src, uint32_t bytes, int tid)
+{
+    const uint4 *s = (const uint4 *)src; uint4 *d = (uint4 *)dst;
+    for (uint32_t i = tid; i < bytes / 16u; i += kBlock) d[i] = s[i];
+}
+__host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// ------------------------------------------------------------------ fused kernel
+template <int STACK, bool SCENE_LDS, bool HIST_LDS>
+__global__ void __launch_bounds__(kBlock) k_fused(const FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+
+    // ---- LDS carve-up (all offsets multiples of 16) ----
+    uint32_t off = 0;
+    int32_t *s_stack = (int32_t *)(smem + off); off += STACK * kBlock * 4;
+    unsigned long long *s_cnt = (unsigned long long *)(smem + off); off += 64;    // 5 counters + next
+    uint32_t *s_next = (uint32_t *)(s_cnt + 6);
+    SceneView sv;
+    sv.n_emitters = a.sc.n_ems; sv.n_tris = a.sc.n_tris;
+    if (SCENE_LDS) {
+        Node *n = (Node *)(smem + off); off += align16(a.sc.n_nodes * sizeof(Node));
+        TriGeom *tg = (TriGeom *)(smem + off); off += align16(a.sc.n_tris * sizeof(TriGeom));
+        TriShade *ts = (TriShade *)(smem + off); off += align16(a.sc.n_tris * sizeof(TriShade));
+        mtr_material *mm = (mtr_material *)(smem + off); off += align16(a.sc.n_mats * sizeof(mtr_material));
+        Emitter *ee = (Emitter *)(smem + off); off += align16(a.sc.n_ems * sizeof(Emitter));
+        copy16(n, a.sc.nodes, align16(a.sc.n_nodes * sizeof(Node)), tid);
+        copy16(tg, a.sc.tgeom, align16(a.sc.n_tris * sizeof(TriGeom)), tid);
+        copy16(ts, a.sc.tshade, align16(a.sc.n_tris * sizeof(TriShade)), tid);
+        copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
+        copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
+        sv.nodes = n; sv.tgeom = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+    } else {
+        sv.nodes = a.sc.nodes; sv.tgeom = a.sc.tgeom; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
+    }
+    float *s_steady = (float *)(smem + off); off += align16(a.G * 16);
+    float *s_hist = (float *)(smem + off);
+    const uint32_t T = a.film.bins;
+    const uint32_t plane = a.G * T;
+
+    if (tid < 6) s_cnt[tid] = 0ull;
+    if (HIST_LDS) for (uint32_t i = tid; i < 3 * plane; i += kBlock) s_hist[i] = 0.0f;
+
+    LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
+    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_paths = 0, n_splats = 0;
+
+    for (uint32_t seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+        const uint32_t pix0 = a.pixel_begin + seg * a.G;
+        const uint32_t npx = min(a.G, a.pixel_end - pix0);
+        const uint32_t n_lanes = npx * a.spp_chunk;
+        for (uint32_t i = tid; i < a.G * 4; i += kBlock) s_steady[i] = 0.0f;
+        if (tid == 0) *s_next = kBlock;
+        __syncthreads();
+
+        // ---- persistent lanes: refill from the LDS work counter when a path ends ----
+        uint32_t i = tid;
+        bool alive = false;
+        Path p;
+        uint32_t g = 0;
+        for (;;) {
+            if (!alive) {
+                if (i >= n_lanes) break;
+                g = i / a.spp_chunk;
+                const uint32_t s = a.spp_begin + (i - g * a.spp_chunk);
+                path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
+                ++n_paths;
+                if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {          // transientpath.py:133-138
+                    Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
+                    ++n_closest;
+                    if (h0.prim >= 0) p.dist = -h0.t;
+                }
+                alive = true;
+            }
+            BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
+            if (HIST_LDS) {
+                LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = g * T;
+                sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                n_splats += sink.n_splats;
+            } else {
+                GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
+                sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                n_splats += sink.n_splats;
+            }
+            n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
+            if (!alive) {
+                // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+                const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
+                if (fx < a.film.width && fy < a.film.height) {
+                    float *sp = s_steady + 4 * g;
+                    lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                }
+                i = atomicAdd(s_next, 1u);
+            }
+        }
+        __syncthreads();
+
+        // ---- flush: each film row is touched once, by its owner, coalesced (16 B / lane) ----
+        for (uint32_t gg = 0; gg < npx; ++gg) {
+            const uint32_t pixel = pix0 + gg;
+            const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;   // == film coords
+            if (cx >= a.film.width || cy >= a.film.height) continue;
+            const size_t fpix = (size_t)cy * a.film.width + cx;
+            if (HIST_LDS) {
+                float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
+                float *h = s_hist + gg * T;
+                for (uint32_t t = tid; t < T; t += kBlock) {
+                    float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
+                    if (r != 0.0f || gc != 0.0f || b != 0.0f) {
+                        float4 v = row[t];
+                        v.x += r; v.y += gc; v.z += b;
+                        row[t] = v;
+                        h[t] = 0.0f; h[t + plane] = 0.0f; h[t + 2 * plane] = 0.0f;
+                    }
+                }
+            }
+            if (tid < 4) {
+                float v = s_steady[4 * gg + tid];
+                if (v != 0.0f) a.steady_out[fpix * 4u + tid] += v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- counters: LDS reduction, then one set of global atomics per workgroup ----
+    atomicAdd(&s_cnt[0], (unsigned long long)n_paths);
+    atomicAdd(&s_cnt[1], (unsigned long long)n_closest);
+    atomicAdd(&s_cnt[2], (unsigned long long)n_shadow);
+    atomicAdd(&s_cnt[3], (unsigned long long)n_splats);
+    atomicAdd(&s_cnt[4], (unsigned long long)n_bounce);
+    __syncthreads();
+    if (tid < 5 && a.counters) atomicAdd(&a.counters->paths + tid, s_cnt[tid]);
+}
+
+static uint32_t scene_lds_bytes(const SceneDev &sc)
+{
+    return align16(sc.n_nodes * sizeof(Node)) + align16(sc.n_tris * sizeof(TriGeom)) +
+           align16(sc.n_tris * sizeof(TriShade)) + align16(sc.n_mats * sizeof(mtr_material)) +
+           align16(sc.n_ems * sizeof(Emitter));
+}
+
+bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_t spp_chunk, int n_cu,
+                FusedArgs &args, FusedConfig &cfg)
+{
+    const uint32_t kLdsMax = 160u * 1024u;
+    int stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
+    if (sc.bvh_depth > 64) return false;
+    uint32_t fixed = stack * kBlock * 4 + 64;
+    uint32_t scene_b = scene_lds_bytes(sc);
+    cfg.scene_lds = scene_b <= 64u * 1024u;
+    if (cfg.scene_lds) fixed += scene_b;
+    // pixels per segment: enough lanes to keep 256 persistent threads busy, rows must fit in LDS
+    const uint32_t row_bytes = film.bins * 12u;
+    const uint32_t hist_budget = 48u * 1024u;
+    uint32_t g_want = (2048u + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
+    if (g_want < 1) g_want = 1;
+    uint32_t g_fit = row_bytes ? hist_budget / row_bytes : 1u;
+    cfg.hist_lds = true;
+    uint32_t G;
+    if (g_fit >= 1) G = g_want < g_fit ? g_want : g_fit;
+    else if (fixed + row_bytes + 64 <= kLdsMax) G = 1;                  // one long row still fits the CU
+    else { G = g_want; cfg.hist_lds = false; }                          // row > LDS: f32 atomics to HBM
+    if (G > n_pixels) G = n_pixels ? n_pixels : 1;
+    if (G > 4096) G = 4096;
+    args.G = G;
+    args.nseg = (n_pixels + G - 1) / G;
+    cfg.stack = stack;
+    cfg.lds_bytes = fixed + align16(G * 16) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
+    if (cfg.lds_bytes > kLdsMax) return false;
+    // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), never more than segments
+    int per_cu = (int)(kLdsMax / cfg.lds_bytes);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    long grid = (long)n_cu * per_cu;
+    if (grid > (long)args.nseg) grid = args.nseg;
+    if (grid < 1) grid = 1;
+    cfg.grid = (int)grid;
+    return true;
+}
+
+template <int STACK>
+static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
+{
+    void (*k)(const FusedArgs) = nullptr;
+    if (cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, true, true>;
+    else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<STACK, true, false>;
+    else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true>;
+    else k = k_fused<STACK, false, false>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
+{
+    switch (cfg.stack) {
+    case 8: return launch_fused_s<8>(args, cfg, stream);
+    case 16: return launch_fused_s<16>(args, cfg, stream);
+    case 32: return launch_fused_s<32>(args, cfg, stream);
+    default: return launch_fused_s<64>(args, cfg, stream);
+    }
+}
+
+// ------------------------------------------------------------------ stand-alone time-bin scatter-add
+// variant 0: one f32 atomic per channel straight into HBM (the contract form of
+// transient_image_block.py:148-149)
+__global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film film, float *out, DevCounters *cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t npix = film.width * film.height;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < s.n; i += stride) {
+        const uint32_t pixel = s.pixel[i];
+        const int32_t bin = film_bin(film, s.opl[i]);
+        if (bin < 0 || pixel >= npix) continue;
+        const size_t idx = ((size_t)pixel * film.bins + (uint32_t)bin) * 4u;
+        unsafeAtomicAdd(out + idx, s.r[i]); unsafeAtomicAdd(out + idx + 1, s.g[i]); unsafeAtomicAdd(out + idx + 2, s.b[i]);
+        ++mine;
+    }
+    if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
+}
+
+// variant 1: splats sorted by pixel.  A workgroup takes a contiguous chunk, walks its pixel runs,
+// accumulates each run in an LDS row (T x 3) and adds the touched bins to HBM once per run.
+constexpr uint32_t kSplatChunk = 8192;
+__global__ void __launch_bounds__(kBlock) k_splat_sorted(mtr_splat_soa s, Film film, float *out, DevCounters *cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = (float *)smem;                    // [3][T]
+    __shared__ uint32_t s_pix, s_end;
+    const uint32_t T = film.bins, npix = film.width * film.height;
+    const int tid = threadIdx.x;
+    for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+    uint32_t mine = 0;
+    const uint64_t n_chunks = (s.n + kSplatChunk - 1) / kSplatChunk;
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint64_t c0 = c * kSplatChunk, c1 = min((unsigned long long)s.n, (unsigned long long)(c0 + kSplatChunk));
+        uint64_t cur = c0;
+        while (cur < c1) {
+            __syncthreads();
+            if (tid == 0) {                                  // run of equal pixel ids starting at cur
+                uint32_t px = s.pixel[cur];
+                s_pix = px;
+            }
+            __syncthreads();
+            const uint32_t px = s_pix;
+            // all threads scan forward cooperatively for the end of the run
+            if (tid == 0) s_end = (uint32_t)(c1 - cur);
+            __syncthreads();
+            for (uint64_t i = cur + tid; i < c1; i += kBlock)
+                if (s.pixel[i] != px) { atomicMin(&s_end, (uint32_t)(i - cur)); break; }
+            __syncthreads();
+            const uint64_t run_end = cur + s_end;
+            if (px < npix) {
+                for (uint64_t i = cur + tid; i < run_end; i += kBlock) {
+                    const int32_t bin = film_bin(film, s.opl[i]);
+                    if (bin < 0) continue;
+                    lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
+                    ++mine;
+                }
+                __syncthreads();
+                float *dst = out + (size_t)px * T * 4u;
+                for (uint32_t t = tid; t < T; t += kBlock) {
+                    float r = row[t], g = row[T + t], b = row[2 * T + t];
+                    if (r != 0.0f || g != 0.0f || b != 0.0f) {
+                        // a pixel's run may continue in the neighbouring chunk -> atomics, once per touched bin
+                        unsafeAtomicAdd(dst + 4 * t, r); unsafeAtomicAdd(dst + 4 * t + 1, g); unsafeAtomicAdd(dst + 4 * t + 2, b);
+                        row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f;
+                    }
+                }
+            }
+            cur = run_end;
+        }
+    }
+    if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
+}
+
+hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
+                            DevCounters *counters, hipStream_t stream)
+{
+    if (s.n == 0) return hipSuccess;
+    if (variant == 0 || (size_t)film.bins * 12u > 150u * 1024u) {
+        uint64_t blocks = (s.n + kBlock - 1) / kBlock;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters);
+    } else {
+        uint64_t chunks = (s.n + kSplatChunk - 1) / kSplatChunk;
+        size_t lds = (size_t)film.bins * 12u;
+        int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+        uint64_t blocks = chunks < (uint64_t)(256 * per_cu) ? chunks : (uint64_t)(256 * per_cu);
+        hipError_t e = hipFuncSetAttribute((const void *)k_splat_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_splat_sorted, dim3((unsigned)blocks), dim3(kBlock), lds, stream, s, film, film_out, counters);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ develop (transient_hdr_film.py:220-248)
+__global__ void __launch_bounds__(kBlock) k_develop_transient(const float4 *__restrict__ in, float *__restrict__ out, uint64_t n)
+{
+    // each thread converts 4 consecutive (R,G,B,W) texels into 12 contiguous floats: 3 x 16-byte stores
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n4 = n / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n4; q += stride) {
+        float4 a = in[4 * q], b = in[4 * q + 1], c = in[4 * q + 2], d = in[4 * q + 3];
+        float wa = a.w == 0.0f ? 1.0f : a.w, wb = b.w == 0.0f ? 1.0f : b.w;
+        float wc = c.w == 0.0f ? 1.0f : c.w, wd = d.w == 0.0f ? 1.0f : d.w;
+        float4 o0 = make_float4(a.x / wa, a.y / wa, a.z / wa, b.x / wb);
+        float4 o1 = make_float4(b.y / wb, b.z / wb, c.x / wc, c.y / wc);
+        float4 o2 = make_float4(c.z / wc, d.x / wd, d.y / wd, d.z / wd);
+        float4 *o = (float4 *)(out + 12 * q);
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    }
+    // tail (n not a multiple of 4)
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float4 a = in[i];
+        float w = a.w == 0.0f ? 1.0f : a.w;
+        out[3 * i] = a.x / w; out[3 * i + 1] = a.y / w; out[3 * i + 2] = a.z / w;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_develop_steady(const float4 *__restrict__ in, float *__restrict__ out, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float4 a = in[i];
+        bool ok = a.w != 0.0f;
+        out[3 * i] = ok ? a.x / a.w : 0.0f; out[3 * i + 1] = ok ? a.y / a.w : 0.0f; out[3 * i + 2] = ok ? a.z / a.w : 0.0f;
+    }
+}
+
+hipError_t launch_develop(const Film &film, const float *t4, float *t3, const float *s4, float *s3, hipStream_t stream)
+{
+    if (t4 && t3) {
+        uint64_t n = (uint64_t)film.width * film.height * film.bins;
+        uint64_t blocks = (n / 4 + kBlock - 1) / kBlock; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_develop_transient, dim3((unsigned)blocks), dim3(kBlock), 0, stream, (const float4 *)t4, t3, n);
+    }
+    if (s4 && s3) {
+        uint64_t n = (uint64_t)film.width * film.height;
+        uint64_t blocks = (n + kBlock - 1) / kBlock; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_develop_steady, dim3((unsigned)blocks), dim3(kBlock), 0, stream, (const float4 *)s4, s3, n);
+    }
+    return hipGetLastError();
+}
+
+} // namespace mtr

@@ -1,0 +1,183 @@
+"""``transient_hdr_film`` plugin surface (mitransient/films/transient_hdr_film.py).
+
+Same property keys and defaults (:114-121), same channel layout — raw (H,W,T,4)
+"RGBW" with W == 0 (:173-202), developed (H,W,T,3) (:220-248) — and the
+same ``prepare`` / ``create_block`` / ``add_transient_data`` / ``develop`` / ``clear`` /
+``traverse`` methods.  Storage is torch tensors in HBM; arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from .. import _cabi
+from ..render.transient_image_block import TransientImageBlock
+from ..runtime import get_context, require_gpu
+from ..scene import Properties, film_desc_from
+from ..tensor import TensorXf
+
+
+class TransientHDRFilm:
+    def __init__(self, props: Properties):
+        # mi.Film base properties [mitsuba3: src/render/film.cpp]
+        w, h = int(props.get("width", 768)), int(props.get("height", 576))
+        self.size_ = (w, h)
+        cw, ch = int(props.get("crop_width", w)), int(props.get("crop_height", h))
+        cx, cy = int(props.get("crop_offset_x", 0)), int(props.get("crop_offset_y", 0))
+        if cx < 0 or cy < 0 or cw <= 0 or ch <= 0 or cx + cw > w or cy + ch > h:
+            raise ValueError("Invalid crop window specification!")
+        self.crop_size_ = (cw, ch)
+        self.crop_offset_ = (cx, cy)
+        self.sample_border_ = bool(props.get("sample_border", False))
+        rf = props.get("rfilter", None)
+        self.rfilter_ = (rf.get("type") if isinstance(rf, dict) else rf) or "gaussian"   # mitsuba's default filter
+        # transient_hdr_film.py:116-121
+        self.temporal_bins = int(props.get("temporal_bins", 2048))
+        self.bin_width_opl = float(props.get("bin_width_opl", 0.003))
+        self.start_opl = float(props.get("start_opl", 0))
+        self.exhaustive_scan = bool(props.get("exhaustive_scan", False))
+        self.laser_scan_width = int(props.get("laser_scan_width", 0))
+        self.laser_scan_height = int(props.get("laser_scan_height", 0))
+        if self.exhaustive_scan:
+            raise NotImplementedError("exhaustive_scan belongs to the NLOS tier (SURVEY §8f)")
+        self.channels = None
+        self.transient_storage = None
+        self._steady_accum = None     # (H, W, 4): sum of L, sample count
+        self._device = None
+
+    # -- mi.Film accessors -------------------------------------------------
+    def size(self):
+        return self.size_
+
+    def crop_size(self):
+        return self.crop_size_
+
+    def crop_offset(self):
+        return self.crop_offset_
+
+    def sample_border(self):
+        return self.sample_border_
+
+    def rfilter(self):
+        return self.rfilter_
+
+    def end_opl(self):
+        return self.start_opl + self.bin_width_opl * self.temporal_bins
+
+    def base_channels_count(self):
+        return 3
+
+    def desc(self) -> _cabi.mtr_film_desc:
+        return film_desc_from(self)
+
+    # -- lifecycle -----------------------------------------------------------
+    def prepare(self, aovs: Sequence[str] = ()):
+        if aovs:
+            raise NotImplementedError("AOVs are not part of the transient_path hot path")
+        torch = require_gpu()
+        W, H = self.size_
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self._device = dev
+        # steady `hdrfilm` accumulator (transient_hdr_film.py:131-144): rgb + weight
+        if self._steady_accum is None or tuple(self._steady_accum.shape) != (H, W, 4) or self._steady_accum.device != dev:
+            self._steady_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        else:
+            self._steady_accum.zero_()
+        return self.prepare_transient_(aovs)
+
+    def prepare_transient_(self, aovs: Sequence[str] = ()):
+        self.channels = list("RGBW") + list(aovs)          # Film base flags carry no Alpha -> "RGBW"
+        self.crop_offset_xyt = (self.crop_offset_[0], self.crop_offset_[1], 0)
+        self.crop_size_xyt = (self.size_[0], self.size_[1], self.temporal_bins)
+        self.transient_storage = self.create_block()
+        return len(self.channels)
+
+    def create_block(self):
+        if (self.transient_storage is not None and self.transient_storage.size_xyt == self.crop_size_xyt
+                and self.transient_storage.torch_tensor().device == self._device):
+            self.transient_storage.clear()                  # reuse the allocation: same zero-filled state
+            return self.transient_storage
+        return TransientImageBlock(size_xyt=self.crop_size_xyt, offset_xyt=self.crop_offset_xyt,
+                                   channel_count=len(self.channels), rfilter=self.rfilter_, device=self._device)
+
+    def clear(self):
+        if self._steady_accum is not None:
+            self._steady_accum.zero_()
+        if self.transient_storage:
+            self.transient_storage.clear()
+
+    def steady_accum(self):
+        return self._steady_accum
+
+    # -- splat from Python (transient_hdr_film.py:250-276) -----------------
+    def add_transient_data(self, pos, distance, wavelengths, spec, ray_weight=1.0, active=None,
+                           laser_x=0, laser_y=0, variant=0):
+        """pos: (n,2) pixel coordinates (incl. crop offset); distance: (n,); spec: (n,3) already
+        multiplied by the sample scale.  Device torch tensors (or anything torch.as_tensor takes)."""
+        torch = require_gpu()
+        dev = self._device
+        pos = torch.as_tensor(pos, dtype=torch.float32, device=dev)
+        distance = torch.as_tensor(distance, dtype=torch.float32, device=dev)
+        spec = torch.as_tensor(spec, dtype=torch.float32, device=dev) * ray_weight
+        px = torch.floor(pos[:, 0]).to(torch.int64) - self.crop_offset_[0]
+        py = torch.floor(pos[:, 1]).to(torch.int64) - self.crop_offset_[1]
+        W, H = self.size_
+        ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+        if active is not None:
+            ok &= torch.as_tensor(active, dtype=torch.bool, device=dev)
+        pixel = torch.where(ok, py * W + px, torch.full_like(px, W * H))   # out-of-range id -> dropped by the kernel
+        return self.transient_storage.put_opl(pixel, distance, spec[:, 0], spec[:, 1], spec[:, 2], self.desc(), variant)
+
+    # -- develop -------------------------------------------------------------
+    def develop(self, raw: bool = False):
+        transient_image = self.develop_transient_(raw=raw)
+        torch = require_gpu()
+        W, H = self.size_
+        ctx = get_context(self._device.index)
+        ctx.bind_current_stream()
+        if raw:
+            steady = self._steady_accum
+        else:
+            steady = torch.empty((H, W, 3), dtype=torch.float32, device=self._device)
+            fd = self.desc()
+            ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), None, None,
+                                               C.c_void_p(self._steady_accum.data_ptr()),
+                                               C.c_void_p(steady.data_ptr())), "mtr_film_develop")
+        return TensorXf(steady), transient_image
+
+    def develop_transient_(self, raw: bool = False):
+        if not self.transient_storage:
+            raise RuntimeError("No transient storage allocated, was prepare_transient_() called first?")
+        if raw:
+            return self.transient_storage.tensor
+        torch = require_gpu()
+        W, H = self.size_
+        data = self.transient_storage.torch_tensor()
+        out = torch.empty((H, W, self.temporal_bins, 3), dtype=torch.float32, device=data.device)
+        ctx = get_context(data.device.index)
+        ctx.bind_current_stream()
+        fd = self.desc()
+        ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), C.c_void_p(data.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), None, None), "mtr_film_develop")
+        return TensorXf(out)
+
+    # -- introspection ---------------------------------------------------------
+    def traverse(self, callback):
+        for k in ("temporal_bins", "bin_width_opl", "start_opl", "exhaustive_scan",
+                  "laser_scan_width", "laser_scan_height"):
+            callback.put(k, getattr(self, k), 0)
+
+    def parameters_changed(self, keys=()):
+        pass
+
+    def to_string(self):
+        return ("TransientHDRFilm[\n"
+                f"  exhaustive_scan = {self.exhaustive_scan},\n  size = {self.size()},\n"
+                f"  crop_size = {self.crop_size()},\n  crop_offset = {self.crop_offset()},\n"
+                f"  sample_border = {self.sample_border()},\n  filter = {self.rfilter()},\n"
+                f"  temporal_bins = {self.temporal_bins},\n  bin_width_opl = {self.bin_width_opl},\n"
+                f"  start_opl = {self.start_opl},\n]")
+
+    __str__ = __repr__ = to_string

@@ -1,0 +1,149 @@
+"""``TransientADIntegrator``: host orchestration of a transient render.
+
+Mirrors mitransient/integrators/common.py — ``__init__`` (:22-30), ``prepare`` (:32-85),
+``render`` (:122-213), ``add_transient_f`` (:411-422), ``check_transient_`` (:424-447) —
+with the Dr.Jit trace replaced by launches of the HIP library: ``sample_rays`` +
+``sample`` + the film splats of one pass are ONE call to ``mtr_render``.
+The AD entry points (render_forward / render_backward, :215-409) are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+from .. import _cabi
+from ..films.transient_hdr_film import TransientHDRFilm
+from ..runtime import get_context
+from ..scene import Properties
+from ..tensor import TensorXf
+
+
+class TransientADIntegrator:
+    def __init__(self, props: Properties):
+        # [mitsuba3: ADIntegrator.__init__] max_depth default 6 (-1 = infinite), rr_depth default 5
+        max_depth = int(props.get("max_depth", 6))
+        if max_depth < 0 and max_depth != -1:
+            raise Exception("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        self.max_depth = max_depth if max_depth != -1 else 0xFFFFFFFF
+        self.rr_depth = int(props.get("rr_depth", 5))
+        if self.rr_depth <= 0:
+            raise Exception("\"rr_depth\" must be set to a value greater than zero!")
+        self.hide_emitters = bool(props.get("hide_emitters", False))
+        # common.py:25-30
+        self.camera_unwarp = bool(props.get("camera_unwarp", False))
+        self.discard_direct_light = bool(props.get("discard_direct_light", False))
+        _ = props.get("gaussian_stddev", 0.5)      # accepted and ignored, as in the reference
+        _ = props.get("temporal_filter", "")
+        _ = props.get("block_size", 0)
+        self.mode = _cabi.MTR_MODE_AUTO            # kernel organisation (extension; not a reference key)
+        m = props.get("amd_mode", None)
+        if m is not None:
+            self.mode = {"auto": 0, "fused": 1, "wavefront": 2}[m]
+        self.last_counters = None
+        self.last_times = None
+        self.collect_stats = False
+
+    def aov_names(self):
+        return []
+
+    # -- common.py:32-85 ---------------------------------------------------
+    def prepare(self, scene, sensor, seed, spp, aovs):
+        film = sensor.film()
+        sampler = sensor.sampler().clone()
+        if spp != 0:
+            sampler.set_sample_count(spp)
+        spp = sampler.sample_count()
+        sampler.set_samples_per_wavefront(spp)
+        film_size = film.crop_size()
+        wavefront_size = film_size[0] * film_size[1] * spp
+        film.prepare(aovs)
+        if wavefront_size <= 2 ** 32:
+            sampler.seed(seed, wavefront_size)
+            return [(sampler, spp)]
+        # common.py:56-85 splits >2^32-sample renders into passes whose seeds are drawn
+        # from a seeder sampler; that multi-pass seeding is not reproduced (no config needs it).
+        raise Exception("renders above 2^32 samples (multi-pass seeding, common.py:56-85) are not supported; "
+                        "shard spp across GPUs or reduce spp")
+
+    def check_transient_(self, scene, sensor):
+        if isinstance(sensor, int):
+            sensor = scene.sensors()[sensor]
+        if not isinstance(sensor.film(), TransientHDRFilm):
+            raise AssertionError("The film of the sensor must be of type transient_hdr_film or phasor_hdr_film")
+
+    def add_transient_f(self, film, pos, ray_weight, sample_scale):
+        """common.py:411-422: closure that pre-multiplies the sample scale and splats."""
+        return (lambda spec, distance, wavelengths=None, active=None, laser_x=None, laser_y=None:
+                film.add_transient_data(pos, distance, wavelengths, spec * sample_scale, ray_weight, active))
+
+    def _flags(self):
+        f = 0
+        if self.camera_unwarp:
+            f |= _cabi.MTR_FLAG_CAMERA_UNWARP
+        if self.discard_direct_light:
+            f |= _cabi.MTR_FLAG_DISCARD_DIRECT_LIGHT
+        return f
+
+    def render_params(self, film, seed_value, spp_total, spp_begin=0, spp_end=None,
+                      pixel_begin=0, pixel_end=None) -> _cabi.mtr_render_params:
+        p = _cabi.mtr_render_params()
+        p.spp_total = spp_total
+        p.spp_begin = spp_begin
+        p.spp_end = spp_total if spp_end is None else spp_end
+        cw, ch = film.crop_size()
+        p.pixel_begin = pixel_begin
+        p.pixel_end = cw * ch if pixel_end is None else pixel_end
+        p.seed = seed_value & 0xFFFFFFFF
+        p.max_depth = -1 if self.max_depth >= 0x7FFFFFFF else int(self.max_depth)
+        p.rr_depth = int(self.rr_depth)
+        p.flags = self._flags()
+        p.mode = int(self.mode)
+        return p
+
+    # -- common.py:122-213 ---------------------------------------------------
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True,
+               progress_callback=None, spp_range=None, pixel_range=None) -> Tuple[TensorXf, TensorXf]:
+        if not develop:
+            raise Exception("develop=True must be specified when invoking AD integrators")
+        if isinstance(sensor, int):
+            sensor = scene.sensors()[sensor]
+        film = sensor.film()
+        self.check_transient_(scene, sensor)
+        samplers_spps = self.prepare(scene=scene, sensor=sensor, seed=seed, spp=spp, aovs=self.aov_names())
+        total_spp = sum(s for _, s in samplers_spps)
+        self.accumulate(scene, sensor, samplers_spps, total_spp, spp_range, pixel_range, progress_callback)
+        return film.develop()
+
+    def accumulate(self, scene, sensor, samplers_spps, total_spp, spp_range=None, pixel_range=None,
+                   progress_callback=None):
+        """The pass loop of render() (common.py:157-210) without prepare/develop: ADDS into the film."""
+        film = sensor.film()
+        ctx = get_context(film._device.index)
+        ctx.bind_current_stream()
+        handle = scene.gpu_handle(ctx, sensor)
+        tptr = C.c_void_p(film.transient_storage.torch_tensor().data_ptr())
+        sptr = C.c_void_p(film.steady_accum().data_ptr())
+        for i, (sampler_i, spp_i) in enumerate(samplers_spps):
+            s0, s1 = (0, spp_i) if spp_range is None else spp_range
+            p0, p1 = (0, None) if pixel_range is None else pixel_range
+            params = self.render_params(film, sampler_i.seed_value(), total_spp, s0, s1, p0, p1)
+            cnt = _cabi.mtr_counters() if self.collect_stats else None
+            tim = _cabi.mtr_kernel_times() if self.collect_stats else None
+            ctx.check(ctx.lib.mtr_render(handle, C.byref(params), tptr, sptr,
+                                         C.byref(cnt) if cnt is not None else None,
+                                         C.byref(tim) if tim is not None else None), "mtr_render")
+            if self.collect_stats:
+                self.last_counters, self.last_times = cnt.as_dict(), tim.as_dict()
+            if progress_callback:
+                progress_callback((i + 1) / len(samplers_spps))
+
+    def render_forward(self, *a, **k):
+        raise NotImplementedError("differentiable rendering (common.py:215-323) is outside the north-star path")
+
+    def render_backward(self, *a, **k):
+        raise NotImplementedError("differentiable rendering (common.py:325-409) is outside the north-star path")
+
+    def to_string(self):
+        return f"{type(self).__name__}[\n  max_depth = {self.max_depth}, \n  rr_depth = {self.rr_depth}\n]"
+
+    __str__ = __repr__ = to_string

@@ -1,0 +1,177 @@
+"""A thin stand-in for the slice of ``import mitsuba as mi`` that mitransient notebooks use
+around the transient_path hot path: ``set_variant``, ``load_dict``, ``render``, ``traverse``,
+``ScalarTransform4f``, ``ScalarColor3d`` (README.md:154-164 of the reference).
+
+    import mitransient_amd.mi as mi
+    mi.set_variant('llvm_ad_rgb')          # accepted; the arithmetic always runs on the MI355X
+    import mitransient_amd as mitr
+    scene = mi.load_dict(mitr.cornell_box())
+    steady, transient = mi.render(scene, spp=1024)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict
+
+from . import _cabi, plugins
+from .scene import Properties, flatten_scene, film_desc_from
+from .sensors import IndependentSampler, PerspectiveSensor
+from .transform import ScalarTransform4f
+from .tensor import TensorXf
+
+Transform4f = ScalarTransform4f
+_variant = None
+
+
+def variant():
+    return _variant
+
+
+def set_variant(*names):
+    """Only the unpolarized RGB variants have a counterpart here."""
+    global _variant
+    for n in names:
+        if n.endswith("_rgb") and "polarized" not in n and not n.startswith("scalar"):
+            _variant = n
+            return
+    raise ValueError(f"unsupported variant(s) {names}: mitransient_amd implements the *_ad_rgb path only")
+
+
+def ScalarColor3d(*v):
+    return [float(x) for x in (v[0] if len(v) == 1 else v)]
+
+
+ScalarColor3f = ScalarColor3d
+
+
+class Scene:
+    def __init__(self, d: Dict[str, Any], base_dir: str = "."):
+        from . import integrators as _i, films as _f  # noqa: F401  (registers the plugins)
+        if d.get("type") != "scene":
+            raise ValueError("load_dict(): expected a dictionary with 'type': 'scene'")
+        self.dict_ = d
+        self.base_dir = base_dir
+        integ = [v for v in d.values() if isinstance(v, dict) and v.get("type", "").startswith("transient")
+                 or isinstance(v, dict) and v.get("type") in ("path", "direct")]
+        sens = [v for v in d.values() if isinstance(v, dict) and v.get("type") in ("perspective", "nlos_capture_meter")]
+        if len(integ) != 1:
+            raise ValueError("load_dict(): exactly one integrator is required")
+        if not sens:
+            raise ValueError("load_dict(): at least one sensor is required")
+        idict = integ[0]
+        self.integrator_ = plugins.create_integrator(idict["type"], Properties(idict["type"], idict))
+        self.sensors_ = []
+        for sd in sens:
+            if sd["type"] != "perspective":
+                raise ValueError(f"failed to instantiate unknown plugin of type \"{sd['type']}\" (supported sensors: perspective)")
+            fd = sd.get("film")
+            if fd is None:
+                raise ValueError("sensor: a 'film' is required")
+            film = plugins.create_film(fd["type"], Properties(fd["type"], fd))
+            smp = sd.get("sampler", {"type": "independent"})
+            if smp.get("type") != "independent":
+                raise ValueError(f"failed to instantiate unknown plugin of type \"{smp.get('type')}\" (supported samplers: independent)")
+            self.sensors_.append(PerspectiveSensor(sd, film, IndependentSampler(Properties("independent", smp))))
+        self._data = {}
+        self._handles = {}
+
+    def sensors(self):
+        return self.sensors_
+
+    def integrator(self):
+        return self.integrator_
+
+    def data(self, sensor=0):
+        """Flat float32 arrays for a sensor (what crosses the C-ABI)."""
+        if isinstance(sensor, int):
+            sensor = self.sensors_[sensor]
+        key = id(sensor)
+        if key not in self._data:
+            self._data[key] = flatten_scene(self.dict_, sensor.film(), sensor.dict_, self.base_dir)
+        sd = self._data[key]
+        sd.film = film_desc_from(sensor.film())
+        return sd
+
+    def gpu_handle(self, ctx, sensor=0):
+        if isinstance(sensor, int):
+            sensor = self.sensors_[sensor]
+        key = (id(sensor), ctx.device_index)
+        sd = self.data(sensor)
+        if key not in self._handles:
+            h = C.c_void_p()
+            d = sd.desc()
+            ctx.check(ctx.lib.mtr_scene_create(ctx.handle, C.byref(d), C.byref(h)), "mtr_scene_create")
+            self._handles[key] = h
+        h = self._handles[key]
+        fd = sd.film
+        ctx.check(ctx.lib.mtr_scene_set_film(h, C.byref(fd)), "mtr_scene_set_film")
+        return h
+
+    def __del__(self):
+        try:
+            lib = _cabi.load_library()
+            for h in self._handles.values():
+                lib.mtr_scene_destroy(h)
+        except Exception:
+            pass
+
+
+def load_dict(d: Dict[str, Any], base_dir: str = ".") -> Scene:
+    return Scene(d, base_dir)
+
+
+def render(scene: Scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0):
+    """``mi.render``: returns ``(steady (H,W,3), transient (H,W,T,3))`` like the reference's
+    TransientADIntegrator.render (common.py:212-213)."""
+    integ = integrator or scene.integrator()
+    return integ.render(scene, sensor=sensor, seed=seed, spp=spp)
+
+
+class _Params(dict):
+    def __init__(self, objs):
+        super().__init__()
+        self._objs = objs
+        self._dirty = set()
+
+    def __setitem__(self, k, v):
+        self._dirty.add(k)
+        super().__setitem__(k, v)
+
+    def update(self, *a, **k):
+        if a or k:
+            return super().update(*a, **k)
+        for key in self._dirty:
+            obj, attr = self._objs[key]
+            setattr(obj, attr, type(getattr(obj, attr))(self[key]))
+        self._dirty.clear()
+
+
+def traverse(obj):
+    """``mi.traverse`` for the film parameters the reference exports (transient_hdr_film.py:295-308)."""
+    objs = {}
+
+    class _CB:
+        def __init__(self, prefix, o):
+            self.prefix, self.o = prefix, o
+
+        def put(self, name, value, flags=0):
+            objs[self.prefix + name] = (self.o, name)
+
+    targets = []
+    if isinstance(obj, Scene):
+        for i, s in enumerate(obj.sensors()):
+            targets.append((f"sensor{'' if i == 0 else i}.film.", s.film()))
+    else:
+        targets.append(("", obj))
+    for prefix, o in targets:
+        o.traverse(_CB(prefix, o))
+    p = _Params(objs)
+    for k, (o, attr) in objs.items():
+        dict.__setitem__(p, k, getattr(o, attr))
+    return p
+
+
+def load_file(path, **kwargs):
+    from .xml_loader import load_file as _lf
+    return _lf(path, **kwargs)

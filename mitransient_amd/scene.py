@@ -1,0 +1,367 @@
+"""Scene dictionaries -> flat arrays (the host half of ``mi.load_dict``).
+
+Only the subset the north-star path needs is accepted: shapes
+``rectangle`` / ``cube`` / ``obj``, BSDFs ``diffuse`` / ``conductor`` /
+``dielectric`` / ``twosided``, the ``area`` emitter on a rectangle, the
+``perspective`` sensor with an ``independent`` sampler and a
+``transient_hdr_film``, and the ``transient_path`` integrator.  Anything else
+raises, in the words Mitsuba uses for an unknown plugin.
+
+Reference for the keys and defaults: mitransient/utils.py:78-220 (cornell_box),
+mitransient/integrators/common.py:22-30, transient_hdr_film.py:114-121.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import _cabi
+from .transform import ScalarTransform4f, to_transform
+
+
+class Properties:
+    """Minimal stand-in for ``mi.Properties``: ``get(name, default)`` + plugin name."""
+
+    def __init__(self, plugin_name: str = "", values: Optional[Dict[str, Any]] = None):
+        self._plugin = plugin_name
+        self._v = dict(values or {})
+        self._queried = set()
+
+    def plugin_name(self):
+        return self._plugin
+
+    def has_property(self, k):
+        return k in self._v
+
+    def get(self, k, default=None):
+        self._queried.add(k)
+        return self._v.get(k, default)
+
+    def __getitem__(self, k):
+        self._queried.add(k)
+        return self._v[k]
+
+    def __setitem__(self, k, v):
+        self._v[k] = v
+
+    def __contains__(self, k):
+        return k in self._v
+
+    def keys(self):
+        return self._v.keys()
+
+    def unqueried(self):
+        return [k for k in self._v if k not in self._queried and k != "type"]
+
+
+def _color3(v, what="color"):
+    if isinstance(v, dict):
+        t = v.get("type")
+        if t not in ("rgb", "spectrum", "uniform"):
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" ({what}: only rgb/constant values are supported)")
+        v = v.get("value")
+    a = np.asarray(v, dtype=np.float64).reshape(-1)
+    if a.size == 1:
+        a = np.repeat(a, 3)
+    if a.size != 3:
+        raise ValueError(f"{what}: expected a scalar or an RGB triple")
+    return a
+
+
+# complex IOR presets of mitsuba's `conductor` (subset; values = mitsuba's RGB-mode table) [upstream-unverified]
+_CONDUCTOR_PRESETS = {
+    "none": ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
+}
+
+_IOR_PRESETS = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "diamond": 2.419,
+                "acrylic glass": 1.49, "polypropylene": 1.49, "pyrex": 1.470, "fused quartz": 1.458}
+
+
+def _ior(v, default):
+    if v is None:
+        v = default
+    if isinstance(v, str):
+        if v not in _IOR_PRESETS:
+            raise ValueError(f"unknown IOR preset '{v}'")
+        return float(_IOR_PRESETS[v])
+    return float(v)
+
+
+class _SceneBuilder:
+    def __init__(self, d: Dict[str, Any], base_dir: str = "."):
+        self.d = d
+        self.base_dir = base_dir
+        self.tri_verts: List[np.ndarray] = []
+        self.tri_mat: List[np.ndarray] = []
+        self.tri_em: List[np.ndarray] = []
+        self.materials: List[_cabi.mtr_material] = []
+        self.mat_cache: Dict[int, int] = {}
+        self.emitters: List[_cabi.mtr_emitter] = []
+        self.shape_names: List[str] = []
+        self.shape_ranges: List[tuple] = []
+
+    # -- BSDFs -------------------------------------------------------------
+    def _resolve(self, v):
+        if isinstance(v, dict) and v.get("type") == "ref":
+            rid = v["id"]
+            if rid not in self.d:
+                raise ValueError(f"reference to unknown object '{rid}'")
+            return self.d[rid], ("ref", rid)
+        return v, ("obj", id(v))
+
+    def material_index(self, v) -> int:
+        bd, key = self._resolve(v)
+        if key in self.mat_cache:
+            return self.mat_cache[key]
+        m = self._make_material(bd)
+        self.materials.append(m)
+        self.mat_cache[key] = len(self.materials) - 1
+        return self.mat_cache[key]
+
+    def _make_material(self, bd) -> _cabi.mtr_material:
+        m = _cabi.mtr_material()
+        m.int_ior, m.ext_ior = 1.0, 1.0
+        for k in range(3):
+            m.c[k] = 1.0
+            m.c2[k] = 1.0
+        t = bd.get("type")
+        if t == "twosided":
+            inner = [v for k, v in bd.items() if isinstance(v, dict) and k != "type"]
+            if len(inner) != 1:
+                raise ValueError("twosided: exactly one nested BSDF is supported")
+            inner_d, _ = self._resolve(inner[0])
+            m = self._make_material(inner_d)
+            if m.type == _cabi.MTR_BSDF_DIELECTRIC:
+                raise ValueError("twosided: only materials without a transmission component can be nested")
+            m.flags |= _cabi.MTR_MAT_TWOSIDED
+            return m
+        if t == "diffuse":
+            m.type = _cabi.MTR_BSDF_DIFFUSE
+            refl = _color3(bd.get("reflectance", 0.5), "diffuse.reflectance")
+            for k in range(3):
+                m.a[k] = np.float32(refl[k])
+        elif t == "conductor":
+            m.type = _cabi.MTR_BSDF_CONDUCTOR
+            if "material" in bd and bd["material"] != "none":
+                raise ValueError("conductor: material presets other than 'none' are not available; pass eta/k")
+            eta = _color3(bd.get("eta", 0.0), "conductor.eta")
+            kk = _color3(bd.get("k", 1.0), "conductor.k")
+            sr = _color3(bd.get("specular_reflectance", 1.0), "conductor.specular_reflectance")
+            for k in range(3):
+                m.a[k], m.b[k], m.c[k] = np.float32(eta[k]), np.float32(kk[k]), np.float32(sr[k])
+        elif t == "dielectric":
+            m.type = _cabi.MTR_BSDF_DIELECTRIC
+            m.int_ior = np.float32(_ior(bd.get("int_ior"), "bk7"))
+            m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
+            sr = _color3(bd.get("specular_reflectance", 1.0), "dielectric.specular_reflectance")
+            st = _color3(bd.get("specular_transmittance", 1.0), "dielectric.specular_transmittance")
+            for k in range(3):
+                m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
+        else:
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, twosided)")
+        return m
+
+    # -- shapes ------------------------------------------------------------
+    def add_shape(self, name: str, sd: Dict[str, Any]):
+        t = sd.get("type")
+        tw = to_transform(sd.get("to_world"))
+        if t == "rectangle":
+            corners = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float64)
+            w = tw.transform_affine(corners)
+            tris = np.stack([w[[0, 1, 2]], w[[0, 2, 3]]])
+        elif t == "cube":
+            tris = tw.transform_affine(_cube_tris().reshape(-1, 3)).reshape(-1, 3, 3)
+        elif t == "obj":
+            fn = sd.get("filename")
+            if not os.path.isabs(fn):
+                fn = os.path.join(self.base_dir, fn)
+            v = load_obj(fn)
+            tris = tw.transform_affine(v.reshape(-1, 3)).reshape(-1, 3, 3)
+        else:
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported shapes: rectangle, cube, obj)")
+        if sd.get("flip_normals", False):
+            tris = tris[:, [0, 2, 1], :]
+        bsdf = None
+        for k, v in sd.items():
+            if isinstance(v, dict) and v.get("type") in ("ref", "diffuse", "conductor", "dielectric", "twosided") and k != "emitter":
+                bsdf = v
+        if bsdf is None:
+            bsdf = {"type": "diffuse", "reflectance": 0.5}     # mitsuba's default BSDF
+        mi_ = self.material_index(bsdf)
+        em_index = -1
+        em = sd.get("emitter")
+        if em is not None:
+            if em.get("type") != "area":
+                raise ValueError(f"failed to instantiate unknown plugin of type \"{em.get('type')}\" (supported emitters: area)")
+            if t != "rectangle":
+                raise ValueError("area emitters are supported on 'rectangle' shapes only")
+            e = _cabi.mtr_emitter()
+            c = tw.transform_affine(np.zeros(3))
+            du = tw.transform_affine(np.array([1.0, 0, 0])) - c
+            dv = tw.transform_affine(np.array([0, 1.0, 0])) - c
+            rad = _color3(em.get("radiance", 1.0), "area.radiance")
+            for k in range(3):
+                e.center[k], e.du[k], e.dv[k], e.radiance[k] = (np.float32(c[k]), np.float32(du[k]),
+                                                                 np.float32(dv[k]), np.float32(rad[k]))
+            self.emitters.append(e)
+            em_index = len(self.emitters) - 1
+        n = tris.shape[0]
+        first = sum(a.shape[0] for a in self.tri_verts)
+        self.tri_verts.append(tris.astype(np.float32))
+        self.tri_mat.append(np.full(n, mi_, dtype=np.uint32))
+        self.tri_em.append(np.full(n, em_index, dtype=np.int32))
+        self.shape_names.append(name)
+        self.shape_ranges.append((first, first + n))
+
+
+def _cube_tris() -> np.ndarray:
+    """[-1,1]^3 as 12 outward-facing (CCW) triangles, shape (12,3,3)."""
+    faces = []
+    for axis in range(3):
+        for sgn in (-1.0, 1.0):
+            u, v = (axis + 1) % 3, (axis + 2) % 3
+            quad = []
+            for (a, b) in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+                p = [0.0, 0.0, 0.0]
+                p[axis] = sgn
+                p[u] = a
+                p[v] = b
+                quad.append(p)
+            if sgn < 0:
+                quad = quad[::-1]
+            faces.append([quad[0], quad[1], quad[2]])
+            faces.append([quad[0], quad[2], quad[3]])
+    return np.asarray(faces, dtype=np.float64)
+
+
+def load_obj(path: str) -> np.ndarray:
+    """Wavefront OBJ -> (n,3,3) float64 triangle soup (positions only, fan-triangulated;
+    ``l``/``vn``/``vt`` and groups are ignored: faces are flat-shaded)."""
+    verts, tris = [], []
+    with open(path, "r") as fh:
+        for line in fh:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    tris.append((idx[0], idx[k], idx[k + 1]))
+    v = np.asarray(verts, dtype=np.float64)
+    t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    return v[t]
+
+
+# -- sensor ---------------------------------------------------------------
+def perspective_matrices(sd: Dict[str, Any], film_size, crop_size, crop_offset):
+    """sample_to_camera and to_world of mitsuba's ``perspective`` sensor
+    [mitsuba3: src/sensors/perspective.cpp, include/mitsuba/render/sensor.h parse_fov/perspective_projection]."""
+    W, H = float(film_size[0]), float(film_size[1])
+    aspect = W / H
+    fov = float(sd.get("fov", 0.0))
+    if "fov" not in sd:
+        if "focal_length" in sd:
+            raise ValueError("perspective: 'focal_length' is not supported; pass 'fov'")
+        raise ValueError("perspective: 'fov' is required")
+    axis = sd.get("fov_axis", "x")
+    if axis == "smaller":
+        axis = "y" if aspect > 1 else "x"
+    elif axis == "larger":
+        axis = "x" if aspect > 1 else "y"
+    if axis == "y":
+        fov = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+    elif axis == "diagonal":
+        diag = 2.0 * math.tan(0.5 * math.radians(fov))
+        width = diag / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        fov = math.degrees(2.0 * math.atan(width * 0.5))
+    elif axis != "x":
+        raise ValueError(f"perspective: unknown fov_axis '{axis}'")
+    near = float(sd.get("near_clip", 1e-2))
+    far = float(sd.get("far_clip", 1e4))
+    rel_size = (crop_size[0] / W, crop_size[1] / H)
+    rel_off = (crop_offset[0] / W, crop_offset[1] / H)
+    T = ScalarTransform4f
+    camera_to_sample = (T().scale([1.0 / rel_size[0], 1.0 / rel_size[1], 1.0])
+                        .translate([-rel_off[0], -rel_off[1], 0.0])
+                        .scale([-0.5, -0.5 * aspect, 1.0])
+                        .translate([-1.0, -1.0 / aspect, 0.0])) @ T.perspective(fov, near, far)
+    sample_to_camera = camera_to_sample.inverse()
+    to_world = to_transform(sd.get("to_world"))
+    return sample_to_camera.matrix, to_world.matrix, near, far
+
+
+class SceneData:
+    """Flat, float32 description of a scene: exactly what crosses the C-ABI."""
+
+    def __init__(self):
+        self.tri_verts = np.zeros((0, 9), np.float32)
+        self.tri_material = np.zeros(0, np.uint32)
+        self.tri_emitter = np.zeros(0, np.int32)
+        self.materials = (_cabi.mtr_material * 1)()
+        self.n_materials = 0
+        self.emitters = (_cabi.mtr_emitter * 1)()
+        self.n_emitters = 0
+        self.camera = _cabi.mtr_camera()
+        self.film = _cabi.mtr_film_desc()
+        self.shape_names: List[str] = []
+        self.shape_ranges: List[tuple] = []
+
+    def desc(self) -> _cabi.mtr_scene_desc:
+        d = _cabi.mtr_scene_desc()
+        d.n_tris = self.tri_verts.shape[0]
+        d.tri_verts = self.tri_verts.ctypes.data_as(C.POINTER(C.c_float))
+        d.tri_material = self.tri_material.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.tri_emitter = self.tri_emitter.ctypes.data_as(C.POINTER(C.c_int32))
+        d.n_materials = self.n_materials
+        d.materials = C.cast(self.materials, C.POINTER(_cabi.mtr_material))
+        d.n_emitters = self.n_emitters
+        d.emitters = C.cast(self.emitters, C.POINTER(_cabi.mtr_emitter))
+        d.camera = self.camera
+        d.film = self.film
+        d._keepalive = self            # arrays must outlive the desc
+        return d
+
+
+def film_desc_from(film) -> _cabi.mtr_film_desc:
+    f = _cabi.mtr_film_desc()
+    f.width, f.height = int(film.size_[0]), int(film.size_[1])
+    f.crop_width, f.crop_height = int(film.crop_size_[0]), int(film.crop_size_[1])
+    f.crop_offset_x, f.crop_offset_y = int(film.crop_offset_[0]), int(film.crop_offset_[1])
+    f.temporal_bins = int(film.temporal_bins)
+    f.start_opl = np.float32(film.start_opl)
+    f.bin_width_opl = np.float32(film.bin_width_opl)
+    return f
+
+
+def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir: str = ".") -> SceneData:
+    b = _SceneBuilder(d, base_dir)
+    for name, v in d.items():
+        if not isinstance(v, dict):
+            continue
+        t = v.get("type")
+        if t in ("rectangle", "cube", "obj", "ply", "sphere", "disk", "cylinder"):
+            b.add_shape(name, v)
+    sd = SceneData()
+    if b.tri_verts:
+        sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
+        sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))
+        sd.tri_emitter = np.ascontiguousarray(np.concatenate(b.tri_em))
+    sd.n_materials = len(b.materials)
+    sd.materials = (_cabi.mtr_material * max(1, sd.n_materials))(*b.materials)
+    sd.n_emitters = len(b.emitters)
+    sd.emitters = (_cabi.mtr_emitter * max(1, sd.n_emitters))(*b.emitters)
+    s2c, tw, near, far = perspective_matrices(sensor_dict, film.size_, film.crop_size_, film.crop_offset_)
+    for i in range(16):
+        sd.camera.sample_to_camera[i] = np.float32(s2c.reshape(-1)[i])
+        sd.camera.to_world[i] = np.float32(tw.reshape(-1)[i])
+    sd.camera.near_clip, sd.camera.far_clip = np.float32(near), np.float32(far)
+    sd.film = film_desc_from(film)
+    sd.shape_names, sd.shape_ranges = b.shape_names, b.shape_ranges
+    return sd

@@ -1,0 +1,847 @@
+/*
+ * mtr_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C, one-lane-at-a-time restatement of the reference hot path
+ *   TransientADIntegrator.render      mitransient/integrators/common.py:122-213
+ *   TransientADIntegrator.prepare     mitransient/integrators/common.py:32-85
+ *   TransientPath.sample              mitransient/integrators/transientpath.py:88-326
+ *   TransientHDRFilm.add_transient_data / develop
+ *                                     mitransient/films/transient_hdr_film.py:210-276
+ *   TransientImageBlock.put_/accum    mitransient/render/transient_image_block.py:79-151
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object.  The product (mitransient_amd/) never does.
+ *
+ * PARITY UNPINNED.  The arithmetic below the reference's Python (ray/scene
+ * intersection, BSDFs, emitter sampling, the PCG32 sampler, the perspective
+ * sensor) lives in the un-vendored third-party dependency
+ *   mitsuba >=3.6.0,<3.9.0 (setup.py:21, version.py:5-7; "latest" 3.8.0) + its pinned drjit,
+ * which is absent from /root/reference and cannot be installed here (no
+ * network, no wheel).  Those parts restate Mitsuba 3's published algorithms
+ * (cited inline as [mitsuba3: file]); the reference holds no golden vectors
+ * for this path (tests/integration/test_nlos.py:117-118 asserts shapes only).
+ * What IS pinned: the official PCG32 known-answer stream, the f32 bin mapping
+ * of transient_hdr_film.py:263-265, the energy identity transient.sum(2) ==
+ * steady (examples/transient-nlos/1-simple-nlos-scenes.ipynb, md cell 8) and
+ * an analytic direct-illumination quadrature (tests/).
+ *
+ * Numerics contract shared with the HIP path: IEEE f32,
+ * no contraction (-ffp-contract=off), fmaf() only where written, 1/x and
+ * sqrtf correctly rounded, sin/cos by the fixed polynomials below.
+ */
+#include "mtr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* [drjit: dot() of a 3-vector is an fma chain] */
+static inline float vdot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+/* [drjit: cross() = fmsub(a.yzx, b.zxy, a.zxy * b.yzx)] */
+static inline v3 vcross(v3 a, v3 b)
+{
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 vnormalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(vdot(a, a));
+    return vscale(a, inv);
+}
+/* a*s + b, per component */
+static inline v3 vfma(v3 a, float s, v3 b) { return V(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
+static inline float mulsign(float x, float s) { return (s < 0.0f || (s == 0.0f && signbit(s))) ? -x : x; }
+
+/* ------------------------------------------------------------------ */
+/* Independent sampler  [mitsuba3: src/samplers/independent.cpp,       */
+/* include/mitsuba/core/random.h sample_tea_32, drjit/random.h PCG32]  */
+/* reference call sites: common.py:52, transientpath.py:193,223-224,256 */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t state, inc; } pcg32;
+
+static void tea32(uint32_t *v0, uint32_t *v1, int rounds)
+{
+    uint32_t a = *v0, b = *v1, sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        a += ((b << 4) + 0xa341316cu) ^ (b + sum) ^ ((b >> 5) + 0xc8013ea4u);
+        b += ((a << 4) + 0xad90777du) ^ (a + sum) ^ ((a >> 5) + 0x7e95761eu);
+    }
+    *v0 = a; *v1 = b;
+}
+static uint32_t pcg32_next_u32(pcg32 *r)
+{
+    uint64_t old = r->state;
+    r->state = old * 0x5851f42d4c957f2dULL + r->inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+}
+static void pcg32_seed(pcg32 *r, uint64_t initstate, uint64_t initseq)
+{
+    r->state = 0u;
+    r->inc = (initseq << 1u) | 1u;
+    pcg32_next_u32(r);
+    r->state += initstate;
+    pcg32_next_u32(r);
+}
+static float pcg32_next_f32(pcg32 *r)
+{
+    union { uint32_t u; float f; } x;
+    x.u = (pcg32_next_u32(r) >> 9) | 0x3f800000u;
+    return x.f - 1.0f;
+}
+/* sampler.seed(seed, wavefront_size): per-lane stream from TEA(seed, lane) */
+static void sampler_seed(pcg32 *r, uint32_t seed_value, uint32_t lane)
+{
+    uint32_t v0 = seed_value, v1 = lane;
+    tea32(&v0, &v1, 4);
+    pcg32_seed(r, (uint64_t)v0, (uint64_t)v1);
+}
+
+/* exported KAT hooks */
+void orc_pcg32_stream(uint64_t initstate, uint64_t initseq, uint32_t n, uint32_t *out_u32, float *out_f32)
+{
+    pcg32 r; pcg32_seed(&r, initstate, initseq);
+    pcg32 r2 = r;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (out_u32) out_u32[i] = pcg32_next_u32(&r);
+        if (out_f32) out_f32[i] = pcg32_next_f32(&r2);
+    }
+}
+void orc_sampler_stream(uint32_t seed_value, uint32_t lane, uint32_t n, float *out)
+{
+    pcg32 r; sampler_seed(&r, seed_value, lane);
+    for (uint32_t i = 0; i < n; ++i) out[i] = pcg32_next_f32(&r);
+}
+void orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *out2)
+{
+    tea32(&v0, &v1, rounds); out2[0] = v0; out2[1] = v1;
+}
+
+/* ------------------------------------------------------------------ */
+/* sin/cos on [-pi/4, pi/4]: fixed minimax polynomials (Cephes sinf /  */
+/* cosf kernels); part of the numerics contract.                       */
+/* ------------------------------------------------------------------ */
+static void sincos_q(float x, float *s, float *c)
+{
+    float z = x * x;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    *s = fmaf(x * z, ps, x);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    *c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+}
+void orc_sincos_q(float x, float *s, float *c) { sincos_q(x, s, c); }
+
+#define ORC_PI       3.14159265358979323846f
+#define ORC_INV_PI   0.31830988618379067154f
+#define ORC_RAY_EPS  (1500.0f * 5.9604644775390625e-8f)          /* [mitsuba3: math::RayEpsilon = Epsilon*1500, Epsilon<float> = 2^-24] */
+#define ORC_SHADOW_EPS (ORC_RAY_EPS * 10.0f)                      /* [mitsuba3: math::ShadowEpsilon] */
+
+/* [mitsuba3: warp::square_to_uniform_disk_concentric] */
+static void square_to_disk(float u1, float u2, float *px, float *py)
+{
+    float x = fmaf(2.0f, u1, -1.0f), y = fmaf(2.0f, u2, -1.0f);
+    int is_zero = (x == 0.0f && y == 0.0f);
+    int q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = (0.25f * ORC_PI) * rp / r;       /* in [-pi/4, pi/4] */
+    if (is_zero) phi = 0.0f;
+    float s, c;
+    sincos_q(phi, &s, &c);
+    if (q13) { float t = s; s = c; c = t; }      /* sincos(pi/2 - phi) */
+    *px = r * c; *py = r * s;
+}
+/* [mitsuba3: warp::square_to_cosine_hemisphere] */
+static v3 square_to_cos_hemi(float u1, float u2)
+{
+    float px, py;
+    square_to_disk(u1, u2, &px, &py);
+    float zz = 1.0f - fmaf(px, px, py * py);
+    float z = sqrtf(zz > 0.0f ? zz : 0.0f);
+    return V(px, py, z);
+}
+void orc_square_to_cos_hemi(float u1, float u2, float *out3)
+{
+    v3 w = square_to_cos_hemi(u1, u2); out3[0] = w.x; out3[1] = w.y; out3[2] = w.z;
+}
+
+/* ------------------------------------------------------------------ */
+/* Scene, derived per-triangle data                                    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    v3 p0, e1, e2;     /* [mitsuba3: Mesh::ray_intersect_triangle] */
+    v3 n, s, t;        /* geometric normal == shading normal (flat); frame s,t [mitsuba3: SurfaceInteraction::initialize_sh_frame] */
+} orc_tri;
+
+typedef struct { v3 lo, hi; int left, right, first, count; } orc_node;
+
+typedef struct {
+    const mtr_scene_desc *d;
+    orc_tri *tris;
+    /* emitters: derived n, inv_area */
+    v3 *em_n; float *em_inv_area;
+    /* own small BVH (median split), only used when use_bvh != 0 */
+    orc_node *nodes; int n_nodes; int *tri_order;
+} orc_scene;
+
+static void build_tris(orc_scene *sc)
+{
+    const mtr_scene_desc *d = sc->d;
+    sc->tris = (orc_tri *)calloc(d->n_tris ? d->n_tris : 1, sizeof(orc_tri));
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
+        const float *v = d->tri_verts + 9 * (size_t)i;
+        orc_tri *T = &sc->tris[i];
+        v3 p0 = V(v[0], v[1], v[2]), p1 = V(v[3], v[4], v[5]), p2 = V(v[6], v[7], v[8]);
+        T->p0 = p0; T->e1 = vsub(p1, p0); T->e2 = vsub(p2, p0);
+        T->n = vnormalize(vcross(T->e1, T->e2));
+        T->s = vnormalize(T->e1);
+        T->t = vcross(T->n, T->s);
+    }
+    sc->em_n = (v3 *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(v3));
+    sc->em_inv_area = (float *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(float));
+    for (uint32_t i = 0; i < d->n_emitters; ++i) {
+        const mtr_emitter *e = &d->emitters[i];
+        v3 du = V(e->du[0], e->du[1], e->du[2]), dv = V(e->dv[0], e->dv[1], e->dv[2]);
+        v3 c = vcross(du, dv);
+        float len = sqrtf(vdot(c, c));
+        sc->em_n[i] = vscale(c, 1.0f / len);
+        /* [mitsuba3: Rectangle: surface_area = |cross(dp_du, dp_dv)|, dp_du = to_world*(2,0,0)] */
+        sc->em_inv_area[i] = 1.0f / (4.0f * len);
+    }
+}
+
+/* ---- the oracle's own BVH: plain median split on the largest axis ---- */
+static void tri_bounds(const float *v, v3 *lo, v3 *hi)
+{
+    *lo = V(INFINITY, INFINITY, INFINITY); *hi = V(-INFINITY, -INFINITY, -INFINITY);
+    for (int k = 0; k < 3; ++k) {
+        float x = v[3 * k], y = v[3 * k + 1], z = v[3 * k + 2];
+        if (x < lo->x) lo->x = x; if (y < lo->y) lo->y = y; if (z < lo->z) lo->z = z;
+        if (x > hi->x) hi->x = x; if (y > hi->y) hi->y = y; if (z > hi->z) hi->z = z;
+    }
+}
+static const float *g_sort_verts; static int g_sort_axis;
+static int cmp_centroid(const void *a, const void *b)
+{
+    int ia = *(const int *)a, ib = *(const int *)b;
+    const float *va = g_sort_verts + 9 * (size_t)ia, *vb = g_sort_verts + 9 * (size_t)ib;
+    float ca = va[g_sort_axis] + va[3 + g_sort_axis] + va[6 + g_sort_axis];
+    float cb = vb[g_sort_axis] + vb[3 + g_sort_axis] + vb[6 + g_sort_axis];
+    return (ca < cb) ? -1 : (ca > cb) ? 1 : (ia - ib);
+}
+static int build_node(orc_scene *sc, int first, int count)
+{
+    int idx = sc->n_nodes++;
+    orc_node *N = &sc->nodes[idx];
+    v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
+    for (int i = first; i < first + count; ++i) {
+        v3 l, h; tri_bounds(sc->d->tri_verts + 9 * (size_t)sc->tri_order[i], &l, &h);
+        if (l.x < lo.x) lo.x = l.x; if (l.y < lo.y) lo.y = l.y; if (l.z < lo.z) lo.z = l.z;
+        if (h.x > hi.x) hi.x = h.x; if (h.y > hi.y) hi.y = h.y; if (h.z > hi.z) hi.z = h.z;
+    }
+    /* pad: culling must be conservative, the triangle test alone decides hits */
+    float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    float pad = 1e-4f * (1.0f + fmaxf(ex, fmaxf(ey, ez)));
+    N->lo = V(lo.x - pad, lo.y - pad, lo.z - pad); N->hi = V(hi.x + pad, hi.y + pad, hi.z + pad);
+    N->first = first; N->count = count; N->left = N->right = -1;
+    if (count <= 2) return idx;
+    int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    g_sort_verts = sc->d->tri_verts; g_sort_axis = axis;
+    qsort(sc->tri_order + first, (size_t)count, sizeof(int), cmp_centroid);
+    int half = count / 2;
+    int l = build_node(sc, first, half);
+    int r = build_node(sc, first + half, count - half);
+    sc->nodes[idx].left = l; sc->nodes[idx].right = r; sc->nodes[idx].count = 0;
+    return idx;
+}
+static void build_bvh(orc_scene *sc)
+{
+    int n = (int)sc->d->n_tris;
+    sc->tri_order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    for (int i = 0; i < n; ++i) sc->tri_order[i] = i;
+    sc->nodes = (orc_node *)malloc(sizeof(orc_node) * (2u * (size_t)(n > 0 ? n : 0) + 1u));
+    sc->n_nodes = 0;
+    if (n) build_node(sc, 0, n);
+}
+static void free_scene(orc_scene *sc)
+{
+    free(sc->tris); free(sc->em_n); free(sc->em_inv_area); free(sc->nodes); free(sc->tri_order);
+}
+
+/* ------------------------------------------------------------------ */
+/* Ray / triangle  [mitsuba3: Mesh::ray_intersect_triangle_impl]       */
+/* ------------------------------------------------------------------ */
+typedef struct { v3 o, d; float maxt; } ray3;
+typedef struct { float t, u, v; int prim; } hit_t;
+
+static inline int tri_test(const orc_tri *T, const ray3 *r, float *t, float *u, float *v)
+{
+    v3 pvec = vcross(r->d, T->e2);
+    float det = vdot(T->e1, pvec);
+    float inv_det = 1.0f / det;
+    v3 tvec = vsub(r->o, T->p0);
+    float uu = vdot(tvec, pvec) * inv_det;
+    if (!(uu >= 0.0f && uu <= 1.0f)) return 0;
+    v3 qvec = vcross(tvec, T->e1);
+    float vv = vdot(r->d, qvec) * inv_det;
+    if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
+    float tt = vdot(T->e2, qvec) * inv_det;
+    if (!(tt >= 0.0f && tt <= r->maxt)) return 0;
+    *t = tt; *u = uu; *v = vv;
+    return 1;
+}
+/* closest hit; ties on t are broken towards the LOWER primitive index so the
+ * result does not depend on traversal order (brute force == any BVH) */
+static inline void hit_update(hit_t *h, float t, float u, float v, int prim)
+{
+    if (t < h->t || (t == h->t && prim < h->prim)) { h->t = t; h->u = u; h->v = v; h->prim = prim; }
+}
+static int box_hit(const orc_node *N, const ray3 *r, v3 inv_d, float tbest)
+{
+    float t0 = (N->lo.x - r->o.x) * inv_d.x, t1 = (N->hi.x - r->o.x) * inv_d.x;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = (N->lo.y - r->o.y) * inv_d.y; t1 = (N->hi.y - r->o.y) * inv_d.y;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (N->lo.z - r->o.z) * inv_d.z; t1 = (N->hi.z - r->o.z) * inv_d.z;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    tf *= 1.0000005f;
+    return tn <= tf && tf >= 0.0f && tn <= tbest;
+}
+static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
+{
+    hit_t h; h.t = INFINITY; h.u = h.v = 0.0f; h.prim = -1;
+    float t, u, v;
+    if (!use_bvh) {
+        for (uint32_t i = 0; i < sc->d->n_tris; ++i)
+            if (tri_test(&sc->tris[i], r, &t, &u, &v)) hit_update(&h, t, u, v, (int)i);
+        return h;
+    }
+    if (!sc->n_nodes) return h;
+    v3 inv_d = V(1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z);
+    int stack[128], sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const orc_node *N = &sc->nodes[stack[--sp]];
+        if (!box_hit(N, r, inv_d, fminf(h.t, r->maxt))) continue;
+        if (N->left < 0) {
+            for (int i = N->first; i < N->first + N->count; ++i) {
+                int p = sc->tri_order[i];
+                if (tri_test(&sc->tris[p], r, &t, &u, &v)) hit_update(&h, t, u, v, p);
+            }
+        } else { stack[sp++] = N->left; stack[sp++] = N->right; }
+    }
+    return h;
+}
+/* [mitsuba3: Scene::ray_test] any hit in [0, maxt] */
+static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
+{
+    float t, u, v;
+    if (!use_bvh) {
+        for (uint32_t i = 0; i < sc->d->n_tris; ++i)
+            if (tri_test(&sc->tris[i], r, &t, &u, &v)) return 1;
+        return 0;
+    }
+    if (!sc->n_nodes) return 0;
+    v3 inv_d = V(1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z);
+    int stack[128], sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const orc_node *N = &sc->nodes[stack[--sp]];
+        if (!box_hit(N, r, inv_d, r->maxt)) continue;
+        if (N->left < 0) {
+            for (int i = N->first; i < N->first + N->count; ++i)
+                if (tri_test(&sc->tris[sc->tri_order[i]], r, &t, &u, &v)) return 1;
+        } else { stack[sp++] = N->left; stack[sp++] = N->right; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Surface interaction  [mitsuba3: Mesh::compute_surface_interaction]  */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int valid; float t; v3 p, n, s, tt, wi; int prim;
+} sinter;
+
+static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
+{
+    sinter si; memset(&si, 0, sizeof si);
+    si.valid = h.prim >= 0; si.t = h.t; si.prim = h.prim;
+    if (!si.valid) return si;
+    const orc_tri *T = &sc->tris[h.prim];
+    const float *vv = sc->d->tri_verts + 9 * (size_t)h.prim;
+    float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
+    /* si.p = fmadd(p0, b0, fmadd(p1, b1, p2 * b2)) */
+    si.p = V(fmaf(vv[0], b0, fmaf(vv[3], b1, vv[6] * b2)),
+             fmaf(vv[1], b0, fmaf(vv[4], b1, vv[7] * b2)),
+             fmaf(vv[2], b0, fmaf(vv[5], b1, vv[8] * b2)));
+    si.n = T->n; si.s = T->s; si.tt = T->t;
+    v3 md = vneg(r->d);
+    si.wi = V(vdot(md, si.s), vdot(md, si.tt), vdot(md, si.n));   /* to_local(-ray.d) */
+    return si;
+}
+/* [mitsuba3: Frame3f::to_world] fmadd(n, v.z, fmadd(t, v.y, s * v.x)) */
+static v3 to_world(const sinter *si, v3 v)
+{
+    return V(fmaf(si->n.x, v.z, fmaf(si->tt.x, v.y, si->s.x * v.x)),
+             fmaf(si->n.y, v.z, fmaf(si->tt.y, v.y, si->s.y * v.x)),
+             fmaf(si->n.z, v.z, fmaf(si->tt.z, v.y, si->s.z * v.x)));
+}
+static v3 to_local(const sinter *si, v3 v) { return V(vdot(v, si->s), vdot(v, si->tt), vdot(v, si->n)); }
+/* [mitsuba3: Interaction::offset_p] */
+static v3 offset_p(const sinter *si, v3 d)
+{
+    float m = fmaxf(fabsf(si->p.x), fmaxf(fabsf(si->p.y), fabsf(si->p.z)));
+    float mag = (1.0f + m) * ORC_RAY_EPS;
+    mag = mulsign(mag, vdot(si->n, d));
+    return vfma(si->n, mag, si->p);
+}
+
+/* ------------------------------------------------------------------ */
+/* BSDFs  [mitsuba3: src/bsdfs/{diffuse,conductor,dielectric,twosided}.cpp,
+ *         include/mitsuba/render/fresnel.h]                           */
+/* ------------------------------------------------------------------ */
+typedef struct { v3 wo; float pdf, eta; int delta; float w[3]; } bsample;
+
+static float fresnel_conductor(float cos_i, float eta_r, float eta_i)
+{
+    float c2 = cos_i * cos_i, s2 = 1.0f - c2, s4 = s2 * s2;
+    float temp1 = eta_r * eta_r - eta_i * eta_i - s2;
+    float q = temp1 * temp1 + 4.0f * eta_i * eta_i * eta_r * eta_r;
+    float a2pb2 = sqrtf(q > 0.0f ? q : 0.0f);
+    float h = 0.5f * (a2pb2 + temp1);
+    float a = sqrtf(h > 0.0f ? h : 0.0f);
+    float term1 = a2pb2 + c2, term2 = 2.0f * cos_i * a;
+    float rs = (term1 - term2) / (term1 + term2);
+    float term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+    float rp = rs * (term3 - term4) / (term3 + term4);
+    return 0.5f * (rs + rp);
+}
+static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, float *eta_it, float *eta_ti)
+{
+    int outside = cos_i >= 0.0f;
+    float rcp_eta = 1.0f / eta;
+    *eta_it = outside ? eta : rcp_eta; *eta_ti = outside ? rcp_eta : eta;
+    float ct2 = fmaf(-fmaf(-cos_i, cos_i, 1.0f), (*eta_ti) * (*eta_ti), 1.0f);
+    float ci = fabsf(cos_i), ct = sqrtf(ct2 > 0.0f ? ct2 : 0.0f);
+    int index_matched = (eta == 1.0f), special = index_matched || (ci == 0.0f);
+    float a_s = fmaf(-(*eta_it), ct, ci) / fmaf(*eta_it, ct, ci);
+    float a_p = fmaf(-(*eta_it), ci, ct) / fmaf(*eta_it, ci, ct);
+    float rr = 0.5f * (a_s * a_s + a_p * a_p);
+    if (special) rr = index_matched ? 0.0f : 1.0f;
+    *r = rr;
+    *cos_t = (cos_i < 0.0f || (cos_i == 0.0f && signbit(cos_i))) ? ct : -ct;   /* mulsign_neg */
+}
+static int bsdf_is_smooth(const mtr_material *m) { return m->type == MTR_BSDF_DIFFUSE; }
+
+/* eval_pdf: returns value (incl. cos) and pdf for a world-frame-local wo */
+static void bsdf_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
+{
+    val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
+    if (m->type != MTR_BSDF_DIFFUSE) return;
+    if ((m->flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    float ci = wi.z, co = wo.z;
+    if (!(ci > 0.0f && co > 0.0f)) return;
+    for (int k = 0; k < 3; ++k) val[k] = (m->a[k] * ORC_INV_PI) * co;
+    *pdf = ORC_INV_PI * co;
+}
+static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float ub, bsample *bs)
+{
+    memset(bs, 0, sizeof *bs); bs->eta = 1.0f;
+    int flip = (m->flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f;
+    if (flip) wi.z = -wi.z;
+    float ci = wi.z;
+    switch (m->type) {
+    case MTR_BSDF_DIFFUSE: {
+        bs->wo = square_to_cos_hemi(ua, ub);
+        bs->pdf = ORC_INV_PI * bs->wo.z;
+        if (ci > 0.0f && bs->pdf > 0.0f) for (int k = 0; k < 3; ++k) bs->w[k] = m->a[k];
+        break; }
+    case MTR_BSDF_CONDUCTOR: {
+        bs->wo = V(-wi.x, -wi.y, wi.z); bs->pdf = 1.0f; bs->delta = 1;
+        if (ci > 0.0f) for (int k = 0; k < 3; ++k) bs->w[k] = m->c[k] * fresnel_conductor(ci, m->a[k], m->b[k]);
+        break; }
+    case MTR_BSDF_DIELECTRIC: {
+        float r, ct, eit, eti;
+        fresnel_dielectric(ci, m->int_ior / m->ext_ior, &r, &ct, &eit, &eti);
+        int refl = u1 <= r;
+        bs->delta = 1;
+        bs->pdf = refl ? r : 1.0f - r;
+        if (refl) { bs->wo = V(-wi.x, -wi.y, wi.z); for (int k = 0; k < 3; ++k) bs->w[k] = m->c[k]; }
+        else { bs->wo = V(-eti * wi.x, -eti * wi.y, ct); bs->eta = eit;
+               for (int k = 0; k < 3; ++k) bs->w[k] = m->c2[k] * (eti * eti); }
+        break; }
+    default: break;
+    }
+    if (flip) bs->wo.z = -bs->wo.z;
+}
+
+/* ------------------------------------------------------------------ */
+/* Film  (transient_hdr_film.py:250-276, transient_image_block.py:103-151) */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t closest, shadow, bounces, splats; } lane_counters;
+typedef struct {
+    const mtr_film_desc *f; float *transient; float *steady;
+    orc_splat_rec *log; uint64_t log_cap; uint64_t *log_n;
+} film_t;
+
+int orc_bin_index(float distance, float start_opl, float bin_width_opl, uint32_t T)
+{
+    float pos_distance = (distance - start_opl) / bin_width_opl;        /* transient_hdr_film.py:263 */
+    if (!(pos_distance >= 0.0f && pos_distance < (float)T)) return -1;  /* :265 */
+    return (int)(uint32_t)floorf(pos_distance);                          /* transient_image_block.py:132 */
+}
+static void add_transient(film_t *F, uint32_t px, uint32_t py, float distance, const float spec[3],
+                          float sample_scale, uint32_t lane, uint32_t depth, uint32_t kind, lane_counters *C)
+{
+    const mtr_film_desc *f = F->f;
+    /* common.py:417-421: spec * sample_scale, then * ray_weight (== 1) */
+    float val[3] = { spec[0] * sample_scale, spec[1] * sample_scale, spec[2] * sample_scale };
+    int bin = orc_bin_index(distance, f->start_opl, f->bin_width_opl, f->temporal_bins);
+    if (bin < 0) return;
+    /* p = floor(pos) - offset (transient_image_block.py:132); pos carries the crop offset */
+    uint32_t x = px - f->crop_offset_x, y = py - f->crop_offset_y;
+    if (!(x < f->width && y < f->height)) return;                        /* :146 */
+    if (val[0] == 0.0f && val[1] == 0.0f && val[2] == 0.0f) return;     /* adding +0 is a no-op */
+    size_t index = (((size_t)y * f->width + x) * f->temporal_bins + (uint32_t)bin) * 4u;  /* :142-144 */
+    for (int k = 0; k < 3; ++k) {
+#pragma omp atomic
+        F->transient[index + k] += val[k];                               /* accum: scatter_reduce(Add) :79-81 */
+    }
+    /* channel 3 ("W") receives alpha = 0.0 (transient_hdr_film.py:269-272): stays 0 */
+    C->splats += 1;
+    if (F->log) {
+        uint64_t i;
+#pragma omp atomic capture
+        i = (*F->log_n)++;
+        if (i < F->log_cap) {
+            orc_splat_rec *R = &F->log[i];
+            R->lane = lane; R->depth_kind = depth | (kind << 16); R->pixel = y * f->width + x; R->bin = (uint32_t)bin;
+            R->r = val[0]; R->g = val[1]; R->b = val[2]; R->opl = distance;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Sensor  [mitsuba3: ADIntegrator.sample_rays (python/ad/integrators/common.py),
+ *          src/sensors/perspective.cpp sample_ray]                    */
+/* ------------------------------------------------------------------ */
+static ray3 sample_ray(const mtr_scene_desc *d, uint32_t px, uint32_t py, float j1, float j2)
+{
+    const mtr_film_desc *f = &d->film; const mtr_camera *c = &d->camera;
+    float pos_x = (float)px + j1, pos_y = (float)py + j2;                /* pos_f = pos + next_2d() */
+    float scale_x = 1.0f / (float)f->crop_width, scale_y = 1.0f / (float)f->crop_height;
+    float off_x = -(float)f->crop_offset_x * scale_x, off_y = -(float)f->crop_offset_y * scale_y;
+    float sx = fmaf(pos_x, scale_x, off_x), sy = fmaf(pos_y, scale_y, off_y);
+    const float *M = c->sample_to_camera;
+    float nx = fmaf(M[0], sx, fmaf(M[1], sy, M[3]));
+    float ny = fmaf(M[4], sx, fmaf(M[5], sy, M[7]));
+    float nz = fmaf(M[8], sx, fmaf(M[9], sy, M[11]));
+    float nw = fmaf(M[12], sx, fmaf(M[13], sy, M[15]));
+    float iw = 1.0f / nw;
+    v3 dl = vnormalize(V(nx * iw, ny * iw, nz * iw));
+    const float *T = c->to_world;
+    ray3 r;
+    r.d = V(fmaf(T[0], dl.x, fmaf(T[1], dl.y, T[2] * dl.z)),
+            fmaf(T[4], dl.x, fmaf(T[5], dl.y, T[6] * dl.z)),
+            fmaf(T[8], dl.x, fmaf(T[9], dl.y, T[10] * dl.z)));
+    float inv_z = 1.0f / dl.z;
+    float near_t = c->near_clip * inv_z, far_t = c->far_clip * inv_z;
+    r.o = vfma(r.d, near_t, V(T[3], T[7], T[11]));
+    r.maxt = far_t - near_t;
+    return r;
+}
+
+/* [mitsuba3: mis_weight in python/ad/integrators/common.py] */
+static float mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    return isfinite(w) ? w : 0.0f;
+}
+
+/* ------------------------------------------------------------------ */
+/* One lane of TransientPath.sample (transientpath.py:88-326)          */
+/* ------------------------------------------------------------------ */
+
+
+static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *F, uint32_t lane,
+                       int use_bvh, lane_counters *C)
+{
+    const mtr_scene_desc *d = sc->d; const mtr_film_desc *f = &d->film;
+    const uint32_t spp = P->spp_total;
+    const float sample_scale = (float)(1.0 / (double)spp);               /* common.py:173-175: python float 1.0/total_spp */
+    const uint32_t max_depth = P->max_depth < 0 ? 0xffffffffu : (uint32_t)P->max_depth;
+    const uint32_t rr_depth = (uint32_t)P->rr_depth;
+
+    /* sample_rays: lane -> pixel */
+    uint32_t idx = lane / spp;
+    uint32_t py = idx / f->crop_width, px = idx - f->crop_width * py;
+    px += f->crop_offset_x; py += f->crop_offset_y;
+
+    pcg32 rng; sampler_seed(&rng, P->seed, lane);                        /* common.py:52 */
+    float j1 = pcg32_next_f32(&rng), j2 = pcg32_next_f32(&rng);
+    ray3 ray = sample_ray(d, px, py, j1, j2);
+
+    /* transientpath.py:118-131 */
+    uint32_t depth = 0; float L[3] = { 0, 0, 0 }, beta[3] = { 1, 1, 1 };   /* β_init == 1, utils.py:9-21 */
+    float eta = 1.0f, distance = 0.0f;
+    int active = 1, prev_delta = 1; v3 prev_p = V(0, 0, 0); float prev_pdf = 1.0f;
+
+    if (P->flags & MTR_FLAG_CAMERA_UNWARP) {                             /* :133-138 */
+        hit_t h = intersect(sc, &ray, use_bvh); C->closest++;
+        if (h.prim >= 0) distance = -h.t;
+    }
+
+    while (active) {                                                     /* :140 */
+        C->bounces++;
+        int active_next = 1;
+        hit_t h = intersect(sc, &ray, use_bvh); C->closest++;            /* :148-151 */
+        sinter si = make_si(sc, &ray, h);
+        distance += si.t * eta;                                          /* :154 (inf on a miss) */
+        const mtr_material *mat = si.valid ? &d->materials[d->tri_material[si.prim]] : NULL;
+        int em = si.valid ? d->tri_emitter[si.prim] : -1;
+
+        /* ---- direct emission :166-176 ---- */
+        float Le[3] = { 0, 0, 0 };
+        if (em >= 0 && !(P->flags & MTR_FLAG_DISCARD_DIRECT_LIGHT)) {
+            /* ds = DirectionSample3f(scene, si, ref=prev_si) */
+            v3 rel = vsub(si.p, prev_p);
+            float dist = sqrtf(vdot(rel, rel));
+            v3 dd = V(rel.x / dist, rel.y / dist, rel.z / dist);
+            /* pdf_emitter_direction(prev_si, ds, ~prev_bsdf_delta) [AreaLight::pdf_direction, Shape::pdf_direction] */
+            float em_pdf = 0.0f;
+            if (!prev_delta) {
+                float dp = vdot(dd, si.n);
+                if (dp < 0.0f) {
+                    float adp = fabsf(dp);
+                    em_pdf = sc->em_inv_area[em] * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
+                    if (d->n_emitters > 1) em_pdf *= 1.0f / (float)d->n_emitters;
+                }
+            }
+            float mis = mis_weight(prev_pdf, em_pdf);
+            /* emitter.eval(si): radiance where cos_theta(si.wi) > 0 [AreaLight::eval] */
+            if (si.wi.z > 0.0f)
+                for (int k = 0; k < 3; ++k) Le[k] = (beta[k] * mis) * d->emitters[em].radiance[k];
+        }
+        add_transient(F, px, py, distance, Le, sample_scale, lane, depth, 0, C);   /* :179-180 */
+
+        /* ---- emitter sampling :185-218 ---- */
+        active_next &= (depth + 1 < max_depth) && si.valid;
+        int active_em = active_next && bsdf_is_smooth(mat);
+        float u1 = pcg32_next_f32(&rng), u2 = pcg32_next_f32(&rng);     /* sampler.next_2d() :193 */
+        float Lr[3] = { 0, 0, 0 }; float ds_dist = 0.0f;
+        if (active_em && d->n_emitters > 0) {
+            /* [Scene::sample_emitter_direction] */
+            uint32_t ei = 0; float pmf = 1.0f;
+            if (d->n_emitters > 1) {
+                float ne = (float)d->n_emitters;
+                float su = u1 * ne;
+                uint32_t i = (uint32_t)su; if (i > d->n_emitters - 1) i = d->n_emitters - 1;
+                ei = i; u1 = su - (float)i; pmf = 1.0f / ne;
+            }
+            const mtr_emitter *E = &d->emitters[ei];
+            /* [Rectangle::sample_position] */
+            float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
+            v3 ep = V(fmaf(E->du[0], a, fmaf(E->dv[0], b, E->center[0])),
+                      fmaf(E->du[1], a, fmaf(E->dv[1], b, E->center[1])),
+                      fmaf(E->du[2], a, fmaf(E->dv[2], b, E->center[2])));
+            v3 en = sc->em_n[ei];
+            /* [Shape::sample_direction] */
+            v3 dd = vsub(ep, si.p);
+            float dist2 = vdot(dd, dd), dist = sqrtf(dist2);
+            dd = V(dd.x / dist, dd.y / dist, dd.z / dist);
+            float dp = vdot(dd, en), adp = fabsf(dp);
+            float x = dist2 / adp;
+            float pdf_dir = sc->em_inv_area[ei] * (isfinite(x) ? x : 0.0f);
+            ds_dist = dist;
+            /* [AreaLight::sample_direction] active &= dot(d,n) < 0 && pdf != 0; spec = radiance / pdf */
+            int ok = (dp < 0.0f) && (pdf_dir != 0.0f);
+            float emw[3] = { 0, 0, 0 };
+            if (ok) for (int k = 0; k < 3; ++k) emw[k] = E->radiance[k] / pdf_dir;
+            float pdf = pdf_dir;
+            if (d->n_emitters > 1) {                                    /* ds.pdf *= pmf; spec *= 1/pmf */
+                pdf = pdf_dir * pmf;
+                for (int k = 0; k < 3; ++k) emw[k] *= (float)d->n_emitters;
+            }
+            int active_e = active_em && (pdf != 0.0f) && ok;            /* :194 (zero-weight lanes skipped) */
+            /* visibility [Interaction::spawn_ray_to + Scene::ray_test] */
+            if (active_e) {
+                v3 o = offset_p(&si, vsub(ep, si.p));
+                v3 sd = vsub(ep, o);
+                float sdist = sqrtf(vdot(sd, sd));
+                ray3 sr; sr.o = o; sr.d = V(sd.x / sdist, sd.y / sdist, sd.z / sdist);
+                sr.maxt = sdist * (1.0f - ORC_SHADOW_EPS);
+                C->shadow++;
+                if (ray_test(sc, &sr, use_bvh)) { emw[0] = emw[1] = emw[2] = 0.0f; }
+                /* :207-213 */
+                v3 wo = to_local(&si, dd);
+                float bv[3], bpdf; bsdf_eval_pdf(mat, si.wi, wo, bv, &bpdf);
+                float mis_em = mis_weight(pdf, bpdf);                   /* ds.delta == false for area lights */
+                for (int k = 0; k < 3; ++k) Lr[k] = ((beta[k] * mis_em) * bv[k]) * emw[k];
+            }
+        }
+        add_transient(F, px, py, distance + ds_dist * eta, Lr, sample_scale, lane, depth, 1, C);   /* :216-218 */
+
+        /* ---- BSDF sampling :222-233 ---- */
+        float s1 = pcg32_next_f32(&rng);
+        float s2a = pcg32_next_f32(&rng), s2b = pcg32_next_f32(&rng);
+        bsample bs; memset(&bs, 0, sizeof bs); bs.eta = 1.0f;
+        if (active_next) bsdf_sample(mat, si.wi, s1, s2a, s2b, &bs);
+        for (int k = 0; k < 3; ++k) L[k] = (L[k] + Le[k]) + Lr[k];      /* :230 */
+        if (active_next) {
+            v3 wo_w = to_world(&si, bs.wo);
+            ray.o = offset_p(&si, wo_w); ray.d = wo_w; ray.maxt = INFINITY;   /* si.spawn_ray :231 */
+        }
+        eta *= bs.eta;                                                   /* :232 */
+        for (int k = 0; k < 3; ++k) beta[k] *= bs.w[k];                  /* :233 */
+        prev_p = si.p; prev_pdf = bs.pdf; prev_delta = bs.delta;   /* :237-240 */
+
+        /* ---- stopping criterion :245-257 ---- */
+        float bmax = fmaxf(beta[0], fmaxf(beta[1], beta[2]));
+        active_next &= (bmax != 0.0f);
+        float rr_prob = fminf(bmax * (eta * eta), 0.95f);
+        active_next &= rr_prob > 0.0f;
+        int rr_active = depth >= rr_depth;
+        if (rr_active) {
+            float inv = rr_prob > 0.0f ? 1.0f / rr_prob : 0.0f;
+            for (int k = 0; k < 3; ++k) beta[k] *= inv;
+        }
+        float rr_u = pcg32_next_f32(&rng);                               /* :256 */
+        int rr_continue = rr_u < rr_prob;
+        active_next &= (!rr_active) || rr_continue;
+
+        if (si.valid) depth += 1;                                        /* :318 */
+        active = active_next;                                            /* :319 */
+    }
+    /* steady splat: block.put(pos, [L.r, L.g, L.b, 1]) common.py:187-200 */
+    if (F->steady) {
+        uint32_t x = px - f->crop_offset_x, y = py - f->crop_offset_y;
+        if (x < f->width && y < f->height) {
+            size_t i = ((size_t)y * f->width + x) * 4u;
+            for (int k = 0; k < 3; ++k) {
+#pragma omp atomic
+                F->steady[i + k] += L[k];
+            }
+#pragma omp atomic
+            F->steady[i + 3] += 1.0f;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Public entry points                                                 */
+/* ------------------------------------------------------------------ */
+int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *transient_hwt4, float *steady_hw4,
+               mtr_counters *out, int n_threads, int use_bvh,
+               orc_splat_rec *log, uint64_t log_cap, uint64_t *log_n)
+{
+    if (!d || !P || !transient_hwt4) return -1;
+    if (P->spp_total == 0 || P->spp_end > P->spp_total || P->spp_begin > P->spp_end) return -1;
+    if ((uint64_t)d->film.crop_width * d->film.crop_height * P->spp_total > (1ull << 32)) return -2;   /* common.py:51 */
+    if (P->pixel_end > d->film.crop_width * d->film.crop_height || P->pixel_begin > P->pixel_end) return -1;
+    orc_scene sc; memset(&sc, 0, sizeof sc); sc.d = d;
+    build_tris(&sc);
+    if (use_bvh) build_bvh(&sc);
+    film_t F; memset(&F, 0, sizeof F);
+    F.f = &d->film; F.transient = transient_hwt4; F.steady = steady_hw4;
+    uint64_t zero = 0; F.log = log; F.log_cap = log_cap; F.log_n = log_n ? log_n : &zero;
+    if (log_n) *log_n = 0;
+    uint64_t closest = 0, shadow = 0, bounces = 0, paths = 0, splats = 0;
+    const int64_t n_pix = (int64_t)P->pixel_end - (int64_t)P->pixel_begin;
+    const uint32_t s0 = P->spp_begin, s1 = P->spp_end;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : closest, shadow, bounces, paths, splats)
+    for (int64_t ip = 0; ip < n_pix; ++ip) {
+        uint32_t pix = P->pixel_begin + (uint32_t)ip;
+        for (uint32_t s = s0; s < s1; ++s) {
+            uint32_t lane = pix * P->spp_total + s;      /* lane identity == RNG identity */
+            lane_counters C = { 0, 0, 0, 0 };
+            trace_lane(&sc, P, &F, lane, use_bvh, &C);
+            closest += C.closest; shadow += C.shadow; bounces += C.bounces; splats += C.splats; paths += 1;
+        }
+    }
+    if (out) {
+        memset(out, 0, sizeof *out);
+        out->paths = paths; out->rays_closest = closest; out->rays_shadow = shadow;
+        out->bounces = bounces; out->splats_issued = splats;
+    }
+    free_scene(&sc);
+    return 0;
+}
+
+/* develop (transient_hdr_film.py:220-248; steady hdrfilm: sum / weight) */
+void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *transient_hwt3,
+                 const float *steady_hw4, float *steady_hw3)
+{
+    size_t npt = (size_t)f->width * f->height * f->temporal_bins;
+    if (transient_hwt4 && transient_hwt3)
+        for (size_t i = 0; i < npt; ++i) {
+            float w = transient_hwt4[4 * i + 3];
+            float dv = (w == 0.0f) ? 1.0f : w;
+            for (int k = 0; k < 3; ++k) transient_hwt3[3 * i + k] = transient_hwt4[4 * i + k] / dv;
+        }
+    size_t np = (size_t)f->width * f->height;
+    if (steady_hw4 && steady_hw3)
+        for (size_t i = 0; i < np; ++i) {
+            float w = steady_hw4[4 * i + 3];
+            for (int k = 0; k < 3; ++k) steady_hw3[3 * i + k] = (w != 0.0f) ? steady_hw4[4 * i + k] / w : 0.0f;
+        }
+}
+
+/* stand-alone splat add (same arithmetic as add_transient) for the scatter-add tests */
+void orc_splat_add(const mtr_film_desc *f, uint64_t n, const uint32_t *pixel, const float *opl,
+                   const float *r, const float *g, const float *b, float *transient_hwt4)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        int bin = orc_bin_index(opl[i], f->start_opl, f->bin_width_opl, f->temporal_bins);
+        if (bin < 0) continue;
+        if (pixel[i] >= f->width * f->height) continue;
+        size_t index = ((size_t)pixel[i] * f->temporal_bins + (uint32_t)bin) * 4u;
+        transient_hwt4[index + 0] += r[i]; transient_hwt4[index + 1] += g[i]; transient_hwt4[index + 2] += b[i];
+    }
+}
+
+/* closest-hit probe for BVH/intersection tests */
+void orc_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3, const float *d3, const float *maxt,
+                   int use_bvh, float *t_out, int32_t *prim_out, uint8_t *occluded_out)
+{
+    orc_scene sc; memset(&sc, 0, sizeof sc); sc.d = d;
+    build_tris(&sc);
+    if (use_bvh) build_bvh(&sc);
+    for (uint32_t i = 0; i < n; ++i) {
+        ray3 r; r.o = V(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]); r.d = V(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+        r.maxt = maxt ? maxt[i] : INFINITY;
+        hit_t h = intersect(&sc, &r, use_bvh);
+        if (t_out) t_out[i] = h.t;
+        if (prim_out) prim_out[i] = h.prim;
+        if (occluded_out) occluded_out[i] = (uint8_t)ray_test(&sc, &r, use_bvh);
+    }
+    free_scene(&sc);
+}
+
+void orc_camera_ray(const mtr_scene_desc *d, uint32_t px, uint32_t py, float j1, float j2, float *o3, float *d3, float *maxt)
+{
+    ray3 r = sample_ray(d, px, py, j1, j2);
+    o3[0] = r.o.x; o3[1] = r.o.y; o3[2] = r.o.z; d3[0] = r.d.x; d3[1] = r.d.y; d3[2] = r.d.z; *maxt = r.maxt;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
