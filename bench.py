@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: Cornell box 512x512, 1024 time bins, 1024 spp per GPU
+(BASELINE.json configs[1]; with N GPUs: N*1024 spp sharded by samples + one RCCL film reduction,
+configs[2] at N=8).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete transient render on every rank: film clear, the path kernel(s) over
+rank's sample slice of all 512^2 pixels, (N>1) reduce-scatter of the raw (H,W,T,4) film over
+RCCL + all-gather of the developed tensor, develop.  Scene, BVH and film live in HBM before the
+timed region starts.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SPLAT_BYTES = 24.0         # algorithmic bytes per issued time-bin contribution
+
+
+def build_scene(width, height, bins, max_depth=8, mode=None):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=width, height=height, temporal_bins=bins, start_opl=3.5,
+                               bin_width_opl=6.0 / bins)
+    d["integrator"]["max_depth"] = max_depth
+    if mode:
+        d["integrator"]["amd_mode"] = mode
+    return mi.load_dict(d)
+
+
+def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
+    """Times the CPU oracle (the build's C restatement, OpenMP over all host cores) on a bounded
+    sample of the SAME workload: all width x height pixels, the first k of spp_total samples."""
+    from oracle import oracle
+    scene = build_scene(width, height, bins)
+    sd = scene.data()
+    integ = scene.integrator()
+    film = scene.sensors()[0].film()
+    cores = oracle.num_threads()
+    # calibration: 1 sample per pixel
+    p = integ.render_params(film, 0, spp_total, 0, 1)
+    t0 = time.perf_counter()
+    _, _, c = oracle.render(sd, p, use_bvh=True)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    k = int(max(1, min(spp_total, target_s / dt)))
+    p = integ.render_params(film, 0, spp_total, 0, k)
+    t0 = time.perf_counter()
+    _, _, c = oracle.render(sd, p, use_bvh=True)
+    dt = time.perf_counter() - t0
+    rays = c["rays_closest"] + c["rays_shadow"]
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "time_bins_per_s": c["splats_issued"] / dt,
+            "sample": f"{width}x{height} px, {bins} bins, samples 0..{k - 1} of {spp_total} per pixel "
+                      f"({c['paths']} paths, {dt:.1f} s, own BVH, OpenMP {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--bins", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel PER GPU (weak scaling)")
+    ap.add_argument("--mode", default=None, choices=[None, "auto", "fused", "wavefront"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mitransient_amd import distributed as mdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene = build_scene(args.width, args.height, args.bins, mode=args.mode)
+    integ = scene.integrator()
+    integ.collect_stats = True
+    spp_total = args.spp * world
+    renderer = mdist.DistributedRenderer(scene, partition="spp", gather=True)
+
+    totals = {"paths": 0, "rays_closest": 0, "rays_shadow": 0, "splats_issued": 0, "bounces": 0}
+    kernel_ms = []
+    trace_launches = 0
+
+    def step(timed):
+        nonlocal trace_launches
+        steady, transient = renderer.render(spp=spp_total, seed=0)
+        if timed:
+            for k in totals:
+                totals[k] += integ.last_counters[k]
+            kernel_ms.append(integ.last_times["trace_ms"])
+            trace_launches += integ.last_times["trace_launches"]
+        return steady, transient
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    del out
+
+    # max over ranks of the elapsed time; sums of the counters
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        for k, v in zip(sorted(totals), c.tolist()):
+            totals[k] = int(v)
+
+    if rank == 0:
+        rays = totals["rays_closest"] + totals["rays_shadow"]
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the dominant kernel (the path kernel), rank 0's launches, HIP events on its stream:
+        # algorithmic bytes per launch = 24 B x splats one launch issues, see DESIGN.md
+        n_launch = max(1, trace_launches)
+        avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        splats_rank0 = totals["splats_issued"] / world
+        bytes_per_launch = SPLAT_BYTES * splats_rank0 / max(1, len(kernel_ms))
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        res = {
+            "metric": "Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mray/s",
+            "time_bins_per_s": totals["splats_issued"] / elapsed,
+            "paths_per_s": totals["paths"] / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
+                                   f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
+                                   f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0",
+                       "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",
+                       "mode": args.mode or "auto"},
+            "roofline": {"kernel": "k_fused" if (args.mode in (None, "auto", "fused")) else "wavefront bounce+scatter",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "counters_per_step": {k: v / args.steps for k, v in totals.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.width, args.height, args.bins, args.spp, args.cpu_seconds)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

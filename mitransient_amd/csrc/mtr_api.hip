@@ -4,7 +4,7 @@
 // BVH2 build, upload), render planning and launches, film develop/clear, the stand-alone
 // scatter-add.  There is no CPU execution path: without a HIP device every entry point fails.
 #include "../../include/mitransient_amd.h"
-#include "mtr_bvh.h"
+#include "mtr_scene_host.h"
 #include "mtr_core.h"
 #include "mtr_kernels.h"
 
@@ -98,14 +98,6 @@ int mtr_ctx_set_stream(mtr_ctx *c, void *s)
 
 } // extern "C"
 
-static Film film_from(const mtr_film_desc &d)
-{
-    Film f;
-    f.width = d.width; f.height = d.height; f.crop_w = d.crop_width; f.crop_h = d.crop_height;
-    f.crop_x = d.crop_offset_x; f.crop_y = d.crop_offset_y; f.bins = d.temporal_bins;
-    f.start_opl = d.start_opl; f.bin_width = d.bin_width_opl;
-    return f;
-}
 static int check_film(mtr_ctx *c, const mtr_film_desc &d)
 {
     if (d.width == 0 || d.height == 0 || d.temporal_bins == 0)
@@ -139,63 +131,21 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     *out = nullptr;
     int rc = check_film(c, d->film);
     if (rc) return rc;
-    if (d->n_tris && (!d->tri_verts || !d->tri_material || !d->tri_emitter))
-        return fail(c, MTR_ERR_INVALID, "mtr_scene_create: triangle arrays missing");
-    if (d->n_materials > 0xffffu || d->n_emitters > 0x7fffu)
-        return fail(c, MTR_ERR_UNSUPPORTED, "mtr_scene_create: too many materials/emitters");
-    for (uint32_t i = 0; i < d->n_tris; ++i) {
-        if (d->tri_material[i] >= d->n_materials) return fail(c, MTR_ERR_INVALID, "triangle references an unknown material");
-        if (d->tri_emitter[i] >= (int32_t)d->n_emitters) return fail(c, MTR_ERR_INVALID, "triangle references an unknown emitter");
-    }
-    for (uint32_t i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].type > MTR_BSDF_NULL) return fail(c, MTR_ERR_UNSUPPORTED, "unknown BSDF type");
+    HostScene hs;
+    if (const char *msg = derive_scene(*d, hs)) return fail(c, MTR_ERR_INVALID, std::string("mtr_scene_create: ") + msg);
     HIP_TRY(c, hipSetDevice(c->device));
 
     mtr_scene *s = new mtr_scene();
     s->ctx = c;
-    s->film = film_from(d->film);
-    memcpy(s->cam.s2c, d->camera.sample_to_camera, sizeof s->cam.s2c);
-    memcpy(s->cam.tw, d->camera.to_world, sizeof s->cam.tw);
-    s->cam.near_clip = d->camera.near_clip; s->cam.far_clip = d->camera.far_clip;
-
-    // BVH2 over the triangles; triangles are stored in leaf order
-    BvhBuild bvh;
-    build_bvh(d->tri_verts, d->n_tris, bvh);
-    std::vector<TriGeom> tg(d->n_tris);
-    std::vector<TriShade> ts(d->n_tris);
-    for (uint32_t slot = 0; slot < d->n_tris; ++slot) {
-        const uint32_t o = bvh.order[slot];
-        const float *v = d->tri_verts + 9 * (size_t)o;
-        TriGeom &g = tg[slot]; TriShade &h = ts[slot];
-        for (int k = 0; k < 3; ++k) { g.p0[k] = v[k]; g.p1[k] = v[3 + k]; g.p2[k] = v[6 + k]; }
-        g.mat_em = d->tri_material[o] | ((uint32_t)(d->tri_emitter[o] + 1) << 16);
-        g.orig = o; g.pad = 0;
-        // flat frame: n = normalize(e1 x e2), s = normalize(e1), t = n x s   (f32, contract in DESIGN.md)
-        f3 p0 = ld3(g.p0), e1 = ld3(g.p1) - p0, e2 = ld3(g.p2) - p0;
-        f3 n = normalize(cross(e1, e2)), sdir = normalize(e1), t = cross(n, sdir);
-        h.n[0] = n.x; h.n[1] = n.y; h.n[2] = n.z; h.s[0] = sdir.x; h.s[1] = sdir.y; h.s[2] = sdir.z;
-        h.t[0] = t.x; h.t[1] = t.y; h.t[2] = t.z; h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
-    }
-    std::vector<Emitter> em(d->n_emitters);
-    for (uint32_t i = 0; i < d->n_emitters; ++i) {
-        const mtr_emitter &e = d->emitters[i];
-        Emitter &E = em[i];
-        for (int k = 0; k < 3; ++k) { E.center[k] = e.center[k]; E.du[k] = e.du[k]; E.dv[k] = e.dv[k]; E.radiance[k] = e.radiance[k]; }
-        f3 cr = cross(ld3(e.du), ld3(e.dv));
-        float len = sqrtf(dot(cr, cr));
-        f3 n = cr * (1.0f / len);
-        E.n[0] = n.x; E.n[1] = n.y; E.n[2] = n.z;
-        E.inv_area = 1.0f / (4.0f * len);
-    }
-    std::vector<mtr_material> mats(d->materials, d->materials + d->n_materials);
+    s->film = hs.film; s->cam = hs.cam;
 
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
-    UP(bvh.nodes, nodes); UP(tg, tgeom); UP(ts, tshade); UP(mats, mats); UP(em, ems);
+    UP(hs.nodes, nodes); UP(hs.tgeom, tgeom); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
 #undef UP
-    s->dev.n_nodes = (uint32_t)bvh.nodes.size(); s->dev.n_tris = d->n_tris;
+    s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_tris = d->n_tris;
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
-    s->dev.bvh_depth = bvh.max_depth; s->n_leaves = bvh.n_leaves;
+    s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     *out = s;
     return MTR_OK;
 }
@@ -213,7 +163,7 @@ int mtr_scene_set_film(mtr_scene *s, const mtr_film_desc *f)
     if (!s || !f) return fail(s ? s->ctx : nullptr, MTR_ERR_INVALID, "mtr_scene_set_film: NULL argument");
     int rc = check_film(s->ctx, *f);
     if (rc) return rc;
-    s->film = film_from(*f);
+    s->film = film_from_desc(*f);
     return MTR_OK;
 }
 
@@ -255,14 +205,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
 
     FusedArgs a{};
     a.sc = s->dev; a.cam = s->cam; a.film = f;
-    a.rc.spp_total = p->spp_total; a.rc.seed = p->seed;
-    a.rc.max_depth = p->max_depth < 0 ? 0xffffffffu : (uint32_t)p->max_depth;
-    a.rc.rr_depth = (uint32_t)p->rr_depth; a.rc.flags = p->flags;
-    a.rc.sample_scale = (float)(1.0 / (double)p->spp_total);          // common.py:173-175
-    a.rc.inv_crop_w = 1.0f / (float)f.crop_w; a.rc.inv_crop_h = 1.0f / (float)f.crop_h;
-    a.rc.off_x = -(float)f.crop_x * a.rc.inv_crop_w; a.rc.off_y = -(float)f.crop_y * a.rc.inv_crop_h;
-    a.rc.n_emitters_f = (float)s->dev.n_ems;
-    a.rc.inv_n_emitters = s->dev.n_ems ? 1.0f / (float)s->dev.n_ems : 0.0f;
+    a.rc = make_render_const(*p, f, s->dev.n_ems);
     a.pixel_begin = p->pixel_begin; a.pixel_end = p->pixel_end;
     a.spp_begin = p->spp_begin; a.spp_chunk = p->spp_end - p->spp_begin;
     a.film_out = t4; a.steady_out = s4;
@@ -311,7 +254,7 @@ int mtr_film_develop(mtr_ctx *c, const mtr_film_desc *fd, const float *t4, float
     int rc = check_film(c, *fd);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, launch_develop(film_from(*fd), t4, t3, s4, s3, c->stream));
+    HIP_TRY(c, launch_develop(film_from_desc(*fd), t4, t3, s4, s3, c->stream));
     return MTR_OK;
 }
 
@@ -325,7 +268,7 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
         return fail(c, MTR_ERR_INVALID, "mtr_splat_add: NULL splat array");
     HIP_TRY(c, hipSetDevice(c->device));
     if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, launch_splat_add(variant, *s, film_from(*fd), t4, nullptr, c->stream));
+    HIP_TRY(c, launch_splat_add(variant, *s, film_from_desc(*fd), t4, nullptr, c->stream));
     if (elapsed_ms) {
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -192,6 +192,11 @@ MTR_HD bool tri_hit(const TriGeom &g, f3 o, f3 d, float tmax, float &t, float &u
     return (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= 0.0f) & (t <= tmax);
 }
 
+MTR_HD float safe_rcp(float x)
+{
+    float r = 1.0f / x;
+    return (fabsf(r) <= 1e28f) ? r : copysignf(1e28f, x);
+}
 // conservative slab test (culling only: hits are decided by tri_hit, ties by primitive index)
 MTR_HD float box_near(const float *lo, const float *hi, f3 id, f3 oid, float tbest)
 {
@@ -210,7 +215,9 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
     Hit h; h.t = kInf; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
     uint32_t best_orig = 0xffffffffu;
     if (sc.n_tris == 0) return h;
-    f3 id = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // reciprocal direction, kept finite so that fma(lo, id, -o*id) never meets inf - inf
+    // (axis-parallel rays); the culling stays conservative because the boxes are padded.
+    f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     f3 oid = mk(o.x * id.x, o.y * id.y, o.z * id.z);
     st.reset();
     int32_t cur = 0;

@@ -1,0 +1,28 @@
+// mtr_scene_host.h — host-side scene ingestion: mtr_scene_desc -> device-layout arrays
+// (BVH2 node packets, leaf-ordered triangles with flat shading frames, emitters with derived
+// normal / inverse area).  Pure C++, no HIP: the API layer uploads the result; the test host
+// harness runs the same arrays through mtr_core.h on the CPU.
+#pragma once
+#include <vector>
+#include "mtr_core.h"
+#include "mtr_bvh.h"
+
+namespace mtr {
+
+struct HostScene {
+    std::vector<Node> nodes;
+    std::vector<TriGeom> tgeom;
+    std::vector<TriShade> tshade;
+    std::vector<mtr_material> mats;
+    std::vector<Emitter> ems;
+    uint32_t bvh_depth = 0, n_leaves = 0;
+    Camera cam{};
+    Film film{};
+};
+
+Film film_from_desc(const mtr_film_desc &d);
+// returns nullptr on success or a static error string
+const char *derive_scene(const mtr_scene_desc &d, HostScene &out);
+RenderConst make_render_const(const mtr_render_params &p, const Film &f, uint32_t n_emitters);
+
+} // namespace mtr

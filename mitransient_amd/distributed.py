@@ -1,0 +1,144 @@
+"""Multi-GPU rendering: one process per GPU, lanes sharded, ONE film reduction over RCCL/xGMI.
+
+The reference is single-device; this is the north-star's extension.  Lanes are
+independent and the RNG stream depends only on (seed, lane = pixel*spp_total + s), so any
+partition of the samples over ranks reproduces the single-GPU sample set exactly; only the
+f32 summation order of the film changes.
+
+Two partitions:
+  * ``spp``  — every rank renders all pixels with its slice of the samples, then the raw
+    (H,W,T,4) films are summed with ``reduce_scatter`` along H: all 7 xGMI links of every GPU
+    carry 1/8 of the film at once (a ring all-reduce would push 2*(7/8)*4 GiB through one link).
+    Each rank develops its row slab; ``all_gather`` (optional) rebuilds the full tensor.
+  * ``rows`` — every rank renders a contiguous block of image rows with all samples: film slabs
+    are disjoint, no reduction at all (gather only).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of range(n) over ``world`` ranks (first n % world ranks get +1)."""
+    base, rem = divmod(n, world)
+    b = rank * base + min(rank, rem)
+    return b, b + base + (1 if rank < rem else 0)
+
+
+def row_slab(height: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows owned by ``rank`` after the reduce-scatter (equal slabs; the film is padded to a multiple of world)."""
+    per = (height + world - 1) // world
+    return min(height, rank * per), min(height, (rank + 1) * per)
+
+
+def reduce_scatter_rows(t, group=None):
+    """Sum a (H, ...) tensor over ranks and return this rank's row slab (rows padded to world*per).
+    Works with any backend torch.distributed offers (nccl = RCCL on ROCm; gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    H = t.shape[0]
+    per = (H + world - 1) // world
+    if per * world != H:
+        pad = torch.zeros((per * world - H,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=0)
+    t = t.contiguous()
+    out = torch.empty((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == "gloo":
+        # gloo has no reduce_scatter_tensor: all_reduce then slice (CPU test path)
+        tt = t.clone()
+        dist.all_reduce(tt, group=group)
+        out.copy_(tt[rank * per:(rank + 1) * per])
+    else:
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+    lo, hi = row_slab(H, world, rank)
+    return out[:hi - lo]
+
+
+def all_gather_rows(slab, height: int, group=None):
+    """Inverse of the scatter: every rank receives the full (H, ...) tensor."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = (height + world - 1) // world
+    if slab.shape[0] != per:
+        pad = torch.zeros((per - slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+        slab = torch.cat([slab, pad], dim=0)
+    slab = slab.contiguous()
+    full = torch.empty((per * world,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(parts, slab, group=group)
+        full = torch.cat(parts, dim=0)
+    else:
+        dist.all_gather_into_tensor(full, slab, group=group)
+    return full[:height]
+
+
+class DistributedRenderer:
+    """Shards one render over the ranks of a process group.
+
+    ``spp`` is the TOTAL sample count; each rank renders ``shard_range(spp, world, rank)`` (partition
+    "spp") or all samples of its rows (partition "rows")."""
+
+    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True):
+        if partition not in ("spp", "rows"):
+            raise ValueError("partition must be 'spp' or 'rows'")
+        self.scene, self.partition, self.group, self.gather = scene, partition, group, gather
+
+    def render(self, spp: int, seed: int = 0, sensor: int = 0):
+        import torch
+        import torch.distributed as dist
+        from .films.transient_hdr_film import TransientHDRFilm  # noqa: F401
+        from .tensor import TensorXf
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        scene = self.scene
+        integ = scene.integrator()
+        sens = scene.sensors()[sensor]
+        film = sens.film()
+        integ.check_transient_(scene, sens)
+        passes = integ.prepare(scene, sens, seed, spp, integ.aov_names())
+        total_spp = sum(s for _, s in passes)
+        W, H = film.size()
+        cw, ch = film.crop_size()
+        if self.partition == "spp":
+            integ.accumulate(scene, sens, passes, total_spp, spp_range=shard_range(total_spp, world, rank))
+        else:
+            r0, r1 = shard_range(ch, world, rank)
+            integ.accumulate(scene, sens, passes, total_spp, pixel_range=(r0 * cw, r1 * cw))
+        raw_t = film.transient_storage.torch_tensor()
+        raw_s = film.steady_accum()
+        if world == 1:
+            return film.develop()
+        if self.partition == "spp":
+            slab_t = reduce_scatter_rows(raw_t, self.group)      # THE film reduction
+            slab_s = reduce_scatter_rows(raw_s, self.group)
+        else:
+            # rows: crop rows == film rows (transient_image_block.py:132 subtracts the crop offset)
+            lo, hi = shard_range(ch, world, rank)
+            slab_t, slab_s = raw_t[lo:hi], raw_s[lo:hi]
+        dev_t, dev_s = film.develop_slab(slab_t, slab_s)
+        if not self.gather:
+            return TensorXf(dev_s), TensorXf(dev_t)
+        if self.partition == "spp":
+            return (TensorXf(all_gather_rows(dev_s, H, self.group)), TensorXf(all_gather_rows(dev_t, H, self.group)))
+        # rows: uneven slabs are padded to the largest before the gather
+        per = (ch + world - 1) // world
+        def pad(x):
+            if x.shape[0] == per:
+                return x
+            return torch.cat([x, torch.zeros((per - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)])
+        parts_t = all_gather_rows(pad(dev_t), per * world, self.group)
+        parts_s = all_gather_rows(pad(dev_s), per * world, self.group)
+        rows_t, rows_s = [], []
+        for r in range(world):
+            a, b = shard_range(ch, world, r)
+            rows_t.append(parts_t[r * per:r * per + (b - a)])
+            rows_s.append(parts_s[r * per:r * per + (b - a)])
+        full_t, full_s = torch.cat(rows_t), torch.cat(rows_s)
+        if full_t.shape[0] < H:
+            full_t = torch.cat([full_t, torch.zeros((H - full_t.shape[0],) + tuple(full_t.shape[1:]), dtype=full_t.dtype, device=full_t.device)])
+            full_s = torch.cat([full_s, torch.zeros((H - full_s.shape[0],) + tuple(full_s.shape[1:]), dtype=full_s.dtype, device=full_s.device)])
+        return TensorXf(full_s), TensorXf(full_t)

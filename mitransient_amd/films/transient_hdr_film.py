@@ -163,6 +163,28 @@ class TransientHDRFilm:
                                            C.c_void_p(out.data_ptr()), None, None), "mtr_film_develop")
         return TensorXf(out)
 
+    def develop_slab(self, raw_t, raw_s):
+        """develop() of a row slab (rows, W, T, 4) / (rows, W, 4): used by the multi-GPU path after the
+        reduce-scatter, so that every GPU develops 1/N of the film."""
+        torch = require_gpu()
+        rows = int(raw_t.shape[0])
+        W = self.size_[0]
+        out_t = torch.empty((rows, W, self.temporal_bins, 3), dtype=torch.float32, device=raw_t.device)
+        out_s = torch.empty((rows, W, 3), dtype=torch.float32, device=raw_t.device)
+        if rows == 0:
+            return out_t, out_s
+        ctx = get_context(raw_t.device.index)
+        ctx.bind_current_stream()
+        fd = self.desc()
+        fd.height = rows
+        fd.crop_height = min(fd.crop_height, rows)
+        fd.crop_offset_y = 0
+        raw_t, raw_s = raw_t.contiguous(), raw_s.contiguous()
+        ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), C.c_void_p(raw_t.data_ptr()),
+                                           C.c_void_p(out_t.data_ptr()), C.c_void_p(raw_s.data_ptr()),
+                                           C.c_void_p(out_s.data_ptr())), "mtr_film_develop")
+        return out_t, out_s
+
     # -- introspection ---------------------------------------------------------
     def traverse(self, callback):
         for k in ("temporal_bins", "bin_width_opl", "start_opl", "exhaustive_scan",

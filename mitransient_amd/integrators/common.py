@@ -56,8 +56,8 @@ class TransientADIntegrator:
         sampler.set_samples_per_wavefront(spp)
         film_size = film.crop_size()
         wavefront_size = film_size[0] * film_size[1] * spp
-        film.prepare(aovs)
         if wavefront_size <= 2 ** 32:
+            film.prepare(aovs)
             sampler.seed(seed, wavefront_size)
             return [(sampler, spp)]
         # common.py:56-85 splits >2^32-sample renders into passes whose seeds are drawn

@@ -187,7 +187,7 @@ class _SceneBuilder:
             tris = tris[:, [0, 2, 1], :]
         bsdf = None
         for k, v in sd.items():
-            if isinstance(v, dict) and v.get("type") in ("ref", "diffuse", "conductor", "dielectric", "twosided") and k != "emitter":
+            if isinstance(v, dict) and k != "emitter":       # any nested object that is not the emitter is the BSDF
                 bsdf = v
         if bsdf is None:
             bsdf = {"type": "diffuse", "reflectance": 0.5}     # mitsuba's default BSDF

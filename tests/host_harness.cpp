@@ -1,0 +1,102 @@
+// host_harness.cpp — TEST-ONLY.  Compiles the product's per-path arithmetic (mtr_core.h, the
+// BVH builder and scene ingestion) for the HOST and runs it one lane at a time, so that the
+// CPU test-suite can compare it against the oracle before any GPU time is spent.  It is never
+// built into libmitransient_amd.so and nothing in mitransient_amd/ can reach it: the product
+// has no CPU path.
+#include "../mitransient_amd/csrc/mtr_core.h"
+#include "../mitransient_amd/csrc/mtr_scene_host.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace mtr;
+
+namespace {
+struct ArrStack {
+    int32_t v[128]; int sp;
+    void reset() { sp = 0; }
+    void push(int32_t x) { if (sp < 128) v[sp++] = x; }
+    int32_t pop() { return v[--sp]; }
+    bool empty() const { return sp == 0; }
+};
+struct HostSink {
+    float *film; uint32_t W, T; uint64_t n;
+    void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b, float, uint32_t, uint32_t)
+    {
+        size_t idx = (((size_t)fy * W + fx) * T + bin) * 4u;
+        film[idx] += r; film[idx + 1] += g; film[idx + 2] += b; ++n;
+    }
+};
+}
+
+extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, float *t4, float *s4, mtr_counters *out)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    SceneView sv;
+    sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
+    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
+    HostSink sink{ t4, hs.film.width, hs.film.bins, 0 };
+    ArrStack st; st.sp = 0;
+    uint64_t closest = 0, shadow = 0, bounces = 0, paths = 0;
+    for (uint32_t pix = p->pixel_begin; pix < p->pixel_end; ++pix)
+        for (uint32_t s = p->spp_begin; s < p->spp_end; ++s) {
+            Path path;
+            path_begin(path, hs.cam, hs.film, rc, pix, s);
+            ++paths;
+            if (rc.flags & MTR_FLAG_CAMERA_UNWARP) {
+                Hit h0 = traverse<false>(sv, path.ray.o, path.ray.d, path.ray.tmax, st);
+                ++closest;
+                if (h0.prim >= 0) path.dist = -h0.t;
+            }
+            bool alive = true;
+            while (alive) {
+                BounceStats bs{ 0, 0 };
+                alive = path_bounce(path, sv, hs.film, rc, st, sink, bs);
+                closest += bs.closest; shadow += bs.shadow; ++bounces;
+            }
+            uint32_t fx = path.px - hs.film.crop_x, fy = path.py - hs.film.crop_y;
+            if (fx < hs.film.width && fy < hs.film.height) {
+                float *sp = s4 + ((size_t)fy * hs.film.width + fx) * 4u;
+                sp[0] += path.L.x; sp[1] += path.L.y; sp[2] += path.L.z; sp[3] += 1.0f;
+            }
+        }
+    if (out) {
+        memset(out, 0, sizeof *out);
+        out->paths = paths; out->rays_closest = closest; out->rays_shadow = shadow;
+        out->bounces = bounces; out->splats_issued = sink.n;
+    }
+    return 0;
+}
+
+extern "C" int hh_bvh_info(const mtr_scene_desc *d, uint32_t *n_nodes, uint32_t *depth, uint32_t *leaves)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    *n_nodes = (uint32_t)hs.nodes.size(); *depth = hs.bvh_depth; *leaves = hs.n_leaves;
+    return 0;
+}
+
+// closest hit / occlusion through the product's BVH, for BVH-vs-brute-force tests
+extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3, const float *d3, const float *maxt,
+                            float *t_out, int32_t *prim_out, uint8_t *occ_out)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    SceneView sv;
+    sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
+    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    ArrStack st; st.sp = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+        float mt = maxt ? maxt[i] : kInf;
+        Hit h = traverse<false>(sv, o, dd, mt, st);
+        t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)hs.tgeom[h.prim].orig : -1;
+        Hit a = traverse<true>(sv, o, dd, mt, st);
+        occ_out[i] = a.prim >= 0;
+    }
+    return 0;
+}

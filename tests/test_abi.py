@@ -1,0 +1,75 @@
+"""The C-ABI library loads and exports every symbol include/mitransient_amd.h declares.
+(No compute calls here: there is no GPU in the CPU test environment and no CPU fallback.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mitransient_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from mitransient_amd import _cabi
+    assert os.path.exists(_cabi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_cabi.EXPORTS) == declared
+    lib.mtr_abi_version.restype = ctypes.c_int
+    assert lib.mtr_abi_version() == _cabi.MTR_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    """sizeof() of the ctypes mirrors against the C compiler's view of the header."""
+    import subprocess
+    import tempfile
+    from mitransient_amd import _cabi
+    names = ["mtr_material", "mtr_emitter", "mtr_camera", "mtr_film_desc", "mtr_scene_desc",
+             "mtr_render_params", "mtr_counters", "mtr_splat_soa", "mtr_kernel_times"]
+    prog = '#include <stdio.h>\n#include "mitransient_amd.h"\nint main(){' + "".join(
+        f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    for n, sz in zip(names, sizes):
+        assert ctypes.sizeof(getattr(_cabi, n)) == sz, n
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product refuses to run (it must never fall back to the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd._cabi import MitransientAMDError
+    mi.set_variant("llvm_ad_rgb")
+    scene = mi.load_dict(mitr.cornell_box())
+    with pytest.raises(MitransientAMDError):
+        mi.render(scene, spp=1)
+    from mitransient_amd import _cabi
+    lib = _cabi.load_library()
+    h = ctypes.c_void_p()
+    assert lib.mtr_ctx_create(0, ctypes.byref(h)) == -2          # MTR_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.mtr_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mitransient_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "libmtr_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,271 @@
+"""Pins for the CPU oracle.  PARITY UNPINNED against real Mitsuba: the reference
+holds no golden vectors for transient_path, so the oracle is anchored on published KATs, on the
+reference's own stated identities and on an analytic quadrature."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_cornell, rel_l2, hh_render
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_pcg32_known_answer(oracle):
+    kat = json.load(open(os.path.join(GOLD, "pcg32_kat.json")))
+    u, f = oracle.pcg32_stream(kat["initstate"], kat["initseq"], len(kat["u32"]))
+    assert [hex(int(x)) for x in u] == kat["u32"]
+    # next_float32 = bitcast((u >> 9) | 0x3f800000) - 1
+    exp = ((u >> 9) | 0x3F800000).astype(np.uint32).view(np.float32) - np.float32(1)
+    assert np.array_equal(f, exp) and np.all((f >= 0) & (f < 1))
+
+
+def test_tea_reference_implementation(oracle):
+    def tea(v0, v1, rounds=4):
+        s = 0
+        M = 0xFFFFFFFF
+        for _ in range(rounds):
+            s = (s + 0x9E3779B9) & M
+            v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) & M ^ ((v1 + s) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+            v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) & M ^ ((v0 + s) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+        return v0, v1
+    for a, b in [(0, 0), (0, 1), (7, 123456), (0xFFFFFFFF, 0xFFFFFFFF), (1, 2 ** 31)]:
+        assert oracle.tea32(a, b) == tea(a, b)
+    # sampler streams of different lanes are distinct and stay in [0,1)
+    s0, s1 = oracle.sampler_stream(0, 0, 64), oracle.sampler_stream(0, 1, 64)
+    assert not np.array_equal(s0, s1) and np.all((s0 >= 0) & (s0 < 1))
+
+
+def test_bin_mapping_kat(oracle):
+    rows = json.load(open(os.path.join(GOLD, "bin_mapping_kat.json")))
+    assert len(rows) > 50
+    for r in rows:
+        d = np.uint32(r["d_bits"]).view(np.float32)
+        assert oracle.bin_index(d, r["start"], r["width"], r["T"]) == r["bin"], r
+    # the f32 edge cases called out in SURVEY §8c
+    assert oracle.bin_index(3.52, 3.5, 0.02, 300) == 0        # (f32(3.52)-3.5)/f32(0.02) < 1
+    assert oracle.bin_index(3.54, 3.5, 0.02, 300) == 1
+    assert oracle.bin_index(9.5, 3.5, 0.02, 300) == -1
+    assert oracle.bin_index(3.5 + 6.0 / 1024, 3.5, 6.0 / 1024, 1024) == 1   # exact widths: exact edges
+
+
+def test_sincos_polynomials(oracle):
+    import ctypes as C
+    xs = np.linspace(-np.pi / 4, np.pi / 4, 2001).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    err = 0.0
+    for x in xs:
+        oracle.lib().orc_sincos_q(C.c_float(float(x)), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
+    assert err < 2e-7
+
+
+def test_cosine_hemisphere_warp(oracle):
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    out = (C.c_float * 3)()
+    zs = []
+    for u1, u2 in rng.random((4000, 2), dtype=np.float32):
+        oracle.lib().orc_square_to_cos_hemi(C.c_float(float(u1)), C.c_float(float(u2)), out)
+        v = np.array(out[:], np.float64)
+        assert abs(np.linalg.norm(v) - 1) < 1e-6 and v[2] >= 0
+        zs.append(v[2])
+    assert abs(np.mean(zs) - 2.0 / 3.0) < 0.02          # E[cos] = 2/3 for a cosine-weighted hemisphere
+
+
+def test_brute_force_equals_own_bvh(oracle, cornell_c1):
+    scene = cornell_c1
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 3, 8)
+    a = oracle.render(sd, p, n_threads=1, use_bvh=False)
+    b = oracle.render(sd, p, n_threads=1, use_bvh=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_golden_snapshot_c1(oracle, cornell_c1):
+    """Regression snapshot of BASELINE config 1 (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "cornell_c1_oracle.npz"))
+    scene = cornell_c1
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 16)
+    t4, s4, cnt = oracle.render(sd, p, use_bvh=True)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    assert [cnt[k] for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")] == list(g["counters"])
+    assert int(np.count_nonzero(t3)) == int(g["nonzero_cells"])
+    assert rel_l2(t3.sum(axis=(0, 1)), g["per_bin"]) < 1e-6
+    assert rel_l2(t3.sum(axis=2), g["per_pixel"]) < 1e-6
+    assert rel_l2(s3, g["steady"]) < 1e-6
+    assert np.all(t4[..., 3] == 0)                       # channel "W" never receives anything
+
+
+def test_energy_identity(oracle):
+    """data_steady == data_transient.sum(axis=2) when the window covers all OPLs
+    (examples/transient-nlos/1-simple-nlos-scenes.ipynb md cell 8; transientpath.py:180,217,230)."""
+    scene = make_cornell(width=32, height=32, bins=128, start=0.0, window=64.0)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 32)
+    t4, s4, _ = oracle.render(sd, p)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    assert rel_l2(t3.sum(axis=2), s3) < 1e-5
+
+
+def test_sample_slices_partition_the_render(oracle, cornell_c1):
+    scene = cornell_c1
+    sd = scene.data()
+    integ, film = scene.integrator(), scene.sensors()[0].film()
+    full = oracle.render(sd, integ.render_params(film, 0, 8), n_threads=1)
+    acc_t = np.zeros_like(full[0], dtype=np.float64)
+    for s0, s1 in [(0, 3), (3, 8)]:
+        part = oracle.render(sd, integ.render_params(film, 0, 8, s0, s1), n_threads=1)
+        acc_t += part[0]
+    assert rel_l2(acc_t, full[0]) < 1e-6
+
+
+# ---------------------------------------------------------------- analytic direct illumination (KAT 4)
+def _direct_scene(unwarp=False):
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    rho = [0.7, 0.5, 0.3]
+    Le = [10.0, 8.0, 6.0]
+    d = {
+        "type": "scene",
+        "integrator": {"type": "transient_path", "max_depth": 2, "camera_unwarp": unwarp},
+        "sensor": {"type": "perspective", "fov": 30.0, "near_clip": 0.01, "far_clip": 100.0,
+                   "to_world": T().look_at(origin=[0, 1.5, 3.0], target=[0, 0, 0], up=[0, 1, 0]),
+                   "sampler": {"type": "independent", "sample_count": 4},
+                   "film": {"type": "transient_hdr_film", "width": 16, "height": 16, "rfilter": {"type": "box"},
+                            "temporal_bins": 120, "start_opl": 0.0 if unwarp else 2.0, "bin_width_opl": 0.1}},
+        "floor": {"type": "rectangle", "to_world": T().rotate([1, 0, 0], -90).scale(4.0),
+                  "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": rho}}},
+        "light": {"type": "rectangle", "to_world": T().translate([0.2, 1.0, -0.3]).rotate([1, 0, 0], 90).scale(0.25),
+                  "bsdf": {"type": "diffuse", "reflectance": 0.0},
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": Le}}},
+    }
+    return mi.load_dict(d), np.array(rho), np.array(Le)
+
+
+@pytest.mark.parametrize("unwarp", [False, True])
+def test_direct_illumination_matches_quadrature(oracle, unwarp):
+    """max_depth=2, one diffuse quad under one quad light: per-time-bin energy equals
+    integral over pixel footprint x light of rho/pi * Le * G, binned by |cam->x| (unless unwarp) + |x->y|."""
+    scene, rho, Le = _direct_scene(unwarp)
+    sd = scene.data()
+    film = scene.sensors()[0].film()
+    spp = 512
+    p = scene.integrator().render_params(film, 0, spp)
+    t4, s4, _ = oracle.render(sd, p)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    got = t3.sum(axis=(0, 1)).astype(np.float64)                # (T,3)
+
+    # float64 quadrature: sub-pixel grid x light grid
+    W = H = 16
+    T, start, width = film.temporal_bins, film.start_opl, film.bin_width_opl
+    sub, nl = 6, 24
+    exp = np.zeros((T, 3))
+    lu = (np.arange(nl) + 0.5) / nl * 2 - 1
+    la, lb = np.meshgrid(lu, lu, indexing="ij")
+    # light: center (0.2,1,-0.3), du=(0.25,0,0), dv = rotX(90)*(0,0.25,0) = (0,0,0.25), normal -y
+    ly = np.stack([0.2 + 0.25 * la, np.full_like(la, 1.0), -0.3 + 0.25 * lb], -1).reshape(-1, 3)
+    dA = (0.5 * 0.5) / (nl * nl)
+    for py in range(H):
+        for px in range(W):
+            for sy in range(sub):
+                for sx in range(sub):
+                    o, dvec, _ = oracle.camera_ray(sd, px, py, (sx + 0.5) / sub, (sy + 0.5) / sub)
+                    o, dvec = o.astype(np.float64), dvec.astype(np.float64)
+                    if dvec[1] >= 0:
+                        continue
+                    tt = -o[1] / dvec[1]
+                    x = o + tt * dvec
+                    if abs(x[0]) > 4 or abs(x[2]) > 4:
+                        continue
+                    v = ly - x
+                    r2 = (v * v).sum(-1)
+                    r = np.sqrt(r2)
+                    cos_x = v[:, 1] / r                      # floor normal +y
+                    cos_y = v[:, 1] / r                      # light normal -y: cos = -(-v).(-y)... = v_y / r
+                    G = np.clip(cos_x, 0, None) * np.clip(cos_y, 0, None) / r2
+                    opl = (0.0 if unwarp else tt) + r
+                    b = np.floor((opl - start) / width).astype(int)
+                    ok = (b >= 0) & (b < T)
+                    contrib = (G * dA / (sub * sub))[:, None] * (rho / np.pi * Le)[None, :]
+                    np.add.at(exp, b[ok], contrib[ok])
+    # Monte-Carlo vs quadrature: totals within 1 %, per-bin shape within 3 % of the peak
+    assert abs(got.sum() - exp.sum()) / exp.sum() < 0.01
+    assert np.abs(got - exp).max() / exp.max() < 0.03
+    # and the steady image is the time integral
+    assert rel_l2(t3.sum(axis=2), s3) < 1e-5
+
+
+def test_ior_scales_optical_path(oracle):
+    """A dielectric slab of thickness h adds eta*h of OPL (transientpath.py:154,232)."""
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+
+    def scene(with_slab):
+        d = {"type": "scene",
+             "integrator": {"type": "transient_path", "max_depth": 6},
+             "sensor": {"type": "perspective", "fov": 1.0, "near_clip": 0.01, "far_clip": 100.0,
+                        "to_world": T().look_at(origin=[0, 0, 5], target=[0, 0, 0], up=[0, 1, 0]),
+                        "sampler": {"type": "independent", "sample_count": 4},
+                        "film": {"type": "transient_hdr_film", "width": 1, "height": 1, "rfilter": {"type": "box"},
+                                 "temporal_bins": 2000, "start_opl": 0.0, "bin_width_opl": 0.005}},
+             # an emitter facing the camera at z = 0
+             "light": {"type": "rectangle", "to_world": T().scale(0.5),
+                       "bsdf": {"type": "diffuse", "reflectance": 0.0},
+                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}}
+        if with_slab:
+            d["slab"] = {"type": "cube", "to_world": T().translate([0, 0, 2.0]).scale([1.0, 1.0, 0.5]),
+                         "bsdf": {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}}
+        return mi.load_dict(d)
+
+    def first_arrival(sc):
+        sd = sc.data()
+        p = sc.integrator().render_params(sc.sensors()[0].film(), 0, 64)
+        t4, s4, _ = oracle.render(sd, p)
+        prof = t4[0, 0, :, 0]
+        return int(np.argmax(prof)), prof
+
+    b0, _ = first_arrival(scene(False))
+    b1, prof = first_arrival(scene(True))
+    # geometric distance 4.99 (near clip 0.01); slab thickness 1.0 at eta 1.5 adds 0.5 of OPL
+    assert abs(b0 * 0.005 - 4.99) < 0.011
+    assert abs((b1 - b0) * 0.005 - 0.5) < 0.011
+
+
+def test_host_harness_matches_oracle_bit_for_bit(oracle, host_harness, cornell_c1):
+    """The product's per-path arithmetic (mtr_core.h + BVH2 builder, compiled for the host by a
+    test-only harness) reproduces the oracle exactly: film, steady image and every counter."""
+    scene = cornell_c1
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 16)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert hc[k] == cnt[k]
+
+
+def test_host_harness_specular_and_flags(oracle, host_harness):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=24, height=24, temporal_bins=96, start_opl=0.0, bin_width_opl=0.125,
+                               crop_width=20, crop_height=11, crop_offset_x=2, crop_offset_y=7)
+    d["mirror"] = {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
+    d["glass"] = {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}
+    d["two"] = {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.2, 0.5, 0.7]}}}
+    d["small-box"]["bsdf"] = {"type": "ref", "id": "glass"}
+    d["large-box"]["bsdf"] = {"type": "ref", "id": "mirror"}
+    d["back"]["bsdf"] = {"type": "ref", "id": "two"}
+    d["integrator"].update(max_depth=-1, rr_depth=3, camera_unwarp=True)
+    scene = mi.load_dict(d)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 7, 12)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc["rays_shadow"] == cnt["rays_shadow"]
+    assert np.count_nonzero(t4) > 1000

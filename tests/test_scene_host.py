@@ -1,0 +1,195 @@
+"""Host logic: transforms, scene-dict flattening, plugin surface, BVH builder (via the test host harness)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import make_cornell
+
+
+def test_transform_chaining_matches_matrix_product():
+    from mitransient_amd.transform import ScalarTransform4f as T
+    t = T().translate([1, 2, 3]).rotate([0, 1, 0], 90).scale([2, 1, 1])
+    p = t.transform_affine(np.array([1.0, 0.0, 0.0]))            # scale -> (2,0,0); rotY(90) -> (0,0,-2); + t
+    assert np.allclose(p, [1, 2, 1])
+    cam = T().look_at(origin=[0, 0, 3.9], target=[0, 0, 0], up=[0, 1, 0])
+    assert np.allclose(cam.transform_vector([0, 0, 1]), [0, 0, -1])
+    assert np.allclose(cam.translation(), [0, 0, 3.9])
+    assert np.allclose((t @ t.inverse()).matrix, np.eye(4), atol=1e-12)
+
+
+def test_cornell_box_values_and_flattening():
+    """utils.py:78-220: 36 triangles, 3 diffuse albedos, one quad light, the film/integrator defaults."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    assert d["integrator"]["type"] == "transient_path" and d["integrator"]["max_depth"] == 8
+    f = d["sensor"]["film"]
+    assert (f["type"], f["width"], f["height"], f["temporal_bins"], f["start_opl"], f["bin_width_opl"]) == \
+        ("transient_hdr_film", 256, 256, 300, 3.5, 0.02)
+    scene = mi.load_dict(d)
+    sd = scene.data()
+    assert sd.tri_verts.shape == (36, 9) and sd.n_materials == 3 and sd.n_emitters == 1
+    assert np.allclose(list(sd.materials[0].a), [0.885809, 0.698859, 0.666422])
+    assert np.allclose(list(sd.emitters[0].radiance), [18.387, 13.9873, 6.75357])
+    assert list(sd.tri_emitter[:2]) == [0, 0] and np.all(sd.tri_emitter[2:] == -1)
+    # light faces down (-y); geometry inside [-1,1]^3 except the open front
+    e = sd.emitters[0]
+    n = np.cross(list(e.du), list(e.dv))
+    assert n[1] < 0 and abs(n[0]) < 1e-9 and abs(n[2]) < 1e-9
+    assert np.abs(sd.tri_verts).max() <= 1.0101          # the tall box dips 0.01 below the floor (utils.py:214)
+    # all box faces point outwards: normal . (centroid - box centre) > 0
+    for name, (a, b) in zip(sd.shape_names, sd.shape_ranges):
+        if "box" not in name:
+            continue
+        tris = sd.tri_verts[a:b].reshape(-1, 3, 3).astype(np.float64)
+        ctr = tris.reshape(-1, 3).mean(0)
+        nn = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+        assert np.all(((tris.mean(1) - ctr) * nn).sum(1) > 0)
+    integ = scene.integrator()
+    assert (integ.max_depth, integ.rr_depth, integ.camera_unwarp, integ.discard_direct_light) == (8, 5, False, False)
+    film = scene.sensors()[0].film()
+    assert film.end_opl() == pytest.approx(9.5)
+    assert scene.sensors()[0].sampler().sample_count() == 256
+
+
+def test_plugin_defaults_and_errors():
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import Properties
+    mi.set_variant("cuda_ad_rgb")
+    with pytest.raises(ValueError):
+        mi.set_variant("scalar_rgb")
+    f = mitr.TransientHDRFilm(Properties("transient_hdr_film", {"rfilter": {"type": "box"}}))
+    assert (f.temporal_bins, f.bin_width_opl, f.start_opl, f.size()) == (2048, 0.003, 0.0, (768, 576))
+    i = mitr.TransientPath(Properties("transient_path", {}))
+    assert (i.max_depth, i.rr_depth, i.camera_unwarp) == (6, 5, False)
+    assert mitr.TransientPath(Properties("transient_path", {"max_depth": -1})).max_depth == 0xFFFFFFFF
+    with pytest.raises(Exception):
+        mitr.TransientPath(Properties("transient_path", {"rr_depth": 0}))
+    d = mitr.cornell_box()
+    d["integrator"]["type"] = "transient_nlos_path"
+    with pytest.raises(ValueError, match="unknown plugin"):
+        mi.load_dict(d)
+    d = mitr.cornell_box()
+    d["floor"]["bsdf"] = {"type": "roughplastic"}
+    with pytest.raises(ValueError, match="unknown plugin"):
+        mi.load_dict(d).data()
+    d = mitr.cornell_box()
+    d["sensor"]["film"]["crop_width"] = 9999
+    with pytest.raises(ValueError):
+        mi.load_dict(d)
+    p = mi.traverse(mi.load_dict(mitr.cornell_box()))
+    assert p["sensor.film.temporal_bins"] == 300
+    p["sensor.film.start_opl"] = 1.0
+    p.update()
+
+
+def test_traverse_updates_film():
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    scene = mi.load_dict(mitr.cornell_box())
+    p = mi.traverse(scene)
+    p["sensor.film.bin_width_opl"] = 0.5
+    p["sensor.film.temporal_bins"] = 12
+    p.update()
+    film = scene.sensors()[0].film()
+    assert film.bin_width_opl == 0.5 and film.temporal_bins == 12
+    assert scene.data().film.temporal_bins == 12
+
+
+def test_perspective_camera_rays(oracle):
+    """centre pixel looks down -z from (0,0,3.9) offset by near_clip; corners span the fov."""
+    scene = make_cornell(width=64, height=64)
+    sd = scene.data()
+    o, d, maxt = oracle.camera_ray(sd, 32, 32, 0.0, 0.0)
+    assert np.allclose(d, [0, 0, -1], atol=1e-6) and np.allclose(o, [0, 0, 3.9 - 0.001], atol=1e-6)
+    assert maxt == pytest.approx(100.0 - 0.001, rel=1e-5)
+    o, d, _ = oracle.camera_ray(sd, 0, 0, 0.0, 0.0)           # top-left pixel: -x (red wall side), +y
+    half = np.tan(np.radians(39.3077 / 2))
+    assert d[0] < 0 and d[1] > 0
+    assert d[0] / -d[2] == pytest.approx(-half, rel=1e-4) and d[1] / -d[2] == pytest.approx(half, rel=1e-4)
+
+
+def _hh_intersect(lib, sd, o, d, maxt=None):
+    n = o.shape[0]
+    t = np.empty(n, np.float32)
+    prim = np.empty(n, np.int32)
+    occ = np.empty(n, np.uint8)
+    fp = C.POINTER(C.c_float)
+    desc = sd.desc()
+    mt = np.ascontiguousarray(maxt, np.float32) if maxt is not None else None
+    rc = lib.hh_intersect(C.byref(desc), n, o.ctypes.data_as(fp), d.ctypes.data_as(fp),
+                          mt.ctypes.data_as(fp) if mt is not None else None, t.ctypes.data_as(fp),
+                          prim.ctypes.data_as(C.POINTER(C.c_int32)), occ.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0
+    return t, prim, occ
+
+
+def test_product_bvh_equals_brute_force(oracle, host_harness):
+    """The product's SAH BVH2 + node-packet traversal returns exactly the oracle's brute-force closest
+    hit (same t bits, same primitive) and the same occlusion answer, for random rays."""
+    scene = make_cornell()
+    sd = scene.data()
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = rng.uniform(-0.95, 0.95, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:100, 0] = 0.0                                           # axis-parallel components (inf reciprocals)
+    d[100:200, 1] = 0.0
+    maxt = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.1, 2.0, n)).astype(np.float32)
+    t0, p0, occ0 = oracle.intersect(sd, o, d, maxt, use_bvh=False)
+    t1, p1, occ1 = _hh_intersect(host_harness, sd, o, d, maxt)
+    assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    assert np.array_equal(p0, p1) and np.array_equal(occ0, occ1)
+    assert (p0 >= 0).mean() > 0.5
+
+
+def test_bvh_structure(host_harness):
+    scene = make_cornell()
+    desc = scene.data().desc()
+    nn, dd, ll = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dd), C.byref(ll)) == 0
+    assert ll.value == nn.value + 1 and 9 <= ll.value <= 36 and dd.value <= 8     # fits the smallest LDS stack
+
+
+def test_bvh_degenerate_inputs(oracle, host_harness):
+    """empty scene, a single triangle, many coincident triangles."""
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import SceneData
+    from mitransient_amd import _cabi
+    base = make_cornell().data()
+
+    def with_tris(v):
+        sd = SceneData()
+        sd.tri_verts = np.ascontiguousarray(v, np.float32).reshape(-1, 9)
+        n = sd.tri_verts.shape[0]
+        sd.tri_material = np.zeros(n, np.uint32)
+        sd.tri_emitter = np.full(n, -1, np.int32)
+        sd.materials, sd.n_materials = base.materials, 1
+        sd.camera, sd.film = base.camera, base.film
+        return sd
+
+    o = np.array([[0.2, 0.2, 2.0]] * 3, np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0.1, 0, -1]], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tri = [[0, 0, 0, 1, 0, 0, 0, 1, 0]]
+    for verts in ([], tri, tri * 9):
+        sd = with_tris(np.array(verts, np.float32))
+        t0, p0, occ0 = oracle.intersect(sd, o, d)
+        t1, p1, occ1 = _hh_intersect(host_harness, sd, o, d)
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(p0, p1)
+        assert np.array_equal(occ0, occ1)
+        if len(verts):
+            assert p0[0] == 0                                   # coincident triangles: lowest index wins
+
+
+def test_obj_loader(tmp_path):
+    from mitransient_amd.scene import load_obj
+    p = tmp_path / "q.obj"
+    p.write_text("# quad + stray line\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nl 1 2\nf 1/1/1 2/1/1 3/1/1 4/1/1\nf -4 -3 -2\n")
+    t = load_obj(str(p))
+    assert t.shape == (3, 3, 3)
+    assert np.allclose(t[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
