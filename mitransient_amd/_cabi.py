@@ -115,6 +115,10 @@ def load_library() -> C.CDLL:
         raise MitransientAMDError(
             f"{LIB_PATH} not found: build the gfx950 HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # torch first: it ships its own libamdhip64; loading ours afterwards makes the dynamic linker
+    # resolve the same soname to the runtime torch already initialised, so device pointers and
+    # streams are shared (two HIP runtimes in one process do not see each other's devices).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.mtr_abi_version.restype = C.c_int

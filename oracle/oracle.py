@@ -70,11 +70,21 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def render(scene_data, params: _cabi.mtr_render_params, n_threads=0, use_bvh=False, log_capacity=0):
-    """Returns (transient (H,W,T,4) f32, steady (H,W,4) f32, counters dict[, log ndarray])."""
-    f = scene_data.film
+def alloc_film(film_desc, prefault=False):
+    f = film_desc
     t4 = np.zeros((f.height, f.width, f.temporal_bins, 4), np.float32)
     s4 = np.zeros((f.height, f.width, 4), np.float32)
+    if prefault:          # touch every page now (np.zeros maps lazily): keeps page faults out of timed regions
+        t4.fill(0.0)
+        s4.fill(0.0)
+    return t4, s4
+
+
+def render(scene_data, params: _cabi.mtr_render_params, n_threads=0, use_bvh=False, log_capacity=0, out=None):
+    """Returns (transient (H,W,T,4) f32, steady (H,W,4) f32, counters dict[, log ndarray]).
+    ``out=(t4, s4)`` accumulates into existing buffers."""
+    f = scene_data.film
+    t4, s4 = out if out is not None else alloc_film(f)
     cnt = _cabi.mtr_counters()
     d = scene_data.desc()
     log = None

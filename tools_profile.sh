@@ -1,0 +1,37 @@
+#!/bin/bash
+# tools_profile.sh <tag> [bench args...] — kernel-trace stats + PMC passes for bench.py on the GPU box.
+# Outputs summaries under gpurun_out/prof_<tag>/ (copy what should be judged into profiles/).
+TAG=$1; shift
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $@"
+rocprofv3 --kernel-trace --stats --truncate-kernels -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_$name -o pmc --output-format csv -- $CMD > $OUT/pmc_$name.log 2>&1
+done
+cd $REPO
+python - <<PY
+import csv, glob, os, collections
+out="$OUT"
+for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
+    print("== kernel stats", f)
+    print(open(f).read()[:3000])
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"][:60]
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
+        cnt[(k,r["Counter_Name"])]+=1
+with open(out+"/pmc_summary.txt","w") as fh:
+    for k,v in agg.items():
+        fh.write(k+"\n")
+        for c,val in sorted(v.items()):
+            n=cnt[(k,c)]
+            fh.write(f"   {c:28s} total {val:.6g}  dispatches {n}  per-dispatch {val/n:.6g}\n")
+print(open(out+"/pmc_summary.txt").read())
+PY
