@@ -95,16 +95,23 @@ struct Builder {
     }
 };
 
-void set_box(float *lo, float *hi, const Box &b)
+void padded(const Box &b, float *lo, float *hi)
 {
     float m = 0.0f;
     for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
     float pad = 2e-5f * (1.0f + m);        // culling must stay conservative under f32 rounding
     for (int k = 0; k < 3; ++k) { lo[k] = b.lo[k] - pad; hi[k] = b.hi[k] + pad; }
 }
-void set_empty(float *lo, float *hi)
+void set_child(Node &n, int c, const Box &b, int32_t ref)
 {
-    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    float lo[3], hi[3];
+    padded(b, lo, hi);
+    node_set_child(n, c, lo, hi, ref);
+}
+void set_empty_child(Node &n, int c, int32_t ref)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    node_set_child(n, c, lo, hi, ref);
 }
 
 } // namespace
@@ -134,8 +141,8 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
     std::vector<Item> stack;
     const Tmp &R = B.tmp[root];
     if (R.left < 0) {                        // the whole scene is one leaf
-        Node nd{}; set_box(nd.lo0, nd.hi0, R.box); set_empty(nd.lo1, nd.hi1);
-        nd.c0 = leaf_ref(R); nd.c1 = leaf_ref(R);
+        Node nd{};
+        set_child(nd, 0, R.box, leaf_ref(R)); set_empty_child(nd, 1, leaf_ref(R));
         out.nodes.push_back(nd); out.max_depth = 1; out.n_leaves = 1;
     } else {
         out.nodes.emplace_back();
@@ -146,11 +153,12 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
             const Tmp &t = B.tmp[it.tmp];
             const Tmp &L = B.tmp[t.left], &Rr = B.tmp[t.right];
             Node nd{};
-            set_box(nd.lo0, nd.hi0, L.box); set_box(nd.lo1, nd.hi1, Rr.box);
-            if (L.left < 0) { nd.c0 = leaf_ref(L); out.n_leaves++; }
-            else { nd.c0 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.left, nd.c0, it.depth + 1 }); }
-            if (Rr.left < 0) { nd.c1 = leaf_ref(Rr); out.n_leaves++; }
-            else { nd.c1 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.right, nd.c1, it.depth + 1 }); }
+            int32_t c0, c1;
+            if (L.left < 0) { c0 = leaf_ref(L); out.n_leaves++; }
+            else { c0 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.left, c0, it.depth + 1 }); }
+            if (Rr.left < 0) { c1 = leaf_ref(Rr); out.n_leaves++; }
+            else { c1 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.right, c1, it.depth + 1 }); }
+            set_child(nd, 0, L.box, c0); set_child(nd, 1, Rr.box, c1);
             out.nodes[it.packet] = nd;
         }
     }

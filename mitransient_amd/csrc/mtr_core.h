@@ -36,13 +36,14 @@ MTR_HD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; retur
 MTR_HD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 MTR_HD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
 MTR_HD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-MTR_HD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// vector / scalar is ONE correctly rounded reciprocal and three multiplies (numerics contract)
+MTR_HD f3 operator/(f3 a, float s) { float r = 1.0f / s; return mk(a.x * r, a.y * r, a.z * r); }
 MTR_HD float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 MTR_HD f3 cross(f3 a, f3 b)
 {
     return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-MTR_HD f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MTR_HD f3 normalize(f3 a) { return a / sqrtf(dot(a, a)); }
 MTR_HD f3 fma3(f3 a, float s, f3 b) { return mk(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
 MTR_HD float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 MTR_HD bool sign_neg(float s) { return s < 0.0f || (s == 0.0f && signbit(s)); }
@@ -126,19 +127,35 @@ MTR_HD f3 cosine_hemisphere(float u1, float u2)
 }
 
 // ---------------------------------------------------------------- scene (device layout)
-// BVH2 "node packet": both children's boxes + refs in one 64-byte, 16-byte-aligned record
-// (4 x ds_read_b128 / global_load_dwordx4).  ref >= 0: inner node; ref < 0: leaf,
-// ~ref = (first_tri << 2) | (count - 1), count in 1..4.  An absent child has an inverted box.
+// 16-byte quads: every record below is read as whole quads (ds_read_b128 from LDS,
+// global_load_dwordx4 from HBM/L2).
+struct alignas(16) q4 { float x, y, z, w; };
+MTR_HD uint32_t fbits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+MTR_HD float bitsf(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+// BVH2 "node packet": both children's boxes + refs in one 64-byte record, child-interleaved so
+// that the two slab tests run as packed pairs:
+//   q[0] = (lo0.x, lo1.x, hi0.x, hi1.x)   q[1] = (.y ...)   q[2] = (.z ...)   q[3] = (c0, c1, -, -)
+// ref >= 0: inner node; ref < 0: leaf, ~ref = (first_tri << 2) | (count - 1), count in 1..4.
+// An absent child has an inverted box (lo = +inf, hi = -inf).
 struct alignas(16) Node {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
-    int32_t c0, c1;
-    uint32_t pad[2];
+    q4 q[4];
 };
-// triangle, split by use: geometry (intersection) and shading data
-struct alignas(16) TriGeom { float p0[3], p1[3], p2[3]; uint32_t mat_em; uint32_t orig; uint32_t pad; };   // 48 B
-// orig: index of the triangle in the caller's array (ties on t go to the lower ORIGINAL index)
-struct alignas(16) TriShade { float n[3], s[3], t[3]; float pad[3]; };                        // 48 B
-// mat_em: material index | (emitter index + 1) << 16
+MTR_HD void node_set_child(Node &n, int c, const float *lo, const float *hi, int32_t ref)
+{
+    float *f = &n.q[0].x;
+    for (int k = 0; k < 3; ++k) { f[4 * k + c] = lo[k]; f[4 * k + 2 + c] = hi[k]; }
+    f[12 + c] = bitsf((uint32_t)ref);
+}
+// triangle, split by use.  Intersection record (3 quads), edges precomputed (e = p - p0, the same
+// f32 subtraction Moller-Trumbore starts with):
+//   g[0] = (p0.x, p0.y, p0.z, e1.x)  g[1] = (e1.y, e1.z, e2.x, e2.y)  g[2] = (e2.z, orig, mat_em, -)
+//   orig:   index of the triangle in the caller's array (ties on t go to the lower ORIGINAL index)
+//   mat_em: material index | (emitter index + 1) << 16
+struct alignas(16) TriGeom { q4 g[3]; };
+// shading record (4 quads): flat frame + the two other vertices (hit point = barycentric blend)
+//   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, -)
+struct alignas(16) TriShade { q4 h[4]; };
 struct alignas(16) Emitter { float center[3], du[3], dv[3], n[3], radiance[3], inv_area; };   // 64 B
 
 struct Camera {
@@ -178,10 +195,15 @@ MTR_HD f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
 // ---------------------------------------------------------------- intersection
 struct Hit { float t, u, v; int32_t prim; };
 
-MTR_HD bool tri_hit(const TriGeom &g, f3 o, f3 d, float tmax, float &t, float &u, float &v)
+MTR_HD float safe_rcp(float x)
 {
-    f3 p0 = ld3(g.p0);
-    f3 e1 = ld3(g.p1) - p0, e2 = ld3(g.p2) - p0;
+    float r = 1.0f / x;
+    return (fabsf(r) <= 1e28f) ? r : copysignf(1e28f, x);
+}
+
+// Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]
+MTR_HD bool tri_hit(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float tmax, float &t, float &u, float &v)
+{
     f3 pvec = cross(d, e2);
     float inv_det = 1.0f / dot(e1, pvec);
     f3 tvec = o - p0;
@@ -192,69 +214,74 @@ MTR_HD bool tri_hit(const TriGeom &g, f3 o, f3 d, float tmax, float &t, float &u
     return (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= 0.0f) & (t <= tmax);
 }
 
-MTR_HD float safe_rcp(float x)
-{
-    float r = 1.0f / x;
-    return (fabsf(r) <= 1e28f) ? r : copysignf(1e28f, x);
-}
-// conservative slab test (culling only: hits are decided by tri_hit, ties by primitive index)
-MTR_HD float box_near(const float *lo, const float *hi, f3 id, f3 oid, float tbest)
-{
-    float ax = fmaf(lo[0], id.x, -oid.x), bx = fmaf(hi[0], id.x, -oid.x);
-    float ay = fmaf(lo[1], id.y, -oid.y), by = fmaf(hi[1], id.y, -oid.y);
-    float az = fmaf(lo[2], id.z, -oid.z), bz = fmaf(hi[2], id.z, -oid.z);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tbest));
-    return (tn <= tf) ? tn : kInf;      // +inf = miss
-}
-
-// Stack: any type with push(int)/pop()/empty(); kernels keep it in LDS, the host harness in an array.
+// "while-while" BVH2 traversal: all lanes of a wave first walk inner nodes until each holds a leaf
+// (or is done), then the wave intersects leaves together — node steps and triangle tests are
+// never serialised against each other inside one wave.  The node step is branch-free except for
+// the pop (selects + an unconditional stack write whose slot only counts when both children hit).
+// Culling is conservative (padded boxes, finite reciprocals): hits are decided by tri_hit alone,
+// ties on t by the ORIGINAL triangle index, so the result is independent of the traversal order.
+// Stack: reset()/push_if(bool,int)/pop()/empty(); kernels keep it in LDS.
 template <bool ANY_HIT, class Stack>
 MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
     Hit h; h.t = kInf; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
     uint32_t best_orig = 0xffffffffu;
     if (sc.n_tris == 0) return h;
-    // reciprocal direction, kept finite so that fma(lo, id, -o*id) never meets inf - inf
-    // (axis-parallel rays); the culling stays conservative because the boxes are padded.
-    f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    f3 oid = mk(o.x * id.x, o.y * id.y, o.z * id.z);
+    const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const f3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
     st.reset();
     int32_t cur = 0;
     float tbest = tmax;
-    for (;;) {
-        if (cur >= 0) {
+    bool done = false;
+    while (!done) {
+        // ---- inner nodes ----
+        while ((cur >= 0) & !done) {
             const Node &n = sc.nodes[cur];
-            float t0 = box_near(n.lo0, n.hi0, id, oid, tbest);
-            float t1 = box_near(n.lo1, n.hi1, id, oid, tbest);
-            int32_t c0 = n.c0, c1 = n.c1;
-            bool h0 = t0 < kInf, h1 = t1 < kInf;
-            if (h0 & h1) {
-                bool near0 = t0 <= t1;
-                st.push(near0 ? c1 : c0);
-                cur = near0 ? c0 : c1;
-                continue;
-            }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else {
-            uint32_t code = ~(uint32_t)cur;
-            uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float t, u, v;
-                int32_t prim = (int32_t)(first + i);
-                const TriGeom &tg = sc.tgeom[prim];
-                if (tri_hit(tg, o, d, tmax, t, u, v)) {
-                    if (ANY_HIT) { h.t = t; h.prim = prim; return h; }
-                    if (t < h.t || (t == h.t && tg.orig < best_orig)) {
-                        h.t = t; h.u = u; h.v = v; h.prim = prim; best_orig = tg.orig;
-                        tbest = t;
-                    }
-                }
+            const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
+            // slabs of child 0 (.x lo, .z hi) and child 1 (.y lo, .w hi)
+            const float ax0 = fmaf(X.x, id.x, noid.x), ax1 = fmaf(X.y, id.x, noid.x);
+            const float bx0 = fmaf(X.z, id.x, noid.x), bx1 = fmaf(X.w, id.x, noid.x);
+            const float ay0 = fmaf(Y.x, id.y, noid.y), ay1 = fmaf(Y.y, id.y, noid.y);
+            const float by0 = fmaf(Y.z, id.y, noid.y), by1 = fmaf(Y.w, id.y, noid.y);
+            const float az0 = fmaf(Z.x, id.z, noid.z), az1 = fmaf(Z.y, id.z, noid.z);
+            const float bz0 = fmaf(Z.z, id.z, noid.z), bz1 = fmaf(Z.w, id.z, noid.z);
+            const float tn0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
+            const float tf0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), tbest));
+            const float tn1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
+            const float tf1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), tbest));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const int32_t c0 = (int32_t)fbits(C.x), c1 = (int32_t)fbits(C.y);
+            const bool near0 = tn0 <= tn1;
+            const bool both = h0 & h1;
+            st.push_if(both, near0 ? c1 : c0);
+            cur = both ? (near0 ? c0 : c1) : (h0 ? c0 : c1);
+            if (!(h0 | h1)) {
+                if (st.empty()) done = true;
+                else cur = st.pop();
             }
         }
-        if (st.empty()) break;
-        cur = st.pop();
+        if (done) break;
+        // ---- leaf ----
+        const uint32_t code = ~(uint32_t)cur;
+        const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int32_t prim = (int32_t)(first + i);
+            const TriGeom &tg = sc.tgeom[prim];
+            const q4 a = tg.g[0], b = tg.g[1], c = tg.g[2];
+            float t, u, v;
+            const bool hit = tri_hit(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, tmax, t, u, v);
+            if (ANY_HIT) {
+                if (hit) { h.t = t; h.prim = prim; return h; }
+            } else {
+                const uint32_t orig = fbits(c.y);
+                const bool better = hit & ((t < h.t) | ((t == h.t) & (orig < best_orig)));
+                h.t = better ? t : h.t; h.u = better ? u : h.u; h.v = better ? v : h.v;
+                h.prim = better ? prim : h.prim; best_orig = better ? orig : best_orig;
+                tbest = better ? t : tbest;
+            }
+        }
+        if (st.empty()) done = true;
+        else cur = st.pop();
     }
     return h;
 }
@@ -425,16 +452,18 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
 
     if (valid) {
-        const TriGeom &g = sc.tgeom[h.prim];
+        const TriGeom &tg = sc.tgeom[h.prim];
         const TriShade &tsd = sc.tshade[h.prim];
+        const q4 ga = tg.g[0], gc = tg.g[2];
+        const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3];
         float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
-        sp = mk(fmaf(g.p0[0], b0, fmaf(g.p1[0], b1, g.p2[0] * b2)),
-                fmaf(g.p0[1], b0, fmaf(g.p1[1], b1, g.p2[1] * b2)),
-                fmaf(g.p0[2], b0, fmaf(g.p1[2], b1, g.p2[2] * b2)));
-        sn = ld3(tsd.n); ss = ld3(tsd.s); stt = ld3(tsd.t);
+        sp = mk(fmaf(ga.x, b0, fmaf(hc.y, b1, hd.x * b2)),
+                fmaf(ga.y, b0, fmaf(hc.z, b1, hd.y * b2)),
+                fmaf(ga.z, b0, fmaf(hc.w, b1, hd.z * b2)));
+        sn = mk(ha.x, ha.y, ha.z); ss = mk(ha.w, hb.x, hb.y); stt = mk(hb.z, hb.w, hc.x);
         f3 md = -p.ray.d;
         wi = mk(dot(md, ss), dot(md, stt), dot(md, sn));
-        const uint32_t mat_em = g.mat_em;
+        const uint32_t mat_em = fbits(gc.z);
         const mtr_material &mat = sc.mats[mat_em & 0xffffu];
         const int32_t em = (int32_t)(mat_em >> 16) - 1;
 
@@ -489,7 +518,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
             float pdf_dir = E.inv_area * ((fabsf(x) <= 3.402823466e+38f) ? x : 0.0f);
             bool ok = (dp < 0.0f) & (pdf_dir != 0.0f);
             if (ok) {
-                f3 emw = mk(E.radiance[0] / pdf_dir, E.radiance[1] / pdf_dir, E.radiance[2] / pdf_dir);
+                f3 emw = ld3(E.radiance) / pdf_dir;
                 float pdf = pdf_dir;
                 if (sc.n_emitters > 1) {
                     pdf = pdf_dir * rc.inv_n_emitters;
@@ -505,7 +534,11 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
                     float sdist = sqrtf(dot(sd, sd));
                     sd = sd / sdist;
                     stats.shadow++;
+#ifdef MTR_EXP_NOSHADOW
+                    Hit sh; sh.prim = -1;
+#else
                     Hit sh = traverse<true>(sc, so, sd, sdist * (1.0f - kShadowEps), st);
+#endif
                     if (sh.prim < 0) {
                         f3 wo = mk(dot(dd, ss), dot(dd, stt), dot(dd, sn));
                         f3 wi_e = wi;

@@ -20,9 +20,10 @@ namespace mtr {
 template <int DEPTH>
 struct LdsStack {
     int32_t *base;     // &stack[tid]; entry k lives at base[k * kBlock]  (one bank column per lane)
-    int sp;
+    int sp;            // DEPTH >= BVH depth, and the array has DEPTH + 1 rows: push_if may write row sp == DEPTH
     __device__ __forceinline__ void reset() { sp = 0; }
-    __device__ __forceinline__ void push(int32_t v) { if (sp < DEPTH) { base[sp * kBlock] = v; ++sp; } }
+    // unconditional LDS write, conditional increment: no branch in the node step
+    __device__ __forceinline__ void push_if(bool c, int32_t v) { base[sp * kBlock] = v; sp += c ? 1 : 0; }
     __device__ __forceinline__ int32_t pop() { --sp; return base[sp * kBlock]; }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
@@ -55,7 +56,9 @@ struct LdsHistSink {
                                           float opl, uint32_t depth, uint32_t kind)
     {
         float *p = hist + row + bin;
+#ifndef MTR_EXP_NOSPLAT
         lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b);
+#endif
         ++n_splats;
         if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
     }
@@ -85,15 +88,18 @@ __device__ __forceinline__ void copy16(void *dst, const void *src, uint32_t byte
 __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // ------------------------------------------------------------------ fused kernel
+#ifndef MTR_FUSED_MIN_WAVES
+#define MTR_FUSED_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
+#endif
 template <int STACK, bool SCENE_LDS, bool HIST_LDS>
-__global__ void __launch_bounds__(kBlock) k_fused(const FusedArgs a)
+__global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
 
     // ---- LDS carve-up (all offsets multiples of 16) ----
     uint32_t off = 0;
-    int32_t *s_stack = (int32_t *)(smem + off); off += STACK * kBlock * 4;
+    int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
     unsigned long long *s_cnt = (unsigned long long *)(smem + off); off += 64;    // 5 counters + next
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
@@ -226,7 +232,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const uint32_t kLdsMax = 160u * 1024u;
     int stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
     if (sc.bvh_depth > 64) return false;
-    uint32_t fixed = stack * kBlock * 4 + 64;
+    uint32_t fixed = (stack + 1) * kBlock * 4 + 64;
     uint32_t scene_b = scene_lds_bytes(sc);
     cfg.scene_lds = scene_b <= 64u * 1024u;
     if (cfg.scene_lds) fixed += scene_b;

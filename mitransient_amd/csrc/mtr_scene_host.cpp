@@ -38,14 +38,17 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         const uint32_t o = bvh.order[slot];
         const float *v = d.tri_verts + 9 * (size_t)o;
         TriGeom &g = s.tgeom[slot]; TriShade &h = s.tshade[slot];
-        for (int k = 0; k < 3; ++k) { g.p0[k] = v[k]; g.p1[k] = v[3 + k]; g.p2[k] = v[6 + k]; }
-        g.mat_em = d.tri_material[o] | ((uint32_t)(d.tri_emitter[o] + 1) << 16);
-        g.orig = o; g.pad = 0;
+        const uint32_t mat_em = d.tri_material[o] | ((uint32_t)(d.tri_emitter[o] + 1) << 16);
         // flat frame: n = normalize(e1 x e2), s = normalize(e1), t = n x s   (f32, contract in DESIGN.md)
-        f3 p0 = ld3(g.p0), e1 = ld3(g.p1) - p0, e2 = ld3(g.p2) - p0;
+        f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
         f3 n = normalize(cross(e1, e2)), sdir = normalize(e1), t = cross(n, sdir);
-        h.n[0] = n.x; h.n[1] = n.y; h.n[2] = n.z; h.s[0] = sdir.x; h.s[1] = sdir.y; h.s[2] = sdir.z;
-        h.t[0] = t.x; h.t[1] = t.y; h.t[2] = t.z; h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
+        g.g[0] = q4{ p0.x, p0.y, p0.z, e1.x };
+        g.g[1] = q4{ e1.y, e1.z, e2.x, e2.y };
+        g.g[2] = q4{ e2.z, bitsf(o), bitsf(mat_em), 0.0f };
+        h.h[0] = q4{ n.x, n.y, n.z, sdir.x };
+        h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
+        h.h[2] = q4{ t.z, v[3], v[4], v[5] };
+        h.h[3] = q4{ v[6], v[7], v[8], 0.0f };
     }
     s.ems.resize(d.n_emitters);
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
@@ -54,7 +57,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         for (int k = 0; k < 3; ++k) { E.center[k] = e.center[k]; E.du[k] = e.du[k]; E.dv[k] = e.dv[k]; E.radiance[k] = e.radiance[k]; }
         f3 cr = cross(ld3(e.du), ld3(e.dv));
         float len = sqrtf(dot(cr, cr));
-        f3 n = cr * (1.0f / len);
+        f3 n = cr / len;
         E.n[0] = n.x; E.n[1] = n.y; E.n[2] = n.z;
         E.inv_area = 1.0f / (4.0f * len);      // rectangle area = |(2 du) x (2 dv)|
     }

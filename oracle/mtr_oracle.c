@@ -51,11 +51,9 @@ static inline v3 vcross(v3 a, v3 b)
 {
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-static inline v3 vnormalize(v3 a)
-{
-    float inv = 1.0f / sqrtf(vdot(a, a));
-    return vscale(a, inv);
-}
+/* vector / scalar: ONE correctly rounded reciprocal, three multiplies [drjit: a / s == a * rcp(s)] */
+static inline v3 vdivs(v3 a, float s) { float r = 1.0f / s; return vscale(a, r); }
+static inline v3 vnormalize(v3 a) { return vdivs(a, sqrtf(vdot(a, a))); }
 /* a*s + b, per component */
 static inline v3 vfma(v3 a, float s, v3 b) { return V(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
 static inline float mulsign(float x, float s) { return (s < 0.0f || (s == 0.0f && signbit(s))) ? -x : x; }
@@ -213,7 +211,7 @@ static void build_tris(orc_scene *sc)
         v3 du = V(e->du[0], e->du[1], e->du[2]), dv = V(e->dv[0], e->dv[1], e->dv[2]);
         v3 c = vcross(du, dv);
         float len = sqrtf(vdot(c, c));
-        sc->em_n[i] = vscale(c, 1.0f / len);
+        sc->em_n[i] = vdivs(c, len);
         /* [mitsuba3: Rectangle: surface_area = |cross(dp_du, dp_dv)|, dp_du = to_world*(2,0,0)] */
         sc->em_inv_area[i] = 1.0f / (4.0f * len);
     }
@@ -615,7 +613,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
             /* ds = DirectionSample3f(scene, si, ref=prev_si) */
             v3 rel = vsub(si.p, prev_p);
             float dist = sqrtf(vdot(rel, rel));
-            v3 dd = V(rel.x / dist, rel.y / dist, rel.z / dist);
+            v3 dd = vdivs(rel, dist);
             /* pdf_emitter_direction(prev_si, ds, ~prev_bsdf_delta) [AreaLight::pdf_direction, Shape::pdf_direction] */
             float em_pdf = 0.0f;
             if (!prev_delta) {
@@ -657,7 +655,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
             /* [Shape::sample_direction] */
             v3 dd = vsub(ep, si.p);
             float dist2 = vdot(dd, dd), dist = sqrtf(dist2);
-            dd = V(dd.x / dist, dd.y / dist, dd.z / dist);
+            dd = vdivs(dd, dist);
             float dp = vdot(dd, en), adp = fabsf(dp);
             float x = dist2 / adp;
             float pdf_dir = sc->em_inv_area[ei] * (isfinite(x) ? x : 0.0f);
@@ -665,7 +663,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
             /* [AreaLight::sample_direction] active &= dot(d,n) < 0 && pdf != 0; spec = radiance / pdf */
             int ok = (dp < 0.0f) && (pdf_dir != 0.0f);
             float emw[3] = { 0, 0, 0 };
-            if (ok) for (int k = 0; k < 3; ++k) emw[k] = E->radiance[k] / pdf_dir;
+            if (ok) { float ip = 1.0f / pdf_dir; for (int k = 0; k < 3; ++k) emw[k] = E->radiance[k] * ip; }
             float pdf = pdf_dir;
             if (d->n_emitters > 1) {                                    /* ds.pdf *= pmf; spec *= 1/pmf */
                 pdf = pdf_dir * pmf;
@@ -677,7 +675,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
                 v3 o = offset_p(&si, vsub(ep, si.p));
                 v3 sd = vsub(ep, o);
                 float sdist = sqrtf(vdot(sd, sd));
-                ray3 sr; sr.o = o; sr.d = V(sd.x / sdist, sd.y / sdist, sd.z / sdist);
+                ray3 sr; sr.o = o; sr.d = vdivs(sd, sdist);
                 sr.maxt = sdist * (1.0f - ORC_SHADOW_EPS);
                 C->shadow++;
                 if (ray_test(sc, &sr, use_bvh)) { emw[0] = emw[1] = emw[2] = 0.0f; }

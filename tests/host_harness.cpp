@@ -13,9 +13,9 @@ using namespace mtr;
 
 namespace {
 struct ArrStack {
-    int32_t v[128]; int sp;
+    int32_t v[130]; int sp;
     void reset() { sp = 0; }
-    void push(int32_t x) { if (sp < 128) v[sp++] = x; }
+    void push_if(bool c, int32_t x) { v[sp] = x; sp += c ? 1 : 0; }
     int32_t pop() { return v[--sp]; }
     bool empty() const { return sp == 0; }
 };
@@ -94,7 +94,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
         f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
         float mt = maxt ? maxt[i] : kInf;
         Hit h = traverse<false>(sv, o, dd, mt, st);
-        t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)hs.tgeom[h.prim].orig : -1;
+        t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)fbits(hs.tgeom[h.prim].g[2].y) : -1;
         Hit a = traverse<true>(sv, o, dd, mt, st);
         occ_out[i] = a.prim >= 0;
     }
