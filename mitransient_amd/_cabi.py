@@ -72,8 +72,10 @@ class mtr_counters(C.Structure):
                 ("reserved", C.c_uint64 * 2)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k in
-                ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces", "splats_overflow")}
+        d = {k: int(getattr(self, k)) for k in
+             ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces", "splats_overflow")}
+        d["reserved"] = [int(self.reserved[0]), int(self.reserved[1])]
+        return d
 
 
 class mtr_splat_soa(C.Structure):

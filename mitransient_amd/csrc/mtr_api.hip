@@ -237,6 +237,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             counters_out->paths = h.paths; counters_out->rays_closest = h.rays_closest;
             counters_out->rays_shadow = h.rays_shadow; counters_out->splats_issued = h.splats_issued;
             counters_out->bounces = h.bounces; counters_out->splats_overflow = h.splats_overflow;
+            counters_out->reserved[0] = h.r0; counters_out->reserved[1] = h.r1;
         }
         if (times_out) {
             memset(times_out, 0, sizeof *times_out);

@@ -214,76 +214,108 @@ MTR_HD bool tri_hit(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float tmax, float &t, float
     return (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= 0.0f) & (t <= tmax);
 }
 
-// "while-while" BVH2 traversal: all lanes of a wave first walk inner nodes until each holds a leaf
-// (or is done), then the wave intersects leaves together — node steps and triangle tests are
-// never serialised against each other inside one wave.  The node step is branch-free except for
-// the pop (selects + an unconditional stack write whose slot only counts when both children hit).
+// ------------------------------------------------------------------------------------------
+// Resumable BVH2 traversal.  A traversal is a small per-lane state machine so that a wave can
+// interleave node steps, leaf steps and shading of DIFFERENT lanes' rays (the wave-level
+// scheduler of k_fused); traverse() below simply runs it to completion.
+//   cur >= 0          : at an inner node packet         -> trav_node_step
+//   kTravDone < cur<0 : holding a leaf (not yet tested) -> trav_leaf_step
+//   cur == kTravDone  : finished, result in h
 // Culling is conservative (padded boxes, finite reciprocals): hits are decided by tri_hit alone,
 // ties on t by the ORIGINAL triangle index, so the result is independent of the traversal order.
 // Stack: reset()/push_if(bool,int)/pop()/empty(); kernels keep it in LDS.
+constexpr int32_t kTravDone = (int32_t)0x80000000;
+
+struct Trav {
+    f3 o, d, id, noid;
+    float tmax, tbest;
+    int32_t cur;
+    Hit h;
+    uint32_t best_orig;
+};
+
+template <class Stack>
+MTR_HD void trav_init(Trav &tr, const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
+{
+    tr.o = o; tr.d = d; tr.tmax = tmax; tr.tbest = tmax;
+    // reciprocal direction kept finite so that fma(lo, id, -o*id) never meets inf - inf (axis-parallel rays)
+    tr.id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    tr.noid = mk(-(o.x * tr.id.x), -(o.y * tr.id.y), -(o.z * tr.id.z));
+    tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1;
+    tr.best_orig = 0xffffffffu;
+    tr.cur = sc.n_tris ? 0 : kTravDone;
+    st.reset();
+}
+
+// one inner-node step: two slab tests, branch-free child selection (unconditional stack write whose
+// slot only counts when both children are hit), pop when neither is hit.
+template <class Stack>
+MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
+{
+    st.count(0);
+    const Node &n = sc.nodes[tr.cur];
+    const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
+    const f3 id = tr.id, noid = tr.noid;
+    // slabs of child 0 (.x lo, .z hi) and child 1 (.y lo, .w hi)
+    const float ax0 = fmaf(X.x, id.x, noid.x), ax1 = fmaf(X.y, id.x, noid.x);
+    const float bx0 = fmaf(X.z, id.x, noid.x), bx1 = fmaf(X.w, id.x, noid.x);
+    const float ay0 = fmaf(Y.x, id.y, noid.y), ay1 = fmaf(Y.y, id.y, noid.y);
+    const float by0 = fmaf(Y.z, id.y, noid.y), by1 = fmaf(Y.w, id.y, noid.y);
+    const float az0 = fmaf(Z.x, id.z, noid.z), az1 = fmaf(Z.y, id.z, noid.z);
+    const float bz0 = fmaf(Z.z, id.z, noid.z), bz1 = fmaf(Z.w, id.z, noid.z);
+    const float tn0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
+    const float tf0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), tr.tbest));
+    const float tn1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
+    const float tf1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), tr.tbest));
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const int32_t c0 = (int32_t)fbits(C.x), c1 = (int32_t)fbits(C.y);
+    const bool near0 = tn0 <= tn1;
+    const bool both = h0 & h1;
+    st.push_if(both, near0 ? c1 : c0);
+    int32_t nxt = both ? (near0 ? c0 : c1) : (h0 ? c0 : c1);
+    if (!(h0 | h1)) nxt = st.empty() ? kTravDone : st.pop();
+    tr.cur = nxt;
+}
+
+// one leaf: 1..4 Moller-Trumbore tests, then pop.  `any_hit` is a per-lane runtime flag so that
+// closest-hit and shadow rays of different lanes share one instruction stream.
+template <class Stack>
+MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
+{
+    const uint32_t code = ~(uint32_t)tr.cur;
+    const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+    bool found = false;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        st.count(1);
+        const int32_t prim = (int32_t)(first + i);
+        const TriGeom &tg = sc.tgeom[prim];
+        const q4 a = tg.g[0], b = tg.g[1], c = tg.g[2];
+        float t, u, v;
+        const bool hit = tri_hit(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), tr.o, tr.d, tr.tmax, t, u, v);
+        const uint32_t orig = fbits(c.y);
+        const bool closer = (t < tr.h.t) | ((t == tr.h.t) & (orig < tr.best_orig));
+        const bool better = hit & (any_hit ? !found : closer);
+        found |= hit;
+        tr.h.t = better ? t : tr.h.t; tr.h.u = better ? u : tr.h.u; tr.h.v = better ? v : tr.h.v;
+        tr.h.prim = better ? prim : tr.h.prim; tr.best_orig = better ? orig : tr.best_orig;
+        tr.tbest = (better & !any_hit) ? t : tr.tbest;
+    }
+    if (any_hit & found) tr.cur = kTravDone;
+    else tr.cur = st.empty() ? kTravDone : st.pop();
+}
+
+// run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
+// intersects leaves together)
 template <bool ANY_HIT, class Stack>
 MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
-    Hit h; h.t = kInf; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    uint32_t best_orig = 0xffffffffu;
-    if (sc.n_tris == 0) return h;
-    const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    const f3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
-    st.reset();
-    int32_t cur = 0;
-    float tbest = tmax;
-    bool done = false;
-    while (!done) {
-        // ---- inner nodes ----
-        while ((cur >= 0) & !done) {
-            const Node &n = sc.nodes[cur];
-            const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
-            // slabs of child 0 (.x lo, .z hi) and child 1 (.y lo, .w hi)
-            const float ax0 = fmaf(X.x, id.x, noid.x), ax1 = fmaf(X.y, id.x, noid.x);
-            const float bx0 = fmaf(X.z, id.x, noid.x), bx1 = fmaf(X.w, id.x, noid.x);
-            const float ay0 = fmaf(Y.x, id.y, noid.y), ay1 = fmaf(Y.y, id.y, noid.y);
-            const float by0 = fmaf(Y.z, id.y, noid.y), by1 = fmaf(Y.w, id.y, noid.y);
-            const float az0 = fmaf(Z.x, id.z, noid.z), az1 = fmaf(Z.y, id.z, noid.z);
-            const float bz0 = fmaf(Z.z, id.z, noid.z), bz1 = fmaf(Z.w, id.z, noid.z);
-            const float tn0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
-            const float tf0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), tbest));
-            const float tn1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
-            const float tf1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), tbest));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const int32_t c0 = (int32_t)fbits(C.x), c1 = (int32_t)fbits(C.y);
-            const bool near0 = tn0 <= tn1;
-            const bool both = h0 & h1;
-            st.push_if(both, near0 ? c1 : c0);
-            cur = both ? (near0 ? c0 : c1) : (h0 ? c0 : c1);
-            if (!(h0 | h1)) {
-                if (st.empty()) done = true;
-                else cur = st.pop();
-            }
-        }
-        if (done) break;
-        // ---- leaf ----
-        const uint32_t code = ~(uint32_t)cur;
-        const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const int32_t prim = (int32_t)(first + i);
-            const TriGeom &tg = sc.tgeom[prim];
-            const q4 a = tg.g[0], b = tg.g[1], c = tg.g[2];
-            float t, u, v;
-            const bool hit = tri_hit(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, tmax, t, u, v);
-            if (ANY_HIT) {
-                if (hit) { h.t = t; h.prim = prim; return h; }
-            } else {
-                const uint32_t orig = fbits(c.y);
-                const bool better = hit & ((t < h.t) | ((t == h.t) & (orig < best_orig)));
-                h.t = better ? t : h.t; h.u = better ? u : h.u; h.v = better ? v : h.v;
-                h.prim = better ? prim : h.prim; best_orig = better ? orig : best_orig;
-                tbest = better ? t : tbest;
-            }
-        }
-        if (st.empty()) done = true;
-        else cur = st.pop();
+    Trav tr;
+    trav_init(tr, sc, o, d, tmax, st);
+    while (tr.cur != kTravDone) {
+        while (tr.cur >= 0) trav_node_step(tr, sc, st);
+        if (tr.cur != kTravDone) trav_leaf_step(tr, sc, st, ANY_HIT);
     }
-    return h;
+    return tr.h;
 }
 
 // ---------------------------------------------------------------- sensor
@@ -411,7 +443,7 @@ struct Path {
 struct BounceStats { uint32_t closest, shadow; };
 
 // lane -> pixel, RNG seeding, jitter, camera ray, loop-state init (transientpath.py:118-131);
-// camera_unwarp pre-pass is done by the caller (it needs a traversal).
+// the camera_unwarp pre-pass is done by the caller (it needs a traversal).
 MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderConst &rc, uint32_t pixel, uint32_t s)
 {
     uint32_t lane = pixel * rc.spp_total + s;
@@ -424,165 +456,184 @@ MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderCo
     p.eta = 1.0f; p.dist = 0.0f; p.prev_pdf = 1.0f; p.depth = 0; p.prev_delta = 1;
 }
 
-// One iteration of the loop of transientpath.py:140-319.
-// Sink: splat(px_film, py_film, bin, r, g, b, opl, depth, kind) for an in-range non-zero contribution.
-// Returns active_next.
-template <class Stack, class Sink>
-MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
-                        Stack &st, Sink &sink, BounceStats &stats)
+// Surface interaction rebuilt from (ray direction, primitive, barycentrics): cheap enough to
+// recompute on both sides of the shadow ray instead of keeping 15 registers alive across it.
+struct HitCtx { f3 sp, sn, ss, stt, wi; uint32_t mat, em_plus1; };
+
+MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
 {
-    // 1. closest hit (:148-151)
-    Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);
-    stats.closest++;
+    HitCtx c;
+    const TriGeom &tg = sc.tgeom[h.prim];
+    const TriShade &tsd = sc.tshade[h.prim];
+    const q4 ga = tg.g[0], gc = tg.g[2];
+    const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3];
+    const float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
+    c.sp = mk(fmaf(ga.x, b0, fmaf(hc.y, b1, hd.x * b2)),
+              fmaf(ga.y, b0, fmaf(hc.z, b1, hd.y * b2)),
+              fmaf(ga.z, b0, fmaf(hc.w, b1, hd.z * b2)));
+    c.sn = mk(ha.x, ha.y, ha.z); c.ss = mk(ha.w, hb.x, hb.y); c.stt = mk(hb.z, hb.w, hc.x);
+    const f3 md = -ray_d;
+    c.wi = mk(dot(md, c.ss), dot(md, c.stt), dot(md, c.sn));
+    const uint32_t mat_em = fbits(gc.z);
+    c.mat = mat_em & 0xffffu; c.em_plus1 = mat_em >> 16;
+    return c;
+}
+
+// [mitsuba3: Interaction::offset_p]
+MTR_HD f3 offset_point(f3 sp, f3 sn, f3 dir)
+{
+    float m = max3(fabsf(sp.x), fabsf(sp.y), fabsf(sp.z));
+    float mag = (1.0f + m) * kRayEps;
+    if (sign_neg(dot(sn, dir))) mag = -mag;
+    return fma3(sn, mag, sp);
+}
+
+// What shade_hit leaves pending while the shadow ray is in flight
+struct Pending {
+    f3 Le;               // emission of this bounce (for L)
+    f3 Lr;               // emitter-sampling contribution IF the shadow ray is unoccluded
+    float opl;           // its optical path length (distance + ds.dist * eta)
+    uint32_t active_next;  // bool: (depth+1 < max_depth) & si.valid
+    uint32_t has_shadow;   // bool: a shadow ray must be traced
+};
+
+// Part A of one loop iteration (transientpath.py:148-218): consumes the closest hit, splats the
+// emission term, samples the emitter and emits the shadow ray.  RNG: next_2d (:193).
+template <class Sink>
+MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &film, const RenderConst &rc,
+                      Sink &sink, Pending &pd, Ray &shadow)
+{
     const bool valid = h.prim >= 0;
-    p.dist += h.t * p.eta;                                   // :154 (inf on a miss)
-
-    bool active_next = ((p.depth + 1u) < rc.max_depth) & valid;     // :185
-    f3 Le = mk(0, 0, 0), Lr = mk(0, 0, 0);
-    const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;   // transient_image_block.py:132
+    p.dist += h.t * p.eta;                                           // :154 (inf on a miss)
+    pd.active_next = (((p.depth + 1u) < rc.max_depth) & valid) ? 1u : 0u;   // :185
+    pd.Le = mk(0, 0, 0); pd.Lr = mk(0, 0, 0); pd.opl = 0.0f; pd.has_shadow = 0u;
+    const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;       // transient_image_block.py:132
     const bool in_film = (fx < film.width) & (fy < film.height);
+    float u1 = rng_f32(p.rng), u2 = rng_f32(p.rng);                  // :193, unconditional for a live lane
+    if (!valid) return;
+    const HitCtx c = hit_ctx(sc, p.ray.d, h);
+    const mtr_material &mat = sc.mats[c.mat];
 
-    // RNG draws are unconditional for a live lane (:193, :223-224, :256)
-    float u1 = rng_f32(p.rng), u2 = rng_f32(p.rng);
+    // direct emission (:166-176)
+    if (c.em_plus1 != 0u && !(rc.flags & MTR_FLAG_DISCARD_DIRECT_LIGHT)) {
+        const Emitter &E = sc.ems[c.em_plus1 - 1u];
+        f3 rel = c.sp - p.prev_p;
+        float dist = sqrtf(dot(rel, rel));
+        f3 dd = rel / dist;
+        float em_pdf = 0.0f;
+        if (!p.prev_delta) {
+            float dp = dot(dd, c.sn);
+            if (dp < 0.0f) {
+                float adp = fabsf(dp);
+                em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
+                if (sc.n_emitters > 1) em_pdf *= rc.inv_n_emitters;
+            }
+        }
+        float mis = mis_weight(p.prev_pdf, em_pdf);
+        if (c.wi.z > 0.0f)
+            pd.Le = mk((p.beta.x * mis) * E.radiance[0], (p.beta.y * mis) * E.radiance[1],
+                       (p.beta.z * mis) * E.radiance[2]);
+        // add_transient(Le, distance) :179-180; common.py:417-421 pre-multiplies the sample scale
+        float vr = pd.Le.x * rc.sample_scale, vg = pd.Le.y * rc.sample_scale, vb = pd.Le.z * rc.sample_scale;
+        if (in_film && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {       // adding +0 is a no-op
+            int32_t bin = film_bin(film, p.dist);
+            if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, p.dist, p.depth, 0u);
+        }
+    }
+
+    // emitter sampling (:188-213); only smooth BSDFs (diffuse) take part
+    if (pd.active_next && mat.type == MTR_BSDF_DIFFUSE && sc.n_emitters > 0 ) {
+        uint32_t ei = 0;
+        if (sc.n_emitters > 1) {
+            float su = u1 * rc.n_emitters_f;
+            uint32_t i = (uint32_t)su;
+            if (i > sc.n_emitters - 1) i = sc.n_emitters - 1;
+            ei = i; u1 = su - (float)i;
+        }
+        const Emitter &E = sc.ems[ei];
+        float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
+        f3 ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),
+                   fmaf(E.du[1], a, fmaf(E.dv[1], b, E.center[1])),
+                   fmaf(E.du[2], a, fmaf(E.dv[2], b, E.center[2])));
+        f3 en = ld3(E.n);
+        f3 dd = ep - c.sp;
+        float dist2 = dot(dd, dd), dist = sqrtf(dist2);
+        dd = dd / dist;
+        float dp = dot(dd, en), adp = fabsf(dp);
+        float x = dist2 / adp;
+        float pdf_dir = E.inv_area * ((fabsf(x) <= 3.402823466e+38f) ? x : 0.0f);
+        if ((dp < 0.0f) & (pdf_dir != 0.0f)) {
+            f3 emw = ld3(E.radiance) / pdf_dir;
+            float pdf = pdf_dir;
+            if (sc.n_emitters > 1) { pdf = pdf_dir * rc.inv_n_emitters; emw = emw * rc.n_emitters_f; }
+            if (pdf != 0.0f) {
+                // BSDF value * cos and MIS (:207-213), evaluated before the visibility test
+                f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
+                f3 wi_e = c.wi;
+                if ((mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
+                // shadow ray: spawn_ray_to(ds.p) + ray_test
+                f3 so = offset_point(c.sp, c.sn, ep - c.sp);
+                f3 sd = ep - so;
+                float sdist = sqrtf(dot(sd, sd));
+                shadow.o = so; shadow.d = sd / sdist; shadow.tmax = sdist * (1.0f - kShadowEps);
+                pd.has_shadow = 1u;
+                if (wi_e.z > 0.0f && wo.z > 0.0f) {
+                    float bpdf = kInvPi * wo.z;
+                    float mis_em = mis_weight(pdf, bpdf);
+                    pd.Lr = mk(((p.beta.x * mis_em) * ((mat.a[0] * kInvPi) * wo.z)) * emw.x,
+                               ((p.beta.y * mis_em) * ((mat.a[1] * kInvPi) * wo.z)) * emw.y,
+                               ((p.beta.z * mis_em) * ((mat.a[2] * kInvPi) * wo.z)) * emw.z);
+                    pd.opl = p.dist + dist * p.eta;                  // :217
+                }
+            }
+        }
+    }
+}
+
+// Part B (transientpath.py:216-257, :318): commits the emitter-sampling term given the shadow-ray
+// answer, samples the BSDF, updates the loop state and applies Russian roulette.
+// RNG: next_1d, next_2d (:223-224), next_1d (:256).  Returns active_next.
+template <class Sink>
+MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd, const SceneView &sc,
+                         const Film &film, const RenderConst &rc, Sink &sink)
+{
+    const bool valid = h.prim >= 0;
+    bool active_next = pd.active_next != 0u;
+    f3 Lr = mk(0, 0, 0);
+    if (pd.has_shadow && !occluded) {
+        Lr = pd.Lr;
+        const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;
+        float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
+        if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
+            int32_t bin = film_bin(film, pd.opl);
+            if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, pd.opl, p.depth, 1u);
+        }
+    }
     float s1 = rng_f32(p.rng), s2a = rng_f32(p.rng), s2b = rng_f32(p.rng);
     float rr_u = rng_f32(p.rng);
 
-    f3 sp = mk(0, 0, 0), sn = mk(0, 0, 1), ss = mk(1, 0, 0), stt = mk(0, 1, 0), wi = mk(0, 0, 0);
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
-
+    f3 sp = mk(0, 0, 0);
+    p.L = mk((p.L.x + pd.Le.x) + Lr.x, (p.L.y + pd.Le.y) + Lr.y, (p.L.z + pd.Le.z) + Lr.z);    // :230
     if (valid) {
-        const TriGeom &tg = sc.tgeom[h.prim];
-        const TriShade &tsd = sc.tshade[h.prim];
-        const q4 ga = tg.g[0], gc = tg.g[2];
-        const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3];
-        float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
-        sp = mk(fmaf(ga.x, b0, fmaf(hc.y, b1, hd.x * b2)),
-                fmaf(ga.y, b0, fmaf(hc.z, b1, hd.y * b2)),
-                fmaf(ga.z, b0, fmaf(hc.w, b1, hd.z * b2)));
-        sn = mk(ha.x, ha.y, ha.z); ss = mk(ha.w, hb.x, hb.y); stt = mk(hb.z, hb.w, hc.x);
-        f3 md = -p.ray.d;
-        wi = mk(dot(md, ss), dot(md, stt), dot(md, sn));
-        const uint32_t mat_em = fbits(gc.z);
-        const mtr_material &mat = sc.mats[mat_em & 0xffffu];
-        const int32_t em = (int32_t)(mat_em >> 16) - 1;
-
-        // 2. direct emission (:166-176)
-        if (em >= 0 && !(rc.flags & MTR_FLAG_DISCARD_DIRECT_LIGHT)) {
-            const Emitter &E = sc.ems[em];
-            f3 rel = sp - p.prev_p;
-            float dist = sqrtf(dot(rel, rel));
-            f3 dd = rel / dist;
-            float em_pdf = 0.0f;
-            if (!p.prev_delta) {
-                float dp = dot(dd, sn);
-                if (dp < 0.0f) {
-                    float adp = fabsf(dp);
-                    em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
-                    if (sc.n_emitters > 1) em_pdf *= rc.inv_n_emitters;
-                }
-            }
-            float mis = mis_weight(p.prev_pdf, em_pdf);
-            if (wi.z > 0.0f)
-                Le = mk((p.beta.x * mis) * E.radiance[0], (p.beta.y * mis) * E.radiance[1],
-                        (p.beta.z * mis) * E.radiance[2]);
+        const HitCtx c = hit_ctx(sc, p.ray.d, h);
+        sp = c.sp;
+        if (active_next) {
+            bs = bsdf_sample(sc.mats[c.mat], c.wi, s1, s2a, s2b);                                // :222-227
+            f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
+                         fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
+                         fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
+            p.ray.o = offset_point(c.sp, c.sn, wo_w);                                            // si.spawn_ray :231
+            p.ray.d = wo_w;
+            p.ray.tmax = kInf;
         }
-        {   // add_transient(Le, distance) :179-180; common.py:417-421 pre-multiplies the sample scale
-            float vr = Le.x * rc.sample_scale, vg = Le.y * rc.sample_scale, vb = Le.z * rc.sample_scale;
-            if (in_film && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {       // adding +0 is a no-op
-                int32_t bin = film_bin(film, p.dist);
-                if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, p.dist, p.depth, 0u);
-            }
-        }
-
-        // 3. emitter sampling (:188-218); only smooth BSDFs (diffuse) take part
-        if (active_next && mat.type == MTR_BSDF_DIFFUSE && sc.n_emitters > 0) {
-            uint32_t ei = 0;
-            if (sc.n_emitters > 1) {
-                float su = u1 * rc.n_emitters_f;
-                uint32_t i = (uint32_t)su;
-                if (i > sc.n_emitters - 1) i = sc.n_emitters - 1;
-                ei = i; u1 = su - (float)i;
-            }
-            const Emitter &E = sc.ems[ei];
-            float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
-            f3 ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),
-                       fmaf(E.du[1], a, fmaf(E.dv[1], b, E.center[1])),
-                       fmaf(E.du[2], a, fmaf(E.dv[2], b, E.center[2])));
-            f3 en = ld3(E.n);
-            f3 dd = ep - sp;
-            float dist2 = dot(dd, dd), dist = sqrtf(dist2);
-            dd = dd / dist;
-            float dp = dot(dd, en), adp = fabsf(dp);
-            float x = dist2 / adp;
-            float pdf_dir = E.inv_area * ((fabsf(x) <= 3.402823466e+38f) ? x : 0.0f);
-            bool ok = (dp < 0.0f) & (pdf_dir != 0.0f);
-            if (ok) {
-                f3 emw = ld3(E.radiance) / pdf_dir;
-                float pdf = pdf_dir;
-                if (sc.n_emitters > 1) {
-                    pdf = pdf_dir * rc.inv_n_emitters;
-                    emw = emw * rc.n_emitters_f;
-                }
-                if (pdf != 0.0f) {
-                    // shadow ray: spawn_ray_to(ds.p) + ray_test
-                    float m = max3(fabsf(sp.x), fabsf(sp.y), fabsf(sp.z));
-                    float mag = (1.0f + m) * kRayEps;
-                    if (sign_neg(dot(sn, ep - sp))) mag = -mag;
-                    f3 so = fma3(sn, mag, sp);
-                    f3 sd = ep - so;
-                    float sdist = sqrtf(dot(sd, sd));
-                    sd = sd / sdist;
-                    stats.shadow++;
-#ifdef MTR_EXP_NOSHADOW
-                    Hit sh; sh.prim = -1;
-#else
-                    Hit sh = traverse<true>(sc, so, sd, sdist * (1.0f - kShadowEps), st);
-#endif
-                    if (sh.prim < 0) {
-                        f3 wo = mk(dot(dd, ss), dot(dd, stt), dot(dd, sn));
-                        f3 wi_e = wi;
-                        if ((mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
-                        if (wi_e.z > 0.0f && wo.z > 0.0f) {
-                            float bpdf = kInvPi * wo.z;
-                            float mis_em = mis_weight(pdf, bpdf);
-                            Lr = mk(((p.beta.x * mis_em) * ((mat.a[0] * kInvPi) * wo.z)) * emw.x,
-                                    ((p.beta.y * mis_em) * ((mat.a[1] * kInvPi) * wo.z)) * emw.y,
-                                    ((p.beta.z * mis_em) * ((mat.a[2] * kInvPi) * wo.z)) * emw.z);
-                            float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
-                            if (in_film && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
-                                float opl = p.dist + dist * p.eta;                  // :217
-                                int32_t bin = film_bin(film, opl);
-                                if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, opl, p.depth, 1u);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-
-        // 4. BSDF sampling (:222-227)
-        if (active_next) bs = bsdf_sample(mat, wi, s1, s2a, s2b);
     }
+    p.eta *= bs.eta;                                                                             // :232
+    p.beta = mk(p.beta.x * bs.w.x, p.beta.y * bs.w.y, p.beta.z * bs.w.z);                        // :233
+    p.prev_p = sp; p.prev_pdf = bs.pdf; p.prev_delta = bs.delta ? 1u : 0u;                      // :237-240
 
-    // 5. loop state (:230-240)
-    p.L = mk((p.L.x + Le.x) + Lr.x, (p.L.y + Le.y) + Lr.y, (p.L.z + Le.z) + Lr.z);
-    if (active_next) {
-        f3 wo_w = mk(fmaf(sn.x, bs.wo.z, fmaf(stt.x, bs.wo.y, ss.x * bs.wo.x)),
-                     fmaf(sn.y, bs.wo.z, fmaf(stt.y, bs.wo.y, ss.y * bs.wo.x)),
-                     fmaf(sn.z, bs.wo.z, fmaf(stt.z, bs.wo.y, ss.z * bs.wo.x)));
-        float m = max3(fabsf(sp.x), fabsf(sp.y), fabsf(sp.z));
-        float mag = (1.0f + m) * kRayEps;
-        if (sign_neg(dot(sn, wo_w))) mag = -mag;
-        p.ray.o = fma3(sn, mag, sp);
-        p.ray.d = wo_w;
-        p.ray.tmax = kInf;
-    }
-    p.eta *= bs.eta;
-    p.beta = mk(p.beta.x * bs.w.x, p.beta.y * bs.w.y, p.beta.z * bs.w.z);
-    p.prev_p = sp; p.prev_pdf = bs.pdf; p.prev_delta = bs.delta ? 1u : 0u;
-
-    // 6. stopping criterion (:245-257)
+    // stopping criterion (:245-257)
     float bmax = max3(p.beta.x, p.beta.y, p.beta.z);
     active_next &= (bmax != 0.0f);
     float rr_prob = fminf(bmax * (p.eta * p.eta), 0.95f);
@@ -593,8 +644,28 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
         p.beta = p.beta * inv;
     }
     active_next &= (!rr_active) | (rr_u < rr_prob);
-    if (valid) p.depth += 1;                                 // :318
+    if (valid) p.depth += 1;                                                                     // :318
     return active_next;
+}
+
+// One whole iteration of the loop of transientpath.py:140-319, run to completion
+// (closest hit -> shade_hit -> shadow ray -> shade_finish).  Returns active_next.
+template <class Stack, class Sink>
+MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
+                        Stack &st, Sink &sink, BounceStats &stats)
+{
+    Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
+    stats.closest++;
+    Pending pd; Ray shadow;
+    shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
+    shade_hit(p, h, sc, film, rc, sink, pd, shadow);
+    bool occluded = false;
+    if (pd.has_shadow) {
+        stats.shadow++;
+        Hit sh = traverse<true>(sc, shadow.o, shadow.d, shadow.tmax, st);
+        occluded = sh.prim >= 0;
+    }
+    return shade_finish(p, h, occluded, pd, sc, film, rc, sink);
 }
 
 } // namespace mtr

@@ -26,6 +26,22 @@ struct LdsStack {
     __device__ __forceinline__ void push_if(bool c, int32_t v) { base[sp * kBlock] = v; sp += c ? 1 : 0; }
     __device__ __forceinline__ int32_t pop() { --sp; return base[sp * kBlock]; }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
+#ifdef MTR_PROFILE_CYCLES      // experiment build: wave-clock per code section (time since the previous mark)
+    unsigned long long t0, cyc[6];
+    __device__ __forceinline__ void prof_mark(int sec) { unsigned long long t = __builtin_readcyclecounter(); cyc[sec] += t - t0; t0 = t; }
+#else
+    __device__ __forceinline__ void prof_mark(int) {}
+#endif
+#ifdef MTR_PROFILE_SIMT        // experiment build: lane-steps vs wave-steps of node / triangle tests
+    unsigned int ls[2], ws[2];
+    __device__ __forceinline__ void count(int k) {
+        ls[k]++;
+        unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) ws[k]++;
+    }
+#else
+    __device__ __forceinline__ void count(int) {}
+#endif
 };
 
 __device__ __forceinline__ void lds_add(float *p, float v)
@@ -128,6 +144,13 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     if (HIST_LDS) for (uint32_t i = tid; i < 3 * plane; i += kBlock) s_hist[i] = 0.0f;
 
     LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
+#ifdef MTR_PROFILE_SIMT
+    st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0;
+#endif
+#ifdef MTR_PROFILE_CYCLES
+    for (int k = 0; k < 6; ++k) st.cyc[k] = 0;
+    st.t0 = __builtin_readcyclecounter();
+#endif
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_paths = 0, n_splats = 0;
 
     for (uint32_t seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
@@ -137,47 +160,59 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
         for (uint32_t i = tid; i < a.G * 4; i += kBlock) s_steady[i] = 0.0f;
         if (tid == 0) *s_next = kBlock;
         __syncthreads();
+        st.prof_mark(5);       // (experiment builds) segment tail + flush + barrier time ends here
 
         // ---- persistent lanes: refill from the LDS work counter when a path ends ----
+        // The two __ballot()s are convergent operations: they pin this loop to ONE wave-synchronous
+        // iteration = (refill dead lanes) + (one bounce for every live lane).  Without them the
+        // compiler threads `alive` through the back edge and nests a per-path inner loop, i.e. dead
+        // lanes wait for the longest path of their wave instead of refilling (measured: 1/3 of the time).
+        // (A finer-grained wave scheduler — node / leaf / shade blocks picked by lane-count ballots —
+        // was measured too: 2.6x SLOWER; see DESIGN.md "what did not work".)
         uint32_t i = tid;
         bool alive = false;
         Path p;
         uint32_t g = 0;
         for (;;) {
-            if (!alive) {
-                if (i >= n_lanes) break;
-                g = i / a.spp_chunk;
-                const uint32_t s = a.spp_begin + (i - g * a.spp_chunk);
-                path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
-                ++n_paths;
-                if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {          // transientpath.py:133-138
-                    Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
-                    ++n_closest;
-                    if (h0.prim >= 0) p.dist = -h0.t;
+            if (__ballot(!alive) != 0ull) {
+                if (!alive && i < n_lanes) {
+                    g = i / a.spp_chunk;
+                    const uint32_t s = a.spp_begin + (i - g * a.spp_chunk);
+                    path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
+                    ++n_paths;
+                    if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {          // transientpath.py:133-138
+                        Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
+                        ++n_closest;
+                        if (h0.prim >= 0) p.dist = -h0.t;
+                    }
+                    alive = true;
+                    st.prof_mark(2);
                 }
-                alive = true;
             }
-            BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
-            if (HIST_LDS) {
-                LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = g * T;
-                sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                n_splats += sink.n_splats;
-            } else {
-                GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
-                sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                n_splats += sink.n_splats;
-            }
-            n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
-            if (!alive) {
-                // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
-                const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
-                if (fx < a.film.width && fy < a.film.height) {
-                    float *sp = s_steady + 4 * g;
-                    lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+            if (__ballot(alive) == 0ull) break;           // the whole wave is out of work
+            if (alive) {
+                BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
+                if (HIST_LDS) {
+                    LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = g * T;
+                    sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                    alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                    n_splats += sink.n_splats;
+                } else {
+                    GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
+                    sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                    alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                    n_splats += sink.n_splats;
                 }
-                i = atomicAdd(s_next, 1u);
+                n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
+                if (!alive) {
+                    // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+                    const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
+                    if (fx < a.film.width && fy < a.film.height) {
+                        float *sp = s_steady + 4 * g;
+                        lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                    }
+                    i = atomicAdd(s_next, 1u);
+                }
             }
         }
         __syncthreads();
@@ -217,6 +252,22 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     atomicAdd(&s_cnt[4], (unsigned long long)n_bounce);
     __syncthreads();
     if (tid < 5 && a.counters) atomicAdd(&a.counters->paths + tid, s_cnt[tid]);
+#ifdef MTR_PROFILE_SIMT
+    if (a.counters) {
+        unsigned long long *c = &a.counters->splats_overflow;
+        atomicAdd(c + 0, ((unsigned long long)st.ls[0] << 32) | st.ws[0]);      // node: lane-steps | wave-steps... (per thread, summed)
+        atomicAdd(c + 1, ((unsigned long long)st.ls[1] << 32) | st.ws[1]);
+    }
+#endif
+#ifdef MTR_PROFILE_CYCLES
+    if ((tid & 63) == 0 && a.counters) {      // one lane per wave; sections: 0 closest 1 any-hit 2 regen 3 shade-A 4 shade-B 5 loop/rest
+        st.prof_mark(5);
+        unsigned long long *c = &a.counters->splats_overflow;      // reuse 3 spare u64 slots: packed pairs of 32-bit Mcycles
+        atomicAdd(c + 0, ((st.cyc[0] >> 10) << 32) | (st.cyc[1] >> 10));
+        atomicAdd(c + 1, ((st.cyc[2] >> 10) << 32) | (st.cyc[3] >> 10));
+        atomicAdd(c + 2, ((st.cyc[4] >> 10) << 32) | (st.cyc[5] >> 10));
+    }
+#endif
 }
 
 static uint32_t scene_lds_bytes(const SceneDev &sc)

@@ -1,0 +1,14 @@
+import sys; sys.path.insert(0,'/root/repo')
+import bench, torch
+scene = bench.build_scene(512,512,1024)
+integ = scene.integrator(); integ.collect_stats=True
+for _ in range(2):
+    s,t = integ.render(scene, spp=1024)
+c = integ.last_counters; tm = integ.last_times
+print(tm)
+v = [c['splats_overflow'], c['reserved'][0], c['reserved'][1]]
+sec = []
+for x in v: sec += [x >> 32, x & 0xffffffff]
+tot = sum(sec)
+names = ['closest-trav','anyhit-trav','regen','shade-A(hit->shadow ray)','shade-B(after shadow)','loop/rest']
+for n,x in zip(names, sec): print('%-28s %5.1f%%' % (n, 100.0*x/tot))

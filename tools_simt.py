@@ -1,0 +1,10 @@
+import sys; sys.path.insert(0,'/root/repo')
+import bench, torch
+scene = bench.build_scene(512,512,1024)
+integ = scene.integrator(); integ.collect_stats=True
+s,t = integ.render(scene, spp=64)
+c = integ.last_counters
+# u64 sums of packed (lane<<32 | wave) overflow the low half into the high half; spp=64 keeps them small enough
+for name, x in (('node step', c['splats_overflow']), ('tri test', c['reserved'][0])):
+    lane, wave = x >> 32, x & 0xffffffff
+    print('%-10s lane-steps %d wave-steps %d  SIMT efficiency %.1f%%  per ray %.2f' % (name, lane, wave, 100.0*lane/(64.0*wave), lane/float(c['rays_closest']+c['rays_shadow'])))
