@@ -14,6 +14,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 using namespace mtr;
 
@@ -26,8 +28,15 @@ struct mtr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
+    void *planes = nullptr, *q_live = nullptr, *q_mat = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
+    uint32_t n_slots = 0, P = 0, rec_cap = 0, rows = 0;
+    uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
+};
+
 struct mtr_scene {
     mtr_ctx *ctx = nullptr;
+    WfWorkspace wf;
     SceneDev dev{};
     Camera cam{};
     Film film{};
@@ -155,6 +164,9 @@ void mtr_scene_destroy(mtr_scene *s)
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     for (void *p : s->allocs) (void)hipFree(p);
+    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_mat, s->wf.counts, s->wf.rec, s->wf.rec_count };
+    for (void *p : w) if (p) (void)hipFree(p);
+    if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
     delete s;
 }
 
@@ -175,6 +187,131 @@ int mtr_scene_bvh_info(const mtr_scene *s, uint32_t *n_nodes, uint32_t *max_dept
     if (n_leaves) *n_leaves = s->n_leaves;
     return MTR_OK;
 }
+
+} // extern "C"
+
+// ---- MTR_MODE_WAVEFRONT: host loop over tiles and bounces ------------------------------------
+static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t rec_cap, uint32_t rows)
+{
+    mtr_ctx *c = s->ctx;
+    WfWorkspace &w = s->wf;
+    if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= rows && w.planes) return MTR_OK;
+    void **ptrs[] = { &w.planes, &w.q_live, &w.q_mat, &w.counts, &w.rec, &w.rec_count };
+    for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
+    HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
+    HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
+    HIP_TRY(c, hipMalloc(&w.counts, (size_t)rows * kWfRow * 4));
+    HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
+    HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
+    if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
+    w.n_slots = n_slots; w.P = P; w.rec_cap = rec_cap; w.rows = rows;
+    return MTR_OK;
+}
+
+static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4, const RenderConst &rc,
+                     float *trace_ms, float *scatter_ms, uint32_t *n_trace, uint32_t *n_scatter, bool timed)
+{
+    mtr_ctx *c = s->ctx;
+    const Film &f = s->film;
+    WfConfig cfg{};
+    if (!wf_plan(s->dev, cfg)) return fail(c, MTR_ERR_UNSUPPORTED, "wavefront: BVH too deep for the LDS stack");
+    const uint32_t n_pixels = p->pixel_end - p->pixel_begin;
+    const uint32_t spp_chunk = p->spp_end - p->spp_begin;
+    // tile = P pixels x S samples, about 2^20 slots
+    const uint32_t kTileSlots = 1u << 20;
+    uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
+    uint32_t P = kTileSlots / S; if (P < 1) P = 1; if (P > n_pixels) P = n_pixels;
+    const uint32_t n_slots_max = P * S;
+    // time-bin records: per-pixel lists sized for 4 contributions per path; the rest (and rows that do not
+    // fit LDS) fall back to f32 atomics on the film
+    const bool rows_fit = (size_t)f.bins * 12u <= 150u * 1024u;
+    const uint32_t rec_cap = rows_fit ? S * 4u : 0u;
+    const bool bounded = p->max_depth >= 0 && p->max_depth <= 256;
+    const uint32_t chunk = bounded ? std::max(1u, (uint32_t)p->max_depth) : 64u;       // bounces between live-count checks
+    const uint32_t rows = chunk + 2;
+    int rc_ = wf_alloc(s, n_slots_max, P, rec_cap, rows);
+    if (rc_) return rc_;
+    WfWorkspace &w = s->wf;
+
+    WfArgs a{};
+    a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
+    a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_mat = (uint32_t *)w.q_mat;
+    a.counts = (uint32_t *)w.counts; a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
+    a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
+    const int grid_full = c->n_cu * 8;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) { HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1)); }
+    float acc_scatter = 0.0f;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
+
+    for (uint32_t s0 = 0; s0 < spp_chunk; s0 += S) {
+        const uint32_t Scur = std::min(S, spp_chunk - s0);
+        for (uint32_t pix = 0; pix < n_pixels; pix += P) {
+            const uint32_t Pcur = std::min(P, n_pixels - pix);
+            a.pix0 = p->pixel_begin + pix; a.P = Pcur; a.spp_begin = p->spp_begin + s0; a.S = Scur;
+            a.n_slots = Pcur * Scur;
+            const int grid = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
+            HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
+            a.depth_row = 0;
+            HIP_TRY(c, launch_wf(a, cfg, 0, grid, c->stream));                       // raygen
+            uint32_t live = a.n_slots, depth = 0;
+            // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
+            const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth);
+            while (live > 0 && depth < max_depth) {
+                // counts rows for this chunk: row 0 = live count of the first bounce of the chunk
+                HIP_TRY(c, hipMemsetAsync(w.counts, 0, (size_t)rows * kWfRow * 4, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(w.counts, &live, 4, hipMemcpyHostToDevice, c->stream));
+                const uint32_t n_b = std::min(chunk, max_depth - depth);
+                // the ping-pong parity of the live queues follows depth_row; a chunk starts at an even row, so
+                // the queue written last by the previous chunk must sit in slot (0): chunk length is even or
+                // the data was just produced by raygen (slot 0).
+                for (uint32_t b = 0; b < n_b; ++b) {
+                    a.depth_row = b;
+                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));               // closest hit + material queues
+                    HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));               // shade + compaction
+                    *n_trace += 2;
+                }
+                depth += n_b;
+                if (depth >= max_depth) break;
+                // unbounded depth: read the live count back (pinned) and, if paths remain, continue
+                HIP_TRY(c, hipMemcpyAsync(w.host_count, (uint32_t *)w.counts + (size_t)n_b * kWfRow, 4,
+                                          hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                live = *w.host_count;
+                if (live && (n_b & 1u)) {           // odd chunk: move the live queue back to parity 0
+                    HIP_TRY(c, hipMemcpyAsync(w.q_live, (uint32_t *)w.q_live + a.n_slots, (size_t)live * 4,
+                                              hipMemcpyDeviceToDevice, c->stream));
+                }
+            }
+            if (timed) {
+                hipEvent_t a0, a1;
+                HIP_TRY(c, hipEventCreate(&a0)); HIP_TRY(c, hipEventCreate(&a1));
+                HIP_TRY(c, hipEventRecord(a0, c->stream));
+                HIP_TRY(c, launch_wf(a, cfg, 3, (int)std::min<uint32_t>(Pcur, (uint32_t)grid_full), c->stream));
+                HIP_TRY(c, hipEventRecord(a1, c->stream));
+                scatter_ev.push_back({ a0, a1 });
+            } else {
+                HIP_TRY(c, launch_wf(a, cfg, 3, (int)std::min<uint32_t>(Pcur, (uint32_t)grid_full), c->stream));
+            }
+            *n_scatter += 1;
+        }
+    }
+    if (timed) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (auto &pr : scatter_ev) {
+            float ms = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+            acc_scatter += ms;
+            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    *scatter_ms = acc_scatter; (void)trace_ms;
+    return MTR_OK;
+}
+
+extern "C" {
 
 int mtr_film_clear(mtr_ctx *c, const mtr_film_desc *f, float *t4, float *s4)
 {
@@ -217,15 +354,20 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     if (s->log.count) HIP_TRY(c, hipMemsetAsync(s->log.count, 0, sizeof(unsigned long long), c->stream));
     if (times_out) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    uint32_t launches = 0;
+    uint32_t launches = 0, scatter_launches = 0;
+    float scatter_ms = 0.0f;
     if (n_pixels && a.spp_chunk) {
-        if (p->mode == MTR_MODE_WAVEFRONT)
-            return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: MTR_MODE_WAVEFRONT is not built in this revision");
-        FusedConfig cfg{};
-        if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, a, cfg))
-            return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
-        HIP_TRY(c, launch_fused(a, cfg, c->stream));
-        launches = 1;
+        if (p->mode == MTR_MODE_WAVEFRONT) {
+            float tr_ms = 0.0f;
+            int r = wf_render(s, p, t4, s4, a.rc, &tr_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr);
+            if (r) return r;
+        } else {
+            FusedConfig cfg{};
+            if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, a, cfg))
+                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
+            HIP_TRY(c, launch_fused(a, cfg, c->stream));
+            launches = 1;
+        }
     }
     if (times_out) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (want_stats) {
@@ -243,7 +385,8 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             memset(times_out, 0, sizeof *times_out);
             float ms = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            times_out->total_ms = ms; times_out->trace_ms = ms; times_out->trace_launches = launches;
+            times_out->total_ms = ms; times_out->trace_ms = ms - scatter_ms; times_out->scatter_ms = scatter_ms;
+            times_out->trace_launches = launches; times_out->scatter_launches = scatter_launches;
         }
     }
     return MTR_OK;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
+#include <cstdlib>
 
 namespace mtr {
 namespace {
@@ -33,7 +34,7 @@ struct Builder {
     std::vector<Tmp> tmp;
 
     static constexpr int kBins = 16;
-    static constexpr uint32_t kLeafTarget = 2, kLeafMax = 4;
+    uint32_t kLeafTarget = 2, kLeafMax = 4;
 
     int build(uint32_t first, uint32_t count)
     {
@@ -121,6 +122,7 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
     out.nodes.clear(); out.order.clear(); out.max_depth = 0; out.n_leaves = 0;
     if (n == 0) return;
     Builder B; B.verts = verts;
+    if (const char *e = getenv("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         Box b; b.reset();

@@ -44,6 +44,37 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
                 FusedArgs &args, FusedConfig &cfg);
 hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream);
 
+// ---- MTR_MODE_WAVEFRONT (mtr_wavefront.hip) ---------------------------------------------------
+constexpr uint32_t kWfKeys = 5;        // material-type queues: diffuse, conductor, dielectric, none, miss
+constexpr uint32_t kWfRow = 8;         // u32 per bounce in `counts`: [0] live count, [1..5] queue counts
+
+struct WfArgs {
+    SceneDev sc;
+    Camera cam;
+    Film film;
+    RenderConst rc;
+    uint32_t pix0, P;                    // tile: crop-window pixels [pix0, pix0 + P)
+    uint32_t spp_begin, S;               // samples [spp_begin, spp_begin + S) of every pixel of the tile
+    uint32_t n_slots;                    // P * S
+    uint32_t depth_row;                  // row of `counts` this launch reads (bounce index within the chunk)
+    float *planes;                       // SoA state, PL_COUNT planes of n_slots
+    uint32_t *q_live;                    // [2][n_slots] ping-pong live queues (slot indices)
+    uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit queues
+    uint32_t *counts;                    // [rows][kWfRow]
+    uint4 *rec;                          // [P][rec_cap] time-bin records (bin, r, g, b)
+    uint32_t *rec_count;                 // [P]
+    uint32_t rec_cap;                    // 0: rows do not fit LDS -> contributions go straight to HBM atomics
+    float *film_out, *steady_out;
+    DevCounters *counters;
+    SplatLog log;
+};
+struct WfConfig { int stack; bool scene_lds; size_t lds_bytes; };
+
+size_t wf_planes_bytes(uint32_t n_slots);
+bool wf_plan(const SceneDev &sc, WfConfig &cfg);
+// which: 0 raygen, 1 trace (closest hit + material-sorted queues), 2 shade, 3 time-bin scatter-add
+hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream);
+
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
                             DevCounters *counters, hipStream_t stream);
 hipError_t launch_develop(const Film &film, const float *t4, float *t3, const float *s4, float *s3, hipStream_t stream);

@@ -1,0 +1,448 @@
+// mtr_wavefront.hip — MTR_MODE_WAVEFRONT: per-bounce kernels over SoA path queues in HBM.
+//
+// One tile = P pixels x S samples = n_slots lanes; a path keeps its SLOT for life (slot = local
+// pixel * S + local sample, so slots are pixel-major and the RNG/lane identity is a pure function
+// of the slot).  State lives in SoA planes of n_slots elements (coalesced 4-byte-per-lane accesses);
+// the queues hold slot indices.
+//
+//   k_wf_raygen   slot -> PCG32 stream, jitter, camera ray, loop-state init       (writes all planes)
+//   per bounce:
+//   k_wf_trace    live queue -> BVH2 closest hit (node packets staged in LDS)     ray planes -> hit planes
+//                 + append of the slot to the queue of its hit MATERIAL TYPE (diffuse / conductor /
+//                 dielectric / none / miss): wave64 ballot + popcount + one atomic per (wave, type)
+//   k_wf_shade    material-sorted queues -> shade_hit, shadow ray (inline any-hit traversal),
+//                 shade_finish; time-bin contributions are appended as 16-byte records to the
+//                 per-pixel lists; survivors are compacted into the next live queue
+//                 (ballot / prefix popcount / one atomic per wave)
+//   k_wf_scatter  the time-bin scatter-add: one workgroup per pixel streams that pixel's records
+//                 (coalesced 16 B/lane) into an LDS row histogram and adds the row to the
+//                 (H,W,T,4) film once; also reduces the pixel's radiance samples into the steady image.
+#include "mtr_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace mtr {
+
+namespace {
+
+template <int DEPTH>
+struct WStack {
+    int32_t *base; int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ void push_if(bool c, int32_t v) { base[sp * kBlock] = v; sp += c ? 1 : 0; }
+    __device__ __forceinline__ int32_t pop() { --sp; return base[sp * kBlock]; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+    __device__ __forceinline__ void prof_mark(int) {}
+    __device__ __forceinline__ void count(int) {}
+};
+
+__host__ __device__ constexpr uint32_t al16(uint32_t x) { return (x + 15u) & ~15u; }
+
+__device__ __forceinline__ void cp16(void *dst, const void *src, uint32_t bytes, int tid)
+{
+    const uint4 *s = (const uint4 *)src; uint4 *d = (uint4 *)dst;
+    for (uint32_t i = tid; i < bytes / 16u; i += kBlock) d[i] = s[i];
+}
+
+// stage the scene in LDS (or point at HBM) and carve the traversal stack
+template <int STACK, bool SCENE_LDS>
+__device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem, int tid, SceneView &sv, WStack<STACK> &st,
+                                         uint32_t &off)
+{
+    off = 0;
+    int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
+    sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    if (SCENE_LDS) {
+        Node *n = (Node *)(smem + off); off += al16(sc.n_nodes * sizeof(Node));
+        TriGeom *tg = (TriGeom *)(smem + off); off += al16(sc.n_tris * sizeof(TriGeom));
+        TriShade *ts = (TriShade *)(smem + off); off += al16(sc.n_tris * sizeof(TriShade));
+        mtr_material *mm = (mtr_material *)(smem + off); off += al16(sc.n_mats * sizeof(mtr_material));
+        Emitter *ee = (Emitter *)(smem + off); off += al16(sc.n_ems * sizeof(Emitter));
+        cp16(n, sc.nodes, al16(sc.n_nodes * sizeof(Node)), tid);
+        cp16(tg, sc.tgeom, al16(sc.n_tris * sizeof(TriGeom)), tid);
+        cp16(ts, sc.tshade, al16(sc.n_tris * sizeof(TriShade)), tid);
+        cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
+        cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
+        sv.nodes = n; sv.tgeom = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        __syncthreads();
+    } else {
+        sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+    }
+    st.base = s_stack + tid; st.sp = 0;
+}
+
+// ---- SoA plane accessors ------------------------------------------------------------------
+enum Plane {
+    PL_OX = 0, PL_OY, PL_OZ, PL_DX, PL_DY, PL_DZ, PL_TMAX,
+    PL_BX, PL_BY, PL_BZ, PL_LX, PL_LY, PL_LZ, PL_PX, PL_PY, PL_PZ,
+    PL_ETA, PL_DIST, PL_PPDF, PL_FLAGS, PL_RS_LO, PL_RS_HI, PL_RI_LO, PL_RI_HI,
+    PL_HT, PL_HU, PL_HV, PL_HPRIM,
+    PL_COUNT
+};
+
+struct Planes {
+    float *base; uint32_t n;
+    __device__ __forceinline__ float &f(int pl, uint32_t slot) const { return base[(size_t)pl * n + slot]; }
+    __device__ __forceinline__ uint32_t &u(int pl, uint32_t slot) const { return ((uint32_t *)base)[(size_t)pl * n + slot]; }
+};
+
+__device__ __forceinline__ void store_ray(const Planes &P, uint32_t s, const Ray &r)
+{
+    P.f(PL_OX, s) = r.o.x; P.f(PL_OY, s) = r.o.y; P.f(PL_OZ, s) = r.o.z;
+    P.f(PL_DX, s) = r.d.x; P.f(PL_DY, s) = r.d.y; P.f(PL_DZ, s) = r.d.z; P.f(PL_TMAX, s) = r.tmax;
+}
+__device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s)
+{
+    Ray r;
+    r.o = mk(P.f(PL_OX, s), P.f(PL_OY, s), P.f(PL_OZ, s));
+    r.d = mk(P.f(PL_DX, s), P.f(PL_DY, s), P.f(PL_DZ, s)); r.tmax = P.f(PL_TMAX, s);
+    return r;
+}
+__device__ __forceinline__ void store_path(const Planes &P, uint32_t s, const Path &p)
+{
+    P.f(PL_BX, s) = p.beta.x; P.f(PL_BY, s) = p.beta.y; P.f(PL_BZ, s) = p.beta.z;
+    P.f(PL_LX, s) = p.L.x; P.f(PL_LY, s) = p.L.y; P.f(PL_LZ, s) = p.L.z;
+    P.f(PL_PX, s) = p.prev_p.x; P.f(PL_PY, s) = p.prev_p.y; P.f(PL_PZ, s) = p.prev_p.z;
+    P.f(PL_ETA, s) = p.eta; P.f(PL_DIST, s) = p.dist; P.f(PL_PPDF, s) = p.prev_pdf;
+    P.u(PL_FLAGS, s) = p.depth | (p.prev_delta << 31);
+    P.u(PL_RS_LO, s) = (uint32_t)p.rng.state; P.u(PL_RS_HI, s) = (uint32_t)(p.rng.state >> 32);
+}
+__device__ __forceinline__ void load_path(const Planes &P, uint32_t s, Path &p)
+{
+    p.beta = mk(P.f(PL_BX, s), P.f(PL_BY, s), P.f(PL_BZ, s));
+    p.L = mk(P.f(PL_LX, s), P.f(PL_LY, s), P.f(PL_LZ, s));
+    p.prev_p = mk(P.f(PL_PX, s), P.f(PL_PY, s), P.f(PL_PZ, s));
+    p.eta = P.f(PL_ETA, s); p.dist = P.f(PL_DIST, s); p.prev_pdf = P.f(PL_PPDF, s);
+    uint32_t fl = P.u(PL_FLAGS, s);
+    p.depth = fl & 0x7fffffffu; p.prev_delta = fl >> 31;
+    p.rng.state = (uint64_t)P.u(PL_RS_LO, s) | ((uint64_t)P.u(PL_RS_HI, s) << 32);
+    p.rng.inc = (uint64_t)P.u(PL_RI_LO, s) | ((uint64_t)P.u(PL_RI_HI, s) << 32);
+}
+
+// slot -> (pixel, sample) of the tile
+__device__ __forceinline__ void slot_to_lane(const WfArgs &a, uint32_t slot, uint32_t &pixel, uint32_t &s, uint32_t &p_local)
+{
+    p_local = slot / a.S;
+    s = a.spp_begin + (slot - p_local * a.S);
+    pixel = a.pix0 + p_local;
+}
+
+// ---- wave64 aggregated append: one atomic per (wave, key) ---------------------------------
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader);
+    return base + rank;
+}
+
+// time-bin contribution -> 16-byte record appended to its pixel's list; list full -> f32 atomics to HBM
+struct RecordSink {
+    uint4 *rec; uint32_t *rec_count; uint32_t rec_cap;
+    float *film; uint32_t film_w, bins;
+    uint32_t p_local, lane;
+    uint32_t n_splats, n_overflow;
+    SplatLog log;
+    __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
+                                          float opl, uint32_t depth, uint32_t kind)
+    {
+        // lanes of a wave that splat together mostly share 1..3 pixels: one atomic per distinct pixel
+        unsigned long long todo = __ballot(1);
+        const uint32_t lane_id = threadIdx.x & 63u;
+        uint32_t idx = 0;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t px = __shfl(p_local, leader);
+            const unsigned long long same = __ballot(p_local == px) & todo;
+            if (p_local == px) {
+                const uint32_t n = (uint32_t)__popcll(same);
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane_id) - 1ull));
+                uint32_t base = 0;
+                if ((int)lane_id == leader) base = atomicAdd(rec_count + px, n);
+                base = __shfl(base, leader);
+                idx = base + rank;
+            }
+            todo &= ~same;
+        }
+        ++n_splats;
+        if (idx < rec_cap) {
+            rec[(size_t)p_local * rec_cap + idx] = make_uint4(bin, __float_as_uint(r), __float_as_uint(g), __float_as_uint(b));
+        } else {
+            ++n_overflow;
+            size_t o = (((size_t)fy * film_w + fx) * bins + bin) * 4u;
+            unsafeAtomicAdd(film + o, r); unsafeAtomicAdd(film + o + 1, g); unsafeAtomicAdd(film + o + 2, b);
+        }
+        if (log.rec) {
+            unsigned long long i = atomicAdd(log.count, 1ull);
+            if (i < log.cap) {
+                uint32_t *R = log.rec + 8 * i;
+                R[0] = lane; R[1] = depth | (kind << 16); R[2] = fy * film_w + fx; R[3] = bin;
+                R[4] = __float_as_uint(r); R[5] = __float_as_uint(g); R[6] = __float_as_uint(b); R[7] = __float_as_uint(opl);
+            }
+        }
+    }
+};
+
+struct NullSink {
+    __device__ __forceinline__ void splat(uint32_t, uint32_t, uint32_t, float, float, float, float, uint32_t, uint32_t) {}
+};
+
+// ---- kernels ---------------------------------------------------------------------------------
+template <int STACK, bool SCENE_LDS>
+__global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    SceneView sv; WStack<STACK> st; uint32_t off;
+    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    const Planes P{ a.planes, a.n_slots };
+    uint32_t n_closest = 0;
+    for (uint32_t slot = blockIdx.x * kBlock + tid; slot < a.n_slots; slot += gridDim.x * kBlock) {
+        uint32_t pixel, s, pl;
+        slot_to_lane(a, slot, pixel, s, pl);
+        Path p;
+        path_begin(p, a.cam, a.film, a.rc, pixel, s);
+        if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {              // transientpath.py:133-138
+            Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
+            ++n_closest;
+            if (h0.prim >= 0) p.dist = -h0.t;
+        }
+        store_ray(P, slot, p.ray);
+        store_path(P, slot, p);
+        P.u(PL_RI_LO, slot) = (uint32_t)p.rng.inc; P.u(PL_RI_HI, slot) = (uint32_t)(p.rng.inc >> 32);
+        a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
+    }
+    if (a.counters) {
+        if (n_closest) atomicAdd(&a.counters->rays_closest, (unsigned long long)n_closest);
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&a.counters->paths, (unsigned long long)a.n_slots);
+    }
+}
+
+// closest hit for the live queue of bounce `a.depth_row`; appends each slot to its material-type queue
+template <int STACK, bool SCENE_LDS>
+__global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const uint32_t *row = a.counts + (size_t)a.depth_row * kWfRow;
+    const uint32_t n_live = row[0];
+    if (blockIdx.x * kBlock >= n_live) return;
+    SceneView sv; WStack<STACK> st; uint32_t off;
+    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    const Planes P{ a.planes, a.n_slots };
+    uint32_t *bucket_cnt = a.counts + (size_t)a.depth_row * kWfRow + 1;
+    const uint32_t *q = a.q_live + (size_t)(a.depth_row & 1u) * a.n_slots;
+    const uint32_t n_round = (n_live + kBlock - 1) / kBlock * kBlock;      // keep whole waves in the loop (ballots)
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n_round; i += gridDim.x * kBlock) {
+        const bool on = i < n_live;
+        uint32_t slot = 0, key = kWfKeys;          // kWfKeys = "no lane"
+        if (on) {
+            slot = q[i];
+            const Ray r = load_ray(P, slot);
+            const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
+            P.f(PL_HT, slot) = h.t; P.f(PL_HU, slot) = h.u; P.f(PL_HV, slot) = h.v; P.u(PL_HPRIM, slot) = (uint32_t)h.prim;
+            key = 4u;                               // miss
+            if (h.prim >= 0) {
+                const uint32_t mat_em = fbits(sv.tgeom[h.prim].g[2].z);
+                key = sv.mats[mat_em & 0xffffu].type;              // 0 diffuse, 1 conductor, 2 dielectric, 3 none
+            }
+        }
+        // sorted-by-material hit queues: bucketed append, one atomic per (wave, material type present)
+#pragma unroll
+        for (uint32_t k = 0; k < kWfKeys; ++k) {
+            const bool mine = on & (key == k);
+            if (__ballot(mine) != 0ull) {
+                const uint32_t pos = wave_append(bucket_cnt + k, mine);
+                if (mine) a.q_mat[(size_t)k * a.n_slots + pos] = slot;
+            }
+        }
+    }
+}
+
+// shade the material-sorted queues of bounce `a.depth_row`
+template <int STACK, bool SCENE_LDS>
+__global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const uint32_t *row = a.counts + (size_t)a.depth_row * kWfRow;
+    uint32_t pre[kWfKeys + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kWfKeys; ++k) pre[k + 1] = pre[k] + row[1 + k];
+    const uint32_t total = pre[kWfKeys];
+    if (blockIdx.x * kBlock >= total) return;
+    SceneView sv; WStack<STACK> st; uint32_t off;
+    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    const Planes P{ a.planes, a.n_slots };
+    uint32_t *next_cnt = a.counts + (size_t)(a.depth_row + 1) * kWfRow;
+    uint32_t *q_next = a.q_live + (size_t)((a.depth_row + 1) & 1u) * a.n_slots;
+    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0;
+    const uint32_t n_round = (total + kBlock - 1) / kBlock * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n_round; i += gridDim.x * kBlock) {
+        const bool on = i < total;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (on) {
+            uint32_t k = 0;
+#pragma unroll
+            for (uint32_t kk = 1; kk < kWfKeys; ++kk) k += (i >= pre[kk]) ? 1u : 0u;
+            slot = a.q_mat[(size_t)k * a.n_slots + (i - pre[k])];
+            uint32_t pixel, s, pl;
+            slot_to_lane(a, slot, pixel, s, pl);
+            Path p;
+            load_path(P, slot, p);
+            p.ray = load_ray(P, slot);
+            const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+            p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+            Hit h;
+            h.t = P.f(PL_HT, slot); h.u = P.f(PL_HU, slot); h.v = P.f(PL_HV, slot); h.prim = (int32_t)P.u(PL_HPRIM, slot);
+            ++n_closest;
+            RecordSink sink;
+            sink.rec = a.rec; sink.rec_count = a.rec_count; sink.rec_cap = a.rec_cap;
+            sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
+            sink.p_local = pl; sink.lane = p.lane; sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
+            Pending pd; Ray shadow;
+            shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
+            shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
+            bool occluded = false;
+            if (pd.has_shadow) {
+                ++n_shadow;
+                Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                occluded = sh.prim >= 0;
+            }
+            alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
+            ++n_bounce;
+            n_splats += sink.n_splats; n_over += sink.n_overflow;
+            store_path(P, slot, p);
+            if (alive) store_ray(P, slot, p.ray);
+        }
+        // wave64 stream compaction of the survivors into the next live queue
+        if (__ballot(alive) != 0ull) {
+            const uint32_t pos = wave_append(next_cnt, alive);
+            if (alive) q_next[pos] = slot;
+        }
+    }
+    // counters: one set of atomics per wave
+    if (a.counters) {
+        const unsigned vals[5] = { n_closest, n_shadow, n_splats, n_bounce, n_over };
+        unsigned long long *dst[5] = { &a.counters->rays_closest, &a.counters->rays_shadow, &a.counters->splats_issued,
+                                       &a.counters->bounces, &a.counters->splats_overflow };
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            unsigned v = vals[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if ((tid & 63) == 0 && v) atomicAdd(dst[k], (unsigned long long)v);
+        }
+    }
+}
+
+// the time-bin scatter-add + steady reduction: one workgroup per pixel of the tile
+__global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = (float *)smem;                         // [3][T]
+    __shared__ float s_red[4][4];
+    const uint32_t T = a.film.bins;
+    const int tid = threadIdx.x;
+    const bool rows = a.rec_cap > 0;                    // false: T*12 B does not fit LDS, shade used HBM atomics
+    if (rows) for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+    __syncthreads();
+    const Planes P{ a.planes, a.n_slots };
+    for (uint32_t pl = blockIdx.x; pl < a.P; pl += gridDim.x) {
+        const uint32_t pixel = a.pix0 + pl;
+        const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;    // film coords (crop offset removed)
+        const bool in_film = (cx < a.film.width) & (cy < a.film.height);
+        const size_t fpix = (size_t)cy * a.film.width + cx;
+        const uint32_t n = rows ? min(a.rec_count[pl], a.rec_cap) : 0u;
+        const uint4 *rec = a.rec + (size_t)pl * a.rec_cap;
+        for (uint32_t i = tid; i < n; i += kBlock) {          // coalesced 16 B / lane
+            const uint4 r = rec[i];
+            float *p = row + r.x;
+            __hip_atomic_fetch_add(p, __uint_as_float(r.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(p + T, __uint_as_float(r.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // steady: sum of the pixel's S radiance samples (planes L), weight = S   (common.py:187-206)
+        float lx = 0.0f, ly = 0.0f, lz = 0.0f;
+        for (uint32_t s = tid; s < a.S; s += kBlock) {
+            const uint32_t slot = pl * a.S + s;
+            lx += P.f(PL_LX, slot); ly += P.f(PL_LY, slot); lz += P.f(PL_LZ, slot);
+        }
+        for (int o = 32; o > 0; o >>= 1) { lx += __shfl_down(lx, o); ly += __shfl_down(ly, o); lz += __shfl_down(lz, o); }
+        if ((tid & 63) == 0) { s_red[tid >> 6][0] = lx; s_red[tid >> 6][1] = ly; s_red[tid >> 6][2] = lz; }
+        __syncthreads();
+        if (in_film) {
+            float4 *dst = (float4 *)(a.film_out + fpix * T * 4u);
+            for (uint32_t t = tid; rows && t < T; t += kBlock) {
+                float r = row[t], g = row[T + t], b = row[2 * T + t];
+                if (r != 0.0f || g != 0.0f || b != 0.0f) {
+                    float4 v = dst[t];
+                    v.x += r; v.y += g; v.z += b;
+                    dst[t] = v;
+                    row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f;
+                }
+            }
+            if (tid < 3) a.steady_out[fpix * 4u + tid] += (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+            if (tid == 3) a.steady_out[fpix * 4u + 3] += (float)a.S;
+        } else if (rows) {
+            for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+template <int STACK, bool SL>
+hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
+{
+    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+size_t wf_planes_bytes(uint32_t n_slots) { return (size_t)PL_COUNT * n_slots * 4u; }
+
+bool wf_plan(const SceneDev &sc, WfConfig &cfg)
+{
+    if (sc.bvh_depth > 64) return false;
+    cfg.stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
+    uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_tris * sizeof(TriGeom)) + al16(sc.n_tris * sizeof(TriShade)) +
+                       al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
+    cfg.scene_lds = scene_b <= 64u * 1024u;
+    cfg.lds_bytes = (size_t)(cfg.stack + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
+    return true;
+}
+
+// which: 0 raygen, 1 trace, 2 shade, 3 scatter
+hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
+{
+    if (which == 3) {
+        size_t lds = a.rec_cap ? (size_t)a.film.bins * 12u : 16u;
+        hipError_t e = hipFuncSetAttribute((const void *)k_wf_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_wf_scatter, dim3(grid), dim3(kBlock), lds, stream, a);
+        return hipGetLastError();
+    }
+#define WF_CASE(S)                                                                             \
+    case S: return cfg.scene_lds ? launch_set<S, true>(a, which, grid, cfg.lds_bytes, stream) \
+                                 : launch_set<S, false>(a, which, grid, cfg.lds_bytes, stream);
+    switch (cfg.stack) {
+        WF_CASE(8) WF_CASE(16) WF_CASE(32)
+    default: return cfg.scene_lds ? launch_set<64, true>(a, which, grid, cfg.lds_bytes, stream)
+                                  : launch_set<64, false>(a, which, grid, cfg.lds_bytes, stream);
+    }
+#undef WF_CASE
+}
+
+} // namespace mtr

@@ -48,9 +48,13 @@ def test_library_is_native_and_loaded():
         assert "libmitransient_amd.so" in fh.read()
 
 
-def test_config1_matches_oracle(oracle):
-    """BASELINE config 1: Cornell 64x64, 64 bins, 16 spp."""
-    scene = make_cornell()
+MODES = ["fused", "wavefront"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_matches_oracle(oracle, mode):
+    """BASELINE config 1: Cornell 64x64, 64 bins, 16 spp — both kernel organisations."""
+    scene = make_cornell(amd_mode=mode)
     s_gpu, t_gpu, s_raw, t_raw = gpu_render(scene, 16, raw=True)
     s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16)
     assert t_gpu.shape == (64, 64, 64, 3) and s_gpu.shape == (64, 64, 3)
@@ -72,11 +76,12 @@ def test_seeds(oracle, seed):
     assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
 
 
-def test_splat_log_matches_oracle(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_splat_log_matches_oracle(oracle, mode):
     """splat-for-splat equality: same (lane, depth, kind, pixel, bin) multiset, same values bit for bit."""
     import torch
     from mitransient_amd.runtime import get_context
-    scene = make_cornell(width=16, height=16, bins=64)
+    scene = make_cornell(width=16, height=16, bins=64, amd_mode=mode)
     integ = scene.integrator()
     film = scene.sensors()[0].film()
     passes = integ.prepare(scene, scene.sensors()[0], 0, 4, [])
@@ -106,17 +111,19 @@ def test_splat_log_matches_oracle(oracle):
         assert np.array_equal(g[k].view(np.uint32), olog[k].view(np.uint32)), k
 
 
-def test_camera_unwarp_and_discard_direct(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_camera_unwarp_and_discard_direct(oracle, mode):
     scene = make_cornell(width=32, height=32, bins=64, start=0.0, window=8.0, camera_unwarp=True,
-                         discard_direct_light=True)
+                         discard_direct_light=True, amd_mode=mode)
     s_gpu, t_gpu = gpu_render(scene, 8)
     s_ref, t_ref, *_ = oracle_render(oracle, scene, 8)
     assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
 
 
-@pytest.mark.parametrize("max_depth,rr_depth", [(1, 5), (2, 5), (3, 1), (12, 2), (-1, 3)])
-def test_depths(oracle, max_depth, rr_depth):
-    scene = make_cornell(width=24, height=24, bins=64, max_depth=max_depth, rr_depth=rr_depth)
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("max_depth,rr_depth", [(0, 5), (1, 5), (2, 5), (3, 1), (12, 2), (-1, 3)])
+def test_depths(oracle, max_depth, rr_depth, mode):
+    scene = make_cornell(width=24, height=24, bins=64, max_depth=max_depth, rr_depth=rr_depth, amd_mode=mode)
     s_gpu, t_gpu = gpu_render(scene, 8)
     s_ref, t_ref, *_ = oracle_render(oracle, scene, 8)
     if np.linalg.norm(t_ref) == 0:
@@ -126,11 +133,13 @@ def test_depths(oracle, max_depth, rr_depth):
     assert rel_l2(s_gpu, s_ref) <= TOL or np.linalg.norm(s_ref) == 0
 
 
-def test_ragged_sizes_and_crop(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_ragged_sizes_and_crop(oracle, mode):
     """non-square film, spp not a power of two, T not a multiple of the block, crop window."""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     d = mitr.cornell_box()
+    d["integrator"]["amd_mode"] = mode
     d["sensor"]["film"].update(width=40, height=24, temporal_bins=100, start_opl=3.0, bin_width_opl=0.07,
                                crop_width=17, crop_height=9, crop_offset_x=5, crop_offset_y=3)
     scene = mi.load_dict(d)
@@ -142,10 +151,11 @@ def test_ragged_sizes_and_crop(oracle):
     assert np.all(t_gpu[9:] == 0) and np.all(t_gpu[:, 17:] == 0)
 
 
-def test_sample_and_pixel_shards_sum_to_whole(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_sample_and_pixel_shards_sum_to_whole(oracle, mode):
     """lane identity == RNG identity: sample slices / pixel slices reproduce the full render (multi-GPU basis)."""
     import torch
-    scene = make_cornell(width=32, height=32, bins=64)
+    scene = make_cornell(width=32, height=32, bins=64, amd_mode=mode)
     s_full, t_full = gpu_render(scene, 12)
     integ = scene.integrator()
     sens = scene.sensors()[0]
@@ -164,11 +174,14 @@ def test_sample_and_pixel_shards_sum_to_whole(oracle):
     assert rel_l2(np.array(t_b), t_ref) <= TOL
 
 
-def test_specular_materials(oracle):
-    """conductor + dielectric + twosided boxes (the BSDF subset of the north star)."""
+@pytest.mark.parametrize("mode", MODES)
+def test_specular_materials(oracle, mode):
+    """conductor + dielectric + twosided boxes (the BSDF subset of the north star); in wavefront mode the
+    hit queues are sorted by material type (diffuse / conductor / dielectric)."""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     d = mitr.cornell_box()
+    d["integrator"]["amd_mode"] = mode
     d["sensor"]["film"].update(width=32, height=32, temporal_bins=128, start_opl=3.0, bin_width_opl=8.0 / 128)
     d["mirror"] = {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
     d["glass"] = {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}
@@ -286,3 +299,20 @@ def test_errors_fail_loudly():
     scene = mi.load_dict(d)
     with pytest.raises(Exception):
         mi.render(scene, spp=1024)            # 2^34 lanes > 2^32 (common.py:51)
+
+
+def test_wavefront_large_tile_and_overflow(oracle):
+    """wavefront mode across several tiles (> 2^20 slots) and with time rows that do not fit LDS
+    (T = 16384: every contribution takes the global-atomic path)."""
+    scene = make_cornell(width=48, height=48, bins=64, amd_mode="wavefront")
+    s_gpu, t_gpu = gpu_render(scene, 600)                       # 1.38 M slots -> 2 tiles, ragged second tile
+    s_ref, t_ref, *_ = oracle_render(oracle, scene, 600)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    scene = make_cornell(width=8, height=8, bins=16384, amd_mode="wavefront")
+    s_gpu, t_gpu = gpu_render(scene, 32)
+    s_ref, t_ref, *_ = oracle_render(oracle, scene, 32)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    assert scene.integrator().last_counters["splats_overflow"] > 0
+    scene = make_cornell(width=8, height=8, bins=16384, amd_mode="fused")      # fused: row > LDS budget -> HBM atomics
+    s_gpu, t_gpu = gpu_render(scene, 32)
+    assert rel_l2(t_gpu, t_ref) <= TOL
