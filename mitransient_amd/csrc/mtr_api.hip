@@ -191,21 +191,21 @@ int mtr_scene_bvh_info(const mtr_scene *s, uint32_t *n_nodes, uint32_t *max_dept
 } // extern "C"
 
 // ---- MTR_MODE_WAVEFRONT: host loop over tiles and bounces ------------------------------------
-static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t rec_cap, uint32_t rows)
+static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, uint32_t rec_cap)
 {
     mtr_ctx *c = s->ctx;
     WfWorkspace &w = s->wf;
-    if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= rows && w.planes) return MTR_OK;
+    if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= n_seg && w.planes) return MTR_OK;
     void **ptrs[] = { &w.planes, &w.q_live, &w.q_mat, &w.counts, &w.rec, &w.rec_count };
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
-    HIP_TRY(c, hipMalloc(&w.counts, (size_t)rows * kWfRow * 4));
+    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (2 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], live_total
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
     if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
-    w.n_slots = n_slots; w.P = P; w.rec_cap = rec_cap; w.rows = rows;
+    w.n_slots = n_slots; w.P = P; w.rec_cap = rec_cap; w.rows = n_seg;
     return MTR_OK;
 }
 
@@ -218,31 +218,32 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     if (!wf_plan(s->dev, cfg)) return fail(c, MTR_ERR_UNSUPPORTED, "wavefront: BVH too deep for the LDS stack");
     const uint32_t n_pixels = p->pixel_end - p->pixel_begin;
     const uint32_t spp_chunk = p->spp_end - p->spp_begin;
-    // tile = P pixels x S samples, about 2^20 slots
-    const uint32_t kTileSlots = 1u << 20;
-    uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
-    uint32_t P = kTileSlots / S; if (P < 1) P = 1; if (P > n_pixels) P = n_pixels;
+    // tile = P pixels x S samples (about 2^22 slots); segment = G whole pixels (about 1024 slots)
+    const uint32_t kTileSlots = 1u << 22, kSegSlots = 1024u;
+    const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
+    const uint32_t G = (kSegSlots + S - 1) / S;
+    uint32_t P = kTileSlots / S; if (P < G) P = G; if (P > n_pixels) P = n_pixels;
     const uint32_t n_slots_max = P * S;
+    const uint32_t seg = G * S;
+    const uint32_t n_seg_max = (P + G - 1) / G;
     // time-bin records: per-pixel lists sized for 4 contributions per path; the rest (and rows that do not
     // fit LDS) fall back to f32 atomics on the film
     const bool rows_fit = (size_t)f.bins * 12u <= 150u * 1024u;
     const uint32_t rec_cap = rows_fit ? S * 4u : 0u;
-    const bool bounded = p->max_depth >= 0 && p->max_depth <= 256;
-    const uint32_t chunk = bounded ? std::max(1u, (uint32_t)p->max_depth) : 64u;       // bounces between live-count checks
-    const uint32_t rows = chunk + 2;
-    int rc_ = wf_alloc(s, n_slots_max, P, rec_cap, rows);
+    int rc_ = wf_alloc(s, n_slots_max, P, n_seg_max, rec_cap);
     if (rc_) return rc_;
     WfWorkspace &w = s->wf;
 
     WfArgs a{};
     a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
     a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_mat = (uint32_t *)w.q_mat;
-    a.counts = (uint32_t *)w.counts; a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
+    a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
+    a.G = G; a.seg = seg;
     const int grid_full = c->n_cu * 8;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) { HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1)); }
-    float acc_scatter = 0.0f;
+    const bool unbounded = p->max_depth < 0 || p->max_depth > 256;
+    // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
+    const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
 
     for (uint32_t s0 = 0; s0 < spp_chunk; s0 += S) {
@@ -251,52 +252,42 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             const uint32_t Pcur = std::min(P, n_pixels - pix);
             a.pix0 = p->pixel_begin + pix; a.P = Pcur; a.spp_begin = p->spp_begin + s0; a.S = Scur;
             a.n_slots = Pcur * Scur;
-            const int grid = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
+            a.seg = G * Scur;                                       // segments always cover whole pixels
+            a.n_seg = (Pcur + G - 1) / G;
+            a.seg_live = (uint32_t *)w.counts;
+            a.seg_mat = (uint32_t *)w.counts + (size_t)2 * a.n_seg;
+            uint32_t *live_total = (uint32_t *)w.counts + (size_t)(2 + kWfKeys) * a.n_seg;
+            a.live_total = unbounded ? live_total : nullptr;
+            const int grid = (int)std::min<uint32_t>(a.n_seg, (uint32_t)grid_full);
+            const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
             HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
-            a.depth_row = 0;
-            HIP_TRY(c, launch_wf(a, cfg, 0, grid, c->stream));                       // raygen
-            uint32_t live = a.n_slots, depth = 0;
-            // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
-            const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth);
-            while (live > 0 && depth < max_depth) {
-                // counts rows for this chunk: row 0 = live count of the first bounce of the chunk
-                HIP_TRY(c, hipMemsetAsync(w.counts, 0, (size_t)rows * kWfRow * 4, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(w.counts, &live, 4, hipMemcpyHostToDevice, c->stream));
-                const uint32_t n_b = std::min(chunk, max_depth - depth);
-                // the ping-pong parity of the live queues follows depth_row; a chunk starts at an even row, so
-                // the queue written last by the previous chunk must sit in slot (0): chunk length is even or
-                // the data was just produced by raygen (slot 0).
-                for (uint32_t b = 0; b < n_b; ++b) {
-                    a.depth_row = b;
-                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));               // closest hit + material queues
-                    HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));               // shade + compaction
-                    *n_trace += 2;
-                }
-                depth += n_b;
-                if (depth >= max_depth) break;
-                // unbounded depth: read the live count back (pinned) and, if paths remain, continue
-                HIP_TRY(c, hipMemcpyAsync(w.host_count, (uint32_t *)w.counts + (size_t)n_b * kWfRow, 4,
-                                          hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                live = *w.host_count;
-                if (live && (n_b & 1u)) {           // odd chunk: move the live queue back to parity 0
-                    HIP_TRY(c, hipMemcpyAsync(w.q_live, (uint32_t *)w.q_live + a.n_slots, (size_t)live * 4,
-                                              hipMemcpyDeviceToDevice, c->stream));
+            a.parity = 0;
+            HIP_TRY(c, launch_wf(a, cfg, 0, grid_gen, c->stream));                   // raygen (writes live list 0)
+            uint32_t depth = 0;
+            while (depth < max_depth) {
+                if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
+                HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));                   // closest hit + material lists
+                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));                   // shade + compaction
+                *n_trace += 2;
+                a.parity ^= 1u;
+                ++depth;
+                if (unbounded && (depth & 7u) == 0) {                                // every 8 bounces: anyone left?
+                    HIP_TRY(c, hipMemcpyAsync(w.host_count, live_total, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (*w.host_count == 0) break;
                 }
             }
+            hipEvent_t a0 = nullptr, a1 = nullptr;
             if (timed) {
-                hipEvent_t a0, a1;
                 HIP_TRY(c, hipEventCreate(&a0)); HIP_TRY(c, hipEventCreate(&a1));
                 HIP_TRY(c, hipEventRecord(a0, c->stream));
-                HIP_TRY(c, launch_wf(a, cfg, 3, (int)std::min<uint32_t>(Pcur, (uint32_t)grid_full), c->stream));
-                HIP_TRY(c, hipEventRecord(a1, c->stream));
-                scatter_ev.push_back({ a0, a1 });
-            } else {
-                HIP_TRY(c, launch_wf(a, cfg, 3, (int)std::min<uint32_t>(Pcur, (uint32_t)grid_full), c->stream));
             }
+            HIP_TRY(c, launch_wf(a, cfg, 3, (int)std::min<uint32_t>(Pcur, (uint32_t)grid_full), c->stream));
+            if (timed) { HIP_TRY(c, hipEventRecord(a1, c->stream)); scatter_ev.push_back({ a0, a1 }); }
             *n_scatter += 1;
         }
     }
+    float acc_scatter = 0.0f;
     if (timed) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (auto &pr : scatter_ev) {
@@ -305,7 +296,6 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             acc_scatter += ms;
             (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
         }
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     *scatter_ms = acc_scatter; (void)trace_ms;
     return MTR_OK;

@@ -46,7 +46,6 @@ hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream
 
 // ---- MTR_MODE_WAVEFRONT (mtr_wavefront.hip) ---------------------------------------------------
 constexpr uint32_t kWfKeys = 5;        // material-type queues: diffuse, conductor, dielectric, none, miss
-constexpr uint32_t kWfRow = 8;         // u32 per bounce in `counts`: [0] live count, [1..5] queue counts
 
 struct WfArgs {
     SceneDev sc;
@@ -56,11 +55,14 @@ struct WfArgs {
     uint32_t pix0, P;                    // tile: crop-window pixels [pix0, pix0 + P)
     uint32_t spp_begin, S;               // samples [spp_begin, spp_begin + S) of every pixel of the tile
     uint32_t n_slots;                    // P * S
-    uint32_t depth_row;                  // row of `counts` this launch reads (bounce index within the chunk)
+    uint32_t G, seg, n_seg;              // segment = G whole pixels = G * S slots, owned by one workgroup per launch
+    uint32_t parity;                     // which of the two live lists this bounce reads
     float *planes;                       // SoA state, PL_COUNT planes of n_slots
-    uint32_t *q_live;                    // [2][n_slots] ping-pong live queues (slot indices)
-    uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit queues
-    uint32_t *counts;                    // [rows][kWfRow]
+    uint32_t *q_live;                    // [2][n_slots] ping-pong live lists (slot indices), segment sg at sg * seg
+    uint32_t *seg_live;                  // [2][n_seg]   their lengths
+    uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit lists, same segmentation
+    uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths
+    uint32_t *live_total;                // optional: number of survivors of this bounce (unbounded-depth renders)
     uint4 *rec;                          // [P][rec_cap] time-bin records (bin, r, g, b)
     uint32_t *rec_count;                 // [P]
     uint32_t rec_cap;                    // 0: rows do not fit LDS -> contributions go straight to HBM atomics

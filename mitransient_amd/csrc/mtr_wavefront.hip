@@ -9,11 +9,16 @@
 //   per bounce:
 //   k_wf_trace    live queue -> BVH2 closest hit (node packets staged in LDS)     ray planes -> hit planes
 //                 + append of the slot to the queue of its hit MATERIAL TYPE (diffuse / conductor /
-//                 dielectric / none / miss): wave64 ballot + popcount + one atomic per (wave, type)
+//                 dielectric / none / miss): wave64 ballot + popcount + one LDS atomic per (wave, type)
 //   k_wf_shade    material-sorted queues -> shade_hit, shadow ray (inline any-hit traversal),
 //                 shade_finish; time-bin contributions are appended as 16-byte records to the
 //                 per-pixel lists; survivors are compacted into the next live queue
-//                 (ballot / prefix popcount / one atomic per wave)
+//                 (ballot / prefix popcount / one LDS atomic per wave)
+// The queues are SEGMENTED: a segment is a fixed range of `seg` slots covering whole pixels, owned by
+// one workgroup per launch; its live list, its five material lists and its pixels' record counters
+// are advanced with workgroup-local LDS counters and written back once — there is not a single
+// global atomic on the data path (a first version with one global tail counter per queue spent
+// its time in ~12 ns same-address atomics: 183 us per launch).
 //   k_wf_scatter  the time-bin scatter-add: one workgroup per pixel streams that pixel's records
 //                 (coalesced 16 B/lane) into an LDS row histogram and adds the row to the
 //                 (H,W,T,4) film once; also reduces the pixel's radiance samples into the steady image.
@@ -50,7 +55,9 @@ template <int STACK, bool SCENE_LDS>
 __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem, int tid, SceneView &sv, WStack<STACK> &st,
                                          uint32_t &off)
 {
-    off = 0;
+    // all LDS scratch lives in the dynamic region, every carve offset a multiple of 16 (a static
+    // __shared__ in front of it would shift the base and mis-align the ds_read_b128 node fetches)
+    off = 64;                                                   // smem[0..63]: workgroup counters
     int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
     sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
     if (SCENE_LDS) {
@@ -143,29 +150,30 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
     return base + rank;
 }
 
-// time-bin contribution -> 16-byte record appended to its pixel's list; list full -> f32 atomics to HBM
+// time-bin contribution -> 16-byte record appended to its pixel's list; list full -> f32 atomics to HBM.
+// The list tails of the segment's pixels live in LDS for the duration of the launch.
 struct RecordSink {
-    uint4 *rec; uint32_t *rec_count; uint32_t rec_cap;
+    uint4 *rec; uint32_t *s_rec_count; uint32_t rec_cap;    // s_rec_count: LDS, indexed by pixel within the segment
     float *film; uint32_t film_w, bins;
-    uint32_t p_local, lane;
+    uint32_t p_local, p_seg, lane;                          // pixel within the tile / within the segment
     uint32_t n_splats, n_overflow;
     SplatLog log;
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
-        // lanes of a wave that splat together mostly share 1..3 pixels: one atomic per distinct pixel
+        // lanes of a wave that splat together mostly share 1..3 pixels: one LDS atomic per distinct pixel
         unsigned long long todo = __ballot(1);
         const uint32_t lane_id = threadIdx.x & 63u;
         uint32_t idx = 0;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t px = __shfl(p_local, leader);
-            const unsigned long long same = __ballot(p_local == px) & todo;
-            if (p_local == px) {
+            const uint32_t px = __shfl(p_seg, leader);
+            const unsigned long long same = __ballot(p_seg == px) & todo;
+            if (p_seg == px) {
                 const uint32_t n = (uint32_t)__popcll(same);
                 const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane_id) - 1ull));
                 uint32_t base = 0;
-                if ((int)lane_id == leader) base = atomicAdd(rec_count + px, n);
+                if ((int)lane_id == leader) base = atomicAdd(s_rec_count + px, n);
                 base = __shfl(base, leader);
                 idx = base + rank;
             }
@@ -219,118 +227,134 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
         P.u(PL_RI_LO, slot) = (uint32_t)p.rng.inc; P.u(PL_RI_HI, slot) = (uint32_t)(p.rng.inc >> 32);
         a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
     }
+    for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock)
+        a.seg_live[sg] = min(a.seg, a.n_slots - sg * a.seg);    // every slot of the segment is live
     if (a.counters) {
         if (n_closest) atomicAdd(&a.counters->rays_closest, (unsigned long long)n_closest);
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&a.counters->paths, (unsigned long long)a.n_slots);
     }
 }
 
-// closest hit for the live queue of bounce `a.depth_row`; appends each slot to its material-type queue
+// closest hit for the live lists of this bounce; every slot is appended to the list of its hit
+// material type inside its segment (sorted-by-material hit queues)
 template <int STACK, bool SCENE_LDS>
 __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_cnt = (uint32_t *)smem;                         // [kWfKeys] list tails of the segment
     const int tid = threadIdx.x;
-    const uint32_t *row = a.counts + (size_t)a.depth_row * kWfRow;
-    const uint32_t n_live = row[0];
-    if (blockIdx.x * kBlock >= n_live) return;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     const Planes P{ a.planes, a.n_slots };
-    uint32_t *bucket_cnt = a.counts + (size_t)a.depth_row * kWfRow + 1;
-    const uint32_t *q = a.q_live + (size_t)(a.depth_row & 1u) * a.n_slots;
-    const uint32_t n_round = (n_live + kBlock - 1) / kBlock * kBlock;      // keep whole waves in the loop (ballots)
-    for (uint32_t i = blockIdx.x * kBlock + tid; i < n_round; i += gridDim.x * kBlock) {
-        const bool on = i < n_live;
-        uint32_t slot = 0, key = kWfKeys;          // kWfKeys = "no lane"
-        if (on) {
-            slot = q[i];
-            const Ray r = load_ray(P, slot);
-            const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
-            P.f(PL_HT, slot) = h.t; P.f(PL_HU, slot) = h.u; P.f(PL_HV, slot) = h.v; P.u(PL_HPRIM, slot) = (uint32_t)h.prim;
-            key = 4u;                               // miss
-            if (h.prim >= 0) {
-                const uint32_t mat_em = fbits(sv.tgeom[h.prim].g[2].z);
-                key = sv.mats[mat_em & 0xffffu].type;              // 0 diffuse, 1 conductor, 2 dielectric, 3 none
+    const uint32_t par = a.parity;
+    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+        const uint32_t n_live = a.seg_live[(size_t)par * a.n_seg + sg];
+        if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
+        __syncthreads();
+        const uint32_t *q = a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+        const uint32_t n_round = (n_live + 63u) & ~63u;                    // whole waves stay in the loop (ballots)
+        for (uint32_t i = tid; i < n_round; i += kBlock) {
+            const bool on = i < n_live;
+            uint32_t slot = 0, key = kWfKeys;
+            if (on) {
+                slot = q[i];
+                const Ray r = load_ray(P, slot);
+                const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
+                P.f(PL_HT, slot) = h.t; P.f(PL_HU, slot) = h.u; P.f(PL_HV, slot) = h.v; P.u(PL_HPRIM, slot) = (uint32_t)h.prim;
+                key = 4u;                           // miss
+                if (h.prim >= 0) {
+                    const uint32_t mat_em = fbits(sv.tgeom[h.prim].g[2].z);
+                    key = sv.mats[mat_em & 0xffffu].type;          // 0 diffuse, 1 conductor, 2 dielectric, 3 none
+                }
             }
-        }
-        // sorted-by-material hit queues: bucketed append, one atomic per (wave, material type present)
 #pragma unroll
-        for (uint32_t k = 0; k < kWfKeys; ++k) {
-            const bool mine = on & (key == k);
-            if (__ballot(mine) != 0ull) {
-                const uint32_t pos = wave_append(bucket_cnt + k, mine);
-                if (mine) a.q_mat[(size_t)k * a.n_slots + pos] = slot;
+            for (uint32_t k = 0; k < kWfKeys; ++k) {
+                const bool mine = on & (key == k);
+                if (__ballot(mine) != 0ull) {
+                    const uint32_t pos = wave_append(&s_cnt[k], mine);
+                    if (mine) a.q_mat[(size_t)k * a.n_slots + (size_t)sg * a.seg + pos] = slot;
+                }
             }
         }
+        __syncthreads();
+        if (tid < (int)kWfKeys) a.seg_mat[(size_t)sg * kWfKeys + tid] = s_cnt[tid];
+        __syncthreads();
     }
 }
 
-// shade the material-sorted queues of bounce `a.depth_row`
+// shade the material-sorted lists of every segment; survivors form the next live list
 template <int STACK, bool SCENE_LDS>
 __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_next_p = (uint32_t *)smem;                      // tail of the segment's next live list
     const int tid = threadIdx.x;
-    const uint32_t *row = a.counts + (size_t)a.depth_row * kWfRow;
-    uint32_t pre[kWfKeys + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kWfKeys; ++k) pre[k + 1] = pre[k] + row[1 + k];
-    const uint32_t total = pre[kWfKeys];
-    if (blockIdx.x * kBlock >= total) return;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
     const Planes P{ a.planes, a.n_slots };
-    uint32_t *next_cnt = a.counts + (size_t)(a.depth_row + 1) * kWfRow;
-    uint32_t *q_next = a.q_live + (size_t)((a.depth_row + 1) & 1u) * a.n_slots;
-    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0;
-    const uint32_t n_round = (total + kBlock - 1) / kBlock * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + tid; i < n_round; i += gridDim.x * kBlock) {
-        const bool on = i < total;
-        bool alive = false;
-        uint32_t slot = 0;
-        if (on) {
-            uint32_t k = 0;
-#pragma unroll
-            for (uint32_t kk = 1; kk < kWfKeys; ++kk) k += (i >= pre[kk]) ? 1u : 0u;
-            slot = a.q_mat[(size_t)k * a.n_slots + (i - pre[k])];
-            uint32_t pixel, s, pl;
-            slot_to_lane(a, slot, pixel, s, pl);
-            Path p;
-            load_path(P, slot, p);
-            p.ray = load_ray(P, slot);
-            const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
-            p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
-            Hit h;
-            h.t = P.f(PL_HT, slot); h.u = P.f(PL_HU, slot); h.v = P.f(PL_HV, slot); h.prim = (int32_t)P.u(PL_HPRIM, slot);
-            ++n_closest;
-            RecordSink sink;
-            sink.rec = a.rec; sink.rec_count = a.rec_count; sink.rec_cap = a.rec_cap;
-            sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
-            sink.p_local = pl; sink.lane = p.lane; sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
-            Pending pd; Ray shadow;
-            shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
-            shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
-            bool occluded = false;
-            if (pd.has_shadow) {
-                ++n_shadow;
-                Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
-                occluded = sh.prim >= 0;
+    const uint32_t par = a.parity;
+    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
+    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+        const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
+        const uint32_t npx = min(a.G, a.P - pl0);
+        for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
+        if (tid == 0) *s_next_p = 0u;
+        __syncthreads();
+        uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
+        for (uint32_t k = 0; k < kWfKeys; ++k) {                 // one material type after the other
+            const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + k];
+            const uint32_t *q = a.q_mat + (size_t)k * a.n_slots + (size_t)sg * a.seg;
+            const uint32_t n_round = (n_k + 63u) & ~63u;
+            for (uint32_t i = tid; i < n_round; i += kBlock) {
+                const bool on = i < n_k;
+                bool alive = false;
+                uint32_t slot = 0;
+                if (on) {
+                    slot = q[i];
+                    uint32_t pixel, s, pl;
+                    slot_to_lane(a, slot, pixel, s, pl);
+                    Path p;
+                    load_path(P, slot, p);
+                    p.ray = load_ray(P, slot);
+                    const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                    p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                    Hit h;
+                    h.t = P.f(PL_HT, slot); h.u = P.f(PL_HU, slot); h.v = P.f(PL_HV, slot); h.prim = (int32_t)P.u(PL_HPRIM, slot);
+                    ++n_closest;
+                    RecordSink sink;
+                    sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
+                    sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
+                    sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = p.lane;
+                    sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
+                    Pending pd; Ray shadow;
+                    shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
+                    shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                    bool occluded = false;
+                    if (pd.has_shadow) {
+                        ++n_shadow;
+                        Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                        occluded = sh.prim >= 0;
+                    }
+                    alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
+                    ++n_bounce;
+                    n_splats += sink.n_splats; n_over += sink.n_overflow;
+                    store_path(P, slot, p);
+                    if (alive) { store_ray(P, slot, p.ray); ++n_alive; }
+                }
+                // wave64 stream compaction of the survivors into the segment's next live list
+                if (__ballot(alive) != 0ull) {
+                    const uint32_t pos = wave_append(s_next_p, alive);
+                    if (alive) q_next[pos] = slot;
+                }
             }
-            alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
-            ++n_bounce;
-            n_splats += sink.n_splats; n_over += sink.n_overflow;
-            store_path(P, slot, p);
-            if (alive) store_ray(P, slot, p.ray);
         }
-        // wave64 stream compaction of the survivors into the next live queue
-        if (__ballot(alive) != 0ull) {
-            const uint32_t pos = wave_append(next_cnt, alive);
-            if (alive) q_next[pos] = slot;
-        }
+        __syncthreads();
+        if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
+        for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
+        __syncthreads();
     }
-    // counters: one set of atomics per wave
+    // counters: one set of atomics per wave (statistics only; `live_total` lets the host stop unbounded renders)
     if (a.counters) {
         const unsigned vals[5] = { n_closest, n_shadow, n_splats, n_bounce, n_over };
         unsigned long long *dst[5] = { &a.counters->rays_closest, &a.counters->rays_shadow, &a.counters->splats_issued,
@@ -342,14 +366,19 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
             if ((tid & 63) == 0 && v) atomicAdd(dst[k], (unsigned long long)v);
         }
     }
+    if (a.live_total) {
+        unsigned v = n_alive;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((tid & 63) == 0 && v) atomicAdd(a.live_total, v);
+    }
 }
 
 // the time-bin scatter-add + steady reduction: one workgroup per pixel of the tile
 __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *row = (float *)smem;                         // [3][T]
-    __shared__ float s_red[4][4];
+    float (*s_red)[4] = (float (*)[4])smem;             // [4][4] wave partial sums (first 64 bytes)
+    float *row = (float *)(smem + 64);                  // [3][T]
     const uint32_t T = a.film.bins;
     const int tid = threadIdx.x;
     const bool rows = a.rec_cap > 0;                    // false: T*12 B does not fit LDS, shade used HBM atomics
@@ -403,6 +432,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
+    lds += al16(a.G * 4u);                                  // k_wf_shade: record-list tails of the segment's pixels
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
@@ -420,7 +450,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
     uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_tris * sizeof(TriGeom)) + al16(sc.n_tris * sizeof(TriShade)) +
                        al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
     cfg.scene_lds = scene_b <= 64u * 1024u;
-    cfg.lds_bytes = (size_t)(cfg.stack + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
+    cfg.lds_bytes = 64 + (size_t)(cfg.stack + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
     return true;
 }
 
@@ -428,7 +458,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
 {
     if (which == 3) {
-        size_t lds = a.rec_cap ? (size_t)a.film.bins * 12u : 16u;
+        size_t lds = 64 + (a.rec_cap ? (size_t)a.film.bins * 12u : 16u);
         hipError_t e = hipFuncSetAttribute((const void *)k_wf_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_wf_scatter, dim3(grid), dim3(kBlock), lds, stream, a);
