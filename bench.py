@@ -66,6 +66,18 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
                       f"film pre-faulted and not cleared inside the timed region)"}
 
 
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools_profile.sh: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    None when no profile of this kernel is committed: bench.py itself cannot collect PMC counters."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +89,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel PER GPU (weak scaling)")
     ap.add_argument("--mode", default=None, choices=[None, "auto", "fused", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scatter-leg", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -139,16 +152,37 @@ def main():
         for k, v in zip(sorted(totals), c.tolist()):
             totals[k] = int(v)
 
+    # ---- untimed extra leg (rank 0, N=1): the same render in wavefront mode, to time the stand-alone
+    # time-bin scatter-add kernel (k_wf_scatter) with HIP events on its stream
+    scatter = None
+    if rank == 0 and world == 1 and not args.no_scatter_leg:
+        sc2 = build_scene(args.width, args.height, args.bins, mode="wavefront")
+        i2 = sc2.integrator()
+        i2.collect_stats = True
+        for _ in range(2):
+            i2.render(sc2, spp=args.spp, seed=0)
+        tm, cn = i2.last_times, i2.last_counters
+        n_l = max(1, tm["scatter_launches"])
+        b_l = SPLAT_BYTES * cn["splats_issued"] / n_l
+        avg = tm["scatter_ms"] / n_l
+        scatter = {"kernel": "k_wf_scatter (MTR_MODE_WAVEFRONT, untimed extra leg)", "bound": "hbm",
+                   "achieved": b_l / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": b_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_wf_scatter"),
+                   "avg_launch_ms": avg, "launches_per_render": n_l, "algorithmic_bytes_per_launch": b_l,
+                   "render_ms_wavefront": tm["total_ms"]}
+        del sc2, i2
+
     if rank == 0:
         rays = totals["rays_closest"] + totals["rays_shadow"]
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (the path kernel), rank 0's launches, HIP events on its stream:
-        # algorithmic bytes per launch = 24 B x splats one launch issues, see DESIGN.md
+        # algorithmic bytes per launch = 24 B x contributions one launch issues
         n_launch = max(1, trace_launches)
-        avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        avg_ms = sum(kernel_ms) / max(1, n_launch) if (args.mode in (None, "auto", "fused")) else sum(kernel_ms) / max(1, len(kernel_ms))
         splats_rank0 = totals["splats_issued"] / world
         bytes_per_launch = SPLAT_BYTES * splats_rank0 / max(1, len(kernel_ms))
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kname = "k_fused" if (args.mode in (None, "auto", "fused")) else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
         res = {
             "metric": "Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU",
             "value": rays / elapsed / 1e6,
@@ -163,14 +197,17 @@ def main():
                                    f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
                                    f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0",
                        "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",
-                       "mode": args.mode or "auto"},
-            "roofline": {"kernel": "k_fused" if (args.mode in (None, "auto", "fused")) else "wavefront bounce+scatter",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                       "mode": args.mode or "auto (fused: scene + per-pixel time histograms in LDS)"},
+            # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
+            # `scatter_add` below is the stand-alone scatter-add kernel of the wavefront organisation
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_fused") if kname == "k_fused" else None,
                          "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "counters_per_step": {k: v / args.steps for k, v in totals.items()},
         }
+        if scatter:
+            res["scatter_add"] = scatter
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.width, args.height, args.bins, args.spp, args.cpu_seconds)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]

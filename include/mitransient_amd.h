@@ -99,7 +99,10 @@ typedef struct mtr_scene_desc {
 
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */
 enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133-138 */
-       MTR_FLAG_DISCARD_DIRECT_LIGHT = 2u  /* common.py:27, transientpath.py:173-176 */ };
+       MTR_FLAG_DISCARD_DIRECT_LIGHT = 2u, /* common.py:27, transientpath.py:173-176 */
+       MTR_FLAG_FILM_ZERO = 4u             /* caller guarantees that the film rows of the rendered pixels are
+                                              all-zero on entry (first pass after TransientImageBlock.clear):
+                                              the row flush may store instead of read-modify-write            */ };
 
 /* which kernel organisation executes the path */
 enum { MTR_MODE_AUTO = 0,

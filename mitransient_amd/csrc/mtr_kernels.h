@@ -66,6 +66,7 @@ struct WfArgs {
     uint4 *rec;                          // [P][rec_cap] time-bin records (bin, r, g, b)
     uint32_t *rec_count;                 // [P]
     uint32_t rec_cap;                    // 0: rows do not fit LDS -> contributions go straight to HBM atomics
+    uint32_t film_zero;                  // film rows of this tile are zero on entry: the row flush stores
     float *film_out, *steady_out;
     DevCounters *counters;
     SplatLog log;

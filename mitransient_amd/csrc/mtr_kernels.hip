@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 for (uint32_t t = tid; t < T; t += kBlock) {
                     float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
                     if (r != 0.0f || gc != 0.0f || b != 0.0f) {
-                        float4 v = row[t];
+                        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];     // accumulate onto earlier passes
                         v.x += r; v.y += gc; v.z += b;
                         row[t] = v;
                         h[t] = 0.0f; h[t + plane] = 0.0f; h[t + 2 * plane] = 0.0f;

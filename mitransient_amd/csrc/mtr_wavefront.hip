@@ -2,7 +2,7 @@
 //
 // One tile = P pixels x S samples = n_slots lanes; a path keeps its SLOT for life (slot = local
 // pixel * S + local sample, so slots are pixel-major and the RNG/lane identity is a pure function
-// of the slot).  State lives in SoA planes of n_slots elements (coalesced 4-byte-per-lane accesses);
+// of the slot).  State lives in 7 SoA planes of float4 (16-byte-per-lane accesses);
 // the queues hold slot indices.
 //
 //   k_wf_raygen   slot -> PCG32 stream, jitter, camera ray, loop-state init       (writes all planes)
@@ -21,7 +21,7 @@
 // its time in ~12 ns same-address atomics: 183 us per launch).
 //   k_wf_scatter  the time-bin scatter-add: one workgroup per pixel streams that pixel's records
 //                 (coalesced 16 B/lane) into an LDS row histogram and adds the row to the
-//                 (H,W,T,4) film once; also reduces the pixel's radiance samples into the steady image.
+//                 (H,W,T,4) film once.
 #include "mtr_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -79,52 +79,45 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     st.base = s_stack + tid; st.sp = 0;
 }
 
-// ---- SoA plane accessors ------------------------------------------------------------------
-enum Plane {
-    PL_OX = 0, PL_OY, PL_OZ, PL_DX, PL_DY, PL_DZ, PL_TMAX,
-    PL_BX, PL_BY, PL_BZ, PL_LX, PL_LY, PL_LZ, PL_PX, PL_PY, PL_PZ,
-    PL_ETA, PL_DIST, PL_PPDF, PL_FLAGS, PL_RS_LO, PL_RS_HI, PL_RI_LO, PL_RI_HI,
-    PL_HT, PL_HU, PL_HV, PL_HPRIM,
-    PL_COUNT
-};
+// ---- SoA-of-quads state: 7 planes of float4 (16 B per lane per access, the coalescing sweet spot;
+// also what keeps the gathers through the slot queues efficient) ----------------------------------
+//   Q_RAY0 (o.xyz, tmax)   Q_RAY1 (d.xyz, eta)      Q_BETA (beta.xyz, dist)   Q_RAD (L.xyz, prev_pdf)
+//   Q_PREV (prev_p.xyz, depth | prev_delta << 31)   Q_RNG (state lo, hi, inc lo, hi)   Q_HIT (t, u, v, prim)
+enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_RNG, Q_HIT, PL_COUNT };
 
 struct Planes {
-    float *base; uint32_t n;
-    __device__ __forceinline__ float &f(int pl, uint32_t slot) const { return base[(size_t)pl * n + slot]; }
-    __device__ __forceinline__ uint32_t &u(int pl, uint32_t slot) const { return ((uint32_t *)base)[(size_t)pl * n + slot]; }
+    float4 *base; uint32_t n;
+    __device__ __forceinline__ float4 &q(int pl, uint32_t slot) const { return base[(size_t)pl * n + slot]; }
 };
 
-__device__ __forceinline__ void store_ray(const Planes &P, uint32_t s, const Ray &r)
+__device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s, float &eta)
 {
-    P.f(PL_OX, s) = r.o.x; P.f(PL_OY, s) = r.o.y; P.f(PL_OZ, s) = r.o.z;
-    P.f(PL_DX, s) = r.d.x; P.f(PL_DY, s) = r.d.y; P.f(PL_DZ, s) = r.d.z; P.f(PL_TMAX, s) = r.tmax;
-}
-__device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s)
-{
-    Ray r;
-    r.o = mk(P.f(PL_OX, s), P.f(PL_OY, s), P.f(PL_OZ, s));
-    r.d = mk(P.f(PL_DX, s), P.f(PL_DY, s), P.f(PL_DZ, s)); r.tmax = P.f(PL_TMAX, s);
+    const float4 a = P.q(Q_RAY0, s), b = P.q(Q_RAY1, s);
+    Ray r; r.o = mk(a.x, a.y, a.z); r.tmax = a.w; r.d = mk(b.x, b.y, b.z); eta = b.w;
     return r;
 }
-__device__ __forceinline__ void store_path(const Planes &P, uint32_t s, const Path &p)
+__device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_inc)
 {
-    P.f(PL_BX, s) = p.beta.x; P.f(PL_BY, s) = p.beta.y; P.f(PL_BZ, s) = p.beta.z;
-    P.f(PL_LX, s) = p.L.x; P.f(PL_LY, s) = p.L.y; P.f(PL_LZ, s) = p.L.z;
-    P.f(PL_PX, s) = p.prev_p.x; P.f(PL_PY, s) = p.prev_p.y; P.f(PL_PZ, s) = p.prev_p.z;
-    P.f(PL_ETA, s) = p.eta; P.f(PL_DIST, s) = p.dist; P.f(PL_PPDF, s) = p.prev_pdf;
-    P.u(PL_FLAGS, s) = p.depth | (p.prev_delta << 31);
-    P.u(PL_RS_LO, s) = (uint32_t)p.rng.state; P.u(PL_RS_HI, s) = (uint32_t)(p.rng.state >> 32);
+    P.q(Q_RAY0, s) = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax);
+    P.q(Q_RAY1, s) = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta);
+    P.q(Q_BETA, s) = make_float4(p.beta.x, p.beta.y, p.beta.z, p.dist);
+    P.q(Q_RAD, s) = make_float4(p.L.x, p.L.y, p.L.z, p.prev_pdf);
+    P.q(Q_PREV, s) = make_float4(p.prev_p.x, p.prev_p.y, p.prev_p.z, __uint_as_float(p.depth | (p.prev_delta << 31)));
+    (void)with_inc;
+    P.q(Q_RNG, s) = make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)),
+                                __uint_as_float((uint32_t)p.rng.inc), __uint_as_float((uint32_t)(p.rng.inc >> 32)));
 }
-__device__ __forceinline__ void load_path(const Planes &P, uint32_t s, Path &p)
+__device__ __forceinline__ void load_state(const Planes &P, uint32_t s, Path &p)
 {
-    p.beta = mk(P.f(PL_BX, s), P.f(PL_BY, s), P.f(PL_BZ, s));
-    p.L = mk(P.f(PL_LX, s), P.f(PL_LY, s), P.f(PL_LZ, s));
-    p.prev_p = mk(P.f(PL_PX, s), P.f(PL_PY, s), P.f(PL_PZ, s));
-    p.eta = P.f(PL_ETA, s); p.dist = P.f(PL_DIST, s); p.prev_pdf = P.f(PL_PPDF, s);
-    uint32_t fl = P.u(PL_FLAGS, s);
+    p.ray = load_ray(P, s, p.eta);
+    const float4 b = P.q(Q_BETA, s), l = P.q(Q_RAD, s), v = P.q(Q_PREV, s), g = P.q(Q_RNG, s);
+    p.beta = mk(b.x, b.y, b.z); p.dist = b.w;
+    p.L = mk(l.x, l.y, l.z); p.prev_pdf = l.w;
+    p.prev_p = mk(v.x, v.y, v.z);
+    const uint32_t fl = __float_as_uint(v.w);
     p.depth = fl & 0x7fffffffu; p.prev_delta = fl >> 31;
-    p.rng.state = (uint64_t)P.u(PL_RS_LO, s) | ((uint64_t)P.u(PL_RS_HI, s) << 32);
-    p.rng.inc = (uint64_t)P.u(PL_RI_LO, s) | ((uint64_t)P.u(PL_RI_HI, s) << 32);
+    p.rng.state = (uint64_t)__float_as_uint(g.x) | ((uint64_t)__float_as_uint(g.y) << 32);
+    p.rng.inc = (uint64_t)__float_as_uint(g.z) | ((uint64_t)__float_as_uint(g.w) << 32);
 }
 
 // slot -> (pixel, sample) of the tile
@@ -180,6 +173,9 @@ struct RecordSink {
             todo &= ~same;
         }
         ++n_splats;
+#ifdef MTR_EXP_WF_NOREC
+        return;
+#endif
         if (idx < rec_cap) {
             rec[(size_t)p_local * rec_cap + idx] = make_uint4(bin, __float_as_uint(r), __float_as_uint(g), __float_as_uint(b));
         } else {
@@ -210,7 +206,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
     const int tid = threadIdx.x;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
-    const Planes P{ a.planes, a.n_slots };
+    const Planes P{ (float4 *)a.planes, a.n_slots };
     uint32_t n_closest = 0;
     for (uint32_t slot = blockIdx.x * kBlock + tid; slot < a.n_slots; slot += gridDim.x * kBlock) {
         uint32_t pixel, s, pl;
@@ -222,9 +218,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
             ++n_closest;
             if (h0.prim >= 0) p.dist = -h0.t;
         }
-        store_ray(P, slot, p.ray);
-        store_path(P, slot, p);
-        P.u(PL_RI_LO, slot) = (uint32_t)p.rng.inc; P.u(PL_RI_HI, slot) = (uint32_t)(p.rng.inc >> 32);
+        store_state(P, slot, p, true);
         a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
     }
     for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock)
@@ -245,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
     const int tid = threadIdx.x;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
-    const Planes P{ a.planes, a.n_slots };
+    const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
         const uint32_t n_live = a.seg_live[(size_t)par * a.n_seg + sg];
@@ -258,9 +252,10 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
             uint32_t slot = 0, key = kWfKeys;
             if (on) {
                 slot = q[i];
-                const Ray r = load_ray(P, slot);
+                float eta_unused;
+                const Ray r = load_ray(P, slot, eta_unused);
                 const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
-                P.f(PL_HT, slot) = h.t; P.f(PL_HU, slot) = h.u; P.f(PL_HV, slot) = h.v; P.u(PL_HPRIM, slot) = (uint32_t)h.prim;
+                P.q(Q_HIT, slot) = make_float4(h.t, h.u, h.v, __uint_as_float((uint32_t)h.prim));
                 key = 4u;                           // miss
                 if (h.prim >= 0) {
                     const uint32_t mat_em = fbits(sv.tgeom[h.prim].g[2].z);
@@ -283,8 +278,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 }
 
 // shade the material-sorted lists of every segment; survivors form the next live list
+#ifndef MTR_WF_SHADE_WAVES
+#define MTR_WF_SHADE_WAVES 4
+#endif
 template <int STACK, bool SCENE_LDS>
-__global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_next_p = (uint32_t *)smem;                      // tail of the segment's next live list
@@ -292,13 +290,15 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
-    const Planes P{ a.planes, a.n_slots };
+    float *s_steady = (float *)(smem + off + al16(a.G * 4u));   // [G][4] radiance sums of the paths that end here
+    const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
     for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
         const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
         const uint32_t npx = min(a.G, a.P - pl0);
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
+        for (uint32_t t = tid; t < 4 * npx; t += kBlock) s_steady[t] = 0.0f;
         if (tid == 0) *s_next_p = 0u;
         __syncthreads();
         uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
@@ -315,12 +315,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
                     uint32_t pixel, s, pl;
                     slot_to_lane(a, slot, pixel, s, pl);
                     Path p;
-                    load_path(P, slot, p);
-                    p.ray = load_ray(P, slot);
+                    load_state(P, slot, p);
                     const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                     p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
                     Hit h;
-                    h.t = P.f(PL_HT, slot); h.u = P.f(PL_HU, slot); h.v = P.f(PL_HV, slot); h.prim = (int32_t)P.u(PL_HPRIM, slot);
+                    { const float4 hq = P.q(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                     ++n_closest;
                     RecordSink sink;
                     sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
@@ -333,14 +332,28 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
+#ifdef MTR_EXP_NOSHADOW
+                        Hit sh; sh.prim = -1;
+#else
                         Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
+#endif
                         occluded = sh.prim >= 0;
                     }
                     alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
-                    store_path(P, slot, p);
-                    if (alive) { store_ray(P, slot, p.ray); ++n_alive; }
+#ifndef MTR_EXP_WF_NOSTORE
+                    store_state(P, slot, p, false);
+#endif
+                    if (alive) ++n_alive;
+                    else {
+                        // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+                        float *sp = s_steady + 4 * (pl - pl0);
+                        __hip_atomic_fetch_add(sp, p.L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 1, p.L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 2, p.L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 3, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
                 // wave64 stream compaction of the survivors into the segment's next live list
                 if (__ballot(alive) != 0ull) {
@@ -352,6 +365,14 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
         __syncthreads();
         if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
+        for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
+            const float v = s_steady[t];
+            if (v != 0.0f) {
+                const uint32_t pixel = a.pix0 + pl0 + (t >> 2);
+                const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;
+                if (cx < a.film.width && cy < a.film.height) a.steady_out[((size_t)cy * a.film.width + cx) * 4u + (t & 3u)] += v;
+            }
+        }
         __syncthreads();
     }
     // counters: one set of atomics per wave (statistics only; `live_total` lets the host stop unbounded renders)
@@ -377,50 +398,62 @@ __global__ void __launch_bounds__(kBlock) k_wf_shade(const WfArgs a)
 __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float (*s_red)[4] = (float (*)[4])smem;             // [4][4] wave partial sums (first 64 bytes)
     float *row = (float *)(smem + 64);                  // [3][T]
     const uint32_t T = a.film.bins;
     const int tid = threadIdx.x;
     const bool rows = a.rec_cap > 0;                    // false: T*12 B does not fit LDS, shade used HBM atomics
     if (rows) for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
     __syncthreads();
-    const Planes P{ a.planes, a.n_slots };
+    const Planes P{ (float4 *)a.planes, a.n_slots };
     for (uint32_t pl = blockIdx.x; pl < a.P; pl += gridDim.x) {
         const uint32_t pixel = a.pix0 + pl;
         const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;    // film coords (crop offset removed)
         const bool in_film = (cx < a.film.width) & (cy < a.film.height);
         const size_t fpix = (size_t)cy * a.film.width + cx;
-        const uint32_t n = rows ? min(a.rec_count[pl], a.rec_cap) : 0u;
+        const uint32_t n_all = a.rec_count[pl];
+        const uint32_t n = rows ? min(n_all, a.rec_cap) : 0u;
+        const bool store_only = a.film_zero && n_all <= a.rec_cap;      // no overflow atomics landed on this row
         const uint4 *rec = a.rec + (size_t)pl * a.rec_cap;
-        for (uint32_t i = tid; i < n; i += kBlock) {          // coalesced 16 B / lane
-            const uint4 r = rec[i];
-            float *p = row + r.x;
-            __hip_atomic_fetch_add(p, __uint_as_float(r.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(p + T, __uint_as_float(r.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // stream the records: 8 independent 16-byte loads in flight per lane (coalesced), then the LDS adds
+        constexpr int kBatch = 8;
+        for (uint32_t base = 0; base < n; base += kBatch * kBlock) {
+            uint4 r[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const uint32_t i = base + k * kBlock + tid;
+                r[k] = (i < n) ? rec[i] : make_uint4(0xffffffffu, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+#ifdef MTR_EXP_SC_NOATOM
+                if (r[k].x == 0xfffffffeu) {
+#else
+                if (r[k].x != 0xffffffffu) {
+#endif
+                    float *p = row + r[k].x;
+                    __hip_atomic_fetch_add(p, __uint_as_float(r[k].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p + T, __uint_as_float(r[k].z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r[k].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
-        // steady: sum of the pixel's S radiance samples (planes L), weight = S   (common.py:187-206)
-        float lx = 0.0f, ly = 0.0f, lz = 0.0f;
-        for (uint32_t s = tid; s < a.S; s += kBlock) {
-            const uint32_t slot = pl * a.S + s;
-            lx += P.f(PL_LX, slot); ly += P.f(PL_LY, slot); lz += P.f(PL_LZ, slot);
-        }
-        for (int o = 32; o > 0; o >>= 1) { lx += __shfl_down(lx, o); ly += __shfl_down(ly, o); lz += __shfl_down(lz, o); }
-        if ((tid & 63) == 0) { s_red[tid >> 6][0] = lx; s_red[tid >> 6][1] = ly; s_red[tid >> 6][2] = lz; }
         __syncthreads();
         if (in_film) {
             float4 *dst = (float4 *)(a.film_out + fpix * T * 4u);
+#ifdef MTR_EXP_SC_NOFLUSH
+            for (uint32_t t = tid; rows && t < T && a.P == 0xffffffffu; t += kBlock) {
+#else
             for (uint32_t t = tid; rows && t < T; t += kBlock) {
+#endif
                 float r = row[t], g = row[T + t], b = row[2 * T + t];
                 if (r != 0.0f || g != 0.0f || b != 0.0f) {
-                    float4 v = dst[t];
+                    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (!store_only) v = dst[t];                  // accumulate onto earlier passes / overflow atomics
                     v.x += r; v.y += g; v.z += b;
                     dst[t] = v;
                     row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f;
                 }
             }
-            if (tid < 3) a.steady_out[fpix * 4u + tid] += (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-            if (tid == 3) a.steady_out[fpix * 4u + 3] += (float)a.S;
         } else if (rows) {
             for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
         }
@@ -432,7 +465,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
-    lds += al16(a.G * 4u);                                  // k_wf_shade: record-list tails of the segment's pixels
+    lds += al16(a.G * 4u) + al16(a.G * 16u);                // k_wf_shade: record-list tails + steady sums of the segment's pixels
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
@@ -441,7 +474,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
 
 } // namespace
 
-size_t wf_planes_bytes(uint32_t n_slots) { return (size_t)PL_COUNT * n_slots * 4u; }
+size_t wf_planes_bytes(uint32_t n_slots) { return (size_t)PL_COUNT * n_slots * 16u; }
 
 bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 {

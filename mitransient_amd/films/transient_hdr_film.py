@@ -45,6 +45,7 @@ class TransientHDRFilm:
         self.channels = None
         self.transient_storage = None
         self._steady_accum = None     # (H, W, 4): sum of L, sample count
+        self.film_is_zero = False     # True between clear()/prepare() and the first accumulated pass
         self._device = None
 
     # -- mi.Film accessors -------------------------------------------------
@@ -92,6 +93,7 @@ class TransientHDRFilm:
         self.crop_offset_xyt = (self.crop_offset_[0], self.crop_offset_[1], 0)
         self.crop_size_xyt = (self.size_[0], self.size_[1], self.temporal_bins)
         self.transient_storage = self.create_block()
+        self.film_is_zero = True
         return len(self.channels)
 
     def create_block(self):
@@ -107,6 +109,7 @@ class TransientHDRFilm:
             self._steady_accum.zero_()
         if self.transient_storage:
             self.transient_storage.clear()
+            self.film_is_zero = True
 
     def steady_accum(self):
         return self._steady_accum
@@ -128,6 +131,7 @@ class TransientHDRFilm:
         if active is not None:
             ok &= torch.as_tensor(active, dtype=torch.bool, device=dev)
         pixel = torch.where(ok, py * W + px, torch.full_like(px, W * H))   # out-of-range id -> dropped by the kernel
+        self.film_is_zero = False
         return self.transient_storage.put_opl(pixel, distance, spec[:, 0], spec[:, 1], spec[:, 2], self.desc(), variant)
 
     # -- develop -------------------------------------------------------------

@@ -127,6 +127,9 @@ class TransientADIntegrator:
             s0, s1 = (0, spp_i) if spp_range is None else spp_range
             p0, p1 = (0, None) if pixel_range is None else pixel_range
             params = self.render_params(film, sampler_i.seed_value(), total_spp, s0, s1, p0, p1)
+            if film.film_is_zero:
+                params.flags |= _cabi.MTR_FLAG_FILM_ZERO      # first pass after clear(): row flushes may store
+            film.film_is_zero = False
             cnt = _cabi.mtr_counters() if self.collect_stats else None
             tim = _cabi.mtr_kernel_times() if self.collect_stats else None
             ctx.check(ctx.lib.mtr_render(handle, C.byref(params), tptr, sptr,

@@ -1,0 +1,9 @@
+#!/bin/bash
+for lib in "$@"; do
+  MITRANSIENT_AMD_LIB=$(pwd)/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode wavefront 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        r = json.loads(l); print('$lib', 'ms/step %.2f' % r['ms_per_step'], 'Mray/s %.0f' % r['value'])
+"
+done

@@ -1,0 +1,7 @@
+import sys; sys.path.insert(0,'/root/repo')
+import bench, torch
+scene = bench.build_scene(512,512,1024, mode='wavefront')
+integ = scene.integrator(); integ.collect_stats=True
+for _ in range(2):
+    s,t = integ.render(scene, spp=1024)
+print(integ.last_times)
