@@ -394,17 +394,38 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
     }
 }
 
-// the time-bin scatter-add + steady reduction: one workgroup per pixel of the tile
+// ---- the time-bin scatter-add: one workgroup per pixel of the tile ------------------------------
+// LDS float atomics (ds_add_f32) retire at a fixed 3 clocks per LANE on gfx950 whatever the address
+// pattern (204 G adds/s for the whole chip, measured), 64-bit integer LDS atomics at 2.7 T/s.  The row
+// is therefore accumulated in signed 2^-kFixShift fixed point with ds_add_u64 and converted back to
+// f32 once per (pixel, bin) at the flush: 13x faster, order-independent (deterministic) sums, and an
+// absolute rounding error of 2^-43 per contribution — below the f32 rounding of any bin sum > 1e-5.
+constexpr int kFixShift = 42;                       // resolution 2.3e-13, range +-2^21 per bin
+__device__ __forceinline__ unsigned long long to_fixed(float v)
+{
+    long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42, exact scaling
+    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;               // never lose a contribution entirely
+    return (unsigned long long)q;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long h)
+{
+    return __ll2float_rn((long long)h) * 2.2737367544323206e-13f; // 2^-42
+}
+
+template <bool FIXED>
 __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *row = (float *)(smem + 64);                  // [3][T]
+    float *row = (float *)(smem + 64);                              // [3][T] f32 ...
+    unsigned long long *row64 = (unsigned long long *)(smem + 64);  // ... or [3][T] fixed point
     const uint32_t T = a.film.bins;
     const int tid = threadIdx.x;
     const bool rows = a.rec_cap > 0;                    // false: T*12 B does not fit LDS, shade used HBM atomics
-    if (rows) for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+    if (rows) {
+        if (FIXED) for (uint32_t t = tid; t < 3 * T; t += kBlock) row64[t] = 0ull;
+        else for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+    }
     __syncthreads();
-    const Planes P{ (float4 *)a.planes, a.n_slots };
     for (uint32_t pl = blockIdx.x; pl < a.P; pl += gridDim.x) {
         const uint32_t pixel = a.pix0 + pl;
         const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;    // film coords (crop offset removed)
@@ -425,37 +446,44 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
             }
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
-#ifdef MTR_EXP_SC_NOATOM
-                if (r[k].x == 0xfffffffeu) {
-#else
                 if (r[k].x != 0xffffffffu) {
-#endif
-                    float *p = row + r[k].x;
-                    __hip_atomic_fetch_add(p, __uint_as_float(r[k].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(p + T, __uint_as_float(r[k].z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r[k].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (FIXED) {
+                        unsigned long long *p = row64 + r[k].x;
+                        atomicAdd(p, to_fixed(__uint_as_float(r[k].y)));
+                        atomicAdd(p + T, to_fixed(__uint_as_float(r[k].z)));
+                        atomicAdd(p + 2 * T, to_fixed(__uint_as_float(r[k].w)));
+                    } else {
+                        float *p = row + r[k].x;
+                        __hip_atomic_fetch_add(p, __uint_as_float(r[k].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(p + T, __uint_as_float(r[k].z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r[k].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
         __syncthreads();
-        if (in_film) {
+        if (rows) {
             float4 *dst = (float4 *)(a.film_out + fpix * T * 4u);
-#ifdef MTR_EXP_SC_NOFLUSH
-            for (uint32_t t = tid; rows && t < T && a.P == 0xffffffffu; t += kBlock) {
-#else
-            for (uint32_t t = tid; rows && t < T; t += kBlock) {
-#endif
-                float r = row[t], g = row[T + t], b = row[2 * T + t];
-                if (r != 0.0f || g != 0.0f || b != 0.0f) {
+            for (uint32_t t = tid; t < T; t += kBlock) {
+                float r, g, b;
+                bool nz;
+                if (FIXED) {
+                    const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
+                    nz = (qr | qg | qb) != 0ull;
+                    r = from_fixed(qr); g = from_fixed(qg); b = from_fixed(qb);
+                    if (nz) { row64[t] = 0ull; row64[T + t] = 0ull; row64[2 * T + t] = 0ull; }
+                } else {
+                    r = row[t]; g = row[T + t]; b = row[2 * T + t];
+                    nz = r != 0.0f || g != 0.0f || b != 0.0f;
+                    if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
+                }
+                if (nz && in_film) {
                     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (!store_only) v = dst[t];                  // accumulate onto earlier passes / overflow atomics
                     v.x += r; v.y += g; v.z += b;
                     dst[t] = v;
-                    row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f;
                 }
             }
-        } else if (rows) {
-            for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
         }
         __syncthreads();
     }
@@ -491,10 +519,13 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
 {
     if (which == 3) {
-        size_t lds = 64 + (a.rec_cap ? (size_t)a.film.bins * 12u : 16u);
-        hipError_t e = hipFuncSetAttribute((const void *)k_wf_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // fixed-point rows need 24 B per bin; fall back to f32 rows (12 B) when that does not leave 2 workgroups per CU
+        const bool fixed = a.rec_cap && (size_t)a.film.bins * 24u <= 72u * 1024u;
+        size_t lds = 64 + (a.rec_cap ? (size_t)a.film.bins * (fixed ? 24u : 12u) : 16u);
+        void (*k)(const WfArgs) = fixed ? k_wf_scatter<true> : k_wf_scatter<false>;
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_wf_scatter, dim3(grid), dim3(kBlock), lds, stream, a);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
         return hipGetLastError();
     }
 #define WF_CASE(S)                                                                             \
