@@ -48,21 +48,27 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
     film = scene.sensors()[0].film()
     cores = oracle.num_threads()
     bufs = oracle.alloc_film(sd.film, prefault=True)      # film allocation/page faults are NOT timed
-    # warm-up (thread pool, caches) with 1 sample per pixel, then a 2-sample calibration, then the bounded sample
+    # warm-up (thread pool, caches), then a 2-sample calibration of both intersection modes of the oracle
+    # (brute force over the 36 triangles / its own BVH); the faster one runs the bounded sample
     oracle.render(sd, integ.render_params(film, 0, spp_total, 0, 1), use_bvh=True, out=bufs)
-    t0 = time.perf_counter()
-    oracle.render(sd, integ.render_params(film, 0, spp_total, 1, 3), use_bvh=True, out=bufs)
-    dt_per_spp = max(time.perf_counter() - t0, 1e-3) / 2.0
+    best = None
+    for use_bvh in (True, False):
+        t0 = time.perf_counter()
+        oracle.render(sd, integ.render_params(film, 0, spp_total, 1, 3), use_bvh=use_bvh, out=bufs)
+        dt2 = max(time.perf_counter() - t0, 1e-3) / 2.0
+        if best is None or dt2 < best[0]:
+            best = (dt2, use_bvh)
+    dt_per_spp, use_bvh = best
     k = int(max(1, min(spp_total - 3, target_s / dt_per_spp)))
     p = integ.render_params(film, 0, spp_total, 3, 3 + k)
     t0 = time.perf_counter()
-    _, _, c = oracle.render(sd, p, use_bvh=True, out=bufs)
+    _, _, c = oracle.render(sd, p, use_bvh=use_bvh, out=bufs)
     dt = time.perf_counter() - t0
     rays = c["rays_closest"] + c["rays_shadow"]
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
             "time_bins_per_s": c["splats_issued"] / dt,
             "sample": f"{width}x{height} px, {bins} bins, samples 3..{2 + k} of {spp_total} per pixel "
-                      f"({c['paths']} paths in {dt:.1f} s; oracle's own BVH, OpenMP {cores} threads, "
+                      f"({c['paths']} paths in {dt:.1f} s; oracle {'BVH' if use_bvh else 'brute-force'} intersection, OpenMP {cores} threads, "
                       f"film pre-faulted and not cleared inside the timed region)"}
 
 

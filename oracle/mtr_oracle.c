@@ -303,16 +303,22 @@ static inline void hit_update(hit_t *h, float t, float u, float v, int prim)
 {
     if (t < h->t || (t == h->t && prim < h->prim)) { h->t = t; h->u = u; h->v = v; h->prim = prim; }
 }
-static int box_hit(const orc_node *N, const ray3 *r, v3 inv_d, float tbest)
+/* culling only (conservative: padded boxes); plain ternaries instead of libm fminf/fmaxf calls */
+#define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define ORC_MAX(a, b) ((a) > (b) ? (a) : (b))
+static inline int box_hit(const orc_node *N, const ray3 *r, v3 inv_d, float tbest)
 {
     float t0 = (N->lo.x - r->o.x) * inv_d.x, t1 = (N->hi.x - r->o.x) * inv_d.x;
-    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    float tn = ORC_MIN(t0, t1), tf = ORC_MAX(t0, t1);
     t0 = (N->lo.y - r->o.y) * inv_d.y; t1 = (N->hi.y - r->o.y) * inv_d.y;
-    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    float a = ORC_MIN(t0, t1), b = ORC_MAX(t0, t1);
+    tn = ORC_MAX(tn, a); tf = ORC_MIN(tf, b);
     t0 = (N->lo.z - r->o.z) * inv_d.z; t1 = (N->hi.z - r->o.z) * inv_d.z;
-    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    a = ORC_MIN(t0, t1); b = ORC_MAX(t0, t1);
+    tn = ORC_MAX(tn, a); tf = ORC_MIN(tf, b);
     tf *= 1.0000005f;
-    return tn <= tf && tf >= 0.0f && tn <= tbest;
+    /* written so that a NaN (0 * inf on an axis-parallel ray) never culls */
+    return !(tn > tf) && !(tf < 0.0f) && !(tn > tbest);
 }
 static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
 {
@@ -328,7 +334,7 @@ static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
     int stack[128], sp = 0; stack[sp++] = 0;
     while (sp) {
         const orc_node *N = &sc->nodes[stack[--sp]];
-        if (!box_hit(N, r, inv_d, fminf(h.t, r->maxt))) continue;
+        if (!box_hit(N, r, inv_d, ORC_MIN(h.t, r->maxt))) continue;
         if (N->left < 0) {
             for (int i = N->first; i < N->first + N->count; ++i) {
                 int p = sc->tri_order[i];
