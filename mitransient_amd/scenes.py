@@ -1,0 +1,74 @@
+"""Procedural test/benchmark scenes built from the supported plugin subset.
+
+``staircase_like`` is a stand-in for the reference's ``examples/diff-transient/staircase`` scene
+(BASELINE config 5: 262 661 triangles, diffuse / conductor / dielectric / twosided mix, one
+rectangle light, max_depth 65, camera_unwarp): the real assets (774 OBJ files, 27 MB) live only in
+the reference checkout, so the divergence stress is reproduced with generated geometry of the same
+size class and material mix.  Every shape is a `cube` or `rectangle` plugin, so the scene goes
+through the ordinary ``load_dict`` path.
+"""
+from __future__ import annotations
+
+import math
+
+from .transform import ScalarTransform4f as T
+
+
+def staircase_like(n_steps=12, balusters=2, tiles=0, width=128, height=128, temporal_bins=256,
+                   max_depth=65, spp=16):
+    """A stair flight inside a room.  Triangle count = 12*(n_steps*(1 + 2*balusters) + 2) + 2*tiles^2*... ;
+    ``tiles`` tessellates the floor into tiles x tiles small two-sided diffuse quads of alternating colour
+    (cheap way to reach 10^5 triangles)."""
+    d = {
+        "type": "scene",
+        "integrator": {"type": "transient_path", "max_depth": max_depth, "rr_depth": 5, "camera_unwarp": True},
+        "sensor": {
+            "type": "perspective", "fov": 55.0, "near_clip": 0.01, "far_clip": 100.0,
+            "to_world": T().look_at(origin=[2.6, 2.4, 5.2], target=[0.0, 1.2, 0.0], up=[0, 1, 0]),
+            "sampler": {"type": "independent", "sample_count": spp},
+            "film": {"type": "transient_hdr_film", "width": width, "height": height, "rfilter": {"type": "box"},
+                     "temporal_bins": temporal_bins, "start_opl": 0.0, "bin_width_opl": 40.0 / temporal_bins},
+        },
+        "wall": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.75, 0.72, 0.68]}}},
+        "wood": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.42, 0.26, 0.13]}},
+        "tile_a": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.8, 0.8]}}},
+        "tile_b": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.15, 0.15, 0.2]}}},
+        "steel": {"type": "conductor", "eta": [2.76, 2.54, 2.27], "k": [3.83, 3.43, 3.04]},
+        "brass": {"type": "twosided", "bsdf": {"type": "conductor", "eta": [0.44, 0.53, 1.03], "k": [3.7, 2.77, 1.97]}},
+        "glass": {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0},
+        "light": {"type": "rectangle", "to_world": T().translate([0.0, 3.95, 0.5]).rotate([1, 0, 0], 90).scale([0.9, 0.6, 1.0]),
+                  "bsdf": {"type": "ref", "id": "wall"},
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [30.0, 30.0, 30.0]}}},
+        # room: 6 x 4 x 8, open towards the camera (+z)
+        "floor": {"type": "rectangle", "to_world": T().rotate([1, 0, 0], -90).scale([3.0, 4.0, 1.0]), "bsdf": {"type": "ref", "id": "wall"}},
+        "ceiling": {"type": "rectangle", "to_world": T().translate([0, 4, 0]).rotate([1, 0, 0], 90).scale([3.0, 4.0, 1.0]), "bsdf": {"type": "ref", "id": "wall"}},
+        "back": {"type": "rectangle", "to_world": T().translate([0, 2, -4]).scale([3.0, 2.0, 1.0]), "bsdf": {"type": "ref", "id": "wall"}},
+        "left": {"type": "rectangle", "to_world": T().translate([-3, 2, 0]).rotate([0, 1, 0], 90).scale([4.0, 2.0, 1.0]), "bsdf": {"type": "ref", "id": "wall"}},
+        "right": {"type": "rectangle", "to_world": T().translate([3, 2, 0]).rotate([0, 1, 0], -90).scale([4.0, 2.0, 1.0]), "bsdf": {"type": "ref", "id": "wall"}},
+        "glass-pane": {"type": "cube", "to_world": T().translate([-1.6, 1.2, 1.5]).scale([0.02, 1.2, 1.0]), "bsdf": {"type": "ref", "id": "glass"}},
+        "mirror": {"type": "cube", "to_world": T().translate([2.9, 1.6, -1.0]).scale([0.03, 1.0, 1.4]), "bsdf": {"type": "ref", "id": "steel"}},
+    }
+    rise, run, sw = 3.0 / n_steps, 5.0 / n_steps, 0.9
+    for i in range(n_steps):
+        y, z = rise * (i + 0.5), 2.5 - run * (i + 0.5)
+        d[f"step{i}"] = {"type": "cube", "to_world": T().translate([0.6, y, z]).scale([sw, rise * 0.5, run * 0.5]),
+                         "bsdf": {"type": "ref", "id": "wood"}}
+        for b in range(balusters):
+            for side, x in ((0, 0.6 - sw + 0.05), (1, 0.6 + sw - 0.05)):
+                zz = z + run * ((b + 0.5) / balusters - 0.5)
+                d[f"bal{i}_{b}_{side}"] = {
+                    "type": "cube", "to_world": T().translate([x, y + rise * 0.5 + 0.45, zz]).rotate([0, 1, 0], 45.0).scale([0.02, 0.45, 0.02]),
+                    "bsdf": {"type": "ref", "id": "brass" if (i + b) % 2 else "steel"}}
+    for side, x in ((0, 0.6 - sw + 0.05), (1, 0.6 + sw - 0.05)):
+        ang = math.degrees(math.atan2(3.0, 5.0))
+        d[f"rail{side}"] = {"type": "cube",
+                            "to_world": T().translate([x, 1.5 + 0.95, 0.0]).rotate([1, 0, 0], ang).scale([0.03, 0.03, 2.95]),
+                            "bsdf": {"type": "ref", "id": "brass"}}
+    for a in range(tiles):
+        for b in range(tiles):
+            x = -3.0 + 6.0 * (a + 0.5) / tiles
+            z = -4.0 + 8.0 * (b + 0.5) / tiles
+            d[f"tile{a}_{b}"] = {"type": "rectangle",
+                                 "to_world": T().translate([x, 0.002, z]).rotate([1, 0, 0], -90).scale([2.9 / tiles, 3.9 / tiles, 1.0]),
+                                 "bsdf": {"type": "ref", "id": "tile_a" if (a + b) % 2 else "tile_b"}}
+    return d
