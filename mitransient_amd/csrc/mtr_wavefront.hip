@@ -230,7 +230,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 }
 
 // closest hit for the live lists of this bounce; every slot is appended to the list of its hit
-// material type inside its segment (sorted-by-material hit queues)
+// material type inside its segment (sorted-by-material hit queues).
+// (Measured and dropped: lanes that fetch their next ray as soon as their own traversal ends, with the
+// next ray prefetched — same instruction count and the same 26/64 active lanes, because the while-while
+// node phase still waits for the longest node run of the wave; and the per-ray append order it needs
+// scrambled the lists, which cost k_wf_shade 40 % in gather efficiency.)
 template <int STACK, bool SCENE_LDS>
 __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 {
