@@ -128,6 +128,20 @@ __device__ __forceinline__ void slot_to_lane(const WfArgs &a, uint32_t slot, uin
     pixel = a.pix0 + p_local;
 }
 
+// ray-direction class used to order the next live list (coherent waves in the next trace):
+// octant of the direction (3 bits) and its dominant axis (2 bits)
+#ifndef MTR_WF_DIRSORT
+#define MTR_WF_DIRSORT 0          // measured on config 2: trace 63 -> 57 ms but shade 93 -> 142 ms (scrambled gathers): off
+#endif
+constexpr uint32_t kDirKeys = 32;
+__device__ __forceinline__ uint32_t ray_dir_key(f3 d)
+{
+    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const uint32_t dom = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+    return oct | (dom << 3);
+}
+
 // ---- wave64 aggregated append: one atomic per (wave, key) ---------------------------------
 __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
 {
@@ -295,6 +309,9 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
     float *s_steady = (float *)(smem + off + al16(a.G * 4u));   // [G][4] radiance sums of the paths that end here
+    // survivors of the segment, staged in LDS so that they can be written out sorted by ray-direction class
+    uint32_t *s_surv = (uint32_t *)(smem + off + al16(a.G * 4u) + al16(a.G * 16u));      // [seg] slot | key << 25
+    uint32_t *s_key = (uint32_t *)smem + 4;                     // [kDirKeys] histogram / cursors (smem[16..])
     const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
@@ -313,7 +330,7 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
             for (uint32_t i = tid; i < n_round; i += kBlock) {
                 const bool on = i < n_k;
                 bool alive = false;
-                uint32_t slot = 0;
+                uint32_t slot = 0, dir_key = 0;
                 if (on) {
                     slot = q[i];
                     uint32_t pixel, s, pl;
@@ -349,7 +366,7 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
 #ifndef MTR_EXP_WF_NOSTORE
                     store_state(P, slot, p, false);
 #endif
-                    if (alive) ++n_alive;
+                    if (alive) { ++n_alive; dir_key = ray_dir_key(p.ray.d); }
                     else {
                         // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
                         float *sp = s_steady + 4 * (pl - pl0);
@@ -362,11 +379,31 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
                 // wave64 stream compaction of the survivors into the segment's next live list
                 if (__ballot(alive) != 0ull) {
                     const uint32_t pos = wave_append(s_next_p, alive);
+#if MTR_WF_DIRSORT
+                    if (alive) s_surv[pos] = slot | (dir_key << 25);
+#else
                     if (alive) q_next[pos] = slot;
+#endif
                 }
             }
         }
         __syncthreads();
+#if MTR_WF_DIRSORT
+        {   // counting sort of the survivors by direction class: coherent waves for the next k_wf_trace
+            const uint32_t m = *s_next_p;
+            if (tid < (int)kDirKeys) s_key[tid] = 0u;
+            __syncthreads();
+            for (uint32_t t = tid; t < m; t += kBlock) atomicAdd(&s_key[s_surv[t] >> 25], 1u);
+            __syncthreads();
+            if (tid == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < kDirKeys; ++k) { uint32_t c = s_key[k]; s_key[k] = acc; acc += c; } }
+            __syncthreads();
+            for (uint32_t t = tid; t < m; t += kBlock) {
+                const uint32_t e = s_surv[t];
+                q_next[atomicAdd(&s_key[e >> 25], 1u)] = e & 0x1ffffffu;
+            }
+            __syncthreads();
+        }
+#endif
         if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
@@ -497,7 +534,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
-    lds += al16(a.G * 4u) + al16(a.G * 16u);                // k_wf_shade: record-list tails + steady sums of the segment's pixels
+    lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg * 4u);   // k_wf_shade: record-list tails, steady sums, survivor staging
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
