@@ -187,9 +187,6 @@ struct RecordSink {
             todo &= ~same;
         }
         ++n_splats;
-#ifdef MTR_EXP_WF_NOREC
-        return;
-#endif
         if (idx < rec_cap) {
             rec[(size_t)p_local * rec_cap + idx] = make_uint4(bin, __float_as_uint(r), __float_as_uint(g), __float_as_uint(b));
         } else {
@@ -353,19 +350,13 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
-#ifdef MTR_EXP_NOSHADOW
-                        Hit sh; sh.prim = -1;
-#else
                         Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
-#endif
                         occluded = sh.prim >= 0;
                     }
                     alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
-#ifndef MTR_EXP_WF_NOSTORE
                     store_state(P, slot, p, false);
-#endif
                     if (alive) { ++n_alive; dir_key = ray_dir_key(p.ray.d); }
                     else {
                         // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)

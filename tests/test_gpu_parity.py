@@ -353,3 +353,95 @@ def test_large_procedural_scene_modes_agree():
     (s_a, t_a), (s_b, t_b) = outs["fused"], outs["wavefront"]
     assert rel_l2(t_a, t_b) <= TOL and rel_l2(s_a, s_b) <= TOL
     assert rel_l2(t_a.sum(axis=2), s_a) <= 5e-3          # window 0..40 covers nearly every path (a few specular chains run longer)
+
+
+# ---------------------------------------------------------------- edge cases
+def _custom_scene(shapes, film, integrator=None, mode="fused"):
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    d = {"type": "scene",
+         "integrator": dict({"type": "transient_path", "max_depth": 4, "amd_mode": mode}, **(integrator or {})),
+         "sensor": {"type": "perspective", "fov": 40.0, "near_clip": 0.01, "far_clip": 50.0,
+                    "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                    "sampler": {"type": "independent", "sample_count": 4},
+                    "film": dict({"type": "transient_hdr_film", "rfilter": {"type": "box"}}, **film)}}
+    d.update(shapes)
+    return mi.load_dict(d)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_empty_scene_and_unlit_scene(oracle, mode):
+    """no geometry at all (every ray escapes) and geometry without any emitter: all-zero outputs, correct counters."""
+    from mitransient_amd.transform import ScalarTransform4f as T
+    film = {"width": 9, "height": 5, "temporal_bins": 16, "bin_width_opl": 1.0}
+    scene = _custom_scene({}, film, mode=mode)
+    s, t = gpu_render(scene, 3)
+    assert t.shape == (5, 9, 16, 3) and not t.any() and not s.any()
+    c = scene.integrator().last_counters
+    assert (c["paths"], c["rays_closest"], c["rays_shadow"], c["splats_issued"]) == (135, 135, 0, 0)
+    quad = {"wall": {"type": "rectangle", "to_world": T().scale(2.0), "bsdf": {"type": "diffuse", "reflectance": 0.5}}}
+    scene = _custom_scene(quad, film, mode=mode)
+    s, t = gpu_render(scene, 3)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 3)
+    assert not t.any() and not t_ref.any()
+    assert scene.integrator().last_counters["bounces"] == cnt["bounces"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_single_pixel_single_sample_and_emitter_only(oracle, mode):
+    """1x1 film, 1 spp, the camera looks straight at a light: the emission lands in exactly one bin."""
+    from mitransient_amd.transform import ScalarTransform4f as T
+    light = {"light": {"type": "rectangle", "to_world": T().scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 0.0},
+                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [2.0, 3.0, 4.0]}}}}
+    film = {"width": 1, "height": 1, "temporal_bins": 100, "bin_width_opl": 0.1}
+    scene = _custom_scene(light, film, mode=mode)
+    s, t = gpu_render(scene, 1)
+    s_ref, t_ref, *_ = oracle_render(oracle, scene, 1)
+    assert np.array_equal(t, t_ref) and np.array_equal(s, s_ref)
+    assert np.count_nonzero(t) == 3 and np.allclose(t.sum(axis=(0, 1, 2)), [2.0, 3.0, 4.0])
+    assert 39 <= int(np.argmax(t[0, 0, :, 0])) <= 43         # OPL 3.99 on the axis (near clip 0.01) ... 3.99/cos(28 deg) in the corner
+
+
+def test_many_samples_few_pixels_and_few_samples_many_pixels(oracle):
+    """ragged segment shapes of the fused kernel: spp >> lanes per segment, and spp = 1 with hundreds of pixels per segment"""
+    for (w, h, spp) in [(3, 2, 3000), (96, 64, 1)]:
+        scene = make_cornell(width=w, height=h, bins=32)
+        s_gpu, t_gpu = gpu_render(scene, spp)
+        s_ref, t_ref, *_ = oracle_render(oracle, scene, spp)
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+
+
+def test_film_parameters_can_change_between_renders(oracle):
+    """mi.traverse(scene)['sensor.film.*'] edits (transient_hdr_film.py:295-308) take effect on the next render."""
+    import mitransient_amd.mi as mi
+    scene = make_cornell(width=16, height=16, bins=32)
+    gpu_render(scene, 4)
+    params = mi.traverse(scene)
+    params["sensor.film.temporal_bins"] = 80
+    params["sensor.film.start_opl"] = 2.0
+    params["sensor.film.bin_width_opl"] = 0.125
+    params.update()
+    s_gpu, t_gpu = gpu_render(scene, 4)
+    s_ref, t_ref, *_ = oracle_render(oracle, scene, 4)
+    assert t_gpu.shape == (16, 16, 80, 3)
+    assert rel_l2(t_gpu, t_ref) <= TOL
+
+
+def test_two_emitters(oracle):
+    """uniform emitter selection with sample reuse [Scene::sample_emitter_direction]"""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    for mode in MODES:
+        d = mitr.cornell_box()
+        d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, bin_width_opl=6.0 / 64)
+        d["integrator"]["amd_mode"] = mode
+        d["light2"] = {"type": "rectangle", "to_world": T().translate([-0.98, 0.0, 0.3]).rotate([0, 1, 0], 90).scale(0.15),
+                       "bsdf": {"type": "ref", "id": "white"},
+                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4.0, 9.0, 2.0]}}}
+        scene = mi.load_dict(d)
+        assert scene.data().n_emitters == 2
+        s_gpu, t_gpu = gpu_render(scene, 16)
+        s_ref, t_ref, *_ = oracle_render(oracle, scene, 16)
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
