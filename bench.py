@@ -109,9 +109,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    # dry-run hooks (single-GPU box): MTR_BENCH_DEVICE pins every rank to one device, MTR_BENCH_BACKEND=gloo
+    # replaces RCCL (which needs one device per rank) so that the N>1 code path can be exercised end to end
+    device_index = int(os.environ.get("MTR_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MTR_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     scene = build_scene(args.width, args.height, args.bins, mode=args.mode)
     integ = scene.integrator()
@@ -128,9 +135,9 @@ def main():
         steady, transient = renderer.render(spp=spp_total, seed=0)
         if timed:
             for k in totals:
-                totals[k] += integ.last_counters[k]
-            kernel_ms.append(integ.last_times["trace_ms"])
-            trace_launches += integ.last_times["trace_launches"]
+                totals[k] += integ.total_counters[k]
+            kernel_ms.append(integ.total_times["trace_ms"])          # sum over the launches of this step
+            trace_launches += integ.total_times["trace_launches"]
         return steady, transient
 
     def fence():
@@ -184,9 +191,10 @@ def main():
         # roofline of the dominant kernel (the path kernel), rank 0's launches, HIP events on its stream:
         # algorithmic bytes per launch = 24 B x contributions one launch issues
         n_launch = max(1, trace_launches)
-        avg_ms = sum(kernel_ms) / max(1, n_launch) if (args.mode in (None, "auto", "fused")) else sum(kernel_ms) / max(1, len(kernel_ms))
+        fused = args.mode in (None, "auto", "fused")
+        avg_ms = sum(kernel_ms) / max(1, n_launch) if fused else sum(kernel_ms) / max(1, len(kernel_ms))
         splats_rank0 = totals["splats_issued"] / world
-        bytes_per_launch = SPLAT_BYTES * splats_rank0 / max(1, len(kernel_ms))
+        bytes_per_launch = SPLAT_BYTES * splats_rank0 / (max(1, n_launch) if fused else max(1, len(kernel_ms)))
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kname = "k_fused" if (args.mode in (None, "auto", "fused")) else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
         res = {

@@ -80,17 +80,21 @@ class DistributedRenderer:
     """Shards one render over the ranks of a process group.
 
     ``spp`` is the TOTAL sample count; each rank renders ``shard_range(spp, world, rank)`` (partition
-    "spp") or all samples of its rows (partition "rows")."""
+    "spp") or all samples of its rows (partition "rows").
 
-    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True):
+    With partition "spp" the film reduction is PIPELINED against the path kernel: the image is rendered
+    in ``bands`` horizontal bands; as soon as a band's kernel has finished (event), its slab of the raw
+    film is reduce-scattered on a side stream while the next band renders, then developed and
+    all-gathered straight into its rows of the output.  Only the last band's communication is exposed."""
+
+    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True, bands: int = 8):
         if partition not in ("spp", "rows"):
             raise ValueError("partition must be 'spp' or 'rows'")
-        self.scene, self.partition, self.group, self.gather = scene, partition, group, gather
+        self.scene, self.partition, self.group, self.gather, self.bands = scene, partition, group, gather, int(bands)
 
     def render(self, spp: int, seed: int = 0, sensor: int = 0):
         import torch
         import torch.distributed as dist
-        from .films.transient_hdr_film import TransientHDRFilm  # noqa: F401
         from .tensor import TensorXf
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
@@ -103,15 +107,20 @@ class DistributedRenderer:
         total_spp = sum(s for _, s in passes)
         W, H = film.size()
         cw, ch = film.crop_size()
+        if world == 1:
+            integ.accumulate(scene, sens, passes, total_spp)
+            return film.develop()
         if self.partition == "spp":
-            integ.accumulate(scene, sens, passes, total_spp, spp_range=shard_range(total_spp, world, rank))
+            my_spp = shard_range(total_spp, world, rank)
+            nb = self.bands
+            if self.gather and nb > 1 and ch == H and cw == W and H % (nb * world) == 0:
+                return self._render_pipelined(integ, sens, film, passes, total_spp, my_spp, nb, world)
+            integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp)
         else:
             r0, r1 = shard_range(ch, world, rank)
             integ.accumulate(scene, sens, passes, total_spp, pixel_range=(r0 * cw, r1 * cw))
         raw_t = film.transient_storage.torch_tensor()
         raw_s = film.steady_accum()
-        if world == 1:
-            return film.develop()
         if self.partition == "spp":
             slab_t = reduce_scatter_rows(raw_t, self.group)      # THE film reduction
             slab_s = reduce_scatter_rows(raw_s, self.group)
@@ -126,6 +135,7 @@ class DistributedRenderer:
             return (TensorXf(all_gather_rows(dev_s, H, self.group)), TensorXf(all_gather_rows(dev_t, H, self.group)))
         # rows: uneven slabs are padded to the largest before the gather
         per = (ch + world - 1) // world
+
         def pad(x):
             if x.shape[0] == per:
                 return x
@@ -142,3 +152,41 @@ class DistributedRenderer:
             full_t = torch.cat([full_t, torch.zeros((H - full_t.shape[0],) + tuple(full_t.shape[1:]), dtype=full_t.dtype, device=full_t.device)])
             full_s = torch.cat([full_s, torch.zeros((H - full_s.shape[0],) + tuple(full_s.shape[1:]), dtype=full_s.dtype, device=full_s.device)])
         return TensorXf(full_s), TensorXf(full_t)
+
+    def _render_pipelined(self, integ, sens, film, passes, total_spp, my_spp, nb, world):
+        """bands of rows: render band b | reduce-scatter + develop + all-gather band b-1 on a side stream"""
+        import torch
+        import torch.distributed as dist
+        from .tensor import TensorXf
+        scene = self.scene
+        W, H = film.size()
+        T = film.temporal_bins
+        raw_t = film.transient_storage.torch_tensor()
+        raw_s = film.steady_accum()
+        dev = raw_t.device
+        out_t = torch.empty((H, W, T, 3), dtype=torch.float32, device=dev)
+        out_s = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        rows_b = H // nb
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=dev)
+        gloo = dist.get_backend(self.group) == "gloo"
+        for b in range(nb):
+            r0, r1 = b * rows_b, (b + 1) * rows_b
+            integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W))
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                if gloo:
+                    side.synchronize()              # gloo collectives are host-driven (CPU test path)
+                slab_t = reduce_scatter_rows(raw_t[r0:r1], self.group)          # THE film reduction, band b
+                slab_s = reduce_scatter_rows(raw_s[r0:r1], self.group)
+                d_t, d_s = film.develop_slab(slab_t, slab_s)
+                got_t = all_gather_rows(d_t, rows_b, self.group)
+                got_s = all_gather_rows(d_s, rows_b, self.group)
+                out_t[r0:r1].copy_(got_t)
+                out_s[r0:r1].copy_(got_s)
+        main.wait_stream(side)
+        return TensorXf(out_s), TensorXf(out_t)

@@ -39,8 +39,10 @@ class TransientADIntegrator:
         m = props.get("amd_mode", None)
         if m is not None:
             self.mode = {"auto": 0, "fused": 1, "wavefront": 2}[m]
-        self.last_counters = None
+        self.last_counters = None      # counters / kernel times of the last mtr_render call ...
         self.last_times = None
+        self.total_counters = None     # ... and summed over every pass since the last prepare()
+        self.total_times = None
         self.collect_stats = False
 
     def aov_names(self):
@@ -55,6 +57,7 @@ class TransientADIntegrator:
         spp = sampler.sample_count()
         sampler.set_samples_per_wavefront(spp)
         film_size = film.crop_size()
+        self.total_counters, self.total_times = None, None
         wavefront_size = film_size[0] * film_size[1] * spp
         if wavefront_size <= 2 ** 32:
             film.prepare(aovs)
@@ -137,6 +140,13 @@ class TransientADIntegrator:
                                          C.byref(tim) if tim is not None else None), "mtr_render")
             if self.collect_stats:
                 self.last_counters, self.last_times = cnt.as_dict(), tim.as_dict()
+                if self.total_counters is None:
+                    self.total_counters = {k: 0 for k in self.last_counters if k != "reserved"}
+                    self.total_times = {k: 0 for k in self.last_times}
+                for k in self.total_counters:
+                    self.total_counters[k] += self.last_counters[k]
+                for k in self.total_times:
+                    self.total_times[k] += self.last_times[k]
             if progress_callback:
                 progress_callback((i + 1) / len(samplers_spps))
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmp, partition):
+def _worker(rank, world, port, tmp, partition, height=18):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -25,7 +25,7 @@ def _worker(rank, world, port, tmp, partition):
     try:
         from conftest import make_cornell
         from mitransient_amd import distributed as md
-        scene = make_cornell(width=24, height=18, bins=48)
+        scene = make_cornell(width=24, height=height, bins=48)
         steady, transient = md.DistributedRenderer(scene, partition=partition, gather=True).render(spp=10, seed=3)
         torch.cuda.synchronize()
         np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
@@ -49,4 +49,22 @@ def test_two_rank_render_equals_single(tmp_path, partition):
         t = np.load(tmp_path / f"t{r}.npy")
         s = np.load(tmp_path / f"s{r}.npy")
         assert t.shape == t_ref.shape and s.shape == s_ref.shape
+        assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+
+
+def test_two_rank_pipelined_band_reduction(tmp_path):
+    """H = 32 = 8 bands x 2 ranks x 2 rows: the band-pipelined reduce-scatter / develop / all-gather path."""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=24, height=32, bins=48)
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=10)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "spp", 32), nprocs=2, join=True)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        assert t.shape == t_ref.shape == (32, 24, 48, 3)
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
