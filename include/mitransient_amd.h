@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 1
+#define MTR_ABI_VERSION 2
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -84,6 +84,37 @@ typedef struct mtr_film_desc {
     float    bin_width_opl;               /* default 0.003                             */
 } mtr_film_desc;
 
+/* ---- NLOS tier: `transient_nlos_path` + `nlos_capture_meter` + `projector` ---------------
+ * (reference: mitransient/integrators/transientnlospath.py:200-249 properties, :251-383 prepare;
+ *  mitransient/sensors/nloscapturemeter.py:93-202; mitsuba's `projector` emitter)            */
+enum { MTR_CAPTURE_SINGLE = 1, MTR_CAPTURE_CONFOCAL = 2 /* Exhaustive (3): 6-D film, not built */ };
+enum { MTR_NLOS_LASER_SAMPLING = 1u,          /* nlos_laser_sampling                              */
+       MTR_NLOS_HG_SAMPLING = 2u,             /* nlos_hidden_geometry_sampling                    */
+       MTR_NLOS_HG_RROULETTE = 4u,            /* nlos_hidden_geometry_sampling_do_rroulette       */
+       MTR_NLOS_HG_INCLUDES_WALL = 8u,        /* nlos_hidden_geometry_sampling_includes_relay_wall*/
+       MTR_NLOS_ACCOUNT_FIRST_LAST = 16u,     /* account_first_and_last_bounces                   */
+       MTR_NLOS_DISCARD_DIRECT = 32u          /* discard_direct_paths                             */ };
+
+typedef struct mtr_shape {          /* one scene shape = a contiguous triangle range */
+    uint32_t first_tri, n_tris;
+    uint32_t is_rectangle;          /* analytic `rectangle` (sample_position by to_world) vs triangle mesh */
+    float    center[3], du[3], dv[3];   /* rectangle only: to_world*(0,0,0), half edges */
+} mtr_shape;
+
+typedef struct mtr_nlos_desc {
+    float    sensor_origin[3];      /* nlos_capture_meter.sensor_origin (nloscapturemeter.py:103-105)     */
+    uint32_t relay_shape;           /* index into shapes[]: the rectangle the sensor is attached to        */
+    float    laser_to_world[16];    /* projector world transform, row-major (after nlos.focus_emitter_*)   */
+    float    laser_fov;             /* degrees, along x                                                    */
+    float    laser_irradiance[3];   /* constant `irradiance` texture                                       */
+    float    laser_scale;           /* `scale` (default 1)                                                 */
+    uint32_t capture_type;          /* MTR_CAPTURE_*                                                       */
+    uint32_t flags;                 /* MTR_NLOS_*                                                          */
+    int32_t  filter_depth;          /* -1 = off (filter_bounces + 1 when that was given)                   */
+    uint32_t n_shapes;
+    const mtr_shape *shapes;        /* host; every triangle of the scene belongs to exactly one shape      */
+} mtr_nlos_desc;
+
 typedef struct mtr_scene_desc {
     uint32_t        n_tris;
     const float    *tri_verts;     /* host, n_tris*9 floats: p0 p1 p2, world space      */
@@ -93,8 +124,9 @@ typedef struct mtr_scene_desc {
     const mtr_material *materials; /* host                                              */
     uint32_t        n_emitters;
     const mtr_emitter  *emitters;  /* host                                              */
-    mtr_camera      camera;
+    mtr_camera      camera;         /* ignored when nlos != NULL                                      */
     mtr_film_desc   film;
+    const mtr_nlos_desc *nlos;      /* NULL: `perspective` sensor + `transient_path`; else the NLOS tier */
 } mtr_scene_desc;
 
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */
@@ -175,6 +207,10 @@ void mtr_scene_destroy(mtr_scene *);
 /* transient_hdr_film traverse()/parameters_changed (transient_hdr_film.py:295-311):
  * change T / start / width between renders. */
 int  mtr_scene_set_film(mtr_scene *, const mtr_film_desc *);
+/* NLOS tier: (re)derive the laser / relay-wall / hidden-geometry tables and the scanned points
+ * (TransientNLOSPath.prepare, transientnlospath.py:251-383) after mitransient.nlos.focus_emitter_*
+ * (nlos.py:5-70) or an integrator property changed.  The shape table must match the scene's triangles. */
+int  mtr_scene_set_nlos(mtr_scene *, const mtr_nlos_desc *);
 /* BVH statistics for tests: nodes, max depth, leaf count. */
 int  mtr_scene_bvh_info(const mtr_scene *, uint32_t *n_nodes, uint32_t *max_depth, uint32_t *n_leaves);
 

@@ -8,9 +8,9 @@
 """
 from .version import __version__                     # noqa: F401
 from .utils import speed_of_light, cornell_box       # noqa: F401
-from . import mi, vis                                # noqa: F401
+from . import mi, vis, nlos                          # noqa: F401
 from . import integrators, films, render, sensors    # noqa: F401
-from .integrators import TransientADIntegrator, TransientPath   # noqa: F401
+from .integrators import TransientADIntegrator, TransientPath, TransientNLOSPath   # noqa: F401
 from .films import TransientHDRFilm                  # noqa: F401
 from .render import TransientImageBlock              # noqa: F401
 from .mi import load_dict                            # noqa: F401

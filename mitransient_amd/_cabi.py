@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 1
+MTR_ABI_VERSION = 2
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -47,6 +47,23 @@ class mtr_film_desc(C.Structure):
                 ("start_opl", C.c_float), ("bin_width_opl", C.c_float)]
 
 
+MTR_CAPTURE_SINGLE, MTR_CAPTURE_CONFOCAL = 1, 2
+MTR_NLOS_LASER_SAMPLING, MTR_NLOS_HG_SAMPLING, MTR_NLOS_HG_RROULETTE = 1, 2, 4
+MTR_NLOS_HG_INCLUDES_WALL, MTR_NLOS_ACCOUNT_FIRST_LAST, MTR_NLOS_DISCARD_DIRECT = 8, 16, 32
+
+
+class mtr_shape(C.Structure):
+    _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("is_rectangle", C.c_uint32),
+                ("center", _f3), ("du", _f3), ("dv", _f3)]
+
+
+class mtr_nlos_desc(C.Structure):
+    _fields_ = [("sensor_origin", _f3), ("relay_shape", C.c_uint32), ("laser_to_world", _f16),
+                ("laser_fov", C.c_float), ("laser_irradiance", _f3), ("laser_scale", C.c_float),
+                ("capture_type", C.c_uint32), ("flags", C.c_uint32), ("filter_depth", C.c_int32),
+                ("n_shapes", C.c_uint32), ("shapes", C.POINTER(mtr_shape))]
+
+
 class mtr_scene_desc(C.Structure):
     _fields_ = [("n_tris", C.c_uint32),
                 ("tri_verts", C.POINTER(C.c_float)),
@@ -57,7 +74,8 @@ class mtr_scene_desc(C.Structure):
                 ("n_emitters", C.c_uint32),
                 ("emitters", C.POINTER(mtr_emitter)),
                 ("camera", mtr_camera),
-                ("film", mtr_film_desc)]
+                ("film", mtr_film_desc),
+                ("nlos", C.POINTER(mtr_nlos_desc))]
 
 
 class mtr_render_params(C.Structure):
@@ -98,7 +116,7 @@ class mtr_kernel_times(C.Structure):
 # Every symbol include/mitransient_amd.h declares (checked by tests/test_abi.py).
 EXPORTS = [
     "mtr_abi_version", "mtr_ctx_create", "mtr_ctx_destroy", "mtr_ctx_set_stream", "mtr_last_error",
-    "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_bvh_info",
+    "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_set_nlos", "mtr_scene_bvh_info",
     "mtr_film_clear", "mtr_render", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
 ]
 
@@ -135,6 +153,7 @@ def load_library() -> C.CDLL:
     lib.mtr_scene_destroy.argtypes = [vp]
     lib.mtr_scene_destroy.restype = None
     lib.mtr_scene_set_film.argtypes = [vp, C.POINTER(mtr_film_desc)]
+    lib.mtr_scene_set_nlos.argtypes = [vp, C.POINTER(mtr_nlos_desc)]
     lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mtr_film_clear.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp]
     lib.mtr_render.argtypes = [vp, C.POINTER(mtr_render_params), vp, vp,

@@ -35,9 +35,19 @@ struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one til
     uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
 };
 
+struct NlosDev {                // NLOS tier: device tables + constants (mtr_scene_set_nlos)
+    bool on = false;
+    NlosConst k{};
+    void *shapes = nullptr, *tables = nullptr, *hg_tris = nullptr, *targets = nullptr;
+    std::vector<mtr_shape> host_shapes;      // kept: the triangle -> shape table of the scene
+};
+
 struct mtr_scene {
     mtr_ctx *ctx = nullptr;
     WfWorkspace wf;
+    NlosDev nlos;
+    std::vector<float> tri_verts;            // host copy (NLOS tables are re-derived when the laser moves)
+    uint32_t n_emitters_area = 0;
     SceneDev dev{};
     Camera cam{};
     Film film{};
@@ -156,7 +166,52 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_tris = d->n_tris;
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
+    s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
+    s->n_emitters_area = d->n_emitters;
+    if (d->nlos) {
+        rc = mtr_scene_set_nlos(s, d->nlos);
+        if (rc) { mtr_scene_destroy(s); return rc; }
+    }
     *out = s;
+    return MTR_OK;
+}
+
+int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
+{
+    if (!s || !n) return fail(s ? s->ctx : nullptr, MTR_ERR_INVALID, "mtr_scene_set_nlos: NULL argument");
+    mtr_ctx *c = s->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    mtr_scene_desc d{};
+    d.n_tris = s->dev.n_tris; d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
+    d.film.width = s->film.width; d.film.height = s->film.height;
+    d.nlos = n;
+    HostNlos hn;
+    if (const char *msg = derive_nlos(d, hn)) return fail(c, MTR_ERR_INVALID, std::string("mtr_scene_set_nlos: ") + msg);
+    NlosDev &D = s->nlos;
+    void **old[] = { &D.shapes, &D.tables, &D.hg_tris, &D.targets };
+    for (void **p : old) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    const size_t ns = hn.shapes.size(), nt = hn.face_pmf.size();
+    HIP_TRY(c, hipMalloc(&D.shapes, ns * sizeof(NlosShape)));
+    HIP_TRY(c, hipMemcpy(D.shapes, hn.shapes.data(), ns * sizeof(NlosShape), hipMemcpyHostToDevice));
+    std::vector<float> tab;                                       // shape_pmf | shape_cdf | face_pmf | face_cdf
+    tab.insert(tab.end(), hn.shape_pmf.begin(), hn.shape_pmf.end());
+    tab.insert(tab.end(), hn.shape_cdf.begin(), hn.shape_cdf.end());
+    tab.insert(tab.end(), hn.face_pmf.begin(), hn.face_pmf.end());
+    tab.insert(tab.end(), hn.face_cdf.begin(), hn.face_cdf.end());
+    HIP_TRY(c, hipMalloc(&D.tables, tab.size() * 4));
+    HIP_TRY(c, hipMemcpy(D.tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&D.hg_tris, hn.hg_tris.size() * sizeof(q4)));
+    HIP_TRY(c, hipMemcpy(D.hg_tris, hn.hg_tris.data(), hn.hg_tris.size() * sizeof(q4), hipMemcpyHostToDevice));
+    const size_t n_targets = (size_t)s->film.width * s->film.height + 1;
+    HIP_TRY(c, hipMalloc(&D.targets, n_targets * sizeof(q4)));
+    D.k = hn.k;
+    D.k.shapes = (const NlosShape *)D.shapes;
+    D.k.shape_pmf = (const float *)D.tables; D.k.shape_cdf = D.k.shape_pmf + ns;
+    D.k.face_pmf = D.k.shape_cdf + ns; D.k.face_cdf = D.k.face_pmf + nt;
+    D.k.hg_tris = (const q4 *)D.hg_tris; D.k.targets = (const q4 *)D.targets;
+    D.k.film_w = s->film.width; D.k.film_h = s->film.height;
+    HIP_TRY(c, launch_nlos_prepare(s->dev, D.k, (q4 *)D.targets, c->stream));    // scanned points + laser axis hit
+    D.on = true;
     return MTR_OK;
 }
 
@@ -168,6 +223,8 @@ void mtr_scene_destroy(mtr_scene *s)
     void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_mat, s->wf.counts, s->wf.rec, s->wf.rec_count };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
+    void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets };
+    for (void *p : nl) if (p) (void)hipFree(p);
     delete s;
 }
 
@@ -341,6 +398,12 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     a.film_out = t4; a.steady_out = s4;
     a.counters = c->d_counters;
     a.log = s->log;
+    a.nlos_on = s->nlos.on ? 1u : 0u;
+    if (s->nlos.on) {
+        a.nlos = s->nlos.k;
+        if (s->nlos.k.film_w != f.width || s->nlos.k.film_h != f.height)
+            return fail(c, MTR_ERR_INVALID, "mtr_render: film size changed after mtr_scene_set_nlos; call it again");
+    }
 
     const uint32_t n_pixels = p->pixel_end - p->pixel_begin;
     const bool want_stats = counters_out || times_out;
@@ -353,6 +416,11 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
         // MTR_MODE_AUTO: the fused kernel when the whole scene can be staged in LDS (measured 143 vs 168 ms on
         // config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
         uint32_t mode = p->mode;
+        if (s->nlos.on) {
+            if (mode == MTR_MODE_WAVEFRONT)
+                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: the NLOS tier runs in the fused kernel only");
+            mode = MTR_MODE_FUSED;
+        }
         if (mode == MTR_MODE_AUTO) {
             FusedArgs probe = a; FusedConfig pc{};
             const bool fits = fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, probe, pc) && pc.scene_lds;

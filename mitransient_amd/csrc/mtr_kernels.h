@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mtr_core.h"
+#include "mtr_nlos.h"
 
 namespace mtr {
 
@@ -35,6 +36,8 @@ struct FusedArgs {
     float *steady_out;                   // (H, W, 4)
     DevCounters *counters;
     SplatLog log;
+    uint32_t nlos_on;                    // 1: transient_nlos_path + nlos_capture_meter (nlos valid)
+    NlosConst nlos;
 };
 
 struct FusedConfig { int stack; bool scene_lds; bool hist_lds; size_t lds_bytes; int grid; };
@@ -43,6 +46,8 @@ struct FusedConfig { int stack; bool scene_lds; bool hist_lds; size_t lds_bytes;
 bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_t spp_chunk, int n_cu,
                 FusedArgs &args, FusedConfig &cfg);
 hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream);
+// NLOS prepare (transientnlospath.py:295-336): one ray per film pixel -> scanned points, + the laser's axis
+hipError_t launch_nlos_prepare(const SceneDev &sc, const NlosConst &nc, q4 *targets, hipStream_t stream);
 
 // ---- MTR_MODE_WAVEFRONT (mtr_wavefront.hip) ---------------------------------------------------
 constexpr uint32_t kWfKeys = 5;        // material-type queues: diffuse, conductor, dielectric, none, miss

@@ -125,7 +125,7 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 #ifndef MTR_FUSED_MIN_WAVES
 #define MTR_FUSED_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
-template <int STACK, bool SCENE_LDS, bool HIST_LDS>
+template <int STACK, bool SCENE_LDS, bool HIST_LDS, bool NLOS>
 __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -196,9 +196,10 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 if (!alive && i < n_lanes) {
                     g = i / a.spp_chunk;
                     const uint32_t s = a.spp_begin + (i - g * a.spp_chunk);
-                    path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
+                    if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pix0 + g, s);
+                    else path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
                     ++n_paths;
-                    if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {          // transientpath.py:133-138
+                    if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
                         Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
                         ++n_closest;
                         if (h0.prim >= 0) p.dist = -h0.t;
@@ -213,12 +214,14 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 if (HIST_LDS) {
                     LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = g * T;
                     sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                    alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                    alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                                 : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
                     n_splats += sink.n_splats;
                 } else {
                     GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                     sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                    alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                    alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                                 : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
                     n_splats += sink.n_splats;
                 }
                 n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
@@ -346,27 +349,68 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     return true;
 }
 
-template <int STACK>
+template <int STACK, bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
-    if (cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, true, true>;
-    else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<STACK, true, false>;
-    else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true>;
-    else k = k_fused<STACK, false, false>;
+    if (cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, true, true, NLOS>;
+    else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<STACK, true, false, NLOS>;
+    else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true, NLOS>;
+    else k = k_fused<STACK, false, false, NLOS>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, stream, args);
     return hipGetLastError();
 }
 
+// NLOS prepare: scanned points of every film pixel + the point the laser's axis hits (Single capture)
+__global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst nc, q4 *targets)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
+    SceneView sv;
+    sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+    sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    const uint32_t n = nc.film_w * nc.film_h;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
+        Ray r;
+        if (i < n) {
+            const uint32_t y = i / nc.film_w, x = i - y * nc.film_w;
+            r = nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);     // linspace(0,1,res,endpoint=False)
+        } else { r.o = nc.l_origin; r.d = nc.l_forward; r.tmax = kInf; }
+        const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
+        f3 p = mk(0, 0, 0);
+        if (h.prim >= 0) p = hit_ctx(sv, r.d, h).sp;
+        targets[i] = q4{ p.x, p.y, p.z, h.prim >= 0 ? 1.0f : 0.0f };
+    }
+}
+
+hipError_t launch_nlos_prepare(const SceneDev &sc, const NlosConst &nc, q4 *targets, hipStream_t stream)
+{
+    const size_t lds = (size_t)65 * kBlock * 4;
+    hipError_t e = hipFuncSetAttribute((const void *)k_nlos_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    uint32_t n = nc.film_w * nc.film_h + 1;
+    uint32_t blocks = (n + kBlock - 1) / kBlock; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_nlos_prepare, dim3(blocks), dim3(kBlock), lds, stream, sc, nc, targets);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
+    if (args.nlos_on) {
+        switch (cfg.stack) {
+        case 8: return launch_fused_s<8, true>(args, cfg, stream);
+        case 16: return launch_fused_s<16, true>(args, cfg, stream);
+        case 32: return launch_fused_s<32, true>(args, cfg, stream);
+        default: return launch_fused_s<64, true>(args, cfg, stream);
+        }
+    }
     switch (cfg.stack) {
-    case 8: return launch_fused_s<8>(args, cfg, stream);
-    case 16: return launch_fused_s<16>(args, cfg, stream);
-    case 32: return launch_fused_s<32>(args, cfg, stream);
-    default: return launch_fused_s<64>(args, cfg, stream);
+    case 8: return launch_fused_s<8, false>(args, cfg, stream);
+    case 16: return launch_fused_s<16, false>(args, cfg, stream);
+    case 32: return launch_fused_s<32, false>(args, cfg, stream);
+    default: return launch_fused_s<64, false>(args, cfg, stream);
     }
 }
 

@@ -1,0 +1,283 @@
+// mtr_nlos.h — per-path arithmetic of the NLOS tier (PRODUCT code, host+device like mtr_core.h).
+//
+// transient_nlos_path (mitransient/integrators/transientnlospath.py) + nlos_capture_meter
+// (mitransient/sensors/nloscapturemeter.py) + mitsuba's `projector`:
+//   nlos_begin()    ADIntegrator.sample_rays + NLOSCaptureMeter.sample_ray (:136-202), loop init (:712-723)
+//   nlos_bounce()   one iteration of TransientNLOSPath.sample (:740-918): closest hit, laser sampling
+//                   (:511-635) or plain emitter sampling (:432-509), hidden-geometry / BSDF sampling
+//                   (:637-670, :797-833), Russian roulette
+// The Mitsuba pieces (Projector::sample_direction, Rectangle/Mesh::sample_position,
+// DiscreteDistribution::sample_reuse_pmf) follow their published algorithms [upstream-unverified].
+#pragma once
+#include "mtr_core.h"
+
+namespace mtr {
+
+constexpr float kDrEps = 5.9604644775390625e-8f;      // dr.epsilon(Float) = 2^-24
+
+struct alignas(16) NlosShape {       // 64 B
+    float center[3], du[3], dv[3], n[3];
+    uint32_t first_tri, n_tris, is_rect;
+    float inv_area;
+};
+
+struct NlosConst {
+    f3 sensor_origin;
+    f3 w_center, w_du, w_dv;          // relay-wall rectangle
+    f3 l_origin, l_forward;           // projector
+    float l_inv[9];                   // rows of the world -> local rotation
+    float l_cot, l_scale;
+    f3 l_irr;
+    uint32_t capture_type, flags;
+    int32_t filter_depth;
+    uint32_t n_shapes;
+    const NlosShape *shapes;
+    const float *shape_pmf, *shape_cdf;
+    const float *face_pmf, *face_cdf;  // per ORIGINAL triangle index, normalised within its shape
+    const q4 *hg_tris;                 // 3 quads per ORIGINAL triangle: (p0, e1.x) (e1.yz, e2.xy) (e2.z, n)
+    const q4 *targets;                 // [W*H] scanned points (film order) + [W*H] = laser target of a Single capture
+    uint32_t film_w, film_h;
+};
+
+// [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
+MTR_HD uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float &reused, float &pmf_out)
+{
+    uint32_t i = 0;
+    while (i + 1 < n && !(value < cdf[i])) ++i;
+    while (i + 1 < n && pmf[i] == 0.0f) ++i;
+    const float prev = i ? cdf[i - 1] : 0.0f;
+    reused = (value - prev) / pmf[i];
+    pmf_out = pmf[i];
+    return i;
+}
+
+MTR_HD f3 rect_point(f3 c, f3 du, f3 dv, float u, float v)
+{
+    const float a = fmaf(u, 2.0f, -1.0f), b = fmaf(v, 2.0f, -1.0f);
+    return mk(fmaf(du.x, a, fmaf(dv.x, b, c.x)), fmaf(du.y, a, fmaf(dv.y, b, c.y)), fmaf(du.z, a, fmaf(dv.z, b, c.z)));
+}
+
+// [mitsuba3: Projector::sample_direction]: weight, ds.dist
+MTR_HD f3 projector_sample(const NlosConst &nc, f3 p, float &dist)
+{
+    const f3 rel = p - nc.l_origin;
+    const f3 loc = mk(dot(mk(nc.l_inv[0], nc.l_inv[1], nc.l_inv[2]), rel), dot(mk(nc.l_inv[3], nc.l_inv[4], nc.l_inv[5]), rel),
+                      dot(mk(nc.l_inv[6], nc.l_inv[7], nc.l_inv[8]), rel));
+    const float iz = 1.0f / loc.z;
+    const float uvx = 0.5f - (0.5f * nc.l_cot) * (loc.x * iz), uvy = 0.5f - (0.5f * nc.l_cot) * (loc.y * iz);
+    const bool ok = (uvx >= 0.0f) & (uvx <= 1.0f) & (uvy >= 0.0f) & (uvy <= 1.0f) & (loc.z > 0.0f);
+    f3 d = nc.l_origin - p;
+    dist = sqrtf(dot(d, d));
+    d = d / dist;
+    const float f = (kPi * nc.l_scale) * (iz * iz) / -dot(nc.l_forward, d);
+    return ok ? mk(nc.l_irr.x * f, nc.l_irr.y * f, nc.l_irr.z * f) : mk(0, 0, 0);
+}
+
+// NLOSCaptureMeter.sample_ray for a film sample in [0,1)^2 (nloscapturemeter.py:136-180)
+MTR_HD Ray nlos_sensor_ray(const NlosConst &nc, float sx, float sy)
+{
+    const float W = (float)nc.film_w, H = (float)nc.film_h;
+    const float gx = (floorf(sx * W) + 0.5f) / W, gy = (floorf(sy * H) + 0.5f) / H;
+    const f3 target = rect_point(nc.w_center, nc.w_du, nc.w_dv, gx, gy);
+    f3 dir = target - nc.sensor_origin;
+    const float dist = sqrtf(dot(dir, dir));
+    Ray r; r.o = nc.sensor_origin; r.d = dir / dist; r.tmax = kInf;
+    return r;
+}
+
+MTR_HD void nlos_begin(Path &p, const NlosConst &nc, const Film &f, const RenderConst &rc, uint32_t pixel, uint32_t s)
+{
+    const uint32_t lane = pixel * rc.spp_total + s;
+    const uint32_t py = pixel / f.crop_w, px = pixel - f.crop_w * py;
+    p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
+    p.rng = rng_seed(rc.seed, lane);
+    const float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
+    const float sx = fmaf((float)p.px + j1, rc.inv_crop_w, rc.off_x), sy = fmaf((float)p.py + j2, rc.inv_crop_h, rc.off_y);
+    p.ray = nlos_sensor_ray(nc, sx, sy);
+    p.beta = mk(1, 1, 1); p.L = mk(0, 0, 0); p.prev_p = mk(0, 0, 0);
+    p.eta = 1.0f; p.dist = 0.0f; p.prev_pdf = 1.0f; p.depth = 0; p.prev_delta = 1;       // distance = ray.time = 0 (:718)
+}
+
+// si.spawn_ray_to(t) [mitsuba3: Interaction::spawn_ray_to]
+MTR_HD Ray spawn_ray_to(f3 sp, f3 sn, f3 t)
+{
+    const f3 o = offset_point(sp, sn, t - sp);
+    f3 dd = t - o;
+    const float dist = sqrtf(dot(dd, dd));
+    Ray r; r.o = o; r.d = dd / dist; r.tmax = dist * (1.0f - kShadowEps);
+    return r;
+}
+
+// diffuse eval (value * cos), the only smooth BSDF of the subset
+MTR_HD f3 bsdf_eval_cos(const mtr_material &m, f3 wi, f3 wo)
+{
+    if (m.type != MTR_BSDF_DIFFUSE) return mk(0, 0, 0);
+    if ((m.flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (!(wi.z > 0.0f && wo.z > 0.0f)) return mk(0, 0, 0);
+    return mk((m.a[0] * kInvPi) * wo.z, (m.a[1] * kInvPi) * wo.z, (m.a[2] * kInvPi) * wo.z);
+}
+
+// emitter_nee_sample (transientnlospath.py:432-509); `depth` is the reference's argument (not the loop depth)
+template <class Stack, class Sink>
+MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 beta, float distance, uint32_t depth,
+                           bool focus_laser, const SceneView &sc, const NlosConst &nc, const Film &film,
+                           const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats)
+{
+    // visibility of the emitter origin (:441)
+    const Ray sr = spawn_ray_to(c.sp, c.sn, nc.l_origin);
+    stats.shadow++;
+    if (traverse<true>(sc, sr.o, sr.d, sr.tmax, st).prim >= 0) return mk(0, 0, 0);
+    (void)rng_f32(p.rng); (void)rng_f32(p.rng);                      // sampler.next_2d(active_e): only visible lanes draw
+    float ds_dist;
+    f3 w;
+    if (focus_laser && nc.capture_type == MTR_CAPTURE_CONFOCAL) {    // :448-458
+        const f3 rel = nc.l_origin - c.sp;
+        const float dist_e = sqrtf(dot(rel, rel));
+        w = projector_sample(nc, fma3(nc.l_forward, dist_e, nc.l_origin), ds_dist);
+    } else {
+        w = projector_sample(nc, c.sp, ds_dist);
+    }
+    const f3 dirn = normalize(nc.l_origin - c.sp);                   // :483
+    const f3 wo = mk(dot(dirn, c.ss), dot(dirn, c.stt), dot(dirn, c.sn));
+    const f3 bv = bsdf_eval_cos(mat, c.wi, wo);
+    if (nc.filter_depth != -1 && depth != (uint32_t)nc.filter_depth) return mk(0, 0, 0);      // :489-490
+    if ((nc.flags & MTR_NLOS_DISCARD_DIRECT) && !(depth > 2)) return mk(0, 0, 0);             // :491-492
+    const f3 Lr = mk((beta.x * bv.x) * w.x, (beta.y * bv.y) * w.y, (beta.z * bv.z) * w.z);    // :493
+    if (nc.flags & MTR_NLOS_ACCOUNT_FIRST_LAST) distance += ds_dist * p.eta;                   // :497-498
+    const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;
+    const float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
+    if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
+        const int32_t bin = film_bin(film, distance);
+        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, distance, p.depth, 1u);   // :506-507
+    }
+    return Lr;
+}
+
+// emitter_laser_targets_sample (:511-564)
+template <class Stack, class Sink>
+MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 lt, uint32_t depth,
+                             const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
+                             Stack &st, Sink &sink, BounceStats &stats)
+{
+    f3 dd = lt - c.sp;
+    const float dl = sqrtf(dot(dd, dd));
+    dd = dd / dl;
+    Ray rb = spawn_ray_to(c.sp, c.sn, lt);
+    stats.shadow++;
+    if (traverse<true>(sc, rb.o, rb.d, rb.tmax, st).prim >= 0) return mk(0, 0, 0);             // :528
+    const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
+    const f3 bs = bsdf_eval_cos(mat, c.wi, wo);                                               // :531-533
+    const Hit h2 = traverse<false>(sc, rb.o, rb.d, kInf, st);                                  // :535-537
+    stats.closest++;
+    if (h2.prim < 0) return mk(0, 0, 0);
+    if (!(bs.x > kDrEps || bs.y > kDrEps || bs.z > kDrEps)) return mk(0, 0, 0);               // :539-540
+    const HitCtx c2 = hit_ctx(sc, rb.d, h2);
+    const f3 md = -dd;
+    const float wlz = dot(md, c2.sn);                                                          // cos_theta(si_bsdf.to_local(-d))
+    if (!(wlz > 0.0f)) return mk(0, 0, 0);                                                     // :543
+    const float pdf_ls = (dl * dl) / wlz;                                                      // :546-551
+    const f3 b2 = mk(p.beta.x * (bs.x / pdf_ls), p.beta.y * (bs.y / pdf_ls), p.beta.z * (bs.z / pdf_ls));
+    return nlos_emitter_nee(p, c2, sc.mats[c2.mat], b2, p.dist + dl * p.eta, depth + 1, true, sc, nc, film, rc, st, sink, stats);
+}
+
+// hidden_geometry_sample (:637-670) incl. _sample_hidden_geometry_position (:385-430)
+MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat, float ua, float ub, const NlosConst &nc)
+{
+    BsdfSample bs;
+    bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
+    float reused, spmf;
+    const uint32_t s = distr_sample_reuse(nc.shape_cdf, nc.shape_pmf, nc.n_shapes, ua, reused, spmf);
+    const NlosShape &S = nc.shapes[s];
+    f3 pp, pn;
+    if (S.is_rect) {
+        pp = rect_point(ld3(S.center), ld3(S.du), ld3(S.dv), reused, ub);
+        pn = ld3(S.n);
+    } else {                                               // [mitsuba3: Mesh::sample_position]
+        float sy = ub;
+        uint32_t fi = 0;
+        if (S.n_tris > 1) { float r2, fp; fi = distr_sample_reuse(nc.face_cdf + S.first_tri, nc.face_pmf + S.first_tri, S.n_tris, ub, r2, fp); sy = r2; }
+        const q4 *t = nc.hg_tris + 3 * (size_t)(S.first_tri + fi);
+        const q4 a = t[0], b = t[1], cc = t[2];
+        const float tt = sqrtf(fmaxf(1.0f - reused, 0.0f));            // warp::square_to_uniform_triangle
+        const float b0 = 1.0f - tt, b1 = tt * sy;
+        pp = mk(fmaf(a.w, b0, fmaf(b.z, b1, a.x)), fmaf(b.x, b0, fmaf(b.w, b1, a.y)), fmaf(b.y, b0, fmaf(cc.x, b1, a.z)));
+        pn = mk(cc.y, cc.z, cc.w);
+    }
+    const float ppdf = S.inv_area * spmf;
+    f3 dd = pp - c.sp;
+    const float dist = sqrtf(dot(dd, dd));
+    dd = dd / dist;
+    const float cos_i = dot(c.sn, dd), cos_g = dot(pn, -dd);
+    const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
+    bs.wo = wo;
+    bs.pdf = ppdf * (dist * dist) / fabsf(cos_g);
+    if (!(cos_i > kDrEps && cos_g > kDrEps)) return bs;
+    if (!(bs.pdf > kDrEps)) return bs;
+    const f3 val = bsdf_eval_cos(mat, c.wi, wo);
+    bs.w = mk(val.x / bs.pdf, val.y / bs.pdf, val.z / bs.pdf);
+    return bs;
+}
+
+// the laser target of this pixel: its own scanned point (Confocal, :337-339, :585-589) or the single point
+MTR_HD f3 nlos_laser_target(const NlosConst &nc, uint32_t px, uint32_t py)
+{
+    const size_t i = (nc.capture_type == MTR_CAPTURE_CONFOCAL) ? (size_t)py * nc.film_w + px : (size_t)nc.film_w * nc.film_h;
+    const q4 t = nc.targets[i];
+    return mk(t.x, t.y, t.z);
+}
+
+// One iteration of TransientNLOSPath.sample (:740-918).  Returns active_next.
+template <class Stack, class Sink>
+MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
+                        Stack &st, Sink &sink, BounceStats &stats)
+{
+    const Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);
+    stats.closest++;
+    const bool valid = h.prim >= 0;
+    if ((nc.flags & MTR_NLOS_ACCOUNT_FIRST_LAST) || p.depth > 0) p.dist += h.t * p.eta;          // :751-752
+    bool active_next = ((p.depth + 1u) < rc.max_depth) & valid;                                   // :782
+    f3 Lr = mk(0, 0, 0);
+    HitCtx c;
+    c.sp = mk(0, 0, 0); c.sn = mk(0, 0, 1); c.ss = mk(1, 0, 0); c.stt = mk(0, 1, 0); c.wi = mk(0, 0, 0); c.mat = 0; c.em_plus1 = 0;
+    if (valid) c = hit_ctx(sc, p.ray.d, h);
+    // the only emitter is the projector (not a surface): Le = 0 (:757-777)
+    if (active_next && sc.mats[c.mat].type == MTR_BSDF_DIFFUSE) {                                 // active_em :785-786
+        if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                                   // emitter_laser_sample: depth + 1
+            Lr = nlos_laser_targets(p, c, sc.mats[c.mat], nlos_laser_target(nc, p.px, p.py), p.depth + 1u, sc, nc, film, rc, st, sink, stats);
+        else
+            Lr = nlos_emitter_nee(p, c, sc.mats[c.mat], p.beta, p.dist, p.depth, false, sc, nc, film, rc, st, sink, stats);
+    }
+    // hidden-geometry / BSDF sampling (:797-833)
+    const bool hg = (nc.flags & MTR_NLOS_HG_SAMPLING) != 0;
+    bool do_hg = hg;
+    float pdf_method = 1.0f;
+    if (hg && (nc.flags & MTR_NLOS_HG_RROULETTE)) { do_hg = rng_f32(p.rng) < 0.5f; pdf_method = 0.5f; }   // :801
+    (void)rng_f32(p.rng);                                                                         // :814 next_1d (unused)
+    const float a2a = rng_f32(p.rng), a2b = rng_f32(p.rng);
+    const float b1 = rng_f32(p.rng), b2a = rng_f32(p.rng), b2b = rng_f32(p.rng);                  // :820
+    const float rr_u = rng_f32(p.rng);                                                            // :857
+    BsdfSample bs;
+    bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
+    if (active_next) {
+        if (do_hg) bs = nlos_hidden_geometry(c, sc.mats[c.mat], a2a, a2b, nc);
+        else bs = bsdf_sample(sc.mats[c.mat], c.wi, b1, b2a, b2b);
+        const f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
+                           fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
+                           fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
+        p.ray.o = offset_point(c.sp, c.sn, wo_w); p.ray.d = wo_w; p.ray.tmax = kInf;
+    }
+    p.L = mk(p.L.x + Lr.x, p.L.y + Lr.y, p.L.z + Lr.z);
+    p.eta *= bs.eta;
+    p.beta = mk((p.beta.x * bs.w.x) / pdf_method, (p.beta.y * bs.w.y) / pdf_method, (p.beta.z * bs.w.z) / pdf_method);   // :833
+    const float bmax = max3(p.beta.x, p.beta.y, p.beta.z);
+    active_next &= (bmax != 0.0f);
+    const float rr_prob = fminf(bmax * (p.eta * p.eta), 0.95f);
+    active_next &= rr_prob > 0.0f;
+    const bool rr_active = p.depth >= rc.rr_depth;
+    if (rr_active) { const float inv = rr_prob > 0.0f ? 1.0f / rr_prob : 0.0f; p.beta = p.beta * inv; }
+    active_next &= (!rr_active) | (rr_u < rr_prob);
+    if (valid) p.depth += 1;
+    return active_next;
+}
+
+} // namespace mtr

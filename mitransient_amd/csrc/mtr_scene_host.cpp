@@ -65,6 +65,93 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     return nullptr;
 }
 
+static double tri_area_d(const float *v)
+{
+    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
+    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
+    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
+{
+    const mtr_nlos_desc *n = d.nlos;
+    if (!n) return "no NLOS description";
+    if (n->capture_type != MTR_CAPTURE_SINGLE && n->capture_type != MTR_CAPTURE_CONFOCAL)
+        return "capture_type must be Single or Confocal (Exhaustive needs the 6-D film)";
+    if (!n->shapes || n->n_shapes == 0 || n->relay_shape >= n->n_shapes) return "NLOS: bad shape table";
+    if (!n->shapes[n->relay_shape].is_rectangle) return "NLOS: the relay wall must be a rectangle";
+    if (d.n_emitters != 0) return "NLOS: area emitters are not supported next to the projector";
+    uint32_t covered = 0;
+    for (uint32_t s = 0; s < n->n_shapes; ++s) {
+        if (n->shapes[s].first_tri != covered) return "NLOS: shapes must tile the triangle array in order";
+        covered += n->shapes[s].n_tris;
+    }
+    if (covered != d.n_tris) return "NLOS: shapes must cover every triangle";
+    NlosConst &k = o.k;
+    k.sensor_origin = mk(n->sensor_origin[0], n->sensor_origin[1], n->sensor_origin[2]);
+    const mtr_shape &rw = n->shapes[n->relay_shape];
+    k.w_center = ld3(rw.center); k.w_du = ld3(rw.du); k.w_dv = ld3(rw.dv);
+    const float *T = n->laser_to_world;
+    k.l_origin = mk(T[3], T[7], T[11]);
+    k.l_forward = mk(T[2], T[6], T[10]);
+    const float inv[9] = { T[0], T[4], T[8], T[1], T[5], T[9], T[2], T[6], T[10] };      // rigid: inverse rotation = transpose
+    memcpy(k.l_inv, inv, sizeof inv);
+    k.l_cot = (float)(1.0 / tan(0.5 * (double)n->laser_fov * 3.14159265358979323846 / 180.0));
+    k.l_scale = n->laser_scale;
+    k.l_irr = ld3(n->laser_irradiance);
+    k.capture_type = n->capture_type; k.flags = n->flags; k.filter_depth = n->filter_depth; k.n_shapes = n->n_shapes;
+    k.film_w = d.film.width; k.film_h = d.film.height;
+
+    const uint32_t ns = n->n_shapes;
+    o.shapes.assign(ns, NlosShape{});
+    o.shape_pmf.assign(ns, 0.0f); o.shape_cdf.assign(ns, 0.0f);
+    o.face_pmf.assign(d.n_tris ? d.n_tris : 1, 0.0f); o.face_cdf.assign(d.n_tris ? d.n_tris : 1, 0.0f);
+    o.hg_tris.assign(3 * (size_t)(d.n_tris ? d.n_tris : 1), q4{ 0, 0, 0, 0 });
+    std::vector<double> area(ns, 0.0);
+    double total = 0.0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        const mtr_shape &S = n->shapes[s];
+        NlosShape &D = o.shapes[s];
+        D.first_tri = S.first_tri; D.n_tris = S.n_tris; D.is_rect = S.is_rectangle;
+        double a = 0.0;
+        for (uint32_t t = 0; t < S.n_tris; ++t) a += tri_area_d(d.tri_verts + 9 * (size_t)(S.first_tri + t));
+        double acc = 0.0;
+        for (uint32_t t = 0; t < S.n_tris; ++t) {
+            const float *v = d.tri_verts + 9 * (size_t)(S.first_tri + t);
+            const double at = tri_area_d(v);
+            acc += at;
+            o.face_pmf[S.first_tri + t] = (float)(at / a);
+            o.face_cdf[S.first_tri + t] = (float)(acc / a);
+            const f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
+            const f3 nn = normalize(cross(e1, e2));
+            q4 *q = &o.hg_tris[3 * (size_t)(S.first_tri + t)];
+            q[0] = q4{ p0.x, p0.y, p0.z, e1.x }; q[1] = q4{ e1.y, e1.z, e2.x, e2.y }; q[2] = q4{ e2.z, nn.x, nn.y, nn.z };
+        }
+        if (S.is_rectangle) {
+            for (int c = 0; c < 3; ++c) { D.center[c] = S.center[c]; D.du[c] = S.du[c]; D.dv[c] = S.dv[c]; }
+            const f3 cr = cross(ld3(S.du), ld3(S.dv));
+            const double len = sqrt((double)cr.x * cr.x + (double)cr.y * cr.y + (double)cr.z * cr.z);
+            a = 4.0 * len;
+            const f3 nn = cr / sqrtf(dot(cr, cr));
+            D.n[0] = nn.x; D.n[1] = nn.y; D.n[2] = nn.z;
+        }
+        D.inv_area = (float)(1.0 / a);
+        // transientnlospath.py:277-292: the relay wall has weight 0 unless ..._includes_relay_wall
+        area[s] = (s == n->relay_shape && !(n->flags & MTR_NLOS_HG_INCLUDES_WALL)) ? 0.0 : a;
+        total += area[s];
+    }
+    if ((n->flags & MTR_NLOS_HG_SAMPLING) && !(total > 0.0))
+        return "Hidden geometry sampling is activated, but the hidden geometry in the scene has zero surface area?";
+    double acc = 0.0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        acc += area[s];
+        o.shape_pmf[s] = total > 0.0 ? (float)(area[s] / total) : 0.0f;
+        o.shape_cdf[s] = total > 0.0 ? (float)(acc / total) : 0.0f;
+    }
+    return nullptr;
+}
+
 RenderConst make_render_const(const mtr_render_params &p, const Film &f, uint32_t n_emitters)
 {
     RenderConst rc{};

@@ -6,6 +6,7 @@
 #include <vector>
 #include "mtr_core.h"
 #include "mtr_bvh.h"
+#include "mtr_nlos.h"
 
 namespace mtr {
 
@@ -19,6 +20,16 @@ struct HostScene {
     Camera cam{};
     Film film{};
 };
+
+// NLOS tier tables (TransientNLOSPath.prepare, transientnlospath.py:251-292): shape / face distributions,
+// rectangle normals, triangles in ORIGINAL order for Mesh::sample_position, projector constants
+struct HostNlos {
+    std::vector<NlosShape> shapes;
+    std::vector<float> shape_pmf, shape_cdf, face_pmf, face_cdf;
+    std::vector<q4> hg_tris;
+    NlosConst k{};            // pointers left null: the caller points them at its copies
+};
+const char *derive_nlos(const mtr_scene_desc &d, HostNlos &out);
 
 Film film_from_desc(const mtr_film_desc &d);
 // returns nullptr on success or a static error string

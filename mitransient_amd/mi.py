@@ -45,39 +45,95 @@ def ScalarColor3d(*v):
 ScalarColor3f = ScalarColor3d
 
 
+_SHAPE_TYPES = ("rectangle", "cube", "obj", "ply", "sphere", "disk", "cylinder")
+
+
+def _make_sensor(sd, shape_obj=None):
+    fd = sd.get("film")
+    if fd is None:
+        raise ValueError("sensor: a 'film' is required")
+    film = plugins.create_film(fd["type"], Properties(fd["type"], fd))
+    smp = sd.get("sampler", {"type": "independent"})
+    if smp.get("type") != "independent":
+        raise ValueError(f"failed to instantiate unknown plugin of type \"{smp.get('type')}\" (supported samplers: independent)")
+    sampler = IndependentSampler(Properties("independent", smp))
+    if sd["type"] == "perspective":
+        return PerspectiveSensor(sd, film, sampler)
+    if sd["type"] == "nlos_capture_meter":
+        from .sensors.nloscapturemeter import NLOSCaptureMeter
+        s = NLOSCaptureMeter(Properties("nlos_capture_meter", sd), film, sampler)
+        s.dict_, s.shape_ = sd, shape_obj
+        return s
+    raise ValueError(f"failed to instantiate unknown plugin of type \"{sd['type']}\" "
+                     "(supported sensors: perspective, nlos_capture_meter)")
+
+
+def _load_shape(d):
+    """a shape dictionary -> Shape object; a nested nlos_capture_meter becomes its sensor"""
+    from .shapes import Shape
+    sh = Shape(d)
+    for k, v in d.items():
+        if isinstance(v, dict) and v.get("type") == "nlos_capture_meter":
+            sh.sensor_ = _make_sensor(v, sh)
+            sh.sensor_key = k
+    return sh
+
+
 class Scene:
     def __init__(self, d: Dict[str, Any], base_dir: str = "."):
         from . import integrators as _i, films as _f  # noqa: F401  (registers the plugins)
+        from .shapes import Shape
+        from .emitters import Projector
         if d.get("type") != "scene":
             raise ValueError("load_dict(): expected a dictionary with 'type': 'scene'")
-        self.dict_ = d
         self.base_dir = base_dir
-        integ = [v for v in d.values() if isinstance(v, dict) and v.get("type", "").startswith("transient")
-                 or isinstance(v, dict) and v.get("type") in ("path", "direct")]
-        sens = [v for v in d.values() if isinstance(v, dict) and v.get("type") in ("perspective", "nlos_capture_meter")]
+        # objects that were loaded on their own (mi.load_dict(shape) / mi.load_dict(projector)) keep their identity,
+        # so that mitransient.nlos.focus_emitter_* edits made later are seen by the render
+        self.shape_objs_, self.emitters_, self.sensors_ = {}, [], []
+        flat = {}
+        for k, v in d.items():
+            if isinstance(v, Shape):
+                self.shape_objs_[k] = v
+                flat[k] = v.dict_
+            elif isinstance(v, Projector):
+                self.emitters_.append(v)
+            elif isinstance(v, dict) and v.get("type") == "projector":
+                e = Projector(Properties("projector", v))
+                e.dict_ = v
+                self.emitters_.append(e)
+            elif isinstance(v, dict) and v.get("type") in _SHAPE_TYPES:
+                self.shape_objs_[k] = _load_shape(v)
+                flat[k] = v
+            else:
+                flat[k] = v
+        self.dict_ = flat
+        integ = [v for v in flat.values() if isinstance(v, dict) and
+                 (str(v.get("type", "")).startswith("transient") or v.get("type") in ("path", "direct"))]
         if len(integ) != 1:
             raise ValueError("load_dict(): exactly one integrator is required")
-        if not sens:
-            raise ValueError("load_dict(): at least one sensor is required")
         idict = integ[0]
         self.integrator_ = plugins.create_integrator(idict["type"], Properties(idict["type"], idict))
-        self.sensors_ = []
-        for sd in sens:
-            if sd["type"] != "perspective":
-                raise ValueError(f"failed to instantiate unknown plugin of type \"{sd['type']}\" (supported sensors: perspective)")
-            fd = sd.get("film")
-            if fd is None:
-                raise ValueError("sensor: a 'film' is required")
-            film = plugins.create_film(fd["type"], Properties(fd["type"], fd))
-            smp = sd.get("sampler", {"type": "independent"})
-            if smp.get("type") != "independent":
-                raise ValueError(f"failed to instantiate unknown plugin of type \"{smp.get('type')}\" (supported samplers: independent)")
-            self.sensors_.append(PerspectiveSensor(sd, film, IndependentSampler(Properties("independent", smp))))
+        for k, v in flat.items():
+            if isinstance(v, dict) and v.get("type") == "perspective":
+                self.sensors_.append(_make_sensor(v))
+        self.relay_names_ = {}
+        for k, sh in self.shape_objs_.items():
+            if sh.sensor() is not None:
+                self.sensors_.append(sh.sensor())
+                self.relay_names_[id(sh.sensor())] = k
+        if not self.sensors_:
+            raise ValueError("load_dict(): at least one sensor is required")
         self._data = {}
         self._handles = {}
 
     def sensors(self):
         return self.sensors_
+
+    def emitters(self):
+        return self.emitters_
+
+    def shapes(self):
+        return list(self.shape_objs_.values())
 
     def integrator(self):
         return self.integrator_
@@ -88,9 +144,16 @@ class Scene:
             sensor = self.sensors_[sensor]
         key = id(sensor)
         if key not in self._data:
-            self._data[key] = flatten_scene(self.dict_, sensor.film(), sensor.dict_, self.base_dir)
+            self._data[key] = flatten_scene(self.dict_, sensor.film(), sensor.dict_, self.base_dir,
+                                            self.relay_names_.get(key))
         sd = self._data[key]
         sd.film = film_desc_from(sensor.film())
+        if key in self.relay_names_:                                    # NLOS tier: rebuilt from the live objects
+            from .scene import nlos_desc_from
+            if len(self.emitters_) != 1:
+                raise AssertionError(f"You have defined multiple ({len(self.emitters_)}) emitters in the scene with a "
+                                     "NLOS capture meter. You should have only 1.")
+            sd.nlos = nlos_desc_from(self.integrator_, sensor, self.emitters_[0], sd.relay_shape)
         return sd
 
     def gpu_handle(self, ctx, sensor=0):
@@ -106,6 +169,9 @@ class Scene:
         h = self._handles[key]
         fd = sd.film
         ctx.check(ctx.lib.mtr_scene_set_film(h, C.byref(fd)), "mtr_scene_set_film")
+        if sd.nlos is not None:
+            d = sd.desc()
+            ctx.check(ctx.lib.mtr_scene_set_nlos(h, d.nlos), "mtr_scene_set_nlos")
         return h
 
     def __del__(self):
@@ -117,8 +183,20 @@ class Scene:
             pass
 
 
-def load_dict(d: Dict[str, Any], base_dir: str = ".") -> Scene:
-    return Scene(d, base_dir)
+def load_dict(d: Dict[str, Any], base_dir: str = "."):
+    """``mi.load_dict``: a scene dictionary -> Scene; a single shape / projector dictionary -> that object
+    (tests/integration/test_nlos.py:86-98 builds the relay wall and the laser this way)."""
+    t = d.get("type")
+    if t == "scene":
+        return Scene(d, base_dir)
+    if t in _SHAPE_TYPES:
+        return _load_shape(d)
+    if t == "projector":
+        from .emitters import Projector
+        e = Projector(Properties("projector", d))
+        e.dict_ = d
+        return e
+    raise ValueError(f"load_dict(): unsupported top-level plugin type \"{t}\"")
 
 
 def render(scene: Scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0):
@@ -143,7 +221,11 @@ class _Params(dict):
             return super().update(*a, **k)
         for key in self._dirty:
             obj, attr = self._objs[key]
-            setattr(obj, attr, type(getattr(obj, attr))(self[key]))
+            cur = getattr(obj, attr)
+            try:
+                setattr(obj, attr, type(cur)(self[key]))
+            except Exception:
+                setattr(obj, attr, self[key])
         self._dirty.clear()
 
 
@@ -162,6 +244,9 @@ def traverse(obj):
     if isinstance(obj, Scene):
         for i, s in enumerate(obj.sensors()):
             targets.append((f"sensor{'' if i == 0 else i}.film.", s.film()))
+    elif hasattr(obj, "film") and callable(obj.film):               # a sensor: its own keys + "film.*"
+        targets.append(("", obj))
+        targets.append(("film.", obj.film()))
     else:
         targets.append(("", obj))
     for prefix, o in targets:

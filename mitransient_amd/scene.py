@@ -103,6 +103,7 @@ class _SceneBuilder:
         self.emitters: List[_cabi.mtr_emitter] = []
         self.shape_names: List[str] = []
         self.shape_ranges: List[tuple] = []
+        self.shapes: List[_cabi.mtr_shape] = []
 
     # -- BSDFs -------------------------------------------------------------
     def _resolve(self, v):
@@ -187,7 +188,8 @@ class _SceneBuilder:
             tris = tris[:, [0, 2, 1], :]
         bsdf = None
         for k, v in sd.items():
-            if isinstance(v, dict) and k != "emitter":       # any nested object that is not the emitter is the BSDF
+            # any nested plugin that is neither the emitter nor a sensor is the BSDF
+            if isinstance(v, dict) and k != "emitter" and not str(v.get("type", "")).startswith("nlos_"):
                 bsdf = v
         if bsdf is None:
             bsdf = {"type": "diffuse", "reflectance": 0.5}     # mitsuba's default BSDF
@@ -216,6 +218,15 @@ class _SceneBuilder:
         self.tri_em.append(np.full(n, em_index, dtype=np.int32))
         self.shape_names.append(name)
         self.shape_ranges.append((first, first + n))
+        sh = _cabi.mtr_shape()
+        sh.first_tri, sh.n_tris, sh.is_rectangle = first, n, 1 if t == "rectangle" else 0
+        if t == "rectangle":
+            c = tw.transform_affine(np.zeros(3))
+            du = tw.transform_affine(np.array([1.0, 0, 0])) - c
+            dv = tw.transform_affine(np.array([0, 1.0, 0])) - c
+            for k in range(3):
+                sh.center[k], sh.du[k], sh.dv[k] = np.float32(c[k]), np.float32(du[k]), np.float32(dv[k])
+        self.shapes.append(sh)
 
 
 def _cube_tris() -> np.ndarray:
@@ -312,6 +323,9 @@ class SceneData:
         self.film = _cabi.mtr_film_desc()
         self.shape_names: List[str] = []
         self.shape_ranges: List[tuple] = []
+        self.shapes = (_cabi.mtr_shape * 1)()
+        self.n_shapes = 0
+        self.nlos = None                 # mtr_nlos_desc for the NLOS tier
 
     def desc(self) -> _cabi.mtr_scene_desc:
         d = _cabi.mtr_scene_desc()
@@ -325,6 +339,10 @@ class SceneData:
         d.emitters = C.cast(self.emitters, C.POINTER(_cabi.mtr_emitter))
         d.camera = self.camera
         d.film = self.film
+        if self.nlos is not None:
+            self.nlos.n_shapes = self.n_shapes
+            self.nlos.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape))
+            d.nlos = C.pointer(self.nlos)
         d._keepalive = self            # arrays must outlive the desc
         return d
 
@@ -340,7 +358,26 @@ def film_desc_from(film) -> _cabi.mtr_film_desc:
     return f
 
 
-def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir: str = ".") -> SceneData:
+def nlos_desc_from(integrator, sensor, emitter, relay_shape: int) -> _cabi.mtr_nlos_desc:
+    """mtr_nlos_desc from the live plugin objects (so that nlos.focus_emitter_* edits are picked up)."""
+    n = _cabi.mtr_nlos_desc()
+    for k in range(3):
+        n.sensor_origin[k] = np.float32(sensor.sensor_origin[k])
+        n.laser_irradiance[k] = np.float32(emitter.irradiance[k])
+    n.relay_shape = relay_shape
+    m = emitter.world_transform().matrix.reshape(-1)
+    for i in range(16):
+        n.laser_to_world[i] = np.float32(m[i])
+    n.laser_fov = np.float32(emitter.fov)
+    n.laser_scale = np.float32(emitter.scale)
+    n.capture_type = int(integrator.capture_type)
+    n.flags = int(integrator.nlos_flags())
+    n.filter_depth = int(integrator.filter_depth)
+    return n
+
+
+def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir: str = ".",
+                  relay_shape_name: Optional[str] = None) -> SceneData:
     b = _SceneBuilder(d, base_dir)
     for name, v in d.items():
         if not isinstance(v, dict):
@@ -357,11 +394,15 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
     sd.materials = (_cabi.mtr_material * max(1, sd.n_materials))(*b.materials)
     sd.n_emitters = len(b.emitters)
     sd.emitters = (_cabi.mtr_emitter * max(1, sd.n_emitters))(*b.emitters)
-    s2c, tw, near, far = perspective_matrices(sensor_dict, film.size_, film.crop_size_, film.crop_offset_)
-    for i in range(16):
-        sd.camera.sample_to_camera[i] = np.float32(s2c.reshape(-1)[i])
-        sd.camera.to_world[i] = np.float32(tw.reshape(-1)[i])
-    sd.camera.near_clip, sd.camera.far_clip = np.float32(near), np.float32(far)
+    sd.n_shapes = len(b.shapes)
+    sd.shapes = (_cabi.mtr_shape * max(1, sd.n_shapes))(*b.shapes)
+    if sensor_dict.get("type") == "perspective":
+        s2c, tw, near, far = perspective_matrices(sensor_dict, film.size_, film.crop_size_, film.crop_offset_)
+        for i in range(16):
+            sd.camera.sample_to_camera[i] = np.float32(s2c.reshape(-1)[i])
+            sd.camera.to_world[i] = np.float32(tw.reshape(-1)[i])
+        sd.camera.near_clip, sd.camera.far_clip = np.float32(near), np.float32(far)
     sd.film = film_desc_from(film)
     sd.shape_names, sd.shape_ranges = b.shape_names, b.shape_ranges
+    sd.relay_shape = b.shape_names.index(relay_shape_name) if relay_shape_name is not None else -1
     return sd

@@ -740,6 +740,376 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
     }
 }
 
+/* ================================================================== */
+/* NLOS tier: TransientNLOSPath (mitransient/integrators/transientnlospath.py)
+ * + NLOSCaptureMeter (mitransient/sensors/nloscapturemeter.py) + mitsuba's `projector`.
+ * Same status as above: the reference's Python is restated literally, the Mitsuba pieces
+ * (projector.sample_direction, Rectangle/Mesh.sample_position, DiscreteDistribution) from
+ * their published algorithms [upstream-unverified].  PARITY UNPINNED.            */
+/* ================================================================== */
+#define ORC_EPS 5.9604644775390625e-8f      /* dr.epsilon(Float) = 2^-24 */
+
+typedef struct {
+    const mtr_nlos_desc *n;
+    /* projector */
+    v3 l_origin, l_forward; float l_inv[12];      /* rows of the inverse rigid transform (world -> local) */
+    float l_cot;                                   /* 1 / tan(fov/2) */
+    /* relay wall rectangle */
+    v3 w_center, w_du, w_dv;
+    /* hidden-geometry distribution over shapes, per-shape face distributions (normalised, f32) */
+    float *shape_pmf, *shape_cdf;
+    float *face_cdf, *face_pmf;                    /* per triangle, within its shape */
+    float *shape_inv_area;
+    v3 *rect_n;                                    /* rectangle shapes: normal */
+    /* scan */
+    v3 *sensor_targets; v3 laser_target_single;
+} nlos_scene;
+
+static double tri_area_d(const float *v)
+{
+    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
+    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
+    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+/* [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 cdf/pmf table */
+static uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float *reused, float *pmf_out)
+{
+    uint32_t i = 0;
+    while (i + 1 < n && !(value < cdf[i])) ++i;
+    while (i + 1 < n && pmf[i] == 0.0f) ++i;
+    float prev = i ? cdf[i - 1] : 0.0f;
+    *reused = (value - prev) / pmf[i];
+    *pmf_out = pmf[i];
+    return i;
+}
+
+/* [mitsuba3: Projector::sample_direction]; returns the weight (spec), ds.dist, ds.d */
+static void projector_sample(const nlos_scene *N, v3 p, float w[3], float *dist, v3 *dir_to_emitter)
+{
+    const float *M = N->l_inv;
+    v3 rel = vsub(p, N->l_origin);
+    v3 loc = V(vdot(V(M[0], M[1], M[2]), rel), vdot(V(M[4], M[5], M[6]), rel), vdot(V(M[8], M[9], M[10]), rel));
+    float iz = 1.0f / loc.z;
+    float uvx = 0.5f - (0.5f * N->l_cot) * (loc.x * iz), uvy = 0.5f - (0.5f * N->l_cot) * (loc.y * iz);
+    int ok = (uvx >= 0.0f && uvx <= 1.0f && uvy >= 0.0f && uvy <= 1.0f && loc.z > 0.0f);
+    v3 d = vsub(N->l_origin, p);
+    float d2 = vdot(d, d);
+    *dist = sqrtf(d2);
+    d = vdivs(d, *dist);
+    *dir_to_emitter = d;
+    /* spec *= pi * scale / (z^2 * -dot(n, d)) : irradiance at z = 1 on the axis */
+    float f = (ORC_PI * N->n->laser_scale) * (iz * iz) / -vdot(N->l_forward, d);
+    for (int k = 0; k < 3; ++k) w[k] = ok ? N->n->laser_irradiance[k] * f : 0.0f;
+}
+
+/* rectangle.sample_position [mitsuba3: Rectangle::sample_position] */
+static v3 rect_point(v3 c, v3 du, v3 dv, float u, float v)
+{
+    float a = fmaf(u, 2.0f, -1.0f), b = fmaf(v, 2.0f, -1.0f);
+    return V(fmaf(du.x, a, fmaf(dv.x, b, c.x)), fmaf(du.y, a, fmaf(dv.y, b, c.y)), fmaf(du.z, a, fmaf(dv.z, b, c.z)));
+}
+
+/* NLOSCaptureMeter.sample_ray (nloscapturemeter.py:136-180) for film sample (sx, sy) in [0,1)^2 */
+static ray3 nlos_sensor_ray(const nlos_scene *N, const mtr_film_desc *f, float sx, float sy)
+{
+    float W = (float)f->width, H = (float)f->height;
+    float gx = (floorf(sx * W) + 0.5f) / W, gy = (floorf(sy * H) + 0.5f) / H;     /* :146-149 pixel centre */
+    v3 target = rect_point(N->w_center, N->w_du, N->w_dv, gx, gy);
+    v3 o = V(N->n->sensor_origin[0], N->n->sensor_origin[1], N->n->sensor_origin[2]);
+    v3 dir = vsub(target, o);
+    float dist = sqrtf(vdot(dir, dir));
+    ray3 r; r.o = o; r.d = vdivs(dir, dist); r.maxt = INFINITY;
+    return r;
+}
+
+static void nlos_build(nlos_scene *N, const orc_scene *sc, int use_bvh)
+{
+    const mtr_scene_desc *d = sc->d; const mtr_nlos_desc *n = d->nlos;
+    memset(N, 0, sizeof *N); N->n = n;
+    const float *T = n->laser_to_world;
+    N->l_origin = V(T[3], T[7], T[11]);
+    N->l_forward = V(T[2], T[6], T[10]);
+    /* rigid: inverse rotation = transpose */
+    float inv[12] = { T[0], T[4], T[8], 0, T[1], T[5], T[9], 0, T[2], T[6], T[10], 0 };
+    memcpy(N->l_inv, inv, sizeof inv);
+    N->l_cot = (float)(1.0 / tan(0.5 * (double)n->laser_fov * 3.14159265358979323846 / 180.0));
+    const mtr_shape *rw = &n->shapes[n->relay_shape];
+    N->w_center = V(rw->center[0], rw->center[1], rw->center[2]);
+    N->w_du = V(rw->du[0], rw->du[1], rw->du[2]); N->w_dv = V(rw->dv[0], rw->dv[1], rw->dv[2]);
+    uint32_t ns = n->n_shapes;
+    N->shape_pmf = calloc(ns, 4); N->shape_cdf = calloc(ns, 4); N->shape_inv_area = calloc(ns, 4);
+    N->rect_n = calloc(ns, sizeof(v3));
+    N->face_cdf = calloc(d->n_tris ? d->n_tris : 1, 4); N->face_pmf = calloc(d->n_tris ? d->n_tris : 1, 4);
+    double *area = calloc(ns, sizeof(double)), total = 0.0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        const mtr_shape *S = &n->shapes[s];
+        double a = 0.0;
+        for (uint32_t t = 0; t < S->n_tris; ++t) a += tri_area_d(d->tri_verts + 9 * (size_t)(S->first_tri + t));
+        double acc = 0.0;
+        for (uint32_t t = 0; t < S->n_tris; ++t) {
+            double at = tri_area_d(d->tri_verts + 9 * (size_t)(S->first_tri + t));
+            acc += at;
+            N->face_pmf[S->first_tri + t] = (float)(at / a);
+            N->face_cdf[S->first_tri + t] = (float)(acc / a);
+        }
+        if (S->is_rectangle) {
+            v3 du = V(S->du[0], S->du[1], S->du[2]), dv = V(S->dv[0], S->dv[1], S->dv[2]);
+            v3 c = vcross(du, dv);
+            double len = sqrt((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z);
+            a = 4.0 * len;
+            N->rect_n[s] = vdivs(c, sqrtf(vdot(c, c)));
+        }
+        N->shape_inv_area[s] = (float)(1.0 / a);
+        /* transientnlospath.py:277-292: the relay wall has weight 0 unless ..._includes_relay_wall */
+        area[s] = (s == n->relay_shape && !(n->flags & MTR_NLOS_HG_INCLUDES_WALL)) ? 0.0 : a;
+        total += area[s];
+    }
+    double acc = 0.0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        acc += area[s];
+        N->shape_pmf[s] = total > 0.0 ? (float)(area[s] / total) : 0.0f;
+        N->shape_cdf[s] = total > 0.0 ? (float)(acc / total) : 0.0f;
+    }
+    free(area);
+    /* scanned points: one ray per film pixel (transientnlospath.py:295-312) */
+    const mtr_film_desc *f = &d->film;
+    N->sensor_targets = calloc((size_t)f->width * f->height, sizeof(v3));
+    for (uint32_t y = 0; y < f->height; ++y)
+        for (uint32_t x = 0; x < f->width; ++x) {
+            ray3 r = nlos_sensor_ray(N, f, (float)x / (float)f->width, (float)y / (float)f->height);
+            hit_t h = intersect(sc, &r, use_bvh);
+            sinter si = make_si(sc, &r, h);
+            N->sensor_targets[(size_t)y * f->width + x] = si.p;          /* (0,0,0) on a miss, like zeros(si) */
+        }
+    /* Single capture: where the laser's optical axis meets the scene (:328-336) */
+    ray3 lr; lr.o = N->l_origin; lr.d = N->l_forward; lr.maxt = INFINITY;
+    hit_t lh = intersect(sc, &lr, use_bvh);
+    sinter lsi = make_si(sc, &lr, lh);
+    N->laser_target_single = lsi.p;
+}
+static void nlos_free(nlos_scene *N)
+{
+    free(N->shape_pmf); free(N->shape_cdf); free(N->shape_inv_area); free(N->rect_n);
+    free(N->face_cdf); free(N->face_pmf); free(N->sensor_targets);
+}
+
+/* si.spawn_ray_to(t) [mitsuba3: Interaction::spawn_ray_to] */
+static ray3 spawn_ray_to(const sinter *si, v3 t)
+{
+    v3 o = offset_p(si, vsub(t, si->p));
+    v3 dd = vsub(t, o);
+    float dist = sqrtf(vdot(dd, dd));
+    ray3 r; r.o = o; r.d = vdivs(dd, dist); r.maxt = dist * (1.0f - ORC_SHADOW_EPS);
+    return r;
+}
+
+/* bsdf.eval(ctx, si, wo): value * cos (diffuse only is smooth) */
+static void bsdf_eval(const mtr_material *m, v3 wi, v3 wo, float val[3])
+{
+    float pdf; bsdf_eval_pdf(m, wi, wo, val, &pdf);
+}
+
+/* emitter_nee_sample (transientnlospath.py:432-509).  `distance` by value: the caller's copy is not changed */
+static void nlos_emitter_nee(const orc_scene *sc, const nlos_scene *N, film_t *F, pcg32 *rng, const sinter *si,
+                             const mtr_material *mat, const float beta[3], float distance, float eta, uint32_t depth,
+                             int active_e, int focus_laser, uint32_t px, uint32_t py, float sample_scale, uint32_t lane,
+                             uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3])
+{
+    const mtr_nlos_desc *n = N->n;
+    Lr[0] = Lr[1] = Lr[2] = 0.0f;
+    if (active_e) {                                                  /* :441 visibility of the emitter origin */
+        ray3 sr = spawn_ray_to(si, N->l_origin);
+        C->shadow++;
+        if (ray_test(sc, &sr, use_bvh)) active_e = 0;
+    }
+    if (!active_e) return;                                           /* masked lanes draw nothing: next_2d(active_e) */
+    float u1 = pcg32_next_f32(rng), u2 = pcg32_next_f32(rng); (void)u1; (void)u2;
+    float w[3], ds_dist; v3 dir;
+    if (focus_laser && n->capture_type == MTR_CAPTURE_CONFOCAL) {    /* :448-458 */
+        v3 rel = vsub(N->l_origin, si->p);
+        float dist_e = sqrtf(vdot(rel, rel));
+        v3 pf = vfma(N->l_forward, dist_e, N->l_origin);
+        projector_sample(N, pf, w, &ds_dist, &dir);
+    } else {
+        projector_sample(N, si->p, w, &ds_dist, &dir);
+    }
+    /* wo = to_local(normalize(ds.p - si.p)) :483 */
+    v3 wo = to_local(si, vnormalize(vsub(N->l_origin, si->p)));
+    float bv[3], bpdf; bsdf_eval_pdf(mat, si->wi, wo, bv, &bpdf);
+    if (n->filter_depth != -1) active_e = active_e && (depth == (uint32_t)n->filter_depth);       /* :489-490 */
+    if (n->flags & MTR_NLOS_DISCARD_DIRECT) active_e = active_e && (depth > 2);                   /* :491-492 */
+    if (!active_e) return;
+    for (int k = 0; k < 3; ++k) Lr[k] = (beta[k] * bv[k]) * w[k];                                /* :493 */
+    if (n->flags & MTR_NLOS_ACCOUNT_FIRST_LAST) distance += ds_dist * eta;                        /* :497-498 */
+    add_transient(F, px, py, distance, Lr, sample_scale, lane, loop_depth, 1, C);                /* :506-507 */
+}
+
+/* emitter_laser_targets_sample (transientnlospath.py:511-564) */
+static void nlos_laser_targets(const orc_scene *sc, const nlos_scene *N, film_t *F, pcg32 *rng, const sinter *si,
+                               const mtr_material *mat, v3 lt, const float beta[3], float distance, float eta,
+                               uint32_t depth, int active_e, uint32_t px, uint32_t py, float sample_scale,
+                               uint32_t lane, uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3])
+{
+    Lr[0] = Lr[1] = Lr[2] = 0.0f;
+    if (!active_e) return;
+    v3 dd = vsub(lt, si->p);
+    float dl = sqrtf(vdot(dd, dd));
+    dd = vdivs(dd, dl);
+    ray3 rb = spawn_ray_to(si, lt);
+    C->shadow++;
+    if (ray_test(sc, &rb, use_bvh)) return;                                   /* :528 */
+    v3 wo = to_local(si, dd);
+    float bs[3]; bsdf_eval(mat, si->wi, wo, bs);                              /* :531-533 */
+    rb.maxt = INFINITY;
+    hit_t h2 = intersect(sc, &rb, use_bvh); C->closest++;                      /* :535-537 */
+    sinter s2 = make_si(sc, &rb, h2);
+    if (!s2.valid) return;
+    if (!(bs[0] > ORC_EPS || bs[1] > ORC_EPS || bs[2] > ORC_EPS)) return;     /* :539-540 */
+    v3 wl = to_local(&s2, vneg(dd));
+    if (!(wl.z > 0.0f)) return;                                               /* :543 */
+    float pdf_ls = (dl * dl) / wl.z;                                          /* :546-551 */
+    float b2[3];
+    for (int k = 0; k < 3; ++k) b2[k] = beta[k] * (bs[k] / pdf_ls);
+    const mtr_material *m2 = &sc->d->materials[sc->d->tri_material[s2.prim]];
+    int smooth_ok = 1; (void)smooth_ok;
+    nlos_emitter_nee(sc, N, F, rng, &s2, m2, b2, distance + dl * eta, eta, depth + 1, 1, 1, px, py, sample_scale, lane,
+                     loop_depth, use_bvh, C, Lr);
+}
+
+/* hidden_geometry_sample (transientnlospath.py:637-670) */
+static void nlos_hidden_geometry(const orc_scene *sc, const nlos_scene *N, const sinter *si, const mtr_material *mat,
+                                 float ua, float ub, int active, bsample *bs)
+{
+    const mtr_scene_desc *d = sc->d; const mtr_nlos_desc *n = N->n;
+    memset(bs, 0, sizeof *bs);                      /* dr.zeros(BSDFSample3f): eta 0 ... */
+    bs->eta = 1.0f;                                 /* ... :662 bs.eta = 1.0 */
+    if (!active) return;
+    /* _sample_hidden_geometry_position (:385-430) */
+    float reused, spmf;
+    uint32_t s = distr_sample_reuse(N->shape_cdf, N->shape_pmf, n->n_shapes, ua, &reused, &spmf);
+    const mtr_shape *S = &n->shapes[s];
+    v3 pp, pn; float ppdf;
+    if (S->is_rectangle) {
+        pp = rect_point(V(S->center[0], S->center[1], S->center[2]), V(S->du[0], S->du[1], S->du[2]),
+                        V(S->dv[0], S->dv[1], S->dv[2]), reused, ub);
+        pn = N->rect_n[s];
+    } else {                                        /* [mitsuba3: Mesh::sample_position] */
+        float r2, fpmf, sy = ub;
+        uint32_t fi = 0;
+        if (S->n_tris > 1) fi = distr_sample_reuse(N->face_cdf + S->first_tri, N->face_pmf + S->first_tri, S->n_tris, ub, &r2, &fpmf), sy = r2;
+        const orc_tri *T = &sc->tris[S->first_tri + fi];
+        float t = sqrtf(fmaxf(1.0f - reused, 0.0f));           /* warp::square_to_uniform_triangle */
+        float b0 = 1.0f - t, b1 = t * sy;
+        pp = V(fmaf(T->e1.x, b0, fmaf(T->e2.x, b1, T->p0.x)), fmaf(T->e1.y, b0, fmaf(T->e2.y, b1, T->p0.y)),
+               fmaf(T->e1.z, b0, fmaf(T->e2.z, b1, T->p0.z)));
+        pn = T->n;
+    }
+    ppdf = N->shape_inv_area[s] * spmf;
+    v3 dd = vsub(pp, si->p);
+    float dist = sqrtf(vdot(dd, dd));
+    dd = vdivs(dd, dist);
+    float cos_i = vdot(si->n, dd), cos_g = vdot(pn, vneg(dd));
+    if (!(cos_i > ORC_EPS && cos_g > ORC_EPS)) { bs->wo = to_local(si, dd); bs->pdf = ppdf * (dist * dist) / fabsf(cos_g); return; }
+    v3 wo = to_local(si, dd);
+    float val[3]; bsdf_eval(mat, si->wi, wo, val);
+    bs->wo = wo;
+    bs->pdf = ppdf * (dist * dist) / fabsf(cos_g);
+    if (!(bs->pdf > ORC_EPS)) return;
+    for (int k = 0; k < 3; ++k) bs->w[k] = val[k] / bs->pdf;
+}
+
+/* one lane of TransientNLOSPath.sample (transientnlospath.py:672-927) */
+static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_render_params *P, film_t *F, uint32_t lane,
+                            int use_bvh, lane_counters *C)
+{
+    const mtr_scene_desc *d = sc->d; const mtr_film_desc *f = &d->film; const mtr_nlos_desc *n = N->n;
+    const uint32_t spp = P->spp_total;
+    const float sample_scale = (float)(1.0 / (double)spp);
+    const uint32_t max_depth = P->max_depth < 0 ? 0xffffffffu : (uint32_t)P->max_depth;
+    const uint32_t rr_depth = (uint32_t)P->rr_depth;
+    uint32_t idx = lane / spp;
+    uint32_t py = idx / f->crop_width, px = idx - f->crop_width * py;
+    px += f->crop_offset_x; py += f->crop_offset_y;
+    pcg32 rng; sampler_seed(&rng, P->seed, lane);
+    float j1 = pcg32_next_f32(&rng), j2 = pcg32_next_f32(&rng);
+    /* sample_rays: pos_adjusted = (pos + jitter) * (1/crop) + offset, then the sensor snaps it to the pixel centre */
+    float scx = 1.0f / (float)f->crop_width, scy = 1.0f / (float)f->crop_height;
+    float sx = fmaf((float)px + j1, scx, -(float)f->crop_offset_x * scx), sy = fmaf((float)py + j2, scy, -(float)f->crop_offset_y * scy);
+    ray3 ray = nlos_sensor_ray(N, f, sx, sy);
+
+    uint32_t depth = 0; float L[3] = { 0, 0, 0 }, beta[3] = { 1, 1, 1 };
+    float eta = 1.0f, distance = 0.0f;                                  /* distance = ray.time = 0 (:718) */
+    int active = 1;
+    /* confocal: this pixel's illuminated point = its scanned point (:337-339, :585-589) */
+    uint32_t fx = px - f->crop_offset_x, fy = py - f->crop_offset_y;
+    v3 lt = N->laser_target_single;
+    if (n->capture_type == MTR_CAPTURE_CONFOCAL) lt = N->sensor_targets[(size_t)py * f->width + px];
+    (void)fx; (void)fy;
+
+    while (active) {
+        C->bounces++;
+        int active_next = 1;
+        hit_t h = intersect(sc, &ray, use_bvh); C->closest++;
+        sinter si = make_si(sc, &ray, h);
+        if ((n->flags & MTR_NLOS_ACCOUNT_FIRST_LAST) || depth > 0) distance += si.t * eta;       /* :751-752 */
+        const mtr_material *mat = si.valid ? &d->materials[d->tri_material[si.prim]] : NULL;
+        /* direct emission (:757-777): the only emitter is the projector, which is not a surface: Le = 0 */
+        active_next &= (depth + 1 < max_depth) && si.valid;                                       /* :782 */
+        int active_em = active_next && bsdf_is_smooth(mat);
+        float Lr[3] = { 0, 0, 0 };
+        if (n->flags & MTR_NLOS_LASER_SAMPLING)                                                   /* emitter_laser_sample: depth + 1 */
+            nlos_laser_targets(sc, N, F, &rng, &si, mat, lt, beta, distance, eta, depth + 1, active_em, px, py, sample_scale,
+                               lane, depth, use_bvh, C, Lr);
+        else
+            nlos_emitter_nee(sc, N, F, &rng, &si, mat, beta, distance, eta, depth, active_em, 0, px, py, sample_scale, lane,
+                             depth, use_bvh, C, Lr);
+        /* BSDF / hidden-geometry sampling (:797-833) */
+        int do_hg = (n->flags & MTR_NLOS_HG_SAMPLING) != 0; float pdf_method = 1.0f;
+        if ((n->flags & MTR_NLOS_HG_SAMPLING) && (n->flags & MTR_NLOS_HG_RROULETTE)) {
+            float u = pcg32_next_f32(&rng);                                                     /* next_1d(active) :801 */
+            do_hg = u < 0.5f; pdf_method = 0.5f;
+        }
+        float a1 = pcg32_next_f32(&rng), a2a = pcg32_next_f32(&rng), a2b = pcg32_next_f32(&rng); (void)a1;   /* :814 */
+        bsample bs_hg; nlos_hidden_geometry(sc, N, &si, mat, a2a, a2b, active_next && do_hg && (n->flags & MTR_NLOS_HG_SAMPLING), &bs_hg);
+        if (!(n->flags & MTR_NLOS_HG_SAMPLING)) { memset(&bs_hg, 0, sizeof bs_hg); }                       /* zeros(BSDFSample3f), 0 */
+        float b1 = pcg32_next_f32(&rng), b2a = pcg32_next_f32(&rng), b2b = pcg32_next_f32(&rng);          /* :820 */
+        bsample bs_n; memset(&bs_n, 0, sizeof bs_n); bs_n.eta = 1.0f;
+        if (active_next && !do_hg) bsdf_sample(mat, si.wi, b1, b2a, b2b, &bs_n);
+        bsample bs = do_hg ? bs_hg : bs_n;
+        for (int k = 0; k < 3; ++k) L[k] = L[k] + Lr[k];
+        if (active_next) {
+            v3 wo_w = to_world(&si, bs.wo);
+            ray.o = offset_p(&si, wo_w); ray.d = wo_w; ray.maxt = INFINITY;
+        }
+        eta *= bs.eta;
+        for (int k = 0; k < 3; ++k) beta[k] = (beta[k] * bs.w[k]) / pdf_method;                  /* :833 */
+        float bmax = fmaxf(beta[0], fmaxf(beta[1], beta[2]));
+        active_next &= (bmax != 0.0f);
+        float rr_prob = fminf(bmax * (eta * eta), 0.95f);
+        active_next &= rr_prob > 0.0f;
+        int rr_active = depth >= rr_depth;
+        if (rr_active) { float inv = rr_prob > 0.0f ? 1.0f / rr_prob : 0.0f; for (int k = 0; k < 3; ++k) beta[k] *= inv; }
+        float rr_u = pcg32_next_f32(&rng);
+        active_next &= (!rr_active) || (rr_u < rr_prob);
+        if (si.valid) depth += 1;
+        active = active_next;
+    }
+    if (F->steady) {
+        uint32_t x = px - f->crop_offset_x, y = py - f->crop_offset_y;
+        if (x < f->width && y < f->height) {
+            size_t i = ((size_t)y * f->width + x) * 4u;
+            for (int k = 0; k < 3; ++k) {
+#pragma omp atomic
+                F->steady[i + k] += L[k];
+            }
+#pragma omp atomic
+            F->steady[i + 3] += 1.0f;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* Public entry points                                                 */
 /* ------------------------------------------------------------------ */
@@ -758,6 +1128,8 @@ int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *trans
     F.f = &d->film; F.transient = transient_hwt4; F.steady = steady_hw4;
     uint64_t zero = 0; F.log = log; F.log_cap = log_cap; F.log_n = log_n ? log_n : &zero;
     if (log_n) *log_n = 0;
+    nlos_scene NS; memset(&NS, 0, sizeof NS);
+    if (d->nlos) nlos_build(&NS, &sc, use_bvh);
     uint64_t closest = 0, shadow = 0, bounces = 0, paths = 0, splats = 0;
     const int64_t n_pix = (int64_t)P->pixel_end - (int64_t)P->pixel_begin;
     const uint32_t s0 = P->spp_begin, s1 = P->spp_end;
@@ -772,7 +1144,8 @@ int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *trans
         for (uint32_t s = s0; s < s1; ++s) {
             uint32_t lane = pix * P->spp_total + s;      /* lane identity == RNG identity */
             lane_counters C = { 0, 0, 0, 0 };
-            trace_lane(&sc, P, &F, lane, use_bvh, &C);
+            if (d->nlos) trace_lane_nlos(&sc, &NS, P, &F, lane, use_bvh, &C);
+            else trace_lane(&sc, P, &F, lane, use_bvh, &C);
             closest += C.closest; shadow += C.shadow; bounces += C.bounces; splats += C.splats; paths += 1;
         }
     }
@@ -781,6 +1154,7 @@ int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *trans
         out->paths = paths; out->rays_closest = closest; out->rays_shadow = shadow;
         out->bounces = bounces; out->splats_issued = splats;
     }
+    if (d->nlos) nlos_free(&NS);
     free_scene(&sc);
     return 0;
 }

@@ -66,3 +66,35 @@ def hh_render(lib, sd, params):
     rc = lib.hh_render(C.byref(d), C.byref(params), t4.ctypes.data_as(fp), s4.ctypes.data_as(fp), C.byref(cnt))
     assert rc == 0
     return t4, s4, cnt.as_dict()
+
+
+def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, **integ):
+    """NLOS scene in the style of tests/integration/test_nlos.py:1-78 and examples/transient-nlos/nlos_Z.xml:
+    2x2 relay wall at the origin with a nlos_capture_meter, projector laser and sensor at (-0.5, 0, 0.25),
+    hidden geometry at z = 1 (a 0.8 x 0.8 quad, or a procedural 'Z' of 6 triangles / 3 quads)."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    relay = mi.load_dict({
+        "type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}},
+        "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
+                        "sensor_origin": [-0.5, 0.0, 0.25],
+                        "film": {"type": "transient_hdr_film", "width": sx, "height": sy, "temporal_bins": bins,
+                                 "bin_width_opl": bin_width, "start_opl": start, "rfilter": {"type": "box"}}}})
+    laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
+                          "irradiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}, "fov": 0.2})
+    idict = {"type": "transient_nlos_path", "max_depth": -1, "nlos_laser_sampling": True,
+             "nlos_hidden_geometry_sampling": True, "capture_type": capture, "temporal_filter": "box"}
+    idict.update(integ)
+    d = {"type": "scene", "integrator": idict, "laser": laser, "relay_wall": relay}
+    white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
+    if hidden == "quad":
+        d["hidden"] = {"type": "rectangle", "to_world": T().translate([0, 0, 1]).rotate([0, 1, 0], 180).scale(0.4), "bsdf": white}
+    else:   # three bars of a 'Z' facing the wall (-z normals), as cubes squashed flat: 36 triangles
+        d["z_top"] = {"type": "cube", "to_world": T().translate([0.0, 0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}
+        d["z_bot"] = {"type": "cube", "to_world": T().translate([0.0, -0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}
+        d["z_diag"] = {"type": "cube", "to_world": T().translate([0.0, 0.0, 1.0]).rotate([0, 0, 1], 40.0).scale([0.5, 0.05, 0.004]), "bsdf": white}
+    scene = mi.load_dict(d)
+    mitr.nlos.focus_emitter_at_relay_wall_pixel((sx / 2, sy / 2), relay, laser)
+    return scene

@@ -5,6 +5,7 @@
 // has no CPU path.
 #include "../mitransient_amd/csrc/mtr_core.h"
 #include "../mitransient_amd/csrc/mtr_scene_host.h"
+#include "../mitransient_amd/csrc/mtr_nlos.h"
 
 #include <cstring>
 #include <vector>
@@ -43,9 +44,46 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     HostSink sink{ t4, hs.film.width, hs.film.bins, 0 };
     ArrStack st; st.sp = 0;
     uint64_t closest = 0, shadow = 0, bounces = 0, paths = 0;
+    // NLOS tier: tables + scanned points (the product computes the latter in k_nlos_prepare)
+    HostNlos hn; std::vector<q4> targets;
+    const bool nlos = d->nlos != nullptr;
+    if (nlos) {
+        if (derive_nlos(*d, hn)) return -2;
+        NlosConst &k = hn.k;
+        k.shapes = hn.shapes.data(); k.shape_pmf = hn.shape_pmf.data(); k.shape_cdf = hn.shape_cdf.data();
+        k.face_pmf = hn.face_pmf.data(); k.face_cdf = hn.face_cdf.data(); k.hg_tris = hn.hg_tris.data();
+        const uint32_t n = k.film_w * k.film_h;
+        targets.resize(n + 1);
+        for (uint32_t i = 0; i <= n; ++i) {
+            Ray r;
+            if (i < n) { uint32_t y = i / k.film_w, x = i - y * k.film_w; r = nlos_sensor_ray(k, (float)x / (float)k.film_w, (float)y / (float)k.film_h); }
+            else { r.o = k.l_origin; r.d = k.l_forward; r.tmax = kInf; }
+            Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
+            f3 pp = mk(0, 0, 0);
+            if (h.prim >= 0) pp = hit_ctx(sv, r.d, h).sp;
+            targets[i] = q4{ pp.x, pp.y, pp.z, 0.0f };
+        }
+        k.targets = targets.data();
+    }
     for (uint32_t pix = p->pixel_begin; pix < p->pixel_end; ++pix)
         for (uint32_t s = p->spp_begin; s < p->spp_end; ++s) {
             Path path;
+            if (nlos) {
+                nlos_begin(path, hn.k, hs.film, rc, pix, s);
+                ++paths;
+                bool alive = true;
+                while (alive) {
+                    BounceStats bs{ 0, 0 };
+                    alive = nlos_bounce(path, sv, hn.k, hs.film, rc, st, sink, bs);
+                    closest += bs.closest; shadow += bs.shadow; ++bounces;
+                }
+                uint32_t fx = path.px - hs.film.crop_x, fy = path.py - hs.film.crop_y;
+                if (fx < hs.film.width && fy < hs.film.height) {
+                    float *sp = s4 + ((size_t)fy * hs.film.width + fx) * 4u;
+                    sp[0] += path.L.x; sp[1] += path.L.y; sp[2] += path.L.z; sp[3] += 1.0f;
+                }
+                continue;
+            }
             path_begin(path, hs.cam, hs.film, rc, pix, s);
             ++paths;
             if (rc.flags & MTR_FLAG_CAMERA_UNWARP) {

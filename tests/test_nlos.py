@@ -1,0 +1,104 @@
+"""NLOS tier: transient_nlos_path + nlos_capture_meter + projector.
+CPU tests: the oracle's restatement against physical pins, and the product's arithmetic (host harness)
+against the oracle, bit for bit.  PARITY UNPINNED against real Mitsuba (see oracle/mtr_oracle.c)."""
+import numpy as np
+import pytest
+
+from conftest import make_nlos, hh_render, rel_l2
+
+CONFIGS = [
+    ("confocal", {}),
+    ("single", {}),
+    ("single", {"nlos_hidden_geometry_sampling": False, "max_depth": 6}),
+    ("confocal", {"nlos_hidden_geometry_sampling_do_rroulette": True, "nlos_hidden_geometry_sampling_includes_relay_wall": True,
+                  "account_first_and_last_bounces": True, "max_depth": 8}),
+    ("confocal", {"filter_bounces": 2}),
+    ("single", {"discard_direct_paths": True, "max_depth": 5}),
+    ("confocal", {"nlos_laser_sampling": False, "max_depth": 4}),
+]
+
+
+def _oracle(oracle, scene, spp, **kw):
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, spp)
+    t4, s4, c = oracle.render(sd, p, **kw)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    return t3, s3, t4, s4, c
+
+
+@pytest.mark.parametrize("capture,integ", CONFIGS)
+def test_host_harness_matches_oracle(oracle, host_harness, capture, integ):
+    for hidden in ("quad", "z"):
+        scene = make_nlos(capture=capture, hidden=hidden, **integ)
+        sd = scene.data()
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 24)
+        t4, s4, c = oracle.render(sd, p, n_threads=1)
+        ht, hs, hc = hh_render(host_harness, sd, p)
+        assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+        for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+            assert hc[k] == c[k], k
+
+
+def test_plugin_surface_and_helpers():
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    scene = make_nlos(sx=4, sy=2, capture="single")
+    integ = scene.integrator()
+    assert isinstance(integ, mitr.TransientNLOSPath)
+    assert (integ.laser_sampling, integ.hg_sampling, integ.hg_sampling_includes_relay_wall, integ.capture_type) == (True, True, False, 1)
+    assert integ.max_depth == 0xFFFFFFFF and integ.filter_depth == -1 and not integ.account_first_and_last_bounces
+    sensor = scene.sensors()[0]
+    assert sensor.film_size == (4.0, 2.0) and list(sensor.sensor_origin) == [-0.5, 0.0, 0.25]
+    assert mi.traverse(sensor)["film.temporal_bins"] == 64
+    # focus_emitter_at_relay_wall_pixel (nlos.py:50-70): pixel (2, 1) of a 4x2 film on the 2x2 wall -> uv (0.5, 0.5) -> origin
+    laser = scene.emitters()[0]
+    fwd = laser.world_transform().transform_vector([0, 0, 1])
+    to_wall = -np.array([-0.5, 0.0, 0.25])
+    assert np.allclose(fwd, to_wall / np.linalg.norm(to_wall), atol=1e-12)
+    assert sensor.laser_bounce_opl == pytest.approx(np.linalg.norm(to_wall))
+    relay = [s for s in scene.shapes() if s.sensor() is sensor][0]
+    mitr.nlos.focus_emitter_at_relay_wall_uv((0.75, 0.25), relay, laser)
+    assert np.allclose(sensor.laser_target, [0.5, -0.5, 0.0])
+    with pytest.raises(AssertionError):
+        make_nlos(camera_unwarp=True)
+    with pytest.raises(NotImplementedError):
+        make_nlos(capture="exhaustive")
+    with pytest.raises(AssertionError):
+        make_nlos(filter_depth=2, filter_bounces=2)
+
+
+def test_three_bounce_arrival_time_and_energy(oracle):
+    """Physical pins of the restatement: (1) with account_first_and_last_bounces=False the first photons of a
+    confocal pixel arrive at OPL = 2 x distance(wall point, nearest hidden point); (2) hidden-geometry sampling
+    and BSDF sampling estimate the same three-bounce energy (pdf conversions of :546-551 and :660-666)."""
+    kw = dict(sx=4, sy=4, bins=200, bin_width=0.01, start=1.5, capture="confocal", max_depth=3)
+    scene = make_nlos(**kw)
+    t3, s3, *_ = _oracle(oracle, scene, 4000)
+    # pixel centres of the 2x2 wall at (+-0.25, +-0.75 ...): nearest hidden point is straight ahead (z = 1) when |x|,|y| <= 0.4
+    f = scene.sensors()[0].film()
+    for (y, x) in [(1, 1), (2, 2), (1, 2)]:
+        prof = t3[y, x, :, 0]
+        first = int(np.nonzero(prof)[0][0])
+        assert abs((f.start_opl + first * f.bin_width_opl) - 2.0) <= 0.011
+    corner = t3[0, 0, :, 0]                                   # wall point (-0.75, -0.75): nearest hidden point is the quad corner
+    d = np.sqrt(0.35 ** 2 + 0.35 ** 2 + 1.0)
+    first = int(np.nonzero(corner)[0][0])
+    assert abs((f.start_opl + first * f.bin_width_opl) - 2 * d) <= 0.03
+    e_hg = t3.sum()
+    scene_b = make_nlos(nlos_hidden_geometry_sampling=False, **kw)
+    t3b, *_ = _oracle(oracle, scene_b, 40000)
+    e_bsdf = t3b.sum()
+    assert abs(e_hg - e_bsdf) / e_bsdf < 0.05
+    # single capture: the laser spot is the wall centre; energy falls off towards the edge pixels
+    scene_s = make_nlos(capture="single", **{k: v for k, v in kw.items() if k != "capture"})
+    t3s, *_ = _oracle(oracle, scene_s, 4000)
+    assert t3s[1:3, 1:3].sum() > t3s[0, 0].sum() * 4
+
+
+def test_brute_force_equals_bvh_nlos(oracle):
+    scene = make_nlos(hidden="z")
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 5, 16)
+    a = oracle.render(sd, p, n_threads=1, use_bvh=False)
+    b = oracle.render(sd, p, n_threads=1, use_bvh=True)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2]
