@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 2
+#define MTR_ABI_VERSION 3
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -59,12 +59,14 @@ typedef struct mtr_material {
     float    c2[3];       /* dielectric: specular_transmittance rgb              */
 } mtr_material;
 
-/* ---- emitters: `area` emitter attached to a `rectangle` shape ----------- */
+/* ---- emitters: `area` emitter attached to a `rectangle` (analytic sampling) or to a triangle mesh ---- */
 typedef struct mtr_emitter {
-    float center[3];      /* to_world * (0,0,0)                                  */
-    float du[3];          /* to_world * (1,0,0) - center  (half edge)            */
-    float dv[3];          /* to_world * (0,1,0) - center  (half edge)            */
+    float center[3];      /* rectangle: to_world * (0,0,0)                       */
+    float du[3];          /* rectangle: to_world * (1,0,0) - center  (half edge) */
+    float dv[3];          /* rectangle: to_world * (0,1,0) - center  (half edge) */
     float radiance[3];
+    uint32_t is_mesh;     /* 1: the emitter is the triangle range below (obj / cube shapes) */
+    uint32_t first_tri, n_tris;
 } mtr_emitter;
 
 /* ---- sensor: `perspective` (utils.py:92-105 of the reference) ----------- */

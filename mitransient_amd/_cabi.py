@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 2
+MTR_ABI_VERSION = 3
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -31,7 +31,8 @@ class mtr_material(C.Structure):
 
 
 class mtr_emitter(C.Structure):
-    _fields_ = [("center", _f3), ("du", _f3), ("dv", _f3), ("radiance", _f3)]
+    _fields_ = [("center", _f3), ("du", _f3), ("dv", _f3), ("radiance", _f3),
+                ("is_mesh", C.c_uint32), ("first_tri", C.c_uint32), ("n_tris", C.c_uint32)]
 
 
 class mtr_camera(C.Structure):

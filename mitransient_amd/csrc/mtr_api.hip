@@ -162,6 +162,8 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
     UP(hs.nodes, nodes); UP(hs.tgeom, tgeom); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
+    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr;
+    if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
 #undef UP
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_tris = d->n_tris;
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;

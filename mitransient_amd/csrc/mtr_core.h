@@ -156,7 +156,10 @@ struct alignas(16) TriGeom { q4 g[3]; };
 // shading record (4 quads): flat frame + the two other vertices (hit point = barycentric blend)
 //   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, -)
 struct alignas(16) TriShade { q4 h[4]; };
-struct alignas(16) Emitter { float center[3], du[3], dv[3], n[3], radiance[3], inv_area; };   // 64 B
+struct alignas(16) Emitter {                       // 80 B
+    float center[3], du[3], dv[3], n[3], radiance[3], inv_area;       // rectangle: analytic sampling
+    uint32_t is_mesh, first_tri, n_tris, pad;                          // mesh: triangle range (ORIGINAL indices)
+};
 
 struct Camera {
     float s2c[16];
@@ -177,7 +180,38 @@ struct SceneView {
     const Emitter *ems;
     uint32_t n_emitters;
     uint32_t n_tris;
+    // area sampling of triangle meshes (mesh emitters, NLOS hidden geometry), by ORIGINAL triangle index:
+    // 3 quads (p0, e1.x) (e1.yz, e2.xy) (e2.z, n) and the face distribution normalised within the mesh
+    const q4 *samp_tris;
+    const float *face_pmf, *face_cdf;
 };
+
+// [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
+MTR_HD uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float &reused, float &pmf_out)
+{
+    uint32_t i = 0;
+    while (i + 1 < n && !(value < cdf[i])) ++i;
+    while (i + 1 < n && pmf[i] == 0.0f) ++i;
+    const float prev = i ? cdf[i - 1] : 0.0f;
+    reused = (value - prev) / pmf[i];
+    pmf_out = pmf[i];
+    return i;
+}
+
+// [mitsuba3: Mesh::sample_position] face by area (reusing sample.y), then warp::square_to_uniform_triangle
+MTR_HD void mesh_sample_position(const q4 *samp_tris, const float *face_cdf, const float *face_pmf, uint32_t first_tri,
+                                 uint32_t n_tris, float u1, float u2, f3 &p, f3 &n)
+{
+    float sy = u2;
+    uint32_t fi = 0;
+    if (n_tris > 1) { float r2, fp; fi = distr_sample_reuse(face_cdf + first_tri, face_pmf + first_tri, n_tris, u2, r2, fp); sy = r2; }
+    const q4 *t = samp_tris + 3 * (size_t)(first_tri + fi);
+    const q4 a = t[0], b = t[1], cc = t[2];
+    const float tt = sqrtf(fmaxf(1.0f - u1, 0.0f));
+    const float b0 = 1.0f - tt, b1 = tt * sy;
+    p = mk(fmaf(a.w, b0, fmaf(b.z, b1, a.x)), fmaf(b.x, b0, fmaf(b.w, b1, a.y)), fmaf(b.y, b0, fmaf(cc.x, b1, a.z)));
+    n = mk(cc.y, cc.z, cc.w);
+}
 
 struct RenderConst {
     uint32_t spp_total;
@@ -551,11 +585,16 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
             ei = i; u1 = su - (float)i;
         }
         const Emitter &E = sc.ems[ei];
-        float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
-        f3 ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),
-                   fmaf(E.du[1], a, fmaf(E.dv[1], b, E.center[1])),
-                   fmaf(E.du[2], a, fmaf(E.dv[2], b, E.center[2])));
-        f3 en = ld3(E.n);
+        f3 ep, en;
+        if (E.is_mesh) {
+            mesh_sample_position(sc.samp_tris, sc.face_cdf, sc.face_pmf, E.first_tri, E.n_tris, u1, u2, ep, en);
+        } else {
+            float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
+            ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),
+                    fmaf(E.du[1], a, fmaf(E.dv[1], b, E.center[1])),
+                    fmaf(E.du[2], a, fmaf(E.dv[2], b, E.center[2])));
+            en = ld3(E.n);
+        }
         f3 dd = ep - c.sp;
         float dist2 = dot(dd, dd), dist = sqrtf(dist2);
         dd = dd / dist;

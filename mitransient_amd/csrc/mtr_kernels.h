@@ -17,6 +17,7 @@ struct SceneDev {
     const TriGeom *tgeom; const TriShade *tshade; uint32_t n_tris;
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;
+    const q4 *samp_tris; const float *face_pmf, *face_cdf;   // mesh-emitter sampling tables (HBM; null without mesh emitters)
     uint32_t bvh_depth;
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS
 };

@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
     sv.n_emitters = a.sc.n_ems; sv.n_tris = a.sc.n_tris;
+    sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf;
     if (SCENE_LDS) {
         Node *n = (Node *)(smem + off); off += align16(a.sc.n_nodes * sizeof(Node));
         TriGeom *tg = (TriGeom *)(smem + off); off += align16(a.sc.n_tris * sizeof(TriGeom));
@@ -371,6 +372,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     SceneView sv;
     sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
     sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     const uint32_t n = nc.film_w * nc.film_h;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
         Ray r;

@@ -39,18 +39,6 @@ struct NlosConst {
     uint32_t film_w, film_h;
 };
 
-// [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
-MTR_HD uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float &reused, float &pmf_out)
-{
-    uint32_t i = 0;
-    while (i + 1 < n && !(value < cdf[i])) ++i;
-    while (i + 1 < n && pmf[i] == 0.0f) ++i;
-    const float prev = i ? cdf[i - 1] : 0.0f;
-    reused = (value - prev) / pmf[i];
-    pmf_out = pmf[i];
-    return i;
-}
-
 MTR_HD f3 rect_point(f3 c, f3 du, f3 dv, float u, float v)
 {
     const float a = fmaf(u, 2.0f, -1.0f), b = fmaf(v, 2.0f, -1.0f);
@@ -193,15 +181,7 @@ MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat,
         pp = rect_point(ld3(S.center), ld3(S.du), ld3(S.dv), reused, ub);
         pn = ld3(S.n);
     } else {                                               // [mitsuba3: Mesh::sample_position]
-        float sy = ub;
-        uint32_t fi = 0;
-        if (S.n_tris > 1) { float r2, fp; fi = distr_sample_reuse(nc.face_cdf + S.first_tri, nc.face_pmf + S.first_tri, S.n_tris, ub, r2, fp); sy = r2; }
-        const q4 *t = nc.hg_tris + 3 * (size_t)(S.first_tri + fi);
-        const q4 a = t[0], b = t[1], cc = t[2];
-        const float tt = sqrtf(fmaxf(1.0f - reused, 0.0f));            // warp::square_to_uniform_triangle
-        const float b0 = 1.0f - tt, b1 = tt * sy;
-        pp = mk(fmaf(a.w, b0, fmaf(b.z, b1, a.x)), fmaf(b.x, b0, fmaf(b.w, b1, a.y)), fmaf(b.y, b0, fmaf(cc.x, b1, a.z)));
-        pn = mk(cc.y, cc.z, cc.w);
+        mesh_sample_position(nc.hg_tris, nc.face_cdf, nc.face_pmf, S.first_tri, S.n_tris, reused, ub, pp, pn);
     }
     const float ppdf = S.inv_area * spmf;
     f3 dd = pp - c.sp;

@@ -13,6 +13,34 @@ Film film_from_desc(const mtr_film_desc &d)
     return f;
 }
 
+static double tri_area_d(const float *v)
+{
+    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
+    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
+    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+// area-sampling tables of one mesh (triangles [first, first + n) of the ORIGINAL order): face distribution with f64
+// sums stored as f32 (Mesh::build_pmf), and (p0, e1, e2, n) quads; returns the mesh area
+static double fill_mesh_tables(const float *tri_verts, uint32_t first, uint32_t n, float *pmf, float *cdf, q4 *quads)
+{
+    double a = 0.0, acc = 0.0;
+    for (uint32_t t = 0; t < n; ++t) a += tri_area_d(tri_verts + 9 * (size_t)(first + t));
+    for (uint32_t t = 0; t < n; ++t) {
+        const float *v = tri_verts + 9 * (size_t)(first + t);
+        const double at = tri_area_d(v);
+        acc += at;
+        pmf[first + t] = (float)(at / a);
+        cdf[first + t] = (float)(acc / a);
+        const f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
+        const f3 nn = normalize(cross(e1, e2));
+        q4 *q = &quads[3 * (size_t)(first + t)];
+        q[0] = q4{ p0.x, p0.y, p0.z, e1.x }; q[1] = q4{ e1.y, e1.z, e2.x, e2.y }; q[2] = q4{ e2.z, nn.x, nn.y, nn.z };
+    }
+    return a;
+}
+
 const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
 {
     if (d.n_tris && (!d.tri_verts || !d.tri_material || !d.tri_emitter)) return "triangle arrays missing";
@@ -54,6 +82,18 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
         const mtr_emitter &e = d.emitters[i];
         Emitter &E = s.ems[i];
+        E.is_mesh = e.is_mesh; E.first_tri = e.first_tri; E.n_tris = e.n_tris; E.pad = 0;
+        if (e.is_mesh) {
+            if (e.n_tris == 0 || (uint64_t)e.first_tri + e.n_tris > d.n_tris) return "mesh emitter: bad triangle range";
+            if (s.samp_tris.empty()) {
+                s.samp_tris.assign(3 * (size_t)d.n_tris, q4{ 0, 0, 0, 0 });
+                s.face_pmf.assign(d.n_tris, 0.0f); s.face_cdf.assign(d.n_tris, 0.0f);
+            }
+            const double a = fill_mesh_tables(d.tri_verts, e.first_tri, e.n_tris, s.face_pmf.data(), s.face_cdf.data(), s.samp_tris.data());
+            for (int k = 0; k < 3; ++k) { E.center[k] = E.du[k] = E.dv[k] = E.n[k] = 0.0f; E.radiance[k] = e.radiance[k]; }
+            E.inv_area = (float)(1.0 / a);
+            continue;
+        }
         for (int k = 0; k < 3; ++k) { E.center[k] = e.center[k]; E.du[k] = e.du[k]; E.dv[k] = e.dv[k]; E.radiance[k] = e.radiance[k]; }
         f3 cr = cross(ld3(e.du), ld3(e.dv));
         float len = sqrtf(dot(cr, cr));
@@ -63,14 +103,6 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     }
     s.mats.assign(d.materials, d.materials + d.n_materials);
     return nullptr;
-}
-
-static double tri_area_d(const float *v)
-{
-    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
-    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
-    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
-    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
 }
 
 const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
@@ -114,20 +146,7 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
         const mtr_shape &S = n->shapes[s];
         NlosShape &D = o.shapes[s];
         D.first_tri = S.first_tri; D.n_tris = S.n_tris; D.is_rect = S.is_rectangle;
-        double a = 0.0;
-        for (uint32_t t = 0; t < S.n_tris; ++t) a += tri_area_d(d.tri_verts + 9 * (size_t)(S.first_tri + t));
-        double acc = 0.0;
-        for (uint32_t t = 0; t < S.n_tris; ++t) {
-            const float *v = d.tri_verts + 9 * (size_t)(S.first_tri + t);
-            const double at = tri_area_d(v);
-            acc += at;
-            o.face_pmf[S.first_tri + t] = (float)(at / a);
-            o.face_cdf[S.first_tri + t] = (float)(acc / a);
-            const f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
-            const f3 nn = normalize(cross(e1, e2));
-            q4 *q = &o.hg_tris[3 * (size_t)(S.first_tri + t)];
-            q[0] = q4{ p0.x, p0.y, p0.z, e1.x }; q[1] = q4{ e1.y, e1.z, e2.x, e2.y }; q[2] = q4{ e2.z, nn.x, nn.y, nn.z };
-        }
+        double a = fill_mesh_tables(d.tri_verts, S.first_tri, S.n_tris, o.face_pmf.data(), o.face_cdf.data(), o.hg_tris.data());
         if (S.is_rectangle) {
             for (int c = 0; c < 3; ++c) { D.center[c] = S.center[c]; D.du[c] = S.du[c]; D.dv[c] = S.dv[c]; }
             const f3 cr = cross(ld3(S.du), ld3(S.dv));

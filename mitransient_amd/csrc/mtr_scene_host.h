@@ -16,6 +16,8 @@ struct HostScene {
     std::vector<TriShade> tshade;
     std::vector<mtr_material> mats;
     std::vector<Emitter> ems;
+    std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView
+    std::vector<float> face_pmf, face_cdf;
     uint32_t bvh_depth = 0, n_leaves = 0;
     Camera cam{};
     Film film{};

@@ -60,6 +60,7 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     off = 64;                                                   // smem[0..63]: workgroup counters
     int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
     sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     if (SCENE_LDS) {
         Node *n = (Node *)(smem + off); off += al16(sc.n_nodes * sizeof(Node));
         TriGeom *tg = (TriGeom *)(smem + off); off += al16(sc.n_tris * sizeof(TriGeom));

@@ -199,16 +199,20 @@ class _SceneBuilder:
         if em is not None:
             if em.get("type") != "area":
                 raise ValueError(f"failed to instantiate unknown plugin of type \"{em.get('type')}\" (supported emitters: area)")
-            if t != "rectangle":
-                raise ValueError("area emitters are supported on 'rectangle' shapes only")
             e = _cabi.mtr_emitter()
-            c = tw.transform_affine(np.zeros(3))
-            du = tw.transform_affine(np.array([1.0, 0, 0])) - c
-            dv = tw.transform_affine(np.array([0, 1.0, 0])) - c
             rad = _color3(em.get("radiance", 1.0), "area.radiance")
+            if t == "rectangle":
+                c = tw.transform_affine(np.zeros(3))
+                du = tw.transform_affine(np.array([1.0, 0, 0])) - c
+                dv = tw.transform_affine(np.array([0, 1.0, 0])) - c
+                for k in range(3):
+                    e.center[k], e.du[k], e.dv[k] = np.float32(c[k]), np.float32(du[k]), np.float32(dv[k])
+            else:                                   # triangle-mesh emitter: sampled by face area [Mesh::sample_position]
+                e.is_mesh = 1
+                e.first_tri = sum(a.shape[0] for a in self.tri_verts)
+                e.n_tris = tris.shape[0]
             for k in range(3):
-                e.center[k], e.du[k], e.dv[k], e.radiance[k] = (np.float32(c[k]), np.float32(du[k]),
-                                                                 np.float32(dv[k]), np.float32(rad[k]))
+                e.radiance[k] = np.float32(rad[k])
             self.emitters.append(e)
             em_index = len(self.emitters) - 1
         n = tris.shape[0]

@@ -187,9 +187,19 @@ typedef struct {
     orc_tri *tris;
     /* emitters: derived n, inv_area */
     v3 *em_n; float *em_inv_area;
+    float *em_face_pmf, *em_face_cdf;          /* mesh emitters: per triangle (original index), normalised within the emitter */
     /* own small BVH (median split), only used when use_bvh != 0 */
     orc_node *nodes; int n_nodes; int *tri_order;
 } orc_scene;
+
+static double orc_tri_area_d(const float *v)
+{
+    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
+    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
+    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+static uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float *reused, float *pmf_out);
 
 static void build_tris(orc_scene *sc)
 {
@@ -206,8 +216,22 @@ static void build_tris(orc_scene *sc)
     }
     sc->em_n = (v3 *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(v3));
     sc->em_inv_area = (float *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(float));
+    sc->em_face_pmf = (float *)calloc(d->n_tris ? d->n_tris : 1, sizeof(float));
+    sc->em_face_cdf = (float *)calloc(d->n_tris ? d->n_tris : 1, sizeof(float));
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         const mtr_emitter *e = &d->emitters[i];
+        if (e->is_mesh) {                       /* [mitsuba3: Mesh::surface_area / m_area_pmf] f64 sums, stored f32 */
+            double a = 0.0, acc = 0.0;
+            for (uint32_t t = 0; t < e->n_tris; ++t) a += orc_tri_area_d(d->tri_verts + 9 * (size_t)(e->first_tri + t));
+            for (uint32_t t = 0; t < e->n_tris; ++t) {
+                double at = orc_tri_area_d(d->tri_verts + 9 * (size_t)(e->first_tri + t));
+                acc += at;
+                sc->em_face_pmf[e->first_tri + t] = (float)(at / a);
+                sc->em_face_cdf[e->first_tri + t] = (float)(acc / a);
+            }
+            sc->em_inv_area[i] = (float)(1.0 / a);
+            continue;
+        }
         v3 du = V(e->du[0], e->du[1], e->du[2]), dv = V(e->dv[0], e->dv[1], e->dv[2]);
         v3 c = vcross(du, dv);
         float len = sqrtf(vdot(c, c));
@@ -272,7 +296,7 @@ static void build_bvh(orc_scene *sc)
 }
 static void free_scene(orc_scene *sc)
 {
-    free(sc->tris); free(sc->em_n); free(sc->em_inv_area); free(sc->nodes); free(sc->tri_order);
+    free(sc->tris); free(sc->em_n); free(sc->em_inv_area); free(sc->em_face_pmf); free(sc->em_face_cdf); free(sc->nodes); free(sc->tri_order);
 }
 
 /* ------------------------------------------------------------------ */
@@ -652,12 +676,23 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
                 ei = i; u1 = su - (float)i; pmf = 1.0f / ne;
             }
             const mtr_emitter *E = &d->emitters[ei];
-            /* [Rectangle::sample_position] */
-            float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
-            v3 ep = V(fmaf(E->du[0], a, fmaf(E->dv[0], b, E->center[0])),
-                      fmaf(E->du[1], a, fmaf(E->dv[1], b, E->center[1])),
-                      fmaf(E->du[2], a, fmaf(E->dv[2], b, E->center[2])));
-            v3 en = sc->em_n[ei];
+            v3 ep, en;
+            if (E->is_mesh) {                   /* [Mesh::sample_position]: face by area (reusing sample.y), uniform triangle */
+                float sy = u2, r2, fp; uint32_t fi = 0;
+                if (E->n_tris > 1) { fi = distr_sample_reuse(sc->em_face_cdf + E->first_tri, sc->em_face_pmf + E->first_tri, E->n_tris, u2, &r2, &fp); sy = r2; }
+                const orc_tri *T = &sc->tris[E->first_tri + fi];
+                float tt = sqrtf(fmaxf(1.0f - u1, 0.0f));
+                float b0 = 1.0f - tt, b1 = tt * sy;
+                ep = V(fmaf(T->e1.x, b0, fmaf(T->e2.x, b1, T->p0.x)), fmaf(T->e1.y, b0, fmaf(T->e2.y, b1, T->p0.y)),
+                       fmaf(T->e1.z, b0, fmaf(T->e2.z, b1, T->p0.z)));
+                en = T->n;
+            } else {                            /* [Rectangle::sample_position] */
+                float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
+                ep = V(fmaf(E->du[0], a, fmaf(E->dv[0], b, E->center[0])),
+                       fmaf(E->du[1], a, fmaf(E->dv[1], b, E->center[1])),
+                       fmaf(E->du[2], a, fmaf(E->dv[2], b, E->center[2])));
+                en = sc->em_n[ei];
+            }
             /* [Shape::sample_direction] */
             v3 dd = vsub(ep, si.p);
             float dist2 = vdot(dd, dd), dist = sqrtf(dist2);
@@ -765,13 +800,7 @@ typedef struct {
     v3 *sensor_targets; v3 laser_target_single;
 } nlos_scene;
 
-static double tri_area_d(const float *v)
-{
-    double e1[3] = { (double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2] };
-    double e2[3] = { (double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2] };
-    double c[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
-    return 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-}
+#define tri_area_d orc_tri_area_d
 
 /* [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 cdf/pmf table */
 static uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float *reused, float *pmf_out)

@@ -40,6 +40,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
     HostSink sink{ t4, hs.film.width, hs.film.bins, 0 };
     ArrStack st; st.sp = 0;
@@ -129,6 +130,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     ArrStack st; st.sp = 0;
     for (uint32_t i = 0; i < n; ++i) {
         f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);

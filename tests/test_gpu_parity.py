@@ -445,3 +445,19 @@ def test_two_emitters(oracle):
         s_gpu, t_gpu = gpu_render(scene, 16)
         s_ref, t_ref, *_ = oracle_render(oracle, scene, 16)
         assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("with_rect", [False, True])
+def test_mesh_area_emitter(oracle, mode, with_rect):
+    """area emitter on a triangle mesh (the reference's cbox_diffuse.xml light is an .obj with an `area` emitter):
+    [Mesh::sample_position] face pmf with sample reuse + uniform triangle warp, tables in HBM"""
+    from test_oracle import mesh_light_cornell
+    scene = mesh_light_cornell(width=32, height=32, bins=128, with_rect=with_rect)
+    scene.integrator().amd_mode = mode
+    s_gpu, t_gpu = gpu_render(scene, 16, seed=5)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16, seed=5)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

@@ -69,7 +69,7 @@ def test_plugin_defaults_and_errors():
     with pytest.raises(Exception):
         mitr.TransientPath(Properties("transient_path", {"rr_depth": 0}))
     d = mitr.cornell_box()
-    d["integrator"]["type"] = "transient_nlos_path"
+    d["integrator"]["type"] = "transient_prbvolpath"          # the differentiable tier is out of scope
     with pytest.raises(ValueError, match="unknown plugin"):
         mi.load_dict(d)
     d = mitr.cornell_box()
