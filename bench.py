@@ -25,10 +25,17 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SPLAT_BYTES = 24.0         # algorithmic bytes per issued time-bin contribution
 
 
+SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry)
+
+
 def build_scene(width, height, bins, max_depth=8, mode=None):
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
+    if SCENE == "staircase":
+        from mitransient_amd.scenes import staircase
+        kw = {"amd_mode": mode} if mode else {}
+        return staircase(width=width, height=height, temporal_bins=bins, max_depth=65, **kw)
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=width, height=height, temporal_bins=bins, start_opl=3.5,
                                bin_width_opl=6.0 / bins)
@@ -89,15 +96,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--bins", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel PER GPU (weak scaling)")
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase"],
+                    help="staircase: BASELINE configs[4] (720x1280, 400 bins, 64 spp, max_depth 65; approximate materials)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--bins", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel PER GPU (weak scaling)")
     ap.add_argument("--mode", default=None, choices=[None, "auto", "fused", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scatter-leg", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    global SCENE
+    SCENE = args.scene
+    dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (720, 1280, 400, 64)}[SCENE]
+    args.width, args.height, args.bins, args.spp = [d if a is None else a
+                                                    for a, d in zip((args.width, args.height, args.bins, args.spp), dflt)]
 
     import torch
     import torch.distributed as dist
@@ -129,15 +143,17 @@ def main():
     totals = {"paths": 0, "rays_closest": 0, "rays_shadow": 0, "splats_issued": 0, "bounces": 0}
     kernel_ms = []
     trace_launches = 0
+    wf_seen = False                      # MTR_MODE_AUTO resolves inside the library: wavefront runs scatter launches
 
     def step(timed):
-        nonlocal trace_launches
+        nonlocal trace_launches, wf_seen
         steady, transient = renderer.render(spp=spp_total, seed=0)
         if timed:
             for k in totals:
                 totals[k] += integ.total_counters[k]
             kernel_ms.append(integ.total_times["trace_ms"])          # sum over the launches of this step
             trace_launches += integ.total_times["trace_launches"]
+            wf_seen = wf_seen or integ.total_times["scatter_launches"] > 0
         return steady, transient
 
     def fence():
@@ -191,14 +207,15 @@ def main():
         # roofline of the dominant kernel (the path kernel), rank 0's launches, HIP events on its stream:
         # algorithmic bytes per launch = 24 B x contributions one launch issues
         n_launch = max(1, trace_launches)
-        fused = args.mode in (None, "auto", "fused")
+        fused = not wf_seen
         avg_ms = sum(kernel_ms) / max(1, n_launch) if fused else sum(kernel_ms) / max(1, len(kernel_ms))
         splats_rank0 = totals["splats_issued"] / world
         bytes_per_launch = SPLAT_BYTES * splats_rank0 / (max(1, n_launch) if fused else max(1, len(kernel_ms)))
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kname = "k_fused" if (args.mode in (None, "auto", "fused")) else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
+        kname = "k_fused" if fused else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
         res = {
-            "metric": "Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU",
+            "metric": ("Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU" if SCENE == "cornell"
+                       else "Mray/s (closest-hit + shadow rays), staircase 720x1280 x 400 bins x 64 spp per GPU"),
             "value": rays / elapsed / 1e6,
             "unit": "Mray/s",
             "time_bins_per_s": totals["splats_issued"] / elapsed,
@@ -207,11 +224,15 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
-                                   f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
-                                   f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0",
+            "config": {"workload": (f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
+                                    f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
+                                    f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0") if SCENE == "cornell" else
+                                   (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, approximate materials), "
+                                    f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 0.1), {args.spp} spp per GPU "
+                                    f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
                        "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",
-                       "mode": args.mode or "auto (fused: scene + per-pixel time histograms in LDS)"},
+                       "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE == "cornell"
+                                             else "auto (wavefront: scene in HBM)")},
             # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
             # `scatter_add` below is the stand-alone scatter-add kernel of the wavefront organisation
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -80,7 +80,9 @@ def _load_shape(d):
 
 
 class Scene:
-    def __init__(self, d: Dict[str, Any], base_dir: str = "."):
+    def __init__(self, d: Dict[str, Any], base_dir: str = ".", approximate_materials: bool = False, geometry=None):
+        self.approximate_materials = approximate_materials
+        self.geometry_ = geometry              # pre-flattened triangles + tables (scene.load_geometry), or None
         from . import integrators as _i, films as _f  # noqa: F401  (registers the plugins)
         from .shapes import Shape
         from .emitters import Projector
@@ -145,7 +147,7 @@ class Scene:
         key = id(sensor)
         if key not in self._data:
             self._data[key] = flatten_scene(self.dict_, sensor.film(), sensor.dict_, self.base_dir,
-                                            self.relay_names_.get(key))
+                                            self.relay_names_.get(key), self.approximate_materials, self.geometry_)
         sd = self._data[key]
         sd.film = film_desc_from(sensor.film())
         if key in self.relay_names_:                                    # NLOS tier: rebuilt from the live objects
@@ -183,12 +185,12 @@ class Scene:
             pass
 
 
-def load_dict(d: Dict[str, Any], base_dir: str = "."):
+def load_dict(d: Dict[str, Any], base_dir: str = ".", approximate_materials: bool = False):
     """``mi.load_dict``: a scene dictionary -> Scene; a single shape / projector dictionary -> that object
     (tests/integration/test_nlos.py:86-98 builds the relay wall and the laser this way)."""
     t = d.get("type")
     if t == "scene":
-        return Scene(d, base_dir)
+        return Scene(d, base_dir, approximate_materials)
     if t in _SHAPE_TYPES:
         return _load_shape(d)
     if t == "projector":

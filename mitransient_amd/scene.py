@@ -1,8 +1,8 @@
 """Scene dictionaries -> flat arrays (the host half of ``mi.load_dict``).
 
 Only the subset the north-star path needs is accepted: shapes
-``rectangle`` / ``cube`` / ``obj``, BSDFs ``diffuse`` / ``conductor`` /
-``dielectric`` / ``twosided``, the ``area`` emitter on a rectangle, the
+``rectangle`` / ``cube`` / ``obj`` / ``ply``, BSDFs ``diffuse`` / ``conductor`` /
+``dielectric`` / ``twosided``, the ``area`` emitter on a rectangle or a mesh, the
 ``perspective`` sensor with an ``independent`` sampler and a
 ``transient_hdr_film``, and the ``transient_path`` integrator.  Anything else
 raises, in the words Mitsuba uses for an unknown plugin.
@@ -58,9 +58,29 @@ class Properties:
         return [k for k in self._v if k not in self._queried and k != "type"]
 
 
-def _color3(v, what="color"):
+def _srgb_to_linear(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.where(a <= 0.04045, a / 12.92, ((a + 0.055) / 1.055) ** 2.4)
+
+
+def bitmap_mean_colour(path: str, raw: bool = False) -> np.ndarray:
+    """mean linear RGB of an 8-bit image (the approximate-materials stand-in for a `bitmap` texture)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im.convert("RGB"), dtype=np.float64) / 255.0
+    if not raw:
+        a = _srgb_to_linear(a)
+    return a.reshape(-1, 3).mean(axis=0)
+
+
+def _color3(v, what="color", approx_base=None):
     if isinstance(v, dict):
         t = v.get("type")
+        if t == "bitmap" and approx_base is not None:
+            fn = v.get("filename")
+            if not os.path.isabs(fn):
+                fn = os.path.join(approx_base, fn)
+            return bitmap_mean_colour(fn, bool(v.get("raw", False)))
         if t not in ("rgb", "spectrum", "uniform"):
             raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" ({what}: only rgb/constant values are supported)")
         v = v.get("value")
@@ -91,10 +111,15 @@ def _ior(v, default):
     return float(v)
 
 
+_EMITTER_TYPES = ("area", "angulararea", "point", "spot", "projector", "constant", "envmap", "directional")
+
+
 class _SceneBuilder:
-    def __init__(self, d: Dict[str, Any], base_dir: str = "."):
+    def __init__(self, d: Dict[str, Any], base_dir: str = ".", approximate_materials: bool = False):
         self.d = d
         self.base_dir = base_dir
+        self.approx = approximate_materials
+        self.mesh_cache: Dict[str, np.ndarray] = {}
         self.tri_verts: List[np.ndarray] = []
         self.tri_mat: List[np.ndarray] = []
         self.tri_em: List[np.ndarray] = []
@@ -130,6 +155,22 @@ class _SceneBuilder:
             m.c[k] = 1.0
             m.c2[k] = 1.0
         t = bd.get("type")
+        ab = self.base_dir if self.approx else None          # bitmap -> mean colour only when approximating
+        if self.approx:
+            # nearest material of the hot path's model (opt-in, documented in DESIGN.md): rough microfacet lobes
+            # collapse to their smooth limit, the plastic coat is dropped, bump/normal maps are ignored
+            if t in ("bumpmap", "normalmap"):
+                inner = [v for k, v in bd.items() if isinstance(v, dict) and v.get("type") not in ("bitmap", None)
+                         and k != "type" and "filename" not in v]
+                if len(inner) != 1:
+                    raise ValueError(f"{t}: exactly one nested BSDF is expected")
+                return self._make_material(self._resolve(inner[0])[0])
+            if t == "roughconductor":
+                bd = dict(bd, type="conductor"); t = "conductor"
+            elif t in ("roughplastic", "plastic"):
+                bd = {"type": "diffuse", "reflectance": bd.get("diffuse_reflectance", 0.5)}; t = "diffuse"
+            elif t in ("roughdielectric", "thindielectric"):
+                bd = dict(bd, type="dielectric"); t = "dielectric"
         if t == "twosided":
             inner = [v for k, v in bd.items() if isinstance(v, dict) and k != "type"]
             if len(inner) != 1:
@@ -142,7 +183,7 @@ class _SceneBuilder:
             return m
         if t == "diffuse":
             m.type = _cabi.MTR_BSDF_DIFFUSE
-            refl = _color3(bd.get("reflectance", 0.5), "diffuse.reflectance")
+            refl = _color3(bd.get("reflectance", 0.5), "diffuse.reflectance", ab)
             for k in range(3):
                 m.a[k] = np.float32(refl[k])
         elif t == "conductor":
@@ -176,26 +217,35 @@ class _SceneBuilder:
             tris = np.stack([w[[0, 1, 2]], w[[0, 2, 3]]])
         elif t == "cube":
             tris = tw.transform_affine(_cube_tris().reshape(-1, 3)).reshape(-1, 3, 3)
-        elif t == "obj":
+        elif t in ("obj", "ply"):
             fn = sd.get("filename")
             if not os.path.isabs(fn):
                 fn = os.path.join(self.base_dir, fn)
-            v = load_obj(fn)
+            if fn not in self.mesh_cache:
+                self.mesh_cache[fn] = load_obj(fn) if t == "obj" else load_ply(fn)
+            v = self.mesh_cache[fn]
             tris = tw.transform_affine(v.reshape(-1, 3)).reshape(-1, 3, 3)
         else:
-            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported shapes: rectangle, cube, obj)")
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported shapes: rectangle, cube, obj, ply)")
         if sd.get("flip_normals", False):
             tris = tris[:, [0, 2, 1], :]
-        bsdf = None
+        bsdf, em = None, None
         for k, v in sd.items():
-            # any nested plugin that is neither the emitter nor a sensor is the BSDF
-            if isinstance(v, dict) and k != "emitter" and not str(v.get("type", "")).startswith("nlos_"):
+            # nested plugins are recognised by type, not by key (keys are arbitrary, as in mitsuba): emitter, sensor,
+            # anything else is the BSDF
+            if not isinstance(v, dict):
+                continue
+            vt = str(v.get("type", ""))
+            if vt in _EMITTER_TYPES:
+                em = v
+            elif vt.startswith("nlos_") or vt in ("perspective", "irradiancemeter"):
+                continue
+            else:
                 bsdf = v
         if bsdf is None:
             bsdf = {"type": "diffuse", "reflectance": 0.5}     # mitsuba's default BSDF
         mi_ = self.material_index(bsdf)
         em_index = -1
-        em = sd.get("emitter")
         if em is not None:
             if em.get("type") != "area":
                 raise ValueError(f"failed to instantiate unknown plugin of type \"{em.get('type')}\" (supported emitters: area)")
@@ -272,6 +322,91 @@ def load_obj(path: str) -> np.ndarray:
     v = np.asarray(verts, dtype=np.float64)
     t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
     return v[t]
+
+
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
+              "double": "f8", "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4",
+              "float32": "f4", "float64": "f8"}
+
+
+def load_ply(path: str) -> np.ndarray:
+    """Stanford PLY (ascii / binary_little_endian / binary_big_endian) -> (n,3,3) float64 triangle soup:
+    vertex x/y/z and the face index list; every other property is skipped; polygons are fan-triangulated."""
+    with open(path, "rb") as fh:
+        if fh.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = fh.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] in ("comment", "obj_info"):
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append((tok[1], int(tok[2]), []))
+            elif tok[0] == "property":
+                elements[-1][2].append(tok[1:])
+            elif tok[0] == "end_header":
+                break
+        body = fh.read()
+    verts, faces = None, []
+    if fmt == "ascii":
+        lines = body.decode("ascii", "replace").split("\n")
+        li = 0
+        for name, count, props in elements:
+            rows = [lines[li + i].split() for i in range(count)]
+            li += count
+            if name == "vertex":
+                names = [p[-1] for p in props]
+                ix = [names.index(a) for a in "xyz"]
+                verts = np.asarray([[float(r[i]) for i in ix] for r in rows], dtype=np.float64)
+            elif name == "face":
+                for r in rows:
+                    n = int(r[0])
+                    idx = [int(x) for x in r[1:1 + n]]
+                    faces.extend((idx[0], idx[k], idx[k + 1]) for k in range(1, n - 1))
+    elif fmt in ("binary_little_endian", "binary_big_endian"):
+        e = "<" if fmt == "binary_little_endian" else ">"
+        off = 0
+        for name, count, props in elements:
+            if all(p[0] != "list" for p in props):
+                dt = np.dtype([(p[1], e + _PLY_TYPES[p[0]]) for p in props])
+                arr = np.frombuffer(body, dtype=dt, count=count, offset=off)
+                off += dt.itemsize * count
+                if name == "vertex":
+                    verts = np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float64)
+            else:
+                if len(props) != 1:
+                    raise ValueError(f"{path}: face element with extra properties is not supported")
+                ct, it = np.dtype(e + _PLY_TYPES[props[0][1]]), np.dtype(e + _PLY_TYPES[props[0][2]])
+                # fast path: every polygon has the same vertex count
+                n0 = int(np.frombuffer(body, dtype=ct, count=1, offset=off)[0]) if count else 0
+                rec = np.dtype([("n", ct), ("i", it, (n0,))]) if n0 else None
+                ok = False
+                if rec is not None and off + rec.itemsize * count <= len(body):
+                    arr = np.frombuffer(body, dtype=rec, count=count, offset=off)
+                    ok = bool(np.all(arr["n"] == n0))
+                if ok:
+                    off += rec.itemsize * count
+                    if name == "face":
+                        idx = arr["i"].astype(np.int64)
+                        for k in range(1, n0 - 1):
+                            faces.extend(map(tuple, idx[:, [0, k, k + 1]]))
+                else:
+                    for _ in range(count):
+                        n = int(np.frombuffer(body, dtype=ct, count=1, offset=off)[0]); off += ct.itemsize
+                        idx = np.frombuffer(body, dtype=it, count=n, offset=off).astype(np.int64); off += it.itemsize * n
+                        if name == "face":
+                            faces.extend((int(idx[0]), int(idx[k]), int(idx[k + 1])) for k in range(1, n - 1))
+    else:
+        raise ValueError(f"{path}: unknown PLY format '{fmt}'")
+    if verts is None:
+        raise ValueError(f"{path}: no vertex element")
+    t = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    return verts[t]
 
 
 # -- sensor ---------------------------------------------------------------
@@ -380,9 +515,38 @@ def nlos_desc_from(integrator, sensor, emitter, relay_shape: int) -> _cabi.mtr_n
     return n
 
 
+def save_geometry(sd: "SceneData", path: str, **meta):
+    """flattened geometry + material / emitter tables of a SceneData -> one .npz (a data fixture that can travel
+    where the scene's asset files cannot); sensor / film / integrator are NOT stored — the caller supplies them"""
+    import json
+    np.savez_compressed(
+        path, tri_verts=sd.tri_verts, tri_material=sd.tri_material.astype(np.uint16 if sd.n_materials < 65536 else np.uint32),
+        tri_emitter=sd.tri_emitter.astype(np.int16),
+        materials=np.frombuffer(bytes(sd.materials), dtype=np.uint8)[:sd.n_materials * C.sizeof(_cabi.mtr_material)],
+        emitters=np.frombuffer(bytes(sd.emitters), dtype=np.uint8)[:sd.n_emitters * C.sizeof(_cabi.mtr_emitter)],
+        abi=np.asarray([_cabi.MTR_ABI_VERSION]), meta=np.asarray(json.dumps(meta)))
+
+
+def load_geometry(path: str) -> Dict[str, Any]:
+    import json
+    z = np.load(path)
+    if int(z["abi"][0]) != _cabi.MTR_ABI_VERSION:
+        raise ValueError(f"{path}: written for C-ABI version {int(z['abi'][0])}, this is {_cabi.MTR_ABI_VERSION}")
+    nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
+    ne = z["emitters"].size // C.sizeof(_cabi.mtr_emitter)
+    mats = (_cabi.mtr_material * max(1, nm)).from_buffer_copy(z["materials"].tobytes().ljust(C.sizeof(_cabi.mtr_material), b"\0"))
+    ems = (_cabi.mtr_emitter * max(1, ne)).from_buffer_copy(z["emitters"].tobytes().ljust(C.sizeof(_cabi.mtr_emitter), b"\0"))
+    return {"tri_verts": np.ascontiguousarray(z["tri_verts"], dtype=np.float32),
+            "tri_material": np.ascontiguousarray(z["tri_material"].astype(np.uint32)),
+            "tri_emitter": np.ascontiguousarray(z["tri_emitter"].astype(np.int32)),
+            "materials": mats, "n_materials": nm, "emitters": ems, "n_emitters": ne,
+            "meta": json.loads(str(z["meta"]))}
+
+
 def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir: str = ".",
-                  relay_shape_name: Optional[str] = None) -> SceneData:
-    b = _SceneBuilder(d, base_dir)
+                  relay_shape_name: Optional[str] = None, approximate_materials: bool = False,
+                  geometry: Optional[Dict[str, Any]] = None) -> SceneData:
+    b = _SceneBuilder(d, base_dir, approximate_materials)
     for name, v in d.items():
         if not isinstance(v, dict):
             continue
@@ -390,6 +554,11 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
         if t in ("rectangle", "cube", "obj", "ply", "sphere", "disk", "cylinder"):
             b.add_shape(name, v)
     sd = SceneData()
+    if geometry is not None:                     # pre-flattened geometry (load_geometry); the dictionary has no shapes
+        if b.tri_verts:
+            raise ValueError("flatten_scene: pre-flattened geometry cannot be mixed with shape plugins")
+        sd.tri_verts, sd.tri_material, sd.tri_emitter = geometry["tri_verts"], geometry["tri_material"], geometry["tri_emitter"]
+        b.materials, b.emitters = list(geometry["materials"])[:geometry["n_materials"]], list(geometry["emitters"])[:geometry["n_emitters"]]
     if b.tri_verts:
         sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
         sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))

@@ -11,6 +11,9 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+import os
+
 from .transform import ScalarTransform4f as T
 
 
@@ -72,3 +75,65 @@ def staircase_like(n_steps=12, balusters=2, tiles=0, width=128, height=128, temp
                                  "to_world": T().translate([x, 0.002, z]).rotate([1, 0, 0], -90).scale([2.9 / tiles, 3.9 / tiles, 1.0]),
                                  "bsdf": {"type": "ref", "id": "tile_a" if (a + b) % 2 else "tile_b"}}
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Scenes of the reference's examples as DATA fixtures: the flattened triangles / material table / emitters of an XML
+# scene (written by tests/golden/make_golden.py from the example assets) plus its sensor / film / integrator
+# dictionaries.  They let the GPU box render the reference's own example scenes without the asset files.
+def _jsonable(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out[k] = _jsonable(v)
+        elif isinstance(v, T):
+            out[k] = {"__matrix__": v.matrix.reshape(-1).tolist()}
+        else:
+            out[k] = v
+    return out
+
+
+def _unjson(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict) and "__matrix__" in v:
+            out[k] = T(np.asarray(v["__matrix__"], dtype=np.float64).reshape(4, 4))
+        elif isinstance(v, dict):
+            out[k] = _unjson(v)
+        else:
+            out[k] = v
+    return out
+
+
+def save_fixture(scene, path, **meta):
+    """a loaded (perspective-sensor) Scene -> .npz fixture: geometry tables + the sensor and integrator dictionaries"""
+    from .scene import save_geometry
+    sensor = scene.sensors()[0]
+    integ = [v for v in scene.dict_.values() if isinstance(v, dict) and str(v.get("type", "")).startswith("transient")][0]
+    save_geometry(scene.data(), path, sensor=_jsonable(sensor.dict_), integrator=_jsonable(integ), **meta)
+
+
+def from_fixture(path, film=None, integrator=None, spp=None):
+    """Scene from a fixture written by ``save_fixture``; ``film`` / ``integrator`` entries override the stored ones"""
+    from . import mi
+    from .scene import load_geometry
+    g = load_geometry(path)
+    sensor = _unjson(g["meta"]["sensor"])
+    integ = _unjson(g["meta"]["integrator"])
+    sensor["film"].update(film or {})
+    integ.update(integrator or {})
+    if spp is not None:
+        sensor.setdefault("sampler", {"type": "independent"})["sample_count"] = spp
+    return mi.Scene({"type": "scene", "integrator": integ, "sensor": sensor}, geometry=g)
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, **integrator):
+    """BASELINE config 5: the reference's examples/diff-transient/staircase/scene.xml ('The Wooden Staircase' by
+    Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles, flattened with approximate_materials=True
+    (roughplastic -> diffuse, roughconductor -> conductor, bitmap -> mean colour, bump map ignored)."""
+    return from_fixture(os.path.join(GOLDEN_DIR, "staircase_geometry.npz"),
+                        film={"width": width, "height": height, "temporal_bins": temporal_bins},
+                        integrator=dict(max_depth=max_depth, **integrator), spp=spp)

@@ -10,6 +10,14 @@ authoring container (no network, no wheel), and its only test holds no numeric v
                            (independent of the C oracle and of the HIP code);
   * cornell_c1_oracle.npz — a regression snapshot of the oracle on BASELINE config 1
                            (per-pixel and per-bin marginals + checksum), NOT a reference output.
+  * cbox_diffuse_scene.npz, cbox_mirror_scene.npz, nlos_Z_geometry.npz, staircase_geometry.npz —
+                           DATA of the reference's example scenes (examples/transient/cornell-box/*.xml,
+                           examples/transient-nlos/Z.obj, examples/diff-transient/staircase/scene.xml = BASELINE
+                           config 5): the triangles in world space, material / emitter tables and the sensor /
+                           film / integrator dictionaries, flattened by mitransient_amd's XML loader from the
+                           asset files under /root/reference (only written when that directory exists).  No
+                           expected outputs: Mitsuba cannot run here.  Staircase: 'The Wooden Staircase' by Wig42,
+                           CC-BY 3.0, Mitsuba version from benedikt-bitterli.me/resources.
 Run:  python tests/golden/make_golden.py
 """
 import json
@@ -65,7 +73,26 @@ def cornell_c1():
             "nonzero_cells": np.int64(np.count_nonzero(t3))}
 
 
+def example_scenes():
+    ref = "/root/reference/examples"
+    if not os.path.isdir(ref):
+        print("reference examples not present: scene fixtures left as they are")
+        return
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scenes import save_fixture
+    from mitransient_amd.scene import load_obj
+    mi.set_variant("llvm_ad_rgb")
+    for name in ("cbox_diffuse", "cbox_mirror"):
+        sc = mi.load_file(f"{ref}/transient/cornell-box/{name}.xml")
+        save_fixture(sc, os.path.join(HERE, f"{name}_scene.npz"), source=f"examples/transient/cornell-box/{name}.xml")
+    sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials=True)
+    save_fixture(sc, os.path.join(HERE, "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
+                 approximate_materials=True)
+    np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
+
+
 if __name__ == "__main__":
+    example_scenes()
     json.dump(pcg32_kat(), open(os.path.join(HERE, "pcg32_kat.json"), "w"), indent=1)
     json.dump(bin_mapping_kat(), open(os.path.join(HERE, "bin_mapping_kat.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "cornell_c1_oracle.npz"), **cornell_c1())

@@ -461,3 +461,35 @@ def test_mesh_area_emitter(oracle, mode, with_rect):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["cbox_diffuse", "cbox_mirror"])
+def test_reference_example_scenes(oracle, name, mode):
+    """the reference's examples/transient/cornell-box/{cbox_diffuse,cbox_mirror}.xml (flattened fixtures; the
+    reference's units: box 550 wide, near clip 10, 400 bins of 6.5 from OPL 1000; mesh light, conductor + glass)"""
+    import os
+    from mitransient_amd.scenes import from_fixture, GOLDEN_DIR
+    scene = from_fixture(os.path.join(GOLDEN_DIR, f"{name}_scene.npz"), film={"width": 48, "height": 48},
+                         integrator={"amd_mode": mode}, spp=32)
+    s_gpu, t_gpu = gpu_render(scene, 32)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 32)
+    assert t_gpu.shape == (48, 48, 400, 3)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_staircase_config5_geometry(oracle, mode):
+    """BASELINE config 5 geometry: examples/diff-transient/staircase/scene.xml, 262,663 triangles in HBM,
+    max_depth 65, camera_unwarp (approximate materials), reduced film"""
+    from mitransient_amd.scenes import staircase
+    scene = staircase(width=45, height=80, spp=4, amd_mode=mode)
+    s_gpu, t_gpu = gpu_render(scene, 4)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 4)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

@@ -1,0 +1,235 @@
+"""``mi.load_file`` (XML scene format), the PLY / OBJ readers, the approximate-materials switch and the scene
+fixtures flattened from the reference's example scenes (CPU tests)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import hh_render
+
+REF = "/root/reference/examples"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+XML = """<scene version="3.3.0">
+    <default name="spp" value="8"/>
+    <default name="res" value="24"/>
+    <default name="integrator" value="transient_path"/>
+    <integrator type='$integrator'>
+        <boolean name="camera_unwarp" value="true"/>
+        <integer name="max_depth" value="5"/>
+        <string name="temporal_filter" value="box"/>
+    </integrator>
+    <sensor type="perspective" id="cam">
+        <string name="fov_axis" value="smaller"/>
+        <float name="near_clip" value="0.01"/>
+        <float name="far_clip" value="100"/>
+        <float name="fov" value="40"/>
+        <transform name="to_world">
+            <lookat origin="0, 0.2, 4" target="0, 0, 0" up="0, 1, 0"/>
+        </transform>
+        <sampler type="independent"><integer name="sample_count" value="$spp"/></sampler>
+        <film type="transient_hdr_film">
+            <integer name="width" value="$res"/>
+            <integer name="height" value="$res"/>
+            <integer name="temporal_bins" value="50"/>
+            <float name="start_opl" value="2.5"/>
+            <float name="bin_width_opl" value="0.2"/>
+            <rfilter type="box"/>
+        </film>
+    </sensor>
+    <bsdf type="diffuse" id="white"><rgb name="reflectance" value="0.8, 0.7, 0.6"/></bsdf>
+    <bsdf type="bumpmap">
+        <bsdf type="twosided" id="metal">
+            <bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf>
+        </bsdf>
+    </bsdf>
+    <shape type="obj" id="light">
+        <string name="filename" value="meshes/quad.obj"/>
+        <transform name="to_world">
+            <scale value="0.4"/>
+            <rotate x="1" angle="90"/>
+            <translate x="0" y="0.99" z="0"/>
+        </transform>
+        <ref id="white"/>
+        <emitter type="area"><rgb name="radiance" value="10, 8, 6"/></emitter>
+    </shape>
+    <shape type="rectangle" id="floor">
+        <transform name="to_world"><rotate x="1" angle="-90"/><translate y="-1"/></transform>
+        <ref id="white"/>
+    </shape>
+    <shape type="rectangle" id="back">
+        <transform name="to_world"><translate z="-1"/></transform>
+        <bsdf type="diffuse"><rgb name="reflectance" value="0.3"/></bsdf>
+    </shape>
+    <shape type="cube" id="box">
+        <transform name="to_world">
+            <matrix value="0.3 0 0 0.2  0 0.3 0 -0.7  0 0 0.3 0.1  0 0 0 1"/>
+        </transform>
+        <ref id="metal"/>
+    </shape>
+    <shape type="ply">
+        <string name="filename" value="meshes/tri.ply"/>
+        <ref id="metal"/>
+    </shape>
+</scene>
+"""
+
+
+def write_assets(tmp_path):
+    (tmp_path / "meshes").mkdir()
+    (tmp_path / "meshes" / "quad.obj").write_text("# quad\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n")
+    (tmp_path / "meshes" / "tri.ply").write_text(
+        "ply\nformat ascii 1.0\ncomment test\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+        "element face 1\nproperty list uchar int vertex_indices\nend_header\n-0.9 -0.9 -0.5\n-0.5 -0.9 -0.5\n-0.7 -0.5 -0.5\n3 0 1 2\n")
+    (tmp_path / "scene.xml").write_text(XML)
+    return str(tmp_path / "scene.xml")
+
+
+def test_xml_matches_equivalent_dictionary(tmp_path, oracle):
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    from mitransient_amd.xml_loader import xml_to_dict
+    mi.set_variant("llvm_ad_rgb")
+    path = write_assets(tmp_path)
+    d = xml_to_dict(path)
+    assert d["type"] == "scene" and d["integrator"]["type"] == "transient_path" and d["integrator"]["camera_unwarp"] is True
+    assert d["cam"]["film"]["width"] == 24 and d["cam"]["sampler"]["sample_count"] == 8
+    assert d["light"]["bsdf"] is d["white"] and d["floor"]["bsdf"] is d["white"]       # refs share the object
+    assert d["box"]["bsdf"]["type"] == "twosided"                                       # nested id, global scope
+    assert xml_to_dict(path, res=16, spp=2)["cam"]["film"]["height"] == 16
+    with pytest.raises(ValueError, match="undefined parameter"):
+        (tmp_path / "bad.xml").write_text('<scene version="3.0.0"><integrator type="$nope"/></scene>')
+        xml_to_dict(str(tmp_path / "bad.xml"))
+
+    scene = mi.load_file(path)
+    white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}}
+    metal = {"type": "twosided", "bsdf": {"type": "conductor", "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.1]}}
+    same = mi.load_dict({
+        "type": "scene",
+        "integrator": {"type": "transient_path", "camera_unwarp": True, "max_depth": 5},
+        "sensor": {"type": "perspective", "fov_axis": "smaller", "near_clip": 0.01, "far_clip": 100.0, "fov": 40.0,
+                   "to_world": T().look_at(origin=[0, 0.2, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                   "sampler": {"type": "independent", "sample_count": 8},
+                   "film": {"type": "transient_hdr_film", "width": 24, "height": 24, "temporal_bins": 50, "start_opl": 2.5,
+                            "bin_width_opl": 0.2, "rfilter": {"type": "box"}}},
+        "white": white, "metal": metal,
+        "light": {"type": "obj", "filename": str(tmp_path / "meshes" / "quad.obj"),
+                  "to_world": T().translate([0, 0.99, 0]).rotate([1, 0, 0], 90).scale(0.4),
+                  "bsdf": {"type": "ref", "id": "white"}, "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [10, 8, 6]}}},
+        "floor": {"type": "rectangle", "to_world": T().translate([0, -1, 0]).rotate([1, 0, 0], -90), "bsdf": {"type": "ref", "id": "white"}},
+        "back": {"type": "rectangle", "to_world": T().translate([0, 0, -1]),
+                 "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.3, 0.3, 0.3]}}},
+        "box": {"type": "cube", "to_world": T().translate([0.2, -0.7, 0.1]).scale(0.3), "bsdf": {"type": "ref", "id": "metal"}},
+        "tri": {"type": "ply", "filename": str(tmp_path / "meshes" / "tri.ply"), "bsdf": {"type": "ref", "id": "metal"}},
+    })
+    a, b = scene.data(), same.data()
+    assert a.tri_verts.shape == (2 + 2 + 2 + 12 + 1, 9)
+    assert np.allclose(a.tri_verts, b.tri_verts, atol=1e-6) and np.array_equal(a.tri_material, b.tri_material)
+    assert np.array_equal(a.tri_emitter, b.tri_emitter) and a.n_materials == b.n_materials == 3
+    assert bytes(a.camera) == bytes(b.camera) and bytes(a.film) == bytes(b.film)
+    assert a.emitters[0].is_mesh == 1 and a.emitters[0].n_tris == 2
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 8)
+    t4, s4, cnt = oracle.render(a, p)
+    assert np.count_nonzero(t4) > 500 and cnt["paths"] == 24 * 24 * 8
+
+
+def test_ply_binary_and_obj_readers(tmp_path):
+    from mitransient_amd.scene import load_ply, load_obj
+    verts = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]], np.float32)
+    faces = [[0, 1, 2, 3], [0, 1, 4], [1, 2, 4]]
+    for fmt, e in (("binary_little_endian", "<"), ("binary_big_endian", ">")):
+        hdr = (f"ply\nformat {fmt} 1.0\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+               "property uchar red\nelement face 3\nproperty list uchar int vertex_indices\nend_header\n").encode()
+        body = b"".join(struct.pack(e + "fffB", *v, 7) for v in verts)
+        body += b"".join(struct.pack(e + "B" + "i" * len(f), len(f), *f) for f in faces)
+        (tmp_path / f"{fmt}.ply").write_bytes(hdr + body)
+        t = load_ply(str(tmp_path / f"{fmt}.ply"))
+        assert t.shape == (4, 3, 3)
+        assert np.array_equal(t[0], verts[[0, 1, 2]]) and np.array_equal(t[1], verts[[0, 2, 3]]) and np.array_equal(t[3], verts[[1, 2, 4]])
+    # uniform polygon size -> the vectorised path
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty double x\nproperty double y\nproperty double z\n"
+           "element face 2\nproperty list uint8 uint32 vertex_index\nend_header\n").encode()
+    body = b"".join(struct.pack("<ddd", *v) for v in verts) + struct.pack("<BIII", 3, 0, 1, 4) + struct.pack("<BIII", 3, 1, 2, 4)
+    (tmp_path / "u.ply").write_bytes(hdr + body)
+    assert np.array_equal(load_ply(str(tmp_path / "u.ply"))[1], verts[[1, 2, 4]].astype(np.float64))
+    (tmp_path / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\n")
+    assert load_obj(str(tmp_path / "neg.obj")).shape == (1, 3, 3)
+
+
+def test_unsupported_materials_raise_unless_approximated(tmp_path):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from PIL import Image
+    mi.set_variant("llvm_ad_rgb")
+    Image.fromarray(np.full((4, 4, 3), 188, np.uint8)).save(str(tmp_path / "grey.png"))
+    d = mitr.cornell_box()
+    d["floor"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "roughplastic", "alpha": 0.1,
+                          "diffuse_reflectance": {"type": "bitmap", "filename": str(tmp_path / "grey.png")}}}
+    d["back"]["bsdf"] = {"type": "bumpmap", "map": {"type": "bitmap", "filename": str(tmp_path / "grey.png")},
+                         "bsdf": {"type": "roughconductor", "alpha": 0.1, "eta": [1.6, 0.9, 0.5], "k": [9.2, 6.3, 4.8]}}
+    with pytest.raises(ValueError, match="unknown plugin"):
+        mi.load_dict(d).data()
+    sd = mi.load_dict(d, approximate_materials=True).data()
+    mats = [sd.materials[i] for i in range(sd.n_materials)]
+    fl = [m for m in mats if m.type == 0 and m.flags == 1]
+    lin = ((188 / 255 + 0.055) / 1.055) ** 2.4                       # sRGB -> linear mean colour of the bitmap
+    assert any(abs(m.a[0] - lin) < 1e-6 for m in fl)
+    assert any(m.type == 1 and abs(m.a[0] - 1.6) < 1e-6 for m in mats)
+
+
+@pytest.mark.parametrize("name", ["cbox_diffuse", "cbox_mirror"])
+def test_example_scene_fixtures_product_equals_oracle(name, oracle, host_harness):
+    """the reference's own example scenes (flattened fixtures): product arithmetic == oracle bit for bit; these
+    scenes are in the reference's units (box ~550 wide, near clip 10, OPL window 1000..3600)"""
+    from mitransient_amd.scenes import from_fixture
+    scene = from_fixture(os.path.join(GOLDEN, f"{name}_scene.npz"), film={"width": 32, "height": 32}, spp=16)
+    film = scene.sensors()[0].film()
+    assert (film.temporal_bins, film.start_opl, film.bin_width_opl) == (400, 1000.0, 6.5)
+    sd = scene.data()
+    assert sd.tri_verts.shape[0] in (36, 38) and sd.n_emitters == 1 and sd.emitters[0].is_mesh == 1
+    p = scene.integrator().render_params(film, 0, 16)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc["bounces"] == cnt["bounces"]
+    assert np.count_nonzero(t4) > 20000
+    # the time-resolved image never exceeds the steady one, and the 1000..3600 window holds most of the energy
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    assert np.all(t3.sum(axis=2) <= s3 * (1 + 2e-3) + 1e-6)
+    assert 0.9 < t3.sum() / s3.sum() <= 1.0 + 1e-3
+
+
+def test_staircase_fixture_product_equals_oracle(oracle, host_harness):
+    """BASELINE config 5 geometry (262,663 triangles, 25 materials; approximate materials), small film"""
+    from mitransient_amd.scenes import staircase
+    scene = staircase(width=27, height=48, spp=2)
+    sd = scene.data()
+    assert sd.tri_verts.shape == (262663, 9) and sd.n_materials == 25 and sd.n_emitters == 1
+    integ = scene.integrator()
+    assert integ.max_depth == 65 and integ.camera_unwarp
+    p = integ.render_params(scene.sensors()[0].film(), 0, 2)
+    t4, s4, cnt = oracle.render(sd, p, use_bvh=True)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc["bounces"] == cnt["bounces"]
+    assert cnt["bounces"] > 4 * cnt["paths"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference examples not present (GPU box)")
+def test_reference_xml_files_load_and_match_fixtures():
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scenes import from_fixture
+    mi.set_variant("llvm_ad_rgb")
+    for name in ("cbox_diffuse", "cbox_mirror"):
+        a = mi.load_file(f"{REF}/transient/cornell-box/{name}.xml", res=32, spp=4)
+        b = from_fixture(os.path.join(GOLDEN, f"{name}_scene.npz"), film={"width": 32, "height": 32}, spp=4)
+        sa, sb = a.data(), b.data()
+        assert np.array_equal(sa.tri_verts, sb.tri_verts) and np.array_equal(sa.tri_material, sb.tri_material)
+        assert bytes(sa.camera) == bytes(sb.camera) and bytes(sa.film) == bytes(sb.film)
+        assert bytes(sa.materials) == bytes(sb.materials)
+        assert a.integrator().max_depth == b.integrator().max_depth
+    with pytest.raises(ValueError, match="unknown plugin"):
+        mi.load_file(f"{REF}/diff-transient/staircase/scene.xml", resx=8, resy=8).data()
+    nl = mi.load_file(f"{REF}/transient-nlos/nlos_Z.xml")
+    assert type(nl.integrator()).__name__ == "TransientNLOSPath" and len(nl.emitters()) == 1
+    assert nl.sensors()[0].film().size() == (64, 64) and nl.sensors()[0].film().temporal_bins == 300
+    assert nl.data().nlos is not None
