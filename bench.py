@@ -35,7 +35,10 @@ def build_scene(width, height, bins, max_depth=8, mode=None):
     if SCENE == "staircase":
         from mitransient_amd.scenes import staircase
         kw = {"amd_mode": mode} if mode else {}
-        return staircase(width=width, height=height, temporal_bins=bins, max_depth=65, **kw)
+        sc = staircase(width=width, height=height, temporal_bins=bins, max_depth=65, **kw)
+        film = sc.sensors()[0].film()
+        film.start_opl, film.bin_width_opl = 0.0, 40.0 / bins     # the reference's 0..40 window (400 x 0.1), SURVEY §8d
+        return sc
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=width, height=height, temporal_bins=bins, start_opl=3.5,
                                bin_width_opl=6.0 / bins)
@@ -97,7 +100,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase"],
-                    help="staircase: BASELINE configs[4] (720x1280, 400 bins, 64 spp, max_depth 65; approximate materials)")
+                    help="staircase: BASELINE configs[4] (512x512, 2048 bins over OPL 0..40, 2048 spp, max_depth 65; "
+                         "the reference's scene.xml geometry with approximate materials)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bins", type=int, default=None)
@@ -109,7 +113,7 @@ def main():
     args = ap.parse_args()
     global SCENE
     SCENE = args.scene
-    dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (720, 1280, 400, 64)}[SCENE]
+    dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (512, 512, 2048, 2048)}[SCENE]
     args.width, args.height, args.bins, args.spp = [d if a is None else a
                                                     for a, d in zip((args.width, args.height, args.bins, args.spp), dflt)]
 
@@ -215,7 +219,7 @@ def main():
         kname = "k_fused" if fused else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
         res = {
             "metric": ("Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU" if SCENE == "cornell"
-                       else "Mray/s (closest-hit + shadow rays), staircase 720x1280 x 400 bins x 64 spp per GPU"),
+                       else "Mray/s (closest-hit + shadow rays), staircase 512^2 x 2048 bins x 2048 spp per GPU"),
             "value": rays / elapsed / 1e6,
             "unit": "Mray/s",
             "time_bins_per_s": totals["splats_issued"] / elapsed,
@@ -228,7 +232,7 @@ def main():
                                     f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0") if SCENE == "cornell" else
                                    (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, approximate materials), "
-                                    f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 0.1), {args.spp} spp per GPU "
+                                    f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
                        "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",
                        "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE == "cornell"
