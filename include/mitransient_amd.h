@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 3
+#define MTR_ABI_VERSION 4
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -84,18 +84,24 @@ typedef struct mtr_film_desc {
     uint32_t temporal_bins;               /* T  (default 2048)                         */
     float    start_opl;                   /* default 0                                 */
     float    bin_width_opl;               /* default 0.003                             */
+    /* `exhaustive_scan` (transient_hdr_film.py:119-121, transient_image_block.py:63-66,134-140): both > 0 makes
+     * the tensor H x W x laser_scan_height x laser_scan_width x T x 4 with the reference's flat index
+     * ((((y*W + x)*laser_scan_width + laser_x)*laser_scan_height + laser_y)*T + t)*4; 0/0 = plain H x W x T x 4 */
+    uint32_t laser_scan_width, laser_scan_height;
 } mtr_film_desc;
 
 /* ---- NLOS tier: `transient_nlos_path` + `nlos_capture_meter` + `projector` ---------------
  * (reference: mitransient/integrators/transientnlospath.py:200-249 properties, :251-383 prepare;
  *  mitransient/sensors/nloscapturemeter.py:93-202; mitsuba's `projector` emitter)            */
-enum { MTR_CAPTURE_SINGLE = 1, MTR_CAPTURE_CONFOCAL = 2 /* Exhaustive (3): 6-D film, not built */ };
+enum { MTR_CAPTURE_SINGLE = 1, MTR_CAPTURE_CONFOCAL = 2,
+       MTR_CAPTURE_EXHAUSTIVE = 3 /* every scanned point x every illuminated point: needs an exhaustive_scan film */ };
 enum { MTR_NLOS_LASER_SAMPLING = 1u,          /* nlos_laser_sampling                              */
        MTR_NLOS_HG_SAMPLING = 2u,             /* nlos_hidden_geometry_sampling                    */
        MTR_NLOS_HG_RROULETTE = 4u,            /* nlos_hidden_geometry_sampling_do_rroulette       */
        MTR_NLOS_HG_INCLUDES_WALL = 8u,        /* nlos_hidden_geometry_sampling_includes_relay_wall*/
        MTR_NLOS_ACCOUNT_FIRST_LAST = 16u,     /* account_first_and_last_bounces                   */
-       MTR_NLOS_DISCARD_DIRECT = 32u          /* discard_direct_paths                             */ };
+       MTR_NLOS_DISCARD_DIRECT = 32u,         /* discard_direct_paths                             */
+       MTR_NLOS_FORCE_EQUAL_GRIDS = 64u       /* force_equal_illumination_scanning (Exhaustive)   */ };
 
 typedef struct mtr_shape {          /* one scene shape = a contiguous triangle range */
     uint32_t first_tri, n_tris;
@@ -113,6 +119,8 @@ typedef struct mtr_nlos_desc {
     uint32_t capture_type;          /* MTR_CAPTURE_*                                                       */
     uint32_t flags;                 /* MTR_NLOS_*                                                          */
     int32_t  filter_depth;          /* -1 = off (filter_bounces + 1 when that was given)                   */
+    float    illumination_scan_fov; /* Exhaustive without FORCE_EQUAL_GRIDS: fov (degrees) of the laser grid scan
+                                       (transientnlospath.py:346-376); the grid is film.laser_scan_width x _height */
     uint32_t n_shapes;
     const mtr_shape *shapes;        /* host; every triangle of the scene belongs to exactly one shape      */
 } mtr_nlos_desc;
@@ -176,6 +184,8 @@ typedef struct mtr_splat_soa {
     const float    *opl;     /* device, n: optical path length                                 */
     const float    *r, *g, *b; /* device, n: value already multiplied by sample_scale          */
     uint64_t        n;
+    const uint32_t *laser;   /* device, n, or NULL (= 0): laser_x*laser_scan_height + laser_y of an
+                                exhaustive_scan film (add_transient_data's laser_x / laser_y)    */
 } mtr_splat_soa;
 
 /* per-kernel timing of the last mtr_render (HIP events on the context stream) */

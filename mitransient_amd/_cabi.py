@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 3
+MTR_ABI_VERSION = 4
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -45,10 +45,12 @@ class mtr_film_desc(C.Structure):
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("temporal_bins", C.c_uint32),
-                ("start_opl", C.c_float), ("bin_width_opl", C.c_float)]
+                ("start_opl", C.c_float), ("bin_width_opl", C.c_float),
+                ("laser_scan_width", C.c_uint32), ("laser_scan_height", C.c_uint32)]
 
 
-MTR_CAPTURE_SINGLE, MTR_CAPTURE_CONFOCAL = 1, 2
+MTR_CAPTURE_SINGLE, MTR_CAPTURE_CONFOCAL, MTR_CAPTURE_EXHAUSTIVE = 1, 2, 3
+MTR_NLOS_FORCE_EQUAL_GRIDS = 64
 MTR_NLOS_LASER_SAMPLING, MTR_NLOS_HG_SAMPLING, MTR_NLOS_HG_RROULETTE = 1, 2, 4
 MTR_NLOS_HG_INCLUDES_WALL, MTR_NLOS_ACCOUNT_FIRST_LAST, MTR_NLOS_DISCARD_DIRECT = 8, 16, 32
 
@@ -62,7 +64,7 @@ class mtr_nlos_desc(C.Structure):
     _fields_ = [("sensor_origin", _f3), ("relay_shape", C.c_uint32), ("laser_to_world", _f16),
                 ("laser_fov", C.c_float), ("laser_irradiance", _f3), ("laser_scale", C.c_float),
                 ("capture_type", C.c_uint32), ("flags", C.c_uint32), ("filter_depth", C.c_int32),
-                ("n_shapes", C.c_uint32), ("shapes", C.POINTER(mtr_shape))]
+                ("illumination_scan_fov", C.c_float), ("n_shapes", C.c_uint32), ("shapes", C.POINTER(mtr_shape))]
 
 
 class mtr_scene_desc(C.Structure):
@@ -100,7 +102,8 @@ class mtr_counters(C.Structure):
 
 class mtr_splat_soa(C.Structure):
     _fields_ = [("pixel", C.c_void_p), ("opl", C.c_void_p),
-                ("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p), ("n", C.c_uint64)]
+                ("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p), ("n", C.c_uint64),
+                ("laser", C.c_void_p)]
 
 
 class mtr_kernel_times(C.Structure):

@@ -51,6 +51,7 @@ struct mtr_scene {
     SceneDev dev{};
     Camera cam{};
     Film film{};
+    mtr_film_desc film_desc{};
     uint32_t n_leaves = 0;
     std::vector<void *> allocs;
     SplatLog log{ nullptr, 0, nullptr };
@@ -126,6 +127,10 @@ static int check_film(mtr_ctx *c, const mtr_film_desc &d)
         d.crop_offset_y + d.crop_height > d.height)
         return fail(c, MTR_ERR_INVALID, "film: invalid crop window");
     if (!(d.bin_width_opl > 0.0f)) return fail(c, MTR_ERR_INVALID, "film: bin_width_opl must be > 0");
+    if ((d.laser_scan_width == 0) != (d.laser_scan_height == 0))
+        return fail(c, MTR_ERR_INVALID, "film: laser_scan_width and laser_scan_height must both be set (exhaustive_scan) or both be 0");
+    if ((uint64_t)d.temporal_bins * (d.laser_scan_width ? d.laser_scan_width : 1u) * (d.laser_scan_height ? d.laser_scan_height : 1u) > 0x7fffffffull)
+        return fail(c, MTR_ERR_INVALID, "film: laser_scan_width * laser_scan_height * temporal_bins exceeds 2^31");
     return MTR_OK;
 }
 
@@ -157,7 +162,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 
     mtr_scene *s = new mtr_scene();
     s->ctx = c;
-    s->film = hs.film; s->cam = hs.cam;
+    s->film = hs.film; s->cam = hs.cam; s->film_desc = d->film;
 
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
@@ -185,7 +190,7 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     HIP_TRY(c, hipSetDevice(c->device));
     mtr_scene_desc d{};
     d.n_tris = s->dev.n_tris; d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
-    d.film.width = s->film.width; d.film.height = s->film.height;
+    d.film = s->film_desc;
     d.nlos = n;
     HostNlos hn;
     if (const char *msg = derive_nlos(d, hn)) return fail(c, MTR_ERR_INVALID, std::string("mtr_scene_set_nlos: ") + msg);
@@ -204,14 +209,13 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     HIP_TRY(c, hipMemcpy(D.tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc(&D.hg_tris, hn.hg_tris.size() * sizeof(q4)));
     HIP_TRY(c, hipMemcpy(D.hg_tris, hn.hg_tris.data(), hn.hg_tris.size() * sizeof(q4), hipMemcpyHostToDevice));
-    const size_t n_targets = (size_t)s->film.width * s->film.height + 1;
+    const size_t n_targets = nlos_target_count(hn.k);
     HIP_TRY(c, hipMalloc(&D.targets, n_targets * sizeof(q4)));
     D.k = hn.k;
     D.k.shapes = (const NlosShape *)D.shapes;
     D.k.shape_pmf = (const float *)D.tables; D.k.shape_cdf = D.k.shape_pmf + ns;
     D.k.face_pmf = D.k.shape_cdf + ns; D.k.face_cdf = D.k.face_pmf + nt;
     D.k.hg_tris = (const q4 *)D.hg_tris; D.k.targets = (const q4 *)D.targets;
-    D.k.film_w = s->film.width; D.k.film_h = s->film.height;
     HIP_TRY(c, launch_nlos_prepare(s->dev, D.k, (q4 *)D.targets, c->stream));    // scanned points + laser axis hit
     D.on = true;
     return MTR_OK;
@@ -236,6 +240,7 @@ int mtr_scene_set_film(mtr_scene *s, const mtr_film_desc *f)
     int rc = check_film(s->ctx, *f);
     if (rc) return rc;
     s->film = film_from_desc(*f);
+    s->film_desc = *f;
     return MTR_OK;
 }
 

@@ -168,8 +168,11 @@ struct Camera {
 };
 
 struct Film {
-    uint32_t width, height, crop_w, crop_h, crop_x, crop_y, bins;
+    uint32_t width, height, crop_w, crop_h, crop_x, crop_y;
+    uint32_t bins;       // length of a pixel's row: T, or Lw*Lh*T for an exhaustive_scan film (row = [laser][t])
     float start_opl, bin_width;
+    uint32_t tbins;      // T: the time bins of one (pixel, laser) histogram
+    uint32_t lasers;     // Lw*Lh (1 without exhaustive_scan)
 };
 
 struct SceneView {
@@ -383,8 +386,15 @@ MTR_HD Ray camera_ray(const Camera &c, const RenderConst &rc, uint32_t px, uint3
 MTR_HD int32_t film_bin(const Film &f, float opl)
 {
     float pos = (opl - f.start_opl) / f.bin_width;
-    if (!(pos >= 0.0f && pos < (float)f.bins)) return -1;
+    if (!(pos >= 0.0f && pos < (float)f.tbins)) return -1;
     return (int32_t)(uint32_t)floorf(pos);
+}
+
+// row position of a contribution of an exhaustive_scan film: [laser][t]; returns -1 when either is out of range
+MTR_HD int32_t film_row_bin(const Film &f, float opl, uint32_t laser)
+{
+    const int32_t b = film_bin(f, opl);
+    return (b < 0 || laser >= f.lasers) ? -1 : (int32_t)(laser * f.tbins + (uint32_t)b);
 }
 
 // ---------------------------------------------------------------- BSDFs

@@ -373,13 +373,9 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
     sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
-    const uint32_t n = nc.film_w * nc.film_h;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
-        Ray r;
-        if (i < n) {
-            const uint32_t y = i / nc.film_w, x = i - y * nc.film_w;
-            r = nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);     // linspace(0,1,res,endpoint=False)
-        } else { r.o = nc.l_origin; r.d = nc.l_forward; r.tmax = kInf; }
+    const uint32_t total = nlos_target_count(nc);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const Ray r = nlos_prepare_ray(nc, i);
         const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
         f3 p = mk(0, 0, 0);
         if (h.prim >= 0) p = hit_ctx(sv, r.d, h).sp;
@@ -392,7 +388,7 @@ hipError_t launch_nlos_prepare(const SceneDev &sc, const NlosConst &nc, q4 *targ
     const size_t lds = (size_t)65 * kBlock * 4;
     hipError_t e = hipFuncSetAttribute((const void *)k_nlos_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    uint32_t n = nc.film_w * nc.film_h + 1;
+    uint32_t n = nlos_target_count(nc);
     uint32_t blocks = (n + kBlock - 1) / kBlock; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_nlos_prepare, dim3(blocks), dim3(kBlock), lds, stream, sc, nc, targets);
     return hipGetLastError();
@@ -426,7 +422,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film f
     uint32_t mine = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < s.n; i += stride) {
         const uint32_t pixel = s.pixel[i];
-        const int32_t bin = film_bin(film, s.opl[i]);
+        const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
         if (bin < 0 || pixel >= npix) continue;
         const size_t idx = ((size_t)pixel * film.bins + (uint32_t)bin) * 4u;
         unsafeAtomicAdd(out + idx, s.r[i]); unsafeAtomicAdd(out + idx + 1, s.g[i]); unsafeAtomicAdd(out + idx + 2, s.b[i]);
@@ -468,7 +464,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_sorted(mtr_splat_soa s, Film f
             const uint64_t run_end = cur + s_end;
             if (px < npix) {
                 for (uint64_t i = cur + tid; i < run_end; i += kBlock) {
-                    const int32_t bin = film_bin(film, s.opl[i]);
+                    const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
                     if (bin < 0) continue;
                     lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
                     ++mine;

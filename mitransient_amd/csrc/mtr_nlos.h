@@ -35,9 +35,16 @@ struct NlosConst {
     const float *shape_pmf, *shape_cdf;
     const float *face_pmf, *face_cdf;  // per ORIGINAL triangle index, normalised within its shape
     const q4 *hg_tris;                 // 3 quads per ORIGINAL triangle: (p0, e1.x) (e1.yz, e2.xy) (e2.z, n)
-    const q4 *targets;                 // [W*H] scanned points (film order) + [W*H] = laser target of a Single capture
+    // [W*H] scanned points (film order) | [1] the point the laser's axis hits (Single) | [laser_w*laser_h] the
+    // illuminated points of an Exhaustive capture (transientnlospath.py:340-381)
+    const q4 *targets;
     uint32_t film_w, film_h;
+    uint32_t laser_w, laser_h;         // Exhaustive: illumination grid (film.laser_scan_width / _height), else 0
+    float illum_tan;                   // Exhaustive without FORCE_EQUAL_GRIDS: tan(illumination_scan_fov / 2)
+    float l_rot[9];                    // rows of the laser's local -> world rotation
 };
+
+MTR_HD uint32_t nlos_target_count(const NlosConst &nc) { return nc.film_w * nc.film_h + 1u + nc.laser_w * nc.laser_h; }
 
 MTR_HD f3 rect_point(f3 c, f3 du, f3 dv, float u, float v)
 {
@@ -70,6 +77,34 @@ MTR_HD Ray nlos_sensor_ray(const NlosConst &nc, float sx, float sy)
     f3 dir = target - nc.sensor_origin;
     const float dist = sqrtf(dot(dir, dir));
     Ray r; r.o = nc.sensor_origin; r.d = dir / dist; r.tmax = kInf;
+    return r;
+}
+
+// the rays of TransientNLOSPath.prepare (:295-381) in the order of NlosConst::targets
+MTR_HD Ray nlos_prepare_ray(const NlosConst &nc, uint32_t i)
+{
+    const uint32_t n = nc.film_w * nc.film_h;
+    Ray r;
+    if (i < n) {                                                           // linspace(0,1,res,endpoint=False), meshgrid 'xy'
+        const uint32_t y = i / nc.film_w, x = i - y * nc.film_w;
+        return nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);
+    }
+    if (i == n) { r.o = nc.l_origin; r.d = nc.l_forward; r.tmax = kInf; return r; }
+    const uint32_t j = i - n - 1u;
+    if (nc.flags & MTR_NLOS_FORCE_EQUAL_GRIDS) {                           // laser_targets = sensor_targets (:344-346)
+        const uint32_t y = j / nc.film_w, x = j - y * nc.film_w;
+        return nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);
+    }
+    // dummy projector with illumination_scan_fov, one ray per grid point [mitsuba3: Projector::sample_ray with a
+    // constant irradiance: uv = sample; near_p = sample_to_camera * (u, v, 0); d = to_world * normalize(near_p)]
+    const uint32_t y = j / nc.laser_w, x = j - y * nc.laser_w;
+    const float u = (float)x / (float)nc.laser_w, v = (float)y / (float)nc.laser_h;
+    const f3 loc = normalize(mk((1.0f - 2.0f * u) * nc.illum_tan, (1.0f - 2.0f * v) * nc.illum_tan, 1.0f));
+    r.o = nc.l_origin;
+    r.d = mk(fmaf(nc.l_rot[0], loc.x, fmaf(nc.l_rot[1], loc.y, nc.l_rot[2] * loc.z)),
+             fmaf(nc.l_rot[3], loc.x, fmaf(nc.l_rot[4], loc.y, nc.l_rot[5] * loc.z)),
+             fmaf(nc.l_rot[6], loc.x, fmaf(nc.l_rot[7], loc.y, nc.l_rot[8] * loc.z)));
+    r.tmax = kInf;
     return r;
 }
 
@@ -108,7 +143,7 @@ MTR_HD f3 bsdf_eval_cos(const mtr_material &m, f3 wi, f3 wo)
 // emitter_nee_sample (transientnlospath.py:432-509); `depth` is the reference's argument (not the loop depth)
 template <class Stack, class Sink>
 MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 beta, float distance, uint32_t depth,
-                           bool focus_laser, const SceneView &sc, const NlosConst &nc, const Film &film,
+                           bool focus_laser, uint32_t laser, const SceneView &sc, const NlosConst &nc, const Film &film,
                            const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats)
 {
     // visibility of the emitter origin (:441)
@@ -118,7 +153,7 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
     (void)rng_f32(p.rng); (void)rng_f32(p.rng);                      // sampler.next_2d(active_e): only visible lanes draw
     float ds_dist;
     f3 w;
-    if (focus_laser && nc.capture_type == MTR_CAPTURE_CONFOCAL) {    // :448-458
+    if (focus_laser && nc.capture_type != MTR_CAPTURE_SINGLE) {      // Confocal or Exhaustive, :448-458
         const f3 rel = nc.l_origin - c.sp;
         const float dist_e = sqrtf(dot(rel, rel));
         w = projector_sample(nc, fma3(nc.l_forward, dist_e, nc.l_origin), ds_dist);
@@ -135,15 +170,15 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
     const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;
     const float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
     if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
-        const int32_t bin = film_bin(film, distance);
-        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, distance, p.depth, 1u);   // :506-507
+        const int32_t bin = film_row_bin(film, distance, laser);                              // [laser_x][laser_y][t], :499-507
+        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, distance, p.depth, 1u);
     }
     return Lr;
 }
 
 // emitter_laser_targets_sample (:511-564)
 template <class Stack, class Sink>
-MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 lt, uint32_t depth,
+MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 lt, uint32_t depth, uint32_t laser,
                              const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
                              Stack &st, Sink &sink, BounceStats &stats)
 {
@@ -165,7 +200,7 @@ MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, 
     if (!(wlz > 0.0f)) return mk(0, 0, 0);                                                     // :543
     const float pdf_ls = (dl * dl) / wlz;                                                      // :546-551
     const f3 b2 = mk(p.beta.x * (bs.x / pdf_ls), p.beta.y * (bs.y / pdf_ls), p.beta.z * (bs.z / pdf_ls));
-    return nlos_emitter_nee(p, c2, sc.mats[c2.mat], b2, p.dist + dl * p.eta, depth + 1, true, sc, nc, film, rc, st, sink, stats);
+    return nlos_emitter_nee(p, c2, sc.mats[c2.mat], b2, p.dist + dl * p.eta, depth + 1, true, laser, sc, nc, film, rc, st, sink, stats);
 }
 
 // hidden_geometry_sample (:637-670) incl. _sample_hidden_geometry_position (:385-430)
@@ -222,10 +257,21 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     if (valid) c = hit_ctx(sc, p.ray.d, h);
     // the only emitter is the projector (not a surface): Le = 0 (:757-777)
     if (active_next && sc.mats[c.mat].type == MTR_BSDF_DIFFUSE) {                                 // active_em :785-786
-        if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                                   // emitter_laser_sample: depth + 1
-            Lr = nlos_laser_targets(p, c, sc.mats[c.mat], nlos_laser_target(nc, p.px, p.py), p.depth + 1u, sc, nc, film, rc, st, sink, stats);
+        if ((nc.flags & MTR_NLOS_LASER_SAMPLING) && nc.capture_type == MTR_CAPTURE_EXHAUSTIVE) {
+            // every illuminated point in turn (:597-621); target i lands in film cell laser_x = i / Ly, laser_y = i % Ly,
+            // i.e. row offset i * T; the steady estimate is the mean over the grid
+            const uint32_t nl = nc.laser_w * nc.laser_h, t0 = nc.film_w * nc.film_h + 1u;
+            for (uint32_t i = 0; i < nl; ++i) {
+                const q4 t = nc.targets[t0 + i];
+                const f3 li = nlos_laser_targets(p, c, sc.mats[c.mat], mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats);
+                Lr = mk(Lr.x + li.x, Lr.y + li.y, Lr.z + li.z);
+            }
+            const float nlf = (float)nl;
+            Lr = mk(Lr.x / nlf, Lr.y / nlf, Lr.z / nlf);
+        } else if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                            // emitter_laser_sample: depth + 1
+            Lr = nlos_laser_targets(p, c, sc.mats[c.mat], nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats);
         else
-            Lr = nlos_emitter_nee(p, c, sc.mats[c.mat], p.beta, p.dist, p.depth, false, sc, nc, film, rc, st, sink, stats);
+            Lr = nlos_emitter_nee(p, c, sc.mats[c.mat], p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats);
     }
     // hidden-geometry / BSDF sampling (:797-833)
     const bool hg = (nc.flags & MTR_NLOS_HG_SAMPLING) != 0;

@@ -8,7 +8,10 @@ Film film_from_desc(const mtr_film_desc &d)
 {
     Film f;
     f.width = d.width; f.height = d.height; f.crop_w = d.crop_width; f.crop_h = d.crop_height;
-    f.crop_x = d.crop_offset_x; f.crop_y = d.crop_offset_y; f.bins = d.temporal_bins;
+    f.crop_x = d.crop_offset_x; f.crop_y = d.crop_offset_y;
+    f.tbins = d.temporal_bins;
+    f.lasers = (d.laser_scan_width && d.laser_scan_height) ? d.laser_scan_width * d.laser_scan_height : 1u;
+    f.bins = f.tbins * f.lasers;
     f.start_opl = d.start_opl; f.bin_width = d.bin_width_opl;
     return f;
 }
@@ -109,8 +112,15 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
 {
     const mtr_nlos_desc *n = d.nlos;
     if (!n) return "no NLOS description";
-    if (n->capture_type != MTR_CAPTURE_SINGLE && n->capture_type != MTR_CAPTURE_CONFOCAL)
-        return "capture_type must be Single or Confocal (Exhaustive needs the 6-D film)";
+    if (n->capture_type != MTR_CAPTURE_SINGLE && n->capture_type != MTR_CAPTURE_CONFOCAL &&
+        n->capture_type != MTR_CAPTURE_EXHAUSTIVE)
+        return "capture_type must be Single, Confocal or Exhaustive";
+    const bool exhaustive = n->capture_type == MTR_CAPTURE_EXHAUSTIVE;
+    if (exhaustive && !(d.film.laser_scan_width && d.film.laser_scan_height))
+        return "Exhaustive capture needs an exhaustive_scan film (laser_scan_width / laser_scan_height > 0)";
+    if (exhaustive && (n->flags & MTR_NLOS_FORCE_EQUAL_GRIDS) &&
+        (d.film.laser_scan_width != d.film.width || d.film.laser_scan_height != d.film.height))
+        return "Sensor and laser scan resolution must be equal if force_equal_illumination_scanning is set to True";
     if (!n->shapes || n->n_shapes == 0 || n->relay_shape >= n->n_shapes) return "NLOS: bad shape table";
     if (!n->shapes[n->relay_shape].is_rectangle) return "NLOS: the relay wall must be a rectangle";
     if (d.n_emitters != 0) return "NLOS: area emitters are not supported next to the projector";
@@ -134,6 +144,10 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
     k.l_irr = ld3(n->laser_irradiance);
     k.capture_type = n->capture_type; k.flags = n->flags; k.filter_depth = n->filter_depth; k.n_shapes = n->n_shapes;
     k.film_w = d.film.width; k.film_h = d.film.height;
+    k.laser_w = exhaustive ? d.film.laser_scan_width : 0u; k.laser_h = exhaustive ? d.film.laser_scan_height : 0u;
+    k.illum_tan = (float)tan(0.5 * (double)n->illumination_scan_fov * 3.14159265358979323846 / 180.0);
+    const float rot[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+    memcpy(k.l_rot, rot, sizeof rot);
 
     const uint32_t ns = n->n_shapes;
     o.shapes.assign(ns, NlosShape{});

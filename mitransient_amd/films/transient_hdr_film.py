@@ -40,8 +40,8 @@ class TransientHDRFilm:
         self.exhaustive_scan = bool(props.get("exhaustive_scan", False))
         self.laser_scan_width = int(props.get("laser_scan_width", 0))
         self.laser_scan_height = int(props.get("laser_scan_height", 0))
-        if self.exhaustive_scan:
-            raise NotImplementedError("exhaustive_scan belongs to the NLOS tier (SURVEY §8f)")
+        if self.exhaustive_scan and not (self.laser_scan_width > 0 and self.laser_scan_height > 0):
+            raise ValueError("exhaustive_scan needs laser_scan_width and laser_scan_height > 0")
         self.channels = None
         self.transient_storage = None
         self._steady_accum = None     # (H, W, 4): sum of L, sample count
@@ -98,11 +98,20 @@ class TransientHDRFilm:
 
     def create_block(self):
         if (self.transient_storage is not None and self.transient_storage.size_xyt == self.crop_size_xyt
-                and self.transient_storage.torch_tensor().device == self._device):
+                and self.transient_storage.torch_tensor().device == self._device
+                and tuple(self.transient_storage.torch_tensor().shape) == self.raw_shape()):
             self.transient_storage.clear()                  # reuse the allocation: same zero-filled state
             return self.transient_storage
         return TransientImageBlock(size_xyt=self.crop_size_xyt, offset_xyt=self.crop_offset_xyt,
+                                   exhaustive_scan=self.exhaustive_scan, laser_scan_width=self.laser_scan_width,
+                                   laser_scan_height=self.laser_scan_height,
                                    channel_count=len(self.channels), rfilter=self.rfilter_, device=self._device)
+
+    def raw_shape(self):
+        W, H = self.size_
+        if self.exhaustive_scan:
+            return (H, W, self.laser_scan_height, self.laser_scan_width, self.temporal_bins, 4)
+        return (H, W, self.temporal_bins, 4)
 
     def clear(self):
         if self._steady_accum is not None:
@@ -132,13 +141,23 @@ class TransientHDRFilm:
             ok &= torch.as_tensor(active, dtype=torch.bool, device=dev)
         pixel = torch.where(ok, py * W + px, torch.full_like(px, W * H))   # out-of-range id -> dropped by the kernel
         self.film_is_zero = False
-        return self.transient_storage.put_opl(pixel, distance, spec[:, 0], spec[:, 1], spec[:, 2], self.desc(), variant)
+        laser = None
+        if self.exhaustive_scan:            # row position laser_x * Lh + laser_y (transient_image_block.py:136-138)
+            lx = torch.as_tensor(laser_x, dtype=torch.int64, device=dev).expand(px.shape)
+            ly = torch.as_tensor(laser_y, dtype=torch.int64, device=dev).expand(px.shape)
+            lok = (lx >= 0) & (lx < self.laser_scan_width) & (ly >= 0) & (ly < self.laser_scan_height)
+            laser = torch.where(lok, lx * self.laser_scan_height + ly,
+                                torch.full_like(lx, self.laser_scan_width * self.laser_scan_height))
+        return self.transient_storage.put_opl(pixel, distance, spec[:, 0], spec[:, 1], spec[:, 2], self.desc(), variant,
+                                              laser=laser)
 
     # -- develop -------------------------------------------------------------
     def develop(self, raw: bool = False):
         transient_image = self.develop_transient_(raw=raw)
         torch = require_gpu()
         W, H = self.size_
+        if self.exhaustive_scan:            # transient_hdr_film.py:213-214: dr.mean(transient_image, axis=-1)
+            return TensorXf(transient_image.torch().mean(dim=-1)), transient_image
         ctx = get_context(self._device.index)
         ctx.bind_current_stream()
         if raw:
@@ -159,7 +178,7 @@ class TransientHDRFilm:
         torch = require_gpu()
         W, H = self.size_
         data = self.transient_storage.torch_tensor()
-        out = torch.empty((H, W, self.temporal_bins, 3), dtype=torch.float32, device=data.device)
+        out = torch.empty(self.raw_shape()[:-1] + (3,), dtype=torch.float32, device=data.device)
         ctx = get_context(data.device.index)
         ctx.bind_current_stream()
         fd = self.desc()
@@ -173,7 +192,7 @@ class TransientHDRFilm:
         torch = require_gpu()
         rows = int(raw_t.shape[0])
         W = self.size_[0]
-        out_t = torch.empty((rows, W, self.temporal_bins, 3), dtype=torch.float32, device=raw_t.device)
+        out_t = torch.empty((rows,) + self.raw_shape()[1:-1] + (3,), dtype=torch.float32, device=raw_t.device)
         out_s = torch.empty((rows, W, 3), dtype=torch.float32, device=raw_t.device)
         if rows == 0:
             return out_t, out_s

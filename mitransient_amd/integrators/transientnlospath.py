@@ -1,8 +1,8 @@
 """``transient_nlos_path`` plugin (mitransient/integrators/transientnlospath.py): the transient path tracer
 with the NLOS-specific sampling routines of [Royo2022] — laser sampling (:511-635), hidden-geometry
-sampling (:637-670) — and the Single / Confocal capture types.  Same properties and defaults as the
-reference (:200-249); the loop (:672-927) runs in the HIP kernels (``nlos_bounce`` in csrc/mtr_core.h).
-Exhaustive captures (6-D film) are not built."""
+sampling (:637-670) — and the Single / Confocal / Exhaustive capture types (Exhaustive with the 6-D
+``exhaustive_scan`` film).  Same properties and defaults as the reference (:200-249); the loop (:672-927) runs
+in the HIP kernels (``nlos_bounce`` in csrc/mtr_nlos.h)."""
 from __future__ import annotations
 
 from .. import _cabi
@@ -25,8 +25,6 @@ class TransientNLOSPath(TransientADIntegrator):
         self.capture_type = int(ct)
         if self.capture_type not in (1, 2, 3):
             raise AssertionError("capture_type must be either an int, a string or a CaptureType enum")
-        if self.capture_type == 3:
-            raise NotImplementedError("capture_type 'exhaustive' needs the 6-D film (SURVEY §8f rank 3)")
         self.force_equal_grids = bool(props.get("force_equal_illumination_scanning", True))
         self.illumination_scan_fov = float(props.get("illumination_scan_fov", 20.0))
         self.laser_sampling = bool(props.get("nlos_laser_sampling", False))
@@ -47,6 +45,7 @@ class TransientNLOSPath(TransientADIntegrator):
         f |= _cabi.MTR_NLOS_HG_INCLUDES_WALL if self.hg_sampling_includes_relay_wall else 0
         f |= _cabi.MTR_NLOS_ACCOUNT_FIRST_LAST if self.account_first_and_last_bounces else 0
         f |= _cabi.MTR_NLOS_DISCARD_DIRECT if self.discard_direct_paths else 0
+        f |= _cabi.MTR_NLOS_FORCE_EQUAL_GRIDS if self.force_equal_grids else 0
         return f
 
     def check_transient_(self, scene, sensor):
@@ -56,6 +55,14 @@ class TransientNLOSPath(TransientADIntegrator):
             sensor = scene.sensors()[sensor]
         if not isinstance(sensor, NLOSCaptureMeter):
             raise AssertionError("transient_nlos_path needs a nlos_capture_meter sensor")
+        film = sensor.film()
+        if self.capture_type == 3:
+            if not getattr(film, "exhaustive_scan", False):
+                raise AssertionError("capture_type 'exhaustive' needs a film with exhaustive_scan=True and "
+                                     "laser_scan_width / laser_scan_height")
+            if self.force_equal_grids and (film.laser_scan_width, film.laser_scan_height) != tuple(film.size()):
+                raise AssertionError("Sensor and laser scan resolution must be equal if "
+                                     "force_equal_illumination_scanning is set to True")       # transientnlospath.py:343-345
         if len(scene.emitters()) != 1:
             raise AssertionError(f"You have defined multiple ({len(scene.emitters())}) emitters in the scene with a "
                                  "NLOS capture meter. You should have only 1.")

@@ -19,8 +19,8 @@ class TransientImageBlock:
     def __init__(self, size_xyt, offset_xyt=(0, 0, 0), exhaustive_scan=False,
                  laser_scan_width=0, laser_scan_height=0, channel_count=4, rfilter=None,
                  border=False, warn_negative=False, warn_invalid=False, device=None):
-        if exhaustive_scan:
-            raise NotImplementedError("exhaustive_scan (6-D film) is outside the transient_path hot path")
+        if exhaustive_scan and not (int(laser_scan_width) > 0 and int(laser_scan_height) > 0):
+            raise ValueError("exhaustive_scan needs laser_scan_width and laser_scan_height > 0")
         if rfilter is not None and rfilter != "box":
             # transient_image_block.py:150-151
             raise RuntimeError("TransientImageBlock::put_(): using a rfilter but it is not supported. "
@@ -29,7 +29,9 @@ class TransientImageBlock:
             raise NotImplementedError("only the RGBW (C=4) channel layout of the rgb variant is supported")
         self.offset_xyt = tuple(int(v) for v in offset_xyt)
         self.size_xyt = tuple(int(v) for v in size_xyt)
-        self.exhaustive_scan = False
+        self.exhaustive_scan = bool(exhaustive_scan)
+        self.laser_scan_width = int(laser_scan_width) if exhaustive_scan else 0
+        self.laser_scan_height = int(laser_scan_height) if exhaustive_scan else 0
         self.channel_count = channel_count
         self.rfilter = None
         self.border_size = 0
@@ -44,8 +46,11 @@ class TransientImageBlock:
         torch = require_gpu()
         W, H, T = self.size_xyt
         dev = self._device if self._device is not None else torch.device("cuda", torch.cuda.current_device())
-        if self._tensor is None or tuple(self._tensor.shape) != (H, W, T, self.channel_count):
-            self._tensor = torch.zeros((H, W, T, self.channel_count), dtype=torch.float32, device=dev)
+        # transient_image_block.py:63-68: (H, W, laser_scan_height, laser_scan_width, T, C) when exhaustive
+        shape = ((H, W, self.laser_scan_height, self.laser_scan_width, T, self.channel_count) if self.exhaustive_scan
+                 else (H, W, T, self.channel_count))
+        if self._tensor is None or tuple(self._tensor.shape) != shape:
+            self._tensor = torch.zeros(shape, dtype=torch.float32, device=dev)
         else:
             self._tensor.zero_()
 
@@ -62,17 +67,19 @@ class TransientImageBlock:
             self.size_xyt = size_xyt
 
     # -- splatting --------------------------------------------------------
-    def put_opl(self, pixel, opl, r, g, b, film_desc: _cabi.mtr_film_desc, variant: int = 0):
+    def put_opl(self, pixel, opl, r, g, b, film_desc: _cabi.mtr_film_desc, variant: int = 0, laser=None):
         """Scatter-add n time-resolved contributions (device torch tensors): pixel u32 (y*W+x),
-        opl f32, r/g/b f32.  This is add_transient_data + put_ + accum in one HIP launch."""
+        opl f32, r/g/b f32, laser u32 (laser_x*laser_scan_height + laser_y; exhaustive films).  This is
+        add_transient_data + put_ + accum in one HIP launch."""
         torch = require_gpu()
         ctx = get_context(self._tensor.device.index)
         ctx.bind_current_stream()
         n = int(pixel.numel())
         pix = pixel.to(device=self._tensor.device, dtype=torch.int32).contiguous()
         arrs = [t.to(device=self._tensor.device, dtype=torch.float32).contiguous() for t in (opl, r, g, b)]
+        las = laser.to(device=self._tensor.device, dtype=torch.int32).contiguous() if laser is not None else None
         soa = _cabi.mtr_splat_soa(pix.data_ptr(), arrs[0].data_ptr(), arrs[1].data_ptr(),
-                                  arrs[2].data_ptr(), arrs[3].data_ptr(), n)
+                                  arrs[2].data_ptr(), arrs[3].data_ptr(), n, las.data_ptr() if las is not None else None)
         ms = C.c_float(0)
         ctx.check(ctx.lib.mtr_splat_add(ctx.handle, C.byref(soa), C.byref(film_desc), int(variant),
                                         C.c_void_p(self._tensor.data_ptr()), C.byref(ms)), "mtr_splat_add")

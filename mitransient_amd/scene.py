@@ -494,6 +494,8 @@ def film_desc_from(film) -> _cabi.mtr_film_desc:
     f.temporal_bins = int(film.temporal_bins)
     f.start_opl = np.float32(film.start_opl)
     f.bin_width_opl = np.float32(film.bin_width_opl)
+    if getattr(film, "exhaustive_scan", False):
+        f.laser_scan_width, f.laser_scan_height = int(film.laser_scan_width), int(film.laser_scan_height)
     return f
 
 
@@ -512,6 +514,7 @@ def nlos_desc_from(integrator, sensor, emitter, relay_shape: int) -> _cabi.mtr_n
     n.capture_type = int(integrator.capture_type)
     n.flags = int(integrator.nlos_flags())
     n.filter_depth = int(integrator.filter_depth)
+    n.illumination_scan_fov = np.float32(integrator.illumination_scan_fov)
     return n
 
 
@@ -524,14 +527,15 @@ def save_geometry(sd: "SceneData", path: str, **meta):
         tri_emitter=sd.tri_emitter.astype(np.int16),
         materials=np.frombuffer(bytes(sd.materials), dtype=np.uint8)[:sd.n_materials * C.sizeof(_cabi.mtr_material)],
         emitters=np.frombuffer(bytes(sd.emitters), dtype=np.uint8)[:sd.n_emitters * C.sizeof(_cabi.mtr_emitter)],
-        abi=np.asarray([_cabi.MTR_ABI_VERSION]), meta=np.asarray(json.dumps(meta)))
+        layout=np.asarray([C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter)]), meta=np.asarray(json.dumps(meta)))
 
 
 def load_geometry(path: str) -> Dict[str, Any]:
     import json
     z = np.load(path)
-    if int(z["abi"][0]) != _cabi.MTR_ABI_VERSION:
-        raise ValueError(f"{path}: written for C-ABI version {int(z['abi'][0])}, this is {_cabi.MTR_ABI_VERSION}")
+    if list(z["layout"]) != [C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter)]:
+        raise ValueError(f"{path}: material / emitter record sizes {list(z['layout'])} do not match this C-ABI; "
+                         "regenerate with tests/golden/make_golden.py")
     nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
     ne = z["emitters"].size // C.sizeof(_cabi.mtr_emitter)
     mats = (_cabi.mtr_material * max(1, nm)).from_buffer_copy(z["materials"].tobytes().ljust(C.sizeof(_cabi.mtr_material), b"\0"))

@@ -526,8 +526,33 @@ int orc_bin_index(float distance, float start_opl, float bin_width_opl, uint32_t
     if (!(pos_distance >= 0.0f && pos_distance < (float)T)) return -1;  /* :265 */
     return (int)(uint32_t)floorf(pos_distance);                          /* transient_image_block.py:132 */
 }
+/* flat element index of a contribution (transient_image_block.py:134-144), without the channel */
+static size_t film_cell(const mtr_film_desc *f, uint32_t x, uint32_t y, uint32_t laser_x, uint32_t laser_y, uint32_t bin)
+{
+    size_t index = (size_t)y * f->width + x;
+    if (f->laser_scan_width && f->laser_scan_height) {                   /* exhaustive_scan :134-140 */
+        index = index * f->laser_scan_width + laser_x;
+        index = index * f->laser_scan_height + laser_y;
+    }
+    return index * f->temporal_bins + bin;                               /* :139 / :143 */
+}
+static size_t film_cells(const mtr_film_desc *f)
+{
+    size_t n = (size_t)f->width * f->height * f->temporal_bins;
+    if (f->laser_scan_width && f->laser_scan_height) n *= (size_t)f->laser_scan_width * f->laser_scan_height;
+    return n;
+}
+static void add_transient_l(film_t *F, uint32_t px, uint32_t py, float distance, const float spec[3],
+                            float sample_scale, uint32_t lane, uint32_t depth, uint32_t kind, lane_counters *C,
+                            uint32_t laser_x, uint32_t laser_y);
 static void add_transient(film_t *F, uint32_t px, uint32_t py, float distance, const float spec[3],
                           float sample_scale, uint32_t lane, uint32_t depth, uint32_t kind, lane_counters *C)
+{
+    add_transient_l(F, px, py, distance, spec, sample_scale, lane, depth, kind, C, 0, 0);
+}
+static void add_transient_l(film_t *F, uint32_t px, uint32_t py, float distance, const float spec[3],
+                            float sample_scale, uint32_t lane, uint32_t depth, uint32_t kind, lane_counters *C,
+                            uint32_t laser_x, uint32_t laser_y)
 {
     const mtr_film_desc *f = F->f;
     /* common.py:417-421: spec * sample_scale, then * ray_weight (== 1) */
@@ -538,7 +563,8 @@ static void add_transient(film_t *F, uint32_t px, uint32_t py, float distance, c
     uint32_t x = px - f->crop_offset_x, y = py - f->crop_offset_y;
     if (!(x < f->width && y < f->height)) return;                        /* :146 */
     if (val[0] == 0.0f && val[1] == 0.0f && val[2] == 0.0f) return;     /* adding +0 is a no-op */
-    size_t index = (((size_t)y * f->width + x) * f->temporal_bins + (uint32_t)bin) * 4u;  /* :142-144 */
+    if (f->laser_scan_width && !(laser_x < f->laser_scan_width && laser_y < f->laser_scan_height)) return;
+    size_t index = film_cell(f, x, y, laser_x, laser_y, (uint32_t)bin) * 4u;             /* :134-144 */
     for (int k = 0; k < 3; ++k) {
 #pragma omp atomic
         F->transient[index + k] += val[k];                               /* accum: scatter_reduce(Add) :79-81 */
@@ -551,7 +577,8 @@ static void add_transient(film_t *F, uint32_t px, uint32_t py, float distance, c
         i = (*F->log_n)++;
         if (i < F->log_cap) {
             orc_splat_rec *R = &F->log[i];
-            R->lane = lane; R->depth_kind = depth | (kind << 16); R->pixel = y * f->width + x; R->bin = (uint32_t)bin;
+            R->lane = lane; R->depth_kind = depth | (kind << 16); R->pixel = y * f->width + x;
+            R->bin = (uint32_t)(film_cell(f, 0, 0, laser_x, laser_y, (uint32_t)bin));     /* position in the pixel's row */
             R->r = val[0]; R->g = val[1]; R->b = val[2]; R->opl = distance;
         }
     }
@@ -798,6 +825,7 @@ typedef struct {
     v3 *rect_n;                                    /* rectangle shapes: normal */
     /* scan */
     v3 *sensor_targets; v3 laser_target_single;
+    v3 *laser_targets; uint32_t laser_w, laser_h;  /* Exhaustive: illuminated points (:340-381) */
 } nlos_scene;
 
 #define tri_area_d orc_tri_area_d
@@ -917,11 +945,36 @@ static void nlos_build(nlos_scene *N, const orc_scene *sc, int use_bvh)
     hit_t lh = intersect(sc, &lr, use_bvh);
     sinter lsi = make_si(sc, &lr, lh);
     N->laser_target_single = lsi.p;
+    if (n->capture_type == MTR_CAPTURE_EXHAUSTIVE) {
+        N->laser_w = f->laser_scan_width; N->laser_h = f->laser_scan_height;
+        const uint32_t nl = N->laser_w * N->laser_h;
+        N->laser_targets = calloc(nl ? nl : 1, sizeof(v3));
+        if (n->flags & MTR_NLOS_FORCE_EQUAL_GRIDS) {                     /* :341-346 (grids checked equal by the caller) */
+            for (uint32_t i = 0; i < nl && i < f->width * f->height; ++i) N->laser_targets[i] = N->sensor_targets[i];
+        } else {
+            /* dummy projector with illumination_scan_fov (:347-381); meshgrid 'xy': point i = (x = i % Lx, y = i / Lx).
+             * [mitsuba3: Projector::sample_ray, constant irradiance]: uv = sample3,
+             * near_p = sample_to_camera * (u, v, 0) = ((1-2u) tan(fov/2), (1-2v) tan(fov/2), 1) * near, d = to_world * normalize(near_p) */
+            const float th = (float)tan(0.5 * (double)n->illumination_scan_fov * 3.14159265358979323846 / 180.0);
+            const float *T = n->laser_to_world;
+            for (uint32_t i = 0; i < nl; ++i) {
+                uint32_t y = i / N->laser_w, x = i - y * N->laser_w;
+                float u = (float)x / (float)N->laser_w, v = (float)y / (float)N->laser_h;
+                v3 loc = vnormalize(V((1.0f - 2.0f * u) * th, (1.0f - 2.0f * v) * th, 1.0f));
+                ray3 r; r.o = N->l_origin; r.maxt = INFINITY;
+                r.d = V(fmaf(T[0], loc.x, fmaf(T[1], loc.y, T[2] * loc.z)), fmaf(T[4], loc.x, fmaf(T[5], loc.y, T[6] * loc.z)),
+                        fmaf(T[8], loc.x, fmaf(T[9], loc.y, T[10] * loc.z)));
+                hit_t h = intersect(sc, &r, use_bvh);
+                sinter si = make_si(sc, &r, h);
+                N->laser_targets[i] = si.p;
+            }
+        }
+    }
 }
 static void nlos_free(nlos_scene *N)
 {
     free(N->shape_pmf); free(N->shape_cdf); free(N->shape_inv_area); free(N->rect_n);
-    free(N->face_cdf); free(N->face_pmf); free(N->sensor_targets);
+    free(N->face_cdf); free(N->face_pmf); free(N->sensor_targets); free(N->laser_targets);
 }
 
 /* si.spawn_ray_to(t) [mitsuba3: Interaction::spawn_ray_to] */
@@ -944,7 +997,7 @@ static void bsdf_eval(const mtr_material *m, v3 wi, v3 wo, float val[3])
 static void nlos_emitter_nee(const orc_scene *sc, const nlos_scene *N, film_t *F, pcg32 *rng, const sinter *si,
                              const mtr_material *mat, const float beta[3], float distance, float eta, uint32_t depth,
                              int active_e, int focus_laser, uint32_t px, uint32_t py, float sample_scale, uint32_t lane,
-                             uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3])
+                             uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3], uint32_t laser_x, uint32_t laser_y)
 {
     const mtr_nlos_desc *n = N->n;
     Lr[0] = Lr[1] = Lr[2] = 0.0f;
@@ -956,7 +1009,7 @@ static void nlos_emitter_nee(const orc_scene *sc, const nlos_scene *N, film_t *F
     if (!active_e) return;                                           /* masked lanes draw nothing: next_2d(active_e) */
     float u1 = pcg32_next_f32(rng), u2 = pcg32_next_f32(rng); (void)u1; (void)u2;
     float w[3], ds_dist; v3 dir;
-    if (focus_laser && n->capture_type == MTR_CAPTURE_CONFOCAL) {    /* :448-458 */
+    if (focus_laser && (n->capture_type == MTR_CAPTURE_CONFOCAL || n->capture_type == MTR_CAPTURE_EXHAUSTIVE)) {   /* :448-458 */
         v3 rel = vsub(N->l_origin, si->p);
         float dist_e = sqrtf(vdot(rel, rel));
         v3 pf = vfma(N->l_forward, dist_e, N->l_origin);
@@ -972,14 +1025,16 @@ static void nlos_emitter_nee(const orc_scene *sc, const nlos_scene *N, film_t *F
     if (!active_e) return;
     for (int k = 0; k < 3; ++k) Lr[k] = (beta[k] * bv[k]) * w[k];                                /* :493 */
     if (n->flags & MTR_NLOS_ACCOUNT_FIRST_LAST) distance += ds_dist * eta;                        /* :497-498 */
-    add_transient(F, px, py, distance, Lr, sample_scale, lane, loop_depth, 1, C);                /* :506-507 */
+    if (n->capture_type != MTR_CAPTURE_EXHAUSTIVE) laser_x = laser_y = 0;                         /* :502-505 */
+    add_transient_l(F, px, py, distance, Lr, sample_scale, lane, loop_depth, 1, C, laser_x, laser_y);   /* :506-507 */
 }
 
 /* emitter_laser_targets_sample (transientnlospath.py:511-564) */
 static void nlos_laser_targets(const orc_scene *sc, const nlos_scene *N, film_t *F, pcg32 *rng, const sinter *si,
                                const mtr_material *mat, v3 lt, const float beta[3], float distance, float eta,
                                uint32_t depth, int active_e, uint32_t px, uint32_t py, float sample_scale,
-                               uint32_t lane, uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3])
+                               uint32_t lane, uint32_t loop_depth, int use_bvh, lane_counters *C, float Lr[3],
+                               uint32_t laser_x, uint32_t laser_y)
 {
     Lr[0] = Lr[1] = Lr[2] = 0.0f;
     if (!active_e) return;
@@ -1004,7 +1059,7 @@ static void nlos_laser_targets(const orc_scene *sc, const nlos_scene *N, film_t 
     const mtr_material *m2 = &sc->d->materials[sc->d->tri_material[s2.prim]];
     int smooth_ok = 1; (void)smooth_ok;
     nlos_emitter_nee(sc, N, F, rng, &s2, m2, b2, distance + dl * eta, eta, depth + 1, 1, 1, px, py, sample_scale, lane,
-                     loop_depth, use_bvh, C, Lr);
+                     loop_depth, use_bvh, C, Lr, laser_x, laser_y);
 }
 
 /* hidden_geometry_sample (transientnlospath.py:637-670) */
@@ -1088,12 +1143,23 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
         active_next &= (depth + 1 < max_depth) && si.valid;                                       /* :782 */
         int active_em = active_next && bsdf_is_smooth(mat);
         float Lr[3] = { 0, 0, 0 };
-        if (n->flags & MTR_NLOS_LASER_SAMPLING)                                                   /* emitter_laser_sample: depth + 1 */
+        if ((n->flags & MTR_NLOS_LASER_SAMPLING) && n->capture_type == MTR_CAPTURE_EXHAUSTIVE) {
+            /* each measured point is illuminated by all the laser points (:590-621) */
+            const uint32_t lrx = N->laser_w, lry = N->laser_h;
+            for (uint32_t i = 0; i < lrx * lry; ++i) {
+                uint32_t laser_x = (uint32_t)((float)i / (float)lry), laser_y = i % lry;          /* :609-610 */
+                float Li[3];
+                nlos_laser_targets(sc, N, F, &rng, &si, mat, N->laser_targets[i], beta, distance, eta, depth + 1, active_em, px, py,
+                                   sample_scale, lane, depth, use_bvh, C, Li, laser_x, laser_y);
+                for (int k = 0; k < 3; ++k) Lr[k] += Li[k];
+            }
+            for (int k = 0; k < 3; ++k) Lr[k] = Lr[k] / (float)(lrx * lry);                       /* :621 */
+        } else if (n->flags & MTR_NLOS_LASER_SAMPLING)                                            /* emitter_laser_sample: depth + 1 */
             nlos_laser_targets(sc, N, F, &rng, &si, mat, lt, beta, distance, eta, depth + 1, active_em, px, py, sample_scale,
-                               lane, depth, use_bvh, C, Lr);
+                               lane, depth, use_bvh, C, Lr, 0, 0);
         else
             nlos_emitter_nee(sc, N, F, &rng, &si, mat, beta, distance, eta, depth, active_em, 0, px, py, sample_scale, lane,
-                             depth, use_bvh, C, Lr);
+                             depth, use_bvh, C, Lr, 0, 0);
         /* BSDF / hidden-geometry sampling (:797-833) */
         int do_hg = (n->flags & MTR_NLOS_HG_SAMPLING) != 0; float pdf_method = 1.0f;
         if ((n->flags & MTR_NLOS_HG_SAMPLING) && (n->flags & MTR_NLOS_HG_RROULETTE)) {
@@ -1192,7 +1258,7 @@ int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *trans
 void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *transient_hwt3,
                  const float *steady_hw4, float *steady_hw3)
 {
-    size_t npt = (size_t)f->width * f->height * f->temporal_bins;
+    size_t npt = film_cells(f);
     if (transient_hwt4 && transient_hwt3)
         for (size_t i = 0; i < npt; ++i) {
             float w = transient_hwt4[4 * i + 3];
@@ -1209,13 +1275,16 @@ void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *tra
 
 /* stand-alone splat add (same arithmetic as add_transient) for the scatter-add tests */
 void orc_splat_add(const mtr_film_desc *f, uint64_t n, const uint32_t *pixel, const float *opl,
-                   const float *r, const float *g, const float *b, float *transient_hwt4)
+                   const float *r, const float *g, const float *b, float *transient_hwt4,
+                   const uint32_t *laser_x, const uint32_t *laser_y)
 {
     for (uint64_t i = 0; i < n; ++i) {
         int bin = orc_bin_index(opl[i], f->start_opl, f->bin_width_opl, f->temporal_bins);
         if (bin < 0) continue;
         if (pixel[i] >= f->width * f->height) continue;
-        size_t index = ((size_t)pixel[i] * f->temporal_bins + (uint32_t)bin) * 4u;
+        uint32_t lx = laser_x ? laser_x[i] : 0, ly = laser_y ? laser_y[i] : 0;
+        if (f->laser_scan_width && !(lx < f->laser_scan_width && ly < f->laser_scan_height)) continue;
+        size_t index = film_cell(f, pixel[i] % f->width, pixel[i] / f->width, lx, ly, (uint32_t)bin) * 4u;
         transient_hwt4[index + 0] += r[i]; transient_hwt4[index + 1] += g[i]; transient_hwt4[index + 2] += b[i];
     }
 }

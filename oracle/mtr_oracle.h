@@ -21,7 +21,8 @@ int  orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *tran
 void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *transient_hwt3,
                  const float *steady_hw4, float *steady_hw3);
 void orc_splat_add(const mtr_film_desc *f, uint64_t n, const uint32_t *pixel, const float *opl,
-                   const float *r, const float *g, const float *b, float *transient_hwt4);
+                   const float *r, const float *g, const float *b, float *transient_hwt4,
+                   const uint32_t *laser_x, const uint32_t *laser_y);
 int  orc_bin_index(float distance, float start_opl, float bin_width_opl, uint32_t T);
 void orc_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3, const float *d3, const float *maxt,
                    int use_bvh, float *t_out, int32_t *prim_out, uint8_t *occluded_out);

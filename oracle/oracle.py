@@ -42,7 +42,7 @@ def lib():
         L.orc_render.restype = C.c_int
         L.orc_develop.argtypes = [C.POINTER(_cabi.mtr_film_desc), fp, fp, fp, fp]
         L.orc_develop.restype = None
-        L.orc_splat_add.argtypes = [C.POINTER(_cabi.mtr_film_desc), C.c_uint64, u32p, fp, fp, fp, fp, fp]
+        L.orc_splat_add.argtypes = [C.POINTER(_cabi.mtr_film_desc), C.c_uint64, u32p, fp, fp, fp, fp, fp, u32p, u32p]
         L.orc_splat_add.restype = None
         L.orc_bin_index.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
         L.orc_bin_index.restype = C.c_int
@@ -70,9 +70,16 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def film_shape(f):
+    """raw tensor shape: (H,W,T,4), or (H,W,Lh,Lw,T,4) for an exhaustive_scan film (transient_image_block.py:63-68)"""
+    if f.laser_scan_width and f.laser_scan_height:
+        return (f.height, f.width, f.laser_scan_height, f.laser_scan_width, f.temporal_bins, 4)
+    return (f.height, f.width, f.temporal_bins, 4)
+
+
 def alloc_film(film_desc, prefault=False):
     f = film_desc
-    t4 = np.zeros((f.height, f.width, f.temporal_bins, 4), np.float32)
+    t4 = np.zeros(film_shape(f), np.float32)
     s4 = np.zeros((f.height, f.width, 4), np.float32)
     if prefault:          # touch every page now (np.zeros maps lazily): keeps page faults out of timed regions
         t4.fill(0.0)
@@ -114,11 +121,14 @@ def develop(film_desc, t4=None, s4=None):
     return t3, s3
 
 
-def splat_add(film_desc, pixel, opl, r, g, b, t4):
+def splat_add(film_desc, pixel, opl, r, g, b, t4, laser_x=None, laser_y=None):
     pixel = np.ascontiguousarray(pixel, np.uint32)
     arrs = [np.ascontiguousarray(x, np.float32) for x in (opl, r, g, b)]
-    lib().orc_splat_add(C.byref(film_desc), len(pixel), pixel.ctypes.data_as(C.POINTER(C.c_uint32)),
-                        *[_fp(a) for a in arrs], _fp(t4))
+    up = C.POINTER(C.c_uint32)
+    lx = np.ascontiguousarray(laser_x, np.uint32) if laser_x is not None else None
+    ly = np.ascontiguousarray(laser_y, np.uint32) if laser_y is not None else None
+    lib().orc_splat_add(C.byref(film_desc), len(pixel), pixel.ctypes.data_as(up), *[_fp(a) for a in arrs], _fp(t4),
+                        lx.ctypes.data_as(up) if lx is not None else None, ly.ctypes.data_as(up) if ly is not None else None)
 
 
 def bin_index(distance, start, width, T):

@@ -58,7 +58,8 @@ def rel_l2(a, b):
 def hh_render(lib, sd, params):
     from mitransient_amd import _cabi
     f = sd.film
-    t4 = np.zeros((f.height, f.width, f.temporal_bins, 4), np.float32)
+    from oracle import oracle as _o
+    t4 = np.zeros(_o.film_shape(f), np.float32)
     s4 = np.zeros((f.height, f.width, 4), np.float32)
     cnt = _cabi.mtr_counters()
     d = sd.desc()
@@ -68,7 +69,8 @@ def hh_render(lib, sd, params):
     return t4, s4, cnt.as_dict()
 
 
-def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, **integ):
+def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, film=None,
+              laser_fov=0.2, **integ):
     """NLOS scene in the style of tests/integration/test_nlos.py:1-78 and examples/transient-nlos/nlos_Z.xml:
     2x2 relay wall at the origin with a nlos_capture_meter, projector laser and sensor at (-0.5, 0, 0.25),
     hidden geometry at z = 1 (a 0.8 x 0.8 quad, or a procedural 'Z' of 6 triangles / 3 quads)."""
@@ -76,14 +78,15 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
     import mitransient_amd.mi as mi
     from mitransient_amd.transform import ScalarTransform4f as T
     mi.set_variant("llvm_ad_rgb")
+    fd = {"type": "transient_hdr_film", "width": sx, "height": sy, "temporal_bins": bins,
+          "bin_width_opl": bin_width, "start_opl": start, "rfilter": {"type": "box"}}
+    fd.update(film or {})
     relay = mi.load_dict({
         "type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}},
         "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
-                        "sensor_origin": [-0.5, 0.0, 0.25],
-                        "film": {"type": "transient_hdr_film", "width": sx, "height": sy, "temporal_bins": bins,
-                                 "bin_width_opl": bin_width, "start_opl": start, "rfilter": {"type": "box"}}}})
+                        "sensor_origin": [-0.5, 0.0, 0.25], "film": fd}})
     laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
-                          "irradiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}, "fov": 0.2})
+                          "irradiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}, "fov": laser_fov})
     idict = {"type": "transient_nlos_path", "max_depth": -1, "nlos_laser_sampling": True,
              "nlos_hidden_geometry_sampling": True, "capture_type": capture, "temporal_filter": "box"}
     idict.update(integ)

@@ -53,12 +53,10 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
         NlosConst &k = hn.k;
         k.shapes = hn.shapes.data(); k.shape_pmf = hn.shape_pmf.data(); k.shape_cdf = hn.shape_cdf.data();
         k.face_pmf = hn.face_pmf.data(); k.face_cdf = hn.face_cdf.data(); k.hg_tris = hn.hg_tris.data();
-        const uint32_t n = k.film_w * k.film_h;
-        targets.resize(n + 1);
-        for (uint32_t i = 0; i <= n; ++i) {
-            Ray r;
-            if (i < n) { uint32_t y = i / k.film_w, x = i - y * k.film_w; r = nlos_sensor_ray(k, (float)x / (float)k.film_w, (float)y / (float)k.film_h); }
-            else { r.o = k.l_origin; r.d = k.l_forward; r.tmax = kInf; }
+        const uint32_t n = nlos_target_count(k);
+        targets.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Ray r = nlos_prepare_ray(k, i);
             Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
             f3 pp = mk(0, 0, 0);
             if (h.prim >= 0) pp = hit_ctx(sv, r.d, h).sp;

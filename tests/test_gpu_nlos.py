@@ -70,3 +70,69 @@ def test_nlos_config4_shape_properties():
     scene.integrator().mode = 2
     with pytest.raises(Exception):
         _gpu(scene, 4)
+
+
+# ---- Exhaustive captures + the 6-D exhaustive_scan film -----------------------------------------------------
+from test_nlos import EXH, exhaustive_scene  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg", EXH)
+def test_exhaustive_matches_oracle(oracle, cfg):
+    scene = exhaustive_scene(**cfg)
+    film = scene.sensors()[0].film()
+    s_gpu, t_gpu = _gpu(scene, 48)
+    sd = scene.data()
+    f = sd.film
+    p = scene.integrator().render_params(film, 0, 48)
+    t6, s4, cnt = oracle.render(sd, p, use_bvh=True)
+    t_ref, _ = oracle.develop(sd.film, t6, None)
+    assert t_gpu.shape == (f.height, f.width, f.laser_scan_height, f.laser_scan_width, f.temporal_bins, 3)
+    assert rel_l2(t_gpu, t_ref) <= TOL
+    # transient_hdr_film.py:213-214: the "steady" image of an exhaustive film is mean(transient, axis=-1)
+    assert s_gpu.shape == t_gpu.shape[:-1] and np.allclose(s_gpu, t_gpu.mean(axis=-1), rtol=1e-6, atol=1e-12)
+    _, raw = film.develop(raw=True)
+    raw = np.array(raw)
+    assert raw.shape == t6.shape and np.array_equal(raw[..., :3] != 0, t6[..., :3] != 0) and not raw[..., 3].any()
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("variant,sort", [(0, False), (1, True)])
+def test_exhaustive_film_add_transient_data(oracle, variant, sort):
+    """film.add_transient_data(pos, distance, wavelengths, spec, ray_weight, active, laser_x, laser_y) on an
+    exhaustive_scan film: the reference's flat index ((((y*W+x)*Lw + laser_x)*Lh + laser_y)*T + t)*C."""
+    import torch
+    import mitransient_amd as mitr
+    from mitransient_amd.scene import Properties
+    W, H, Lw, Lh, T = 5, 4, 3, 2, 32
+    film = mitr.TransientHDRFilm(Properties("transient_hdr_film", {
+        "width": W, "height": H, "temporal_bins": T, "bin_width_opl": 0.1, "start_opl": 1.0, "rfilter": {"type": "box"},
+        "exhaustive_scan": True, "laser_scan_width": Lw, "laser_scan_height": Lh}))
+    film.prepare([])
+    rng = np.random.default_rng(7)
+    n = 20000
+    pos = rng.uniform([-0.5, -0.5], [W + 0.5, H + 0.5], size=(n, 2)).astype(np.float32)
+    if sort:
+        order = np.lexsort((pos[:, 0].astype(int), pos[:, 1].astype(int)))
+        pos = pos[order]
+    dist = rng.uniform(0.8, 4.4, n).astype(np.float32)
+    spec = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    lx = rng.integers(0, Lw + 1, n)              # Lw / Lh themselves are out of range -> dropped
+    ly = rng.integers(0, Lh + 1, n)
+    film.add_transient_data(pos, dist, None, spec, 1.0, None, lx, ly, variant=variant)
+    torch.cuda.synchronize()
+    _, raw = film.develop(raw=True)
+    raw = np.array(raw)
+    assert raw.shape == (H, W, Lh, Lw, T, 4)
+    px, py = np.floor(pos[:, 0]).astype(np.int64), np.floor(pos[:, 1]).astype(np.int64)
+    ok = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (lx < Lw) & (ly < Lh)
+    ref = np.zeros(raw.shape, np.float32)
+    oracle.splat_add(film.desc(), (py * W + px)[ok], dist[ok], spec[ok, 0], spec[ok, 1], spec[ok, 2], ref, lx[ok], ly[ok])
+    assert np.count_nonzero(ref) > 1000
+    assert np.allclose(raw, ref, rtol=1e-5, atol=1e-6)
+    # independent statement of the index: memory order is [y][x][laser_x][laser_y][t]
+    flat = raw.reshape(H, W, Lw, Lh, T, 4)
+    i = int(np.argmax(ok & (dist > 1.0) & (dist < 4.2)))
+    b = int(np.floor((np.float32(dist[i]) - np.float32(1.0)) / np.float32(0.1)))
+    assert flat[py[i], px[i], lx[i], ly[i], b, 0] > 0

@@ -61,8 +61,7 @@ def test_plugin_surface_and_helpers():
     assert np.allclose(sensor.laser_target, [0.5, -0.5, 0.0])
     with pytest.raises(AssertionError):
         make_nlos(camera_unwarp=True)
-    with pytest.raises(NotImplementedError):
-        make_nlos(capture="exhaustive")
+    assert make_nlos(capture="exhaustive").integrator().capture_type == 3
     with pytest.raises(AssertionError):
         make_nlos(filter_depth=2, filter_bounces=2)
 
@@ -102,3 +101,78 @@ def test_brute_force_equals_bvh_nlos(oracle):
     a = oracle.render(sd, p, n_threads=1, use_bvh=False)
     b = oracle.render(sd, p, n_threads=1, use_bvh=True)
     assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+# ---- Exhaustive captures + the 6-D exhaustive_scan film ---------------------------------
+def exhaustive_scene(sx=4, sy=4, lw=4, lh=4, equal=True, bins=48, **integ):
+    kw = dict(capture="exhaustive", sx=sx, sy=sy, bins=bins, bin_width=0.05, start=1.8,
+              film={"exhaustive_scan": True, "laser_scan_width": lw, "laser_scan_height": lh},
+              force_equal_illumination_scanning=equal, illumination_scan_fov=60.0)
+    kw.update(integ)
+    return make_nlos(**kw)
+
+
+EXH = [dict(), dict(sx=3, sy=2, lw=3, lh=2, max_depth=5),
+       dict(sx=4, sy=3, lw=3, lh=2, equal=False), dict(sx=3, sy=3, lw=2, lh=2, equal=False, nlos_laser_sampling=False, nlos_hidden_geometry_sampling=False, max_depth=4, laser_fov=70.0),
+       dict(sx=2, sy=2, lw=2, lh=2, account_first_and_last_bounces=True, nlos_hidden_geometry_sampling_do_rroulette=True, max_depth=6)]
+
+
+@pytest.mark.parametrize("cfg", EXH)
+def test_exhaustive_host_harness_matches_oracle(oracle, host_harness, cfg):
+    scene = exhaustive_scene(**cfg)
+    sd = scene.data()
+    f = sd.film
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 48)
+    t6, s4, c = oracle.render(sd, p, n_threads=1)
+    assert t6.shape == (f.height, f.width, f.laser_scan_height, f.laser_scan_width, f.temporal_bins, 4)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t6, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert hc[k] == c[k], k
+    assert np.count_nonzero(t6) > (50 if cfg.get("nlos_laser_sampling", True) else 10)
+    if not cfg.get("nlos_laser_sampling", True):      # plain emitter sampling: everything lands in laser cell (0, 0)
+        flat = t6.reshape(f.height, f.width, -1, f.temporal_bins, 4)
+        assert np.count_nonzero(flat[:, :, 1:]) == 0
+
+
+def test_exhaustive_first_arrival_and_energy(oracle):
+    """every (scanned point s, illuminated point l) pair holds its own histogram: 3-bounce light l -> hidden quad
+    (plane z = 1) -> s arrives first at |l - s'| with s' the mirror image of s (when the mirror point lies on the
+    quad); and sum over lasers and time of the film / (Lw*Lh) == the steady estimate (transientnlospath.py:621)."""
+    W = H = 4
+    bins, width, start = 240, 0.01, 1.9
+    scene = exhaustive_scene(sx=W, sy=H, lw=W, lh=H, bins=bins, bin_width=width, start=start, max_depth=3)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 400)
+    t6, s4, c = oracle.render(sd, p)
+    t = t6.reshape(H, W, W * H, bins, 4)[..., 0]
+    relay = [s for s in scene.shapes() if s.sensor() is not None][0]
+    pts = np.array([[relay.sample_position(0, ((x + 0.5) / W, (y + 0.5) / H)).p for x in range(W)] for y in range(H)])
+    checked = 0
+    for py in range(H):
+        for px in range(W):
+            for i in range(W * H):
+                l, s = pts[i // W, i % W], pts[py, px]                      # target i = y * W + x (meshgrid 'xy')
+                mid = 0.5 * (l + s)
+                if max(abs(mid[0]), abs(mid[1])) > 0.3:
+                    continue
+                opl = np.sqrt(np.sum((l[:2] - s[:2]) ** 2) + 4.0)
+                prof = t[py, px, i]
+                assert prof.sum() > 0
+                first = int(np.argmax(prof > 0))
+                assert abs(first - (opl - start) / width) <= 1.5, (px, py, i, first, (opl - start) / width)
+                checked += 1
+    assert checked > 60
+    # window 1.9 .. 4.3 covers every 3-bounce path of this scene
+    tot = t6[..., :3].reshape(H, W, -1, 3).sum(axis=2) / (W * H)
+    _, s3 = oracle.develop(sd.film, None, s4)
+    assert np.allclose(tot, s3, rtol=1e-3, atol=1e-7)
+
+
+def test_exhaustive_needs_matching_film():
+    with pytest.raises(AssertionError, match="exhaustive_scan"):
+        sc = make_nlos(capture="exhaustive")
+        sc.integrator().check_transient_(sc, 0)
+    with pytest.raises(AssertionError, match="must be equal"):
+        sc = exhaustive_scene(sx=4, sy=4, lw=2, lh=2, equal=True)
+        sc.integrator().check_transient_(sc, 0)
