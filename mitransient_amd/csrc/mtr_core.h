@@ -130,6 +130,18 @@ MTR_HD f3 cosine_hemisphere(float u1, float u2)
 // 16-byte quads: every record below is read as whole quads (ds_read_b128 from LDS,
 // global_load_dwordx4 from HBM/L2).
 struct alignas(16) q4 { float x, y, z, w; };
+// two independent f32 lanes of one register pair: v_pk_fma_f32 on the device (same roundings as two fmaf)
+struct f2 { float x, y; };
+MTR_HD f2 fma2(f2 a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f r = __builtin_elementwise_fma(v2f{ a.x, a.y }, v2f{ b, b }, v2f{ c, c });
+    return f2{ r.x, r.y };
+#else
+    return f2{ fmaf(a.x, b, c), fmaf(a.y, b, c) };
+#endif
+}
 MTR_HD uint32_t fbits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 MTR_HD float bitsf(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
@@ -293,24 +305,24 @@ MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
     const Node &n = sc.nodes[tr.cur];
     const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
     const f3 id = tr.id, noid = tr.noid;
-    // slabs of child 0 (.x lo, .z hi) and child 1 (.y lo, .w hi)
-    const float ax0 = fmaf(X.x, id.x, noid.x), ax1 = fmaf(X.y, id.x, noid.x);
-    const float bx0 = fmaf(X.z, id.x, noid.x), bx1 = fmaf(X.w, id.x, noid.x);
-    const float ay0 = fmaf(Y.x, id.y, noid.y), ay1 = fmaf(Y.y, id.y, noid.y);
-    const float by0 = fmaf(Y.z, id.y, noid.y), by1 = fmaf(Y.w, id.y, noid.y);
-    const float az0 = fmaf(Z.x, id.z, noid.z), az1 = fmaf(Z.y, id.z, noid.z);
-    const float bz0 = fmaf(Z.z, id.z, noid.z), bz1 = fmaf(Z.w, id.z, noid.z);
-    const float tn0 = fmaxf(fmaxf(fminf(ax0, bx0), fminf(ay0, by0)), fmaxf(fminf(az0, bz0), 0.0f));
-    const float tf0 = fminf(fminf(fmaxf(ax0, bx0), fmaxf(ay0, by0)), fminf(fmaxf(az0, bz0), tr.tbest));
-    const float tn1 = fmaxf(fmaxf(fminf(ax1, bx1), fminf(ay1, by1)), fmaxf(fminf(az1, bz1), 0.0f));
-    const float tf1 = fminf(fminf(fmaxf(ax1, bx1), fmaxf(ay1, by1)), fminf(fmaxf(az1, bz1), tr.tbest));
+    // slab planes of both children as packed pairs (.x child 0, .y child 1).  The reciprocal direction is finite
+    // (safe_rcp), so fma(p, id, noid) is monotonic in p: the entry plane is `lo` when id >= 0 and `hi` otherwise —
+    // selecting it by the sign gives bit for bit what min/max of the two plane distances gives, in fewer instructions.
+    const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
+    const f2 nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x), fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
+    const f2 ny = fma2(sy ? f2{ Y.z, Y.w } : f2{ Y.x, Y.y }, id.y, noid.y), fy = fma2(sy ? f2{ Y.x, Y.y } : f2{ Y.z, Y.w }, id.y, noid.y);
+    const f2 nz = fma2(sz ? f2{ Z.z, Z.w } : f2{ Z.x, Z.y }, id.z, noid.z), fz = fma2(sz ? f2{ Z.x, Z.y } : f2{ Z.z, Z.w }, id.z, noid.z);
+    const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
+    const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
+    const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
+    const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const int32_t c0 = (int32_t)fbits(C.x), c1 = (int32_t)fbits(C.y);
     const bool near0 = tn0 <= tn1;
-    const bool both = h0 & h1;
+    const bool both = h0 && h1;
     st.push_if(both, near0 ? c1 : c0);
     int32_t nxt = both ? (near0 ? c0 : c1) : (h0 ? c0 : c1);
-    if (!(h0 | h1)) nxt = st.empty() ? kTravDone : st.pop();
+    if (!(h0 || h1)) nxt = st.empty() ? kTravDone : st.pop();
     tr.cur = nxt;
 }
 
