@@ -30,7 +30,7 @@ struct mtr_ctx {
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
-    void *planes = nullptr, *q_live = nullptr, *q_mat = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
+    void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
     uint32_t n_slots = 0, P = 0, rec_cap = 0, rows = 0;
     uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
 };
@@ -226,7 +226,7 @@ void mtr_scene_destroy(mtr_scene *s)
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_mat, s->wf.counts, s->wf.rec, s->wf.rec_count };
+    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.counts, s->wf.rec, s->wf.rec_count };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
     void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets };
@@ -261,10 +261,11 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     mtr_ctx *c = s->ctx;
     WfWorkspace &w = s->wf;
     if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= n_seg && w.planes) return MTR_OK;
-    void **ptrs[] = { &w.planes, &w.q_live, &w.q_mat, &w.counts, &w.rec, &w.rec_count };
+    void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.counts, &w.rec, &w.rec_count };
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
+    HIP_TRY(c, hipMalloc(&w.q_ray, (size_t)2 * n_slots * 32));                       // rays of the live lists, in list order
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (2 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], live_total
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
@@ -302,7 +303,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
 
     WfArgs a{};
     a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
-    a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_mat = (uint32_t *)w.q_mat;
+    a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_ray = (float4 *)w.q_ray; a.q_mat = (uint32_t *)w.q_mat;
     a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
     a.G = G; a.seg = seg;

@@ -360,10 +360,21 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
     Trav tr;
     trav_init(tr, sc, o, d, tmax, st);
+#ifdef MTR_PROFILE_SIMT
+    uint32_t my_nodes = 0;
+#endif
     while (tr.cur != kTravDone) {
-        while (tr.cur >= 0) trav_node_step(tr, sc, st);
+        while (tr.cur >= 0) {
+            trav_node_step(tr, sc, st);
+#ifdef MTR_PROFILE_SIMT
+            ++my_nodes;
+#endif
+        }
         if (tr.cur != kTravDone) trav_leaf_step(tr, sc, st, ANY_HIT);
     }
+#ifdef MTR_PROFILE_SIMT
+    st.tail(my_nodes);
+#endif
     return tr.h;
 }
 

@@ -65,6 +65,7 @@ struct WfArgs {
     uint32_t parity;                     // which of the two live lists this bounce reads
     float *planes;                       // SoA state, PL_COUNT planes of n_slots
     uint32_t *q_live;                    // [2][n_slots] ping-pong live lists (slot indices), segment sg at sg * seg
+    float4 *q_ray;                       // [2][n_slots][2] the rays of the live lists IN LIST ORDER: (o, tmax) (d, eta)
     uint32_t *seg_live;                  // [2][n_seg]   their lengths
     uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit lists, same segmentation
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths

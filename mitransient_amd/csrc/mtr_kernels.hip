@@ -33,7 +33,14 @@ struct LdsStack {
     __device__ __forceinline__ void prof_mark(int) {}
 #endif
 #ifdef MTR_PROFILE_SIMT        // experiment build: lane-steps vs wave-steps of node / triangle tests
-    unsigned int ls[2], ws[2];
+    unsigned int ls[2], ws[2], wmax;
+    // wave maximum of the per-lane node-step count of one traverse() call (the floor of its wave-steps)
+    __device__ __forceinline__ void tail(unsigned int mine) {
+        unsigned int mx = 0;
+        for (int bit = 11; bit >= 0; --bit) { const unsigned int c = mx | (1u << bit); if (__ballot(mine >= c) != 0ull) mx = c; }
+        unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) wmax += mx;
+    }
     __device__ __forceinline__ void count(int k) {
         ls[k]++;
         unsigned long long m = __ballot(1);
@@ -164,7 +171,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
 
     LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
-    st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0;
+    st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0; st.wmax = 0;
 #endif
 #ifdef MTR_PROFILE_CYCLES
     for (int k = 0; k < 6; ++k) st.cyc[k] = 0;
@@ -291,6 +298,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
         unsigned long long *c = &a.counters->splats_overflow;
         atomicAdd(c + 0, ((unsigned long long)st.ls[0] << 32) | st.ws[0]);      // node: lane-steps | wave-steps... (per thread, summed)
         atomicAdd(c + 1, ((unsigned long long)st.ls[1] << 32) | st.ws[1]);
+        atomicAdd(c + 2, (unsigned long long)st.wmax);
     }
 #endif
 #ifdef MTR_PROFILE_CYCLES

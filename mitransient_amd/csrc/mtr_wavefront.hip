@@ -40,6 +40,7 @@ struct WStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ void prof_mark(int) {}
     __device__ __forceinline__ void count(int) {}
+    __device__ __forceinline__ void tail(unsigned int) {}
 };
 
 __host__ __device__ constexpr uint32_t al16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -232,6 +233,8 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
         }
         store_state(P, slot, p, true);
         a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
+        a.q_ray[2 * (size_t)slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax);
+        a.q_ray[2 * (size_t)slot + 1] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta);
     }
     for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock)
         a.seg_live[sg] = min(a.seg, a.n_slots - sg * a.seg);    // every slot of the segment is live
@@ -243,47 +246,95 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 
 // closest hit for the live lists of this bounce; every slot is appended to the list of its hit
 // material type inside its segment (sorted-by-material hit queues).
-// (Measured and dropped: lanes that fetch their next ray as soon as their own traversal ends, with the
-// next ray prefetched — same instruction count and the same 26/64 active lanes, because the while-while
-// node phase still waits for the longest node run of the wave; and the per-ray append order it needs
-// scrambled the lists, which cost k_wf_shade 40 % in gather efficiency.)
+//
+// Traversal is PERSISTENT per lane with DYNAMIC FETCH and PHASE VOTING.  Measured on the plain one-ray-per-lane
+// while-while loop (in-kernel counters, config 2): a wave spends 73 % of its node steps waiting for its slowest ray
+// (sum of per-call wave-maxima / wave steps) — mean / max lane work is 1/3 — and another 1.37x on node runs of
+// unequal length; refilling lanes alone does not help (tried first: with every lane busy the node phase still waits for
+// the longest of 64 node runs).  So: (1) a lane whose ray is finished takes the next ray of the segment's list from an
+// LDS cursor as soon as a quarter of the wave is idle; (2) every iteration the wave executes ONE step of the phase
+// that holds more lanes — an inner-node step or a leaf — instead of running each phase to completion.
+// Rays finish out of order, so the material lists are built afterwards in list order from the hit materials kept in
+// LDS (a scrambled append order costs k_wf_shade its gather coalescing).
+#ifndef MTR_WF_REFILL_MIN
+#define MTR_WF_REFILL_MIN 16
+#endif
 template <int STACK, bool SCENE_LDS>
 __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_cnt = (uint32_t *)smem;                         // [kWfKeys] list tails of the segment
+    uint32_t *s_fetch = (uint32_t *)smem + 8;                   // cursor into the segment's live list
     const int tid = threadIdx.x;
+    const uint32_t lane_id = (uint32_t)tid & 63u;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    uint8_t *s_key = (uint8_t *)(smem + off);                   // [seg] hit material type per list position
     const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
+#ifdef MTR_PROFILE_SIMT
+    unsigned long long prof[4] = { 0, 0, 0, 0 };      // node iterations, lanes in them, leaf iterations, lanes in them
+#endif
     for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
         const uint32_t n_live = a.seg_live[(size_t)par * a.n_seg + sg];
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
+        if (tid == 0) *s_fetch = 0u;
         __syncthreads();
         const uint32_t *q = a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+
+        Trav tr;
+        tr.cur = kTravDone; tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1; tr.best_orig = 0xffffffffu;
+        tr.o = mk(0, 0, 0); tr.d = mk(0, 0, 1); tr.id = mk(0, 0, 0); tr.noid = mk(0, 0, 0); tr.tmax = 0.0f; tr.tbest = 0.0f;
+        uint32_t slot = 0, pos = 0;
+        bool pending = false;                                   // a finished ray whose result is not written yet
+        const float4 *qr = a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);   // rays in list order
+        st.reset();
+        for (;;) {
+            const bool idle = tr.cur == kTravDone;
+            const unsigned long long m_idle = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__popcll(m_idle);
+            if (n_idle >= MTR_WF_REFILL_MIN) {
+                if (idle && pending) {
+                    P.q(Q_HIT, slot) = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
+                    uint32_t key = 4u;                          // miss
+                    if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tgeom[tr.h.prim].g[2].z) & 0xffffu].type;
+                    s_key[pos] = (uint8_t)key;
+                    pending = false;
+                }
+                const int leader = __ffsll((long long)m_idle) - 1;
+                uint32_t base = 0;
+                if ((int)lane_id == leader) base = atomicAdd(s_fetch, n_idle);
+                base = __shfl(base, leader);
+                const uint32_t idx = base + (uint32_t)__popcll(m_idle & ((1ull << lane_id) - 1ull));
+                if (idle && idx < n_live) {
+                    pos = idx; slot = q[idx];
+                    const float4 r0 = qr[2 * (size_t)idx], r1 = qr[2 * (size_t)idx + 1];
+                    trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, st);
+                    pending = true;
+                }
+            }
+            const bool at_node = tr.cur >= 0, at_leaf = (tr.cur < 0) & (tr.cur != kTravDone);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+            if (n_node + n_leaf == 0u) break;                   // nothing running and nothing left to fetch
+#ifdef MTR_PROFILE_SIMT
+            if (lane_id == 0) { if (n_node >= n_leaf) { prof[0] += 1; prof[1] += n_node; } else { prof[2] += 1; prof[3] += n_leaf; } }
+#endif
+            if (n_node >= n_leaf) { if (at_node) trav_node_step(tr, sv, st); }
+            else { if (at_leaf) trav_leaf_step(tr, sv, st, false); }
+        }
+        __syncthreads();
+        // material lists in list order
         const uint32_t n_round = (n_live + 63u) & ~63u;                    // whole waves stay in the loop (ballots)
         for (uint32_t i = tid; i < n_round; i += kBlock) {
             const bool on = i < n_live;
-            uint32_t slot = 0, key = kWfKeys;
-            if (on) {
-                slot = q[i];
-                float eta_unused;
-                const Ray r = load_ray(P, slot, eta_unused);
-                const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
-                P.q(Q_HIT, slot) = make_float4(h.t, h.u, h.v, __uint_as_float((uint32_t)h.prim));
-                key = 4u;                           // miss
-                if (h.prim >= 0) {
-                    const uint32_t mat_em = fbits(sv.tgeom[h.prim].g[2].z);
-                    key = sv.mats[mat_em & 0xffffu].type;          // 0 diffuse, 1 conductor, 2 dielectric, 3 none
-                }
-            }
+            const uint32_t key = on ? (uint32_t)s_key[i] : kWfKeys;
+            const uint32_t sl = on ? q[i] : 0u;
 #pragma unroll
             for (uint32_t k = 0; k < kWfKeys; ++k) {
                 const bool mine = on & (key == k);
                 if (__ballot(mine) != 0ull) {
-                    const uint32_t pos = wave_append(&s_cnt[k], mine);
-                    if (mine) a.q_mat[(size_t)k * a.n_slots + (size_t)sg * a.seg + pos] = slot;
+                    const uint32_t p2 = wave_append(&s_cnt[k], mine);
+                    if (mine) a.q_mat[(size_t)k * a.n_slots + (size_t)sg * a.seg + p2] = sl;
                 }
             }
         }
@@ -291,6 +342,12 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
         if (tid < (int)kWfKeys) a.seg_mat[(size_t)sg * kWfKeys + tid] = s_cnt[tid];
         __syncthreads();
     }
+#ifdef MTR_PROFILE_SIMT
+    if (lane_id == 0 && a.counters) {
+        atomicAdd(&a.counters->r0, (prof[0] << 32) | (prof[1] >> 6));      // node iterations | lanes / 64
+        atomicAdd(&a.counters->r1, (prof[2] << 32) | (prof[3] >> 6));
+    }
+#endif
 }
 
 // shade the material-sorted lists of every segment; survivors form the next live list
@@ -321,6 +378,7 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
         if (tid == 0) *s_next_p = 0u;
         __syncthreads();
         uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
+        float4 *r_next = a.q_ray + 2 * ((size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg);
         for (uint32_t k = 0; k < kWfKeys; ++k) {                 // one material type after the other
             const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + k];
             const uint32_t *q = a.q_mat + (size_t)k * a.n_slots + (size_t)sg * a.seg;
@@ -329,6 +387,7 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
                 const bool on = i < n_k;
                 bool alive = false;
                 uint32_t slot = 0, dir_key = 0;
+                f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1); float ray_tmax = 0.0f;
                 if (on) {
                     slot = q[i];
                     uint32_t pixel, s, pl;
@@ -358,6 +417,7 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     store_state(P, slot, p, false);
+                    ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
                     if (alive) { ++n_alive; dir_key = ray_dir_key(p.ray.d); }
                     else {
                         // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
@@ -374,7 +434,11 @@ __global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const W
 #if MTR_WF_DIRSORT
                     if (alive) s_surv[pos] = slot | (dir_key << 25);
 #else
-                    if (alive) q_next[pos] = slot;
+                    if (alive) {
+                        q_next[pos] = slot;
+                        r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, ray_tmax);
+                        r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, 0.0f);
+                    }
 #endif
                 }
             }
