@@ -188,6 +188,7 @@ struct Film {
 };
 
 struct SceneView {
+    bool node_pairs;          // scene staged in LDS: fetch the entry / exit planes of a node by sign-dependent OFFSETS
     const Node *nodes;
     const TriGeom *tgeom;
     const TriShade *tshade;
@@ -281,6 +282,7 @@ struct Trav {
     int32_t cur;
     Hit h;
     uint32_t best_orig;
+    uint32_t sel[6];      // node_pairs: byte offsets of the (entry, exit) plane pairs of x, y, z inside a node packet
 };
 
 template <class Stack>
@@ -292,6 +294,10 @@ MTR_HD void trav_init(Trav &tr, const SceneView &sc, f3 o, f3 d, float tmax, Sta
     tr.noid = mk(-(o.x * tr.id.x), -(o.y * tr.id.y), -(o.z * tr.id.z));
     tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1;
     tr.best_orig = 0xffffffffu;
+    if (sc.node_pairs) {
+        const uint32_t sx = tr.id.x < 0.0f ? 8u : 0u, sy = tr.id.y < 0.0f ? 8u : 0u, sz = tr.id.z < 0.0f ? 8u : 0u;
+        tr.sel[0] = sx; tr.sel[1] = 8u - sx; tr.sel[2] = 16u + sy; tr.sel[3] = 24u - sy; tr.sel[4] = 32u + sz; tr.sel[5] = 40u - sz;
+    }
     tr.cur = sc.n_tris ? 0 : kTravDone;
     st.reset();
 }
@@ -302,22 +308,33 @@ template <class Stack>
 MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
 {
     st.count(0);
-    const Node &n = sc.nodes[tr.cur];
-    const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
     const f3 id = tr.id, noid = tr.noid;
     // slab planes of both children as packed pairs (.x child 0, .y child 1).  The reciprocal direction is finite
     // (safe_rcp), so fma(p, id, noid) is monotonic in p: the entry plane is `lo` when id >= 0 and `hi` otherwise —
     // selecting it by the sign gives bit for bit what min/max of the two plane distances gives, in fewer instructions.
-    const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
-    const f2 nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x), fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
-    const f2 ny = fma2(sy ? f2{ Y.z, Y.w } : f2{ Y.x, Y.y }, id.y, noid.y), fy = fma2(sy ? f2{ Y.x, Y.y } : f2{ Y.z, Y.w }, id.y, noid.y);
-    const f2 nz = fma2(sz ? f2{ Z.z, Z.w } : f2{ Z.x, Z.y }, id.z, noid.z), fz = fma2(sz ? f2{ Z.x, Z.y } : f2{ Z.z, Z.w }, id.z, noid.z);
+    f2 nx, fx, ny, fy, nz, fz;
+    int32_t c0, c1;
+    if (sc.node_pairs) {      // LDS: six 8-byte reads at per-ray offsets (one address computation each) instead of selects
+        const char *nb = (const char *)sc.nodes + ((size_t)(uint32_t)tr.cur << 6);
+        nx = fma2(*(const f2 *)(nb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(nb + tr.sel[1]), id.x, noid.x);
+        ny = fma2(*(const f2 *)(nb + tr.sel[2]), id.y, noid.y); fy = fma2(*(const f2 *)(nb + tr.sel[3]), id.y, noid.y);
+        nz = fma2(*(const f2 *)(nb + tr.sel[4]), id.z, noid.z); fz = fma2(*(const f2 *)(nb + tr.sel[5]), id.z, noid.z);
+        const f2 cc = *(const f2 *)(nb + 48);
+        c0 = (int32_t)fbits(cc.x); c1 = (int32_t)fbits(cc.y);
+    } else {
+        const Node &n = sc.nodes[tr.cur];
+        const q4 X = n.q[0], Y = n.q[1], Z = n.q[2], C = n.q[3];
+        const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
+        nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x); fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
+        ny = fma2(sy ? f2{ Y.z, Y.w } : f2{ Y.x, Y.y }, id.y, noid.y); fy = fma2(sy ? f2{ Y.x, Y.y } : f2{ Y.z, Y.w }, id.y, noid.y);
+        nz = fma2(sz ? f2{ Z.z, Z.w } : f2{ Z.x, Z.y }, id.z, noid.z); fz = fma2(sz ? f2{ Z.x, Z.y } : f2{ Z.z, Z.w }, id.z, noid.z);
+        c0 = (int32_t)fbits(C.x); c1 = (int32_t)fbits(C.y);
+    }
     const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
     const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
     const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
     const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    const int32_t c0 = (int32_t)fbits(C.x), c1 = (int32_t)fbits(C.y);
     const bool near0 = tn0 <= tn1;
     const bool both = h0 && h1;
     st.push_if(both, near0 ? c1 : c0);

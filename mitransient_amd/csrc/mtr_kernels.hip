@@ -158,8 +158,10 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
         copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
         sv.nodes = n; sv.tgeom = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.node_pairs = true;
     } else {
         sv.nodes = a.sc.nodes; sv.tgeom = a.sc.tgeom; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
+        sv.node_pairs = false;
     }
     float *s_steady = (float *)(smem + off); off += align16(a.G * 16);
     float *s_hist = (float *)(smem + off);
@@ -379,6 +381,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
     sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+    sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     const uint32_t total = nlos_target_count(nc);

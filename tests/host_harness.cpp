@@ -32,12 +32,17 @@ struct HostSink {
 };
 }
 
+// both plane-fetch forms of trav_node_step (selects / sign-dependent offsets) are run through the CPU tests
+static bool g_node_pairs = false;
+extern "C" void hh_set_node_pairs(int on) { g_node_pairs = on != 0; }
+
 extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, float *t4, float *s4, mtr_counters *out)
 {
     HostScene hs;
     if (derive_scene(*d, hs)) return -1;
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.node_pairs = g_node_pairs;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -126,6 +131,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     if (derive_scene(*d, hs)) return -1;
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.node_pairs = g_node_pairs;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();

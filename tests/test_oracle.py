@@ -236,7 +236,15 @@ def test_ior_scales_optical_path(oracle):
     assert abs((b1 - b0) * 0.005 - 0.5) < 0.011
 
 
-def test_host_harness_matches_oracle_bit_for_bit(oracle, host_harness, cornell_c1):
+@pytest.fixture(params=[0, 1], ids=["plane-selects", "plane-offsets"])
+def node_pairs(request, host_harness):
+    """both forms of the node step's entry / exit plane fetch (selects for HBM scenes, sign-dependent offsets in LDS)"""
+    host_harness.hh_set_node_pairs(request.param)
+    yield request.param
+    host_harness.hh_set_node_pairs(0)
+
+
+def test_host_harness_matches_oracle_bit_for_bit(oracle, host_harness, cornell_c1, node_pairs):
     """The product's per-path arithmetic (mtr_core.h + BVH2 builder, compiled for the host by a
     test-only harness) reproduces the oracle exactly: film, steady image and every counter."""
     scene = cornell_c1
@@ -249,7 +257,7 @@ def test_host_harness_matches_oracle_bit_for_bit(oracle, host_harness, cornell_c
         assert hc[k] == cnt[k]
 
 
-def test_host_harness_specular_and_flags(oracle, host_harness):
+def test_host_harness_specular_and_flags(oracle, host_harness, node_pairs):
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     d = mitr.cornell_box()

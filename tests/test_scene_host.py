@@ -127,7 +127,16 @@ def _hh_intersect(lib, sd, o, d, maxt=None):
     return t, prim, occ
 
 
-def test_product_bvh_equals_brute_force(oracle, host_harness):
+@pytest.mark.parametrize("pairs", [0, 1])
+def test_product_bvh_equals_brute_force(oracle, host_harness, pairs):
+    host_harness.hh_set_node_pairs(pairs)
+    try:
+        _bvh_equals_brute_force(oracle, host_harness)
+    finally:
+        host_harness.hh_set_node_pairs(0)
+
+
+def _bvh_equals_brute_force(oracle, host_harness):
     """The product's SAH BVH2 + node-packet traversal returns exactly the oracle's brute-force closest
     hit (same t bits, same primitive) and the same occlusion answer, for random rays."""
     scene = make_cornell()
