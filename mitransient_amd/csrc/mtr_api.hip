@@ -166,11 +166,11 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
-    UP(hs.nodes, nodes); UP(hs.tgeom, tgeom); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
+    UP(hs.nodes, nodes); UP(hs.tpairs, tpairs); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
     s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr;
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
 #undef UP
-    s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_tris = d->n_tris;
+    s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
@@ -189,7 +189,7 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     mtr_ctx *c = s->ctx;
     HIP_TRY(c, hipSetDevice(c->device));
     mtr_scene_desc d{};
-    d.n_tris = s->dev.n_tris; d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
+    d.n_tris = (uint32_t)(s->tri_verts.size() / 9); d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
     d.film = s->film_desc;
     d.nlos = n;
     HostNlos hn;

@@ -135,8 +135,13 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
     int root = B.build(0, n);
 
     // flatten: one packet per inner Tmp node
+    // leaves are laid out in slot space: each starts on an even slot, odd leaves get a pad slot
+    out.order.clear();
     auto leaf_ref = [&](const Tmp &t) -> int32_t {
-        uint32_t code = (t.first << 2) | (t.count - 1u);
+        const uint32_t first = (uint32_t)out.order.size();
+        for (uint32_t k = 0; k < t.count; ++k) out.order.push_back(B.order[t.first + k]);
+        if (t.count & 1u) out.order.push_back(kPadSlot);
+        uint32_t code = (first << 2) | (t.count - 1u);
         return (int32_t)~code;
     };
     struct Item { int tmp; int packet; uint32_t depth; };
@@ -144,7 +149,8 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
     const Tmp &R = B.tmp[root];
     if (R.left < 0) {                        // the whole scene is one leaf
         Node nd{};
-        set_child(nd, 0, R.box, leaf_ref(R)); set_empty_child(nd, 1, leaf_ref(R));
+        const int32_t ref = leaf_ref(R);
+        set_child(nd, 0, R.box, ref); set_empty_child(nd, 1, ref);
         out.nodes.push_back(nd); out.max_depth = 1; out.n_leaves = 1;
     } else {
         out.nodes.emplace_back();
@@ -164,7 +170,6 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
             out.nodes[it.packet] = nd;
         }
     }
-    out.order = B.order;
 }
 
 } // namespace mtr

@@ -6,9 +6,13 @@
 
 namespace mtr {
 
+constexpr uint32_t kPadSlot = 0xffffffffu;
+
 struct BvhBuild {
     std::vector<Node> nodes;        // packet 0 is the root
-    std::vector<uint32_t> order;    // order[i] = original index of the triangle stored at slot i
+    // order[slot] = original index of the triangle stored at that slot; every leaf starts on an EVEN slot and a leaf with an
+    // odd triangle count is followed by one pad slot (kPadSlot)
+    std::vector<uint32_t> order;
     uint32_t max_depth = 0;         // packets on the longest root-to-leaf chain (= traversal stack bound)
     uint32_t n_leaves = 0;
 };

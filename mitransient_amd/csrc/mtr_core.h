@@ -132,6 +132,23 @@ MTR_HD f3 cosine_hemisphere(float u1, float u2)
 struct alignas(16) q4 { float x, y, z, w; };
 // two independent f32 lanes of one register pair: v_pk_fma_f32 on the device (same roundings as two fmaf)
 struct f2 { float x, y; };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+MTR_HD f2 mul2(f2 a, f2 b) { const v2f_ r = v2f_{ a.x, a.y } * v2f_{ b.x, b.y }; return f2{ r.x, r.y }; }
+MTR_HD f2 mul2(f2 a, float b) { const v2f_ r = v2f_{ a.x, a.y } * v2f_{ b, b }; return f2{ r.x, r.y }; }
+MTR_HD f2 rsub2(float a, f2 b) { const v2f_ r = v2f_{ a, a } - v2f_{ b.x, b.y }; return f2{ r.x, r.y }; }          // a - b
+MTR_HD f2 add2(f2 a, f2 b) { const v2f_ r = v2f_{ a.x, a.y } + v2f_{ b.x, b.y }; return f2{ r.x, r.y }; }
+MTR_HD f2 fma2(f2 a, f2 b, f2 c) { const v2f_ r = __builtin_elementwise_fma(v2f_{ a.x, a.y }, v2f_{ b.x, b.y }, v2f_{ c.x, c.y }); return f2{ r.x, r.y }; }
+MTR_HD f2 fma2(f2 a, float b, f2 c) { const v2f_ r = __builtin_elementwise_fma(v2f_{ a.x, a.y }, v2f_{ b, b }, v2f_{ c.x, c.y }); return f2{ r.x, r.y }; }
+#else
+MTR_HD f2 mul2(f2 a, f2 b) { return f2{ a.x * b.x, a.y * b.y }; }
+MTR_HD f2 mul2(f2 a, float b) { return f2{ a.x * b, a.y * b }; }
+MTR_HD f2 rsub2(float a, f2 b) { return f2{ a - b.x, a - b.y }; }
+MTR_HD f2 add2(f2 a, f2 b) { return f2{ a.x + b.x, a.y + b.y }; }
+MTR_HD f2 fma2(f2 a, f2 b, f2 c) { return f2{ fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y) }; }
+MTR_HD f2 fma2(f2 a, float b, f2 c) { return f2{ fmaf(a.x, b, c.x), fmaf(a.y, b, c.y) }; }
+#endif
+MTR_HD f2 neg2(f2 a) { return f2{ -a.x, -a.y }; }
 MTR_HD f2 fma2(f2 a, float b, float c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -159,15 +176,18 @@ MTR_HD void node_set_child(Node &n, int c, const float *lo, const float *hi, int
     for (int k = 0; k < 3; ++k) { f[4 * k + c] = lo[k]; f[4 * k + 2 + c] = hi[k]; }
     f[12 + c] = bitsf((uint32_t)ref);
 }
-// triangle, split by use.  Intersection record (3 quads), edges precomputed (e = p - p0, the same
-// f32 subtraction Moller-Trumbore starts with):
-//   g[0] = (p0.x, p0.y, p0.z, e1.x)  g[1] = (e1.y, e1.z, e2.x, e2.y)  g[2] = (e2.z, orig, mat_em, -)
-//   orig:   index of the triangle in the caller's array (ties on t go to the lower ORIGINAL index)
-//   mat_em: material index | (emitter index + 1) << 16
-struct alignas(16) TriGeom { q4 g[3]; };
-// shading record (4 quads): flat frame + the two other vertices (hit point = barycentric blend)
-//   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, -)
-struct alignas(16) TriShade { q4 h[4]; };
+// triangles, split by use and stored by SLOT: every leaf starts on an even slot and owns ceil(count / 2) pairs of slots
+// (an odd leaf repeats its last triangle in the pad slot; the pad is never reported as a hit).
+// Intersection record = one PAIR of slots with the two triangles interleaved, so that one 16-byte read delivers two
+// (A, B) register pairs for the packed Moller-Trumbore of trav_leaf_step; edges precomputed (e = p - p0, the same f32
+// subtraction Moller-Trumbore starts with):
+//   g[0] = (p0.x A,B  p0.y A,B)  g[1] = (p0.z A,B  e1.x A,B)  g[2] = (e1.y A,B  e1.z A,B)  g[3] = (e2.x A,B  e2.y A,B)
+//   g[4] = (e2.z A,B  orig A, orig B)     orig: index of the triangle in the caller's array (ties on t go to the lower one)
+struct alignas(16) TriPair { q4 g[5]; };
+// shading record per slot (5 quads): flat frame, the three vertices (hit point = barycentric blend), material | emitter
+//   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, p0.x)
+//   h[4] = (p0.y, p0.z, mat_em, orig)      mat_em: material index | (emitter index + 1) << 16
+struct alignas(16) TriShade { q4 h[5]; };
 struct alignas(16) Emitter {                       // 80 B
     float center[3], du[3], dv[3], n[3], radiance[3], inv_area;       // rectangle: analytic sampling
     uint32_t is_mesh, first_tri, n_tris, pad;                          // mesh: triangle range (ORIGINAL indices)
@@ -190,12 +210,12 @@ struct Film {
 struct SceneView {
     bool node_pairs;          // scene staged in LDS: fetch the entry / exit planes of a node by sign-dependent OFFSETS
     const Node *nodes;
-    const TriGeom *tgeom;
+    const TriPair *tpairs;    // [n_slots / 2]
     const TriShade *tshade;
     const mtr_material *mats;
     const Emitter *ems;
     uint32_t n_emitters;
-    uint32_t n_tris;
+    uint32_t n_slots;         // triangle slots (even; >= the triangle count)
     // area sampling of triangle meshes (mesh emitters, NLOS hidden geometry), by ORIGINAL triangle index:
     // 3 quads (p0, e1.x) (e1.yz, e2.xy) (e2.z, n) and the face distribution normalised within the mesh
     const q4 *samp_tris;
@@ -251,19 +271,6 @@ MTR_HD float safe_rcp(float x)
     return (fabsf(r) <= 1e28f) ? r : copysignf(1e28f, x);
 }
 
-// Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]
-MTR_HD bool tri_hit(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float tmax, float &t, float &u, float &v)
-{
-    f3 pvec = cross(d, e2);
-    float inv_det = 1.0f / dot(e1, pvec);
-    f3 tvec = o - p0;
-    u = dot(tvec, pvec) * inv_det;
-    f3 qvec = cross(tvec, e1);
-    v = dot(d, qvec) * inv_det;
-    t = dot(e2, qvec) * inv_det;
-    return (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= 0.0f) & (t <= tmax);
-}
-
 // ------------------------------------------------------------------------------------------
 // Resumable BVH2 traversal.  A traversal is a small per-lane state machine so that a wave can
 // interleave node steps, leaf steps and shading of DIFFERENT lanes' rays (the wave-level
@@ -271,7 +278,7 @@ MTR_HD bool tri_hit(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float tmax, float &t, float
 //   cur >= 0          : at an inner node packet         -> trav_node_step
 //   kTravDone < cur<0 : holding a leaf (not yet tested) -> trav_leaf_step
 //   cur == kTravDone  : finished, result in h
-// Culling is conservative (padded boxes, finite reciprocals): hits are decided by tri_hit alone,
+// Culling is conservative (padded boxes, finite reciprocals): hits are decided by the triangle test alone,
 // ties on t by the ORIGINAL triangle index, so the result is independent of the traversal order.
 // Stack: reset()/push_if(bool,int)/pop()/empty(); kernels keep it in LDS.
 constexpr int32_t kTravDone = (int32_t)0x80000000;
@@ -298,7 +305,7 @@ MTR_HD void trav_init(Trav &tr, const SceneView &sc, f3 o, f3 d, float tmax, Sta
         const uint32_t sx = tr.id.x < 0.0f ? 8u : 0u, sy = tr.id.y < 0.0f ? 8u : 0u, sz = tr.id.z < 0.0f ? 8u : 0u;
         tr.sel[0] = sx; tr.sel[1] = 8u - sx; tr.sel[2] = 16u + sy; tr.sel[3] = 24u - sy; tr.sel[4] = 32u + sz; tr.sel[5] = 40u - sz;
     }
-    tr.cur = sc.n_tris ? 0 : kTravDone;
+    tr.cur = sc.n_slots ? 0 : kTravDone;
     st.reset();
 }
 
@@ -351,20 +358,52 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     const uint32_t code = ~(uint32_t)tr.cur;
     const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
     bool found = false;
-    for (uint32_t i = 0; i < cnt; ++i) {
+    // Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]: pvec = cross(d, e2); inv_det = 1 / dot(e1, pvec);
+    // tvec = o - p0; u = dot(tvec, pvec) * inv_det; qvec = cross(tvec, e1); v = dot(d, qvec) * inv_det;
+    // t = dot(e2, qvec) * inv_det; hit iff 0 <= u <= 1, v >= 0, u + v <= 1, 0 <= t <= tmax  (cross and dot as fma chains).
+    // Two triangles of the leaf per pass, one in each half of a register pair (v_pk_mul/add/fma_f32): either half is bit
+    // for bit what a scalar evaluation gives; a leaf with an odd count has its last triangle repeated in the pad slot,
+    // whose result is ignored.
+    for (uint32_t i = 0; i < cnt; i += 2u) {
         st.count(1);
-        const int32_t prim = (int32_t)(first + i);
-        const TriGeom &tg = sc.tgeom[prim];
-        const q4 a = tg.g[0], b = tg.g[1], c = tg.g[2];
-        float t, u, v;
-        const bool hit = tri_hit(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), tr.o, tr.d, tr.tmax, t, u, v);
-        const uint32_t orig = fbits(c.y);
-        const bool closer = (t < tr.h.t) | ((t == tr.h.t) & (orig < tr.best_orig));
-        const bool better = hit & (any_hit ? !found : closer);
-        found |= hit;
-        tr.h.t = better ? t : tr.h.t; tr.h.u = better ? u : tr.h.u; tr.h.v = better ? v : tr.h.v;
-        tr.h.prim = better ? prim : tr.h.prim; tr.best_orig = better ? orig : tr.best_orig;
-        tr.tbest = (better & !any_hit) ? t : tr.tbest;
+        const bool two = (i + 1u) < cnt;
+        const int32_t pa = (int32_t)(first + i), pb = pa + 1;
+        const TriPair &tp = sc.tpairs[(first + i) >> 1];
+        const q4 g0 = tp.g[0], g1 = tp.g[1], g2 = tp.g[2], g3 = tp.g[3], g4 = tp.g[4];
+        const f2 p0x{ g0.x, g0.y }, p0y{ g0.z, g0.w }, p0z{ g1.x, g1.y };
+        const f2 e1x{ g1.z, g1.w }, e1y{ g2.x, g2.y }, e1z{ g2.z, g2.w };
+        const f2 e2x{ g3.x, g3.y }, e2y{ g3.z, g3.w }, e2z{ g4.x, g4.y };
+        const uint32_t orig_a = fbits(g4.z), orig_b = fbits(g4.w);
+        const f3 o = tr.o, d = tr.d;
+        // pvec = cross(d, e2)
+        const f2 pvx = fma2(e2z, d.y, neg2(mul2(e2y, d.z))), pvy = fma2(e2x, d.z, neg2(mul2(e2z, d.x))), pvz = fma2(e2y, d.x, neg2(mul2(e2x, d.y)));
+        const f2 det = fma2(e1x, pvx, fma2(e1y, pvy, mul2(e1z, pvz)));                 // dot(e1, pvec)
+        const f2 inv_det{ 1.0f / det.x, 1.0f / det.y };
+        const f2 tvx = rsub2(o.x, p0x), tvy = rsub2(o.y, p0y), tvz = rsub2(o.z, p0z);  // tvec = o - p0
+        const f2 u = mul2(fma2(tvx, pvx, fma2(tvy, pvy, mul2(tvz, pvz))), inv_det);    // dot(tvec, pvec) * inv_det
+        // qvec = cross(tvec, e1)
+        const f2 qx = fma2(tvy, e1z, neg2(mul2(tvz, e1y))), qy = fma2(tvz, e1x, neg2(mul2(tvx, e1z))), qz = fma2(tvx, e1y, neg2(mul2(tvy, e1x)));
+        const f2 v = mul2(fma2(qx, d.x, fma2(qy, d.y, mul2(qz, d.z))), inv_det);       // dot(d, qvec) * inv_det
+        const f2 t = mul2(fma2(e2x, qx, fma2(e2y, qy, mul2(e2z, qz))), inv_det);       // dot(e2, qvec) * inv_det
+        const f2 uv = add2(u, v);
+        {
+            const bool hit = (u.x >= 0.0f) && (u.x <= 1.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= 0.0f) && (t.x <= tr.tmax);
+            const bool closer = (t.x < tr.h.t) || ((t.x == tr.h.t) && (orig_a < tr.best_orig));
+            const bool better = hit && (any_hit ? !found : closer);
+            found = found || hit;
+            tr.h.t = better ? t.x : tr.h.t; tr.h.u = better ? u.x : tr.h.u; tr.h.v = better ? v.x : tr.h.v;
+            tr.h.prim = better ? pa : tr.h.prim; tr.best_orig = better ? orig_a : tr.best_orig;
+            tr.tbest = (better && !any_hit) ? t.x : tr.tbest;
+        }
+        {
+            const bool hit = two && (u.y >= 0.0f) && (u.y <= 1.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= 0.0f) && (t.y <= tr.tmax);
+            const bool closer = (t.y < tr.h.t) || ((t.y == tr.h.t) && (orig_b < tr.best_orig));
+            const bool better = hit && (any_hit ? !found : closer);
+            found = found || hit;
+            tr.h.t = better ? t.y : tr.h.t; tr.h.u = better ? u.y : tr.h.u; tr.h.v = better ? v.y : tr.h.v;
+            tr.h.prim = better ? pb : tr.h.prim; tr.best_orig = better ? orig_b : tr.best_orig;
+            tr.tbest = (better && !any_hit) ? t.y : tr.tbest;
+        }
     }
     if (any_hit & found) tr.cur = kTravDone;
     else tr.cur = st.empty() ? kTravDone : st.pop();
@@ -547,18 +586,16 @@ struct HitCtx { f3 sp, sn, ss, stt, wi; uint32_t mat, em_plus1; };
 MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
 {
     HitCtx c;
-    const TriGeom &tg = sc.tgeom[h.prim];
     const TriShade &tsd = sc.tshade[h.prim];
-    const q4 ga = tg.g[0], gc = tg.g[2];
-    const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3];
+    const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3], he = tsd.h[4];
     const float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
-    c.sp = mk(fmaf(ga.x, b0, fmaf(hc.y, b1, hd.x * b2)),
-              fmaf(ga.y, b0, fmaf(hc.z, b1, hd.y * b2)),
-              fmaf(ga.z, b0, fmaf(hc.w, b1, hd.z * b2)));
+    c.sp = mk(fmaf(hd.w, b0, fmaf(hc.y, b1, hd.x * b2)),
+              fmaf(he.x, b0, fmaf(hc.z, b1, hd.y * b2)),
+              fmaf(he.y, b0, fmaf(hc.w, b1, hd.z * b2)));
     c.sn = mk(ha.x, ha.y, ha.z); c.ss = mk(ha.w, hb.x, hb.y); c.stt = mk(hb.z, hb.w, hc.x);
     const f3 md = -ray_d;
     c.wi = mk(dot(md, c.ss), dot(md, c.stt), dot(md, c.sn));
-    const uint32_t mat_em = fbits(gc.z);
+    const uint32_t mat_em = fbits(he.z);
     c.mat = mat_em & 0xffffu; c.em_plus1 = mat_em >> 16;
     return c;
 }

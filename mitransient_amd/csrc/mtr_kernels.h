@@ -14,7 +14,7 @@ struct DevCounters {                 // device mirror of mtr_counters (u64 atomi
 
 struct SceneDev {
     const Node *nodes; uint32_t n_nodes;
-    const TriGeom *tgeom; const TriShade *tshade; uint32_t n_tris;
+    const TriPair *tpairs; const TriShade *tshade; uint32_t n_slots;   // triangle slots (even), see mtr_core.h
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;
     const q4 *samp_tris; const float *face_pmf, *face_cdf;   // mesh-emitter sampling tables (HBM; null without mesh emitters)

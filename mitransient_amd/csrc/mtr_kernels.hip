@@ -144,23 +144,23 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     unsigned long long *s_cnt = (unsigned long long *)(smem + off); off += 64;    // 5 counters + next
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
-    sv.n_emitters = a.sc.n_ems; sv.n_tris = a.sc.n_tris;
+    sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
     sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf;
     if (SCENE_LDS) {
         Node *n = (Node *)(smem + off); off += align16(a.sc.n_nodes * sizeof(Node));
-        TriGeom *tg = (TriGeom *)(smem + off); off += align16(a.sc.n_tris * sizeof(TriGeom));
-        TriShade *ts = (TriShade *)(smem + off); off += align16(a.sc.n_tris * sizeof(TriShade));
+        TriPair *tg = (TriPair *)(smem + off); off += align16(a.sc.n_slots / 2 * sizeof(TriPair));
+        TriShade *ts = (TriShade *)(smem + off); off += align16(a.sc.n_slots * sizeof(TriShade));
         mtr_material *mm = (mtr_material *)(smem + off); off += align16(a.sc.n_mats * sizeof(mtr_material));
         Emitter *ee = (Emitter *)(smem + off); off += align16(a.sc.n_ems * sizeof(Emitter));
         copy16(n, a.sc.nodes, align16(a.sc.n_nodes * sizeof(Node)), tid);
-        copy16(tg, a.sc.tgeom, align16(a.sc.n_tris * sizeof(TriGeom)), tid);
-        copy16(ts, a.sc.tshade, align16(a.sc.n_tris * sizeof(TriShade)), tid);
+        copy16(tg, a.sc.tpairs, align16(a.sc.n_slots / 2 * sizeof(TriPair)), tid);
+        copy16(ts, a.sc.tshade, align16(a.sc.n_slots * sizeof(TriShade)), tid);
         copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = n; sv.tgeom = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
     } else {
-        sv.nodes = a.sc.nodes; sv.tgeom = a.sc.tgeom; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
+        sv.nodes = a.sc.nodes; sv.tpairs = a.sc.tpairs; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
         sv.node_pairs = false;
     }
     float *s_steady = (float *)(smem + off); off += align16(a.G * 16);
@@ -316,8 +316,8 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
 
 static uint32_t scene_lds_bytes(const SceneDev &sc)
 {
-    return align16(sc.n_nodes * sizeof(Node)) + align16(sc.n_tris * sizeof(TriGeom)) +
-           align16(sc.n_tris * sizeof(TriShade)) + align16(sc.n_mats * sizeof(mtr_material)) +
+    return align16(sc.n_nodes * sizeof(Node)) + align16(sc.n_slots / 2 * sizeof(TriPair)) +
+           align16(sc.n_slots * sizeof(TriShade)) + align16(sc.n_mats * sizeof(mtr_material)) +
            align16(sc.n_ems * sizeof(Emitter));
 }
 
@@ -380,9 +380,9 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
-    sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+    sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
     sv.node_pairs = false;
-    sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     const uint32_t total = nlos_target_count(nc);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {

@@ -64,22 +64,27 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     BvhBuild bvh;
     build_bvh(d.tri_verts, d.n_tris, bvh);
     s.nodes = bvh.nodes; s.bvh_depth = bvh.max_depth; s.n_leaves = bvh.n_leaves;
-    s.tgeom.resize(d.n_tris); s.tshade.resize(d.n_tris);
-    for (uint32_t slot = 0; slot < d.n_tris; ++slot) {
-        const uint32_t o = bvh.order[slot];
+    const uint32_t n_slots = (uint32_t)bvh.order.size();
+    s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
+    for (uint32_t slot = 0; slot < n_slots; ++slot) {
+        const uint32_t o = bvh.order[slot] != kPadSlot ? bvh.order[slot] : bvh.order[slot - 1];   // pad: repeat the leaf's last triangle
+        s.slot_orig[slot] = o;
         const float *v = d.tri_verts + 9 * (size_t)o;
-        TriGeom &g = s.tgeom[slot]; TriShade &h = s.tshade[slot];
+        TriShade &h = s.tshade[slot];
         const uint32_t mat_em = d.tri_material[o] | ((uint32_t)(d.tri_emitter[o] + 1) << 16);
         // flat frame: n = normalize(e1 x e2), s = normalize(e1), t = n x s   (f32, contract in DESIGN.md)
         f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
         f3 n = normalize(cross(e1, e2)), sdir = normalize(e1), t = cross(n, sdir);
-        g.g[0] = q4{ p0.x, p0.y, p0.z, e1.x };
-        g.g[1] = q4{ e1.y, e1.z, e2.x, e2.y };
-        g.g[2] = q4{ e2.z, bitsf(o), bitsf(mat_em), 0.0f };
+        float *g = &s.tpairs[slot >> 1].g[0].x;            // interleaved pair record: dword 2*k + half
+        const float comp[9] = { p0.x, p0.y, p0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };
+        const uint32_t half = slot & 1u;
+        for (int k = 0; k < 9; ++k) g[2 * k + half] = comp[k];
+        g[18 + half] = bitsf(o);
         h.h[0] = q4{ n.x, n.y, n.z, sdir.x };
         h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
         h.h[2] = q4{ t.z, v[3], v[4], v[5] };
-        h.h[3] = q4{ v[6], v[7], v[8], 0.0f };
+        h.h[3] = q4{ v[6], v[7], v[8], p0.x };
+        h.h[4] = q4{ p0.y, p0.z, bitsf(mat_em), bitsf(o) };
     }
     s.ems.resize(d.n_emitters);
     for (uint32_t i = 0; i < d.n_emitters; ++i) {

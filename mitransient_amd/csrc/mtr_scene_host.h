@@ -12,8 +12,9 @@ namespace mtr {
 
 struct HostScene {
     std::vector<Node> nodes;
-    std::vector<TriGeom> tgeom;
-    std::vector<TriShade> tshade;
+    std::vector<TriPair> tpairs;               // [n_slots / 2]
+    std::vector<TriShade> tshade;              // [n_slots]
+    std::vector<uint32_t> slot_orig;           // [n_slots] original triangle index (pad slots: the triangle they repeat)
     std::vector<mtr_material> mats;
     std::vector<Emitter> ems;
     std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView

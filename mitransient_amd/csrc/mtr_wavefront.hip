@@ -60,24 +60,24 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     // __shared__ in front of it would shift the base and mis-align the ds_read_b128 node fetches)
     off = 64;                                                   // smem[0..63]: workgroup counters
     int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
-    sv.n_emitters = sc.n_ems; sv.n_tris = sc.n_tris;
+    sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     if (SCENE_LDS) {
         Node *n = (Node *)(smem + off); off += al16(sc.n_nodes * sizeof(Node));
-        TriGeom *tg = (TriGeom *)(smem + off); off += al16(sc.n_tris * sizeof(TriGeom));
-        TriShade *ts = (TriShade *)(smem + off); off += al16(sc.n_tris * sizeof(TriShade));
+        TriPair *tg = (TriPair *)(smem + off); off += al16(sc.n_slots / 2 * sizeof(TriPair));
+        TriShade *ts = (TriShade *)(smem + off); off += al16(sc.n_slots * sizeof(TriShade));
         mtr_material *mm = (mtr_material *)(smem + off); off += al16(sc.n_mats * sizeof(mtr_material));
         Emitter *ee = (Emitter *)(smem + off); off += al16(sc.n_ems * sizeof(Emitter));
         cp16(n, sc.nodes, al16(sc.n_nodes * sizeof(Node)), tid);
-        cp16(tg, sc.tgeom, al16(sc.n_tris * sizeof(TriGeom)), tid);
-        cp16(ts, sc.tshade, al16(sc.n_tris * sizeof(TriShade)), tid);
+        cp16(tg, sc.tpairs, al16(sc.n_slots / 2 * sizeof(TriPair)), tid);
+        cp16(ts, sc.tshade, al16(sc.n_slots * sizeof(TriShade)), tid);
         cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
         cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = n; sv.tgeom = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = false;        // measured: the 6 offset registers cost k_wf_trace more than the selects (+2.5 %)
         __syncthreads();
     } else {
-        sv.nodes = sc.nodes; sv.tgeom = sc.tgeom; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+        sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
         sv.node_pairs = false;
     }
     st.base = s_stack + tid; st.sp = 0;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
                 if (idle && pending) {
                     P.q(Q_HIT, slot) = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
                     uint32_t key = 4u;                          // miss
-                    if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tgeom[tr.h.prim].g[2].z) & 0xffffu].type;
+                    if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
                     s_key[pos] = (uint8_t)key;
                     pending = false;
                 }
@@ -353,11 +353,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 }
 
 // shade the material-sorted lists of every segment; survivors form the next live list
-#ifndef MTR_WF_SHADE_WAVES
-#define MTR_WF_SHADE_WAVES 4
-#endif
+// waves per SIMD the register allocator leaves room for: a scene in HBM/L2 needs the occupancy to hide its latency
+// (4: 425 ms vs 3: 452 ms on the staircase); with the scene in LDS the 168 registers of 3 waves avoid 29 spilled
+// dwords (187 ms vs 215 ms per config-2 render)
 template <int STACK, bool SCENE_LDS>
-__global__ void __launch_bounds__(kBlock, MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_next_p = (uint32_t *)smem;                      // tail of the segment's next live list
@@ -607,7 +607,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 {
     if (sc.bvh_depth > 64) return false;
     cfg.stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
-    uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_tris * sizeof(TriGeom)) + al16(sc.n_tris * sizeof(TriShade)) +
+    uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_slots / 2 * sizeof(TriPair)) + al16(sc.n_slots * sizeof(TriShade)) +
                        al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
     cfg.scene_lds = scene_b <= 64u * 1024u;
     cfg.lds_bytes = 64 + (size_t)(cfg.stack + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;

@@ -41,10 +41,10 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     HostScene hs;
     if (derive_scene(*d, hs)) return -1;
     SceneView sv;
-    sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
-    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
     HostSink sink{ t4, hs.film.width, hs.film.bins, 0 };
@@ -130,17 +130,17 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     HostScene hs;
     if (derive_scene(*d, hs)) return -1;
     SceneView sv;
-    sv.nodes = hs.nodes.data(); sv.tgeom = hs.tgeom.data(); sv.tshade = hs.tshade.data();
+    sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
-    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_tris = (uint32_t)hs.tgeom.size();
+    sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     ArrStack st; st.sp = 0;
     for (uint32_t i = 0; i < n; ++i) {
         f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
         float mt = maxt ? maxt[i] : kInf;
         Hit h = traverse<false>(sv, o, dd, mt, st);
-        t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)fbits(hs.tgeom[h.prim].g[2].y) : -1;
+        t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)hs.slot_orig[h.prim] : -1;
         Hit a = traverse<true>(sv, o, dd, mt, st);
         occ_out[i] = a.prim >= 0;
     }
