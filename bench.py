@@ -62,7 +62,8 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
     # (brute force over the 36 triangles / its own BVH); the faster one runs the bounded sample
     oracle.render(sd, integ.render_params(film, 0, spp_total, 0, 1), use_bvh=True, out=bufs)
     best = None
-    for use_bvh in (True, False):
+    # (brute force is only a candidate for tiny scenes: it is O(triangles) per ray)
+    for use_bvh in ((True, False) if sd.tri_verts.shape[0] <= 256 else (True,)):
         t0 = time.perf_counter()
         oracle.render(sd, integ.render_params(film, 0, spp_total, 1, 3), use_bvh=use_bvh, out=bufs)
         dt2 = max(time.perf_counter() - t0, 1e-3) / 2.0
