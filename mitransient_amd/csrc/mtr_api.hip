@@ -284,9 +284,12 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     if (!wf_plan(s->dev, cfg)) return fail(c, MTR_ERR_UNSUPPORTED, "wavefront: BVH too deep for the LDS stack");
     const uint32_t n_pixels = p->pixel_end - p->pixel_begin;
     const uint32_t spp_chunk = p->spp_end - p->spp_begin;
-    // tile = P pixels x S samples (about 2^22 slots); segment = G whole pixels (about 1024 slots)
-    uint32_t kTileSlots = 1u << 25; const uint32_t kSegSlots = 1024u;      // measured: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms per config-2 render
+    // tile = P pixels x S samples (2^25 slots); segment = G whole pixels (about 4096 slots: with the persistent
+    // k_wf_trace a segment is drained once per launch, so longer segments waste less — staircase 1024: 425 ms,
+    // 2048: 390, 4096: 360, 8192: 397)
+    uint32_t kTileSlots = 1u << 25; uint32_t kSegSlots = 4096u;      // tiles measured: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms per config-2 render
     if (const char *e = getenv("MTR_WF_TILE_LOG2")) kTileSlots = 1u << atoi(e);      // experiments
+    if (const char *e = getenv("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
     const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
     const uint32_t G = (kSegSlots + S - 1) / S;
     uint32_t P = kTileSlots / S; if (P < G) P = G; if (P > n_pixels) P = n_pixels;

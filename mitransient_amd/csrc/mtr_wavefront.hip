@@ -134,18 +134,6 @@ __device__ __forceinline__ void slot_to_lane(const WfArgs &a, uint32_t slot, uin
 
 // ray-direction class used to order the next live list (coherent waves in the next trace):
 // octant of the direction (3 bits) and its dominant axis (2 bits)
-#ifndef MTR_WF_DIRSORT
-#define MTR_WF_DIRSORT 0          // measured on config 2: trace 63 -> 57 ms but shade 93 -> 142 ms (scrambled gathers): off
-#endif
-constexpr uint32_t kDirKeys = 32;
-__device__ __forceinline__ uint32_t ray_dir_key(f3 d)
-{
-    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    const uint32_t dom = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
-    return oct | (dom << 3);
-}
-
 // ---- wave64 aggregated append: one atomic per (wave, key) ---------------------------------
 __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
 {
@@ -366,9 +354,6 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
     float *s_steady = (float *)(smem + off + al16(a.G * 4u));   // [G][4] radiance sums of the paths that end here
-    // survivors of the segment, staged in LDS so that they can be written out sorted by ray-direction class
-    uint32_t *s_surv = (uint32_t *)(smem + off + al16(a.G * 4u) + al16(a.G * 16u));      // [seg] slot | key << 25
-    uint32_t *s_key = (uint32_t *)smem + 4;                     // [kDirKeys] histogram / cursors (smem[16..])
     const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
@@ -388,7 +373,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
             for (uint32_t i = tid; i < n_round; i += kBlock) {
                 const bool on = i < n_k;
                 bool alive = false;
-                uint32_t slot = 0, dir_key = 0;
+                uint32_t slot = 0;
                 f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1); float ray_tmax = 0.0f;
                 if (on) {
                     slot = q[i];
@@ -420,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     store_state(P, slot, p, false);
                     ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
-                    if (alive) { ++n_alive; dir_key = ray_dir_key(p.ray.d); }
+                    if (alive) ++n_alive;
                     else {
                         // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
                         float *sp = s_steady + 4 * (pl - pl0);
@@ -433,35 +418,15 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                 // wave64 stream compaction of the survivors into the segment's next live list
                 if (__ballot(alive) != 0ull) {
                     const uint32_t pos = wave_append(s_next_p, alive);
-#if MTR_WF_DIRSORT
-                    if (alive) s_surv[pos] = slot | (dir_key << 25);
-#else
                     if (alive) {
                         q_next[pos] = slot;
                         r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, ray_tmax);
                         r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, 0.0f);
                     }
-#endif
                 }
             }
         }
         __syncthreads();
-#if MTR_WF_DIRSORT
-        {   // counting sort of the survivors by direction class: coherent waves for the next k_wf_trace
-            const uint32_t m = *s_next_p;
-            if (tid < (int)kDirKeys) s_key[tid] = 0u;
-            __syncthreads();
-            for (uint32_t t = tid; t < m; t += kBlock) atomicAdd(&s_key[s_surv[t] >> 25], 1u);
-            __syncthreads();
-            if (tid == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < kDirKeys; ++k) { uint32_t c = s_key[k]; s_key[k] = acc; acc += c; } }
-            __syncthreads();
-            for (uint32_t t = tid; t < m; t += kBlock) {
-                const uint32_t e = s_surv[t];
-                q_next[atomicAdd(&s_key[e >> 25], 1u)] = e & 0x1ffffffu;
-            }
-            __syncthreads();
-        }
-#endif
         if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
@@ -592,7 +557,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
-    lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg * 4u);   // k_wf_shade: record-list tails, steady sums, survivor staging
+    lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
