@@ -30,7 +30,7 @@ struct mtr_ctx {
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
-    void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
+    void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *q_shadow = nullptr, *r_shadow = nullptr, *occ = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
     uint32_t n_slots = 0, P = 0, rec_cap = 0, rows = 0;
     uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
 };
@@ -226,7 +226,7 @@ void mtr_scene_destroy(mtr_scene *s)
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.counts, s->wf.rec, s->wf.rec_count };
+    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
     void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets };
@@ -261,13 +261,16 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     mtr_ctx *c = s->ctx;
     WfWorkspace &w = s->wf;
     if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= n_seg && w.planes) return MTR_OK;
-    void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.counts, &w.rec, &w.rec_count };
+    void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.q_shadow, &w.r_shadow, &w.occ, &w.counts, &w.rec, &w.rec_count };
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.q_ray, (size_t)2 * n_slots * 32));                       // rays of the live lists, in list order
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
-    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (2 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], live_total
+    HIP_TRY(c, hipMalloc(&w.q_shadow, (size_t)n_slots * 4));
+    HIP_TRY(c, hipMalloc(&w.r_shadow, (size_t)n_slots * 32));
+    HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots));
+    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (3 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
     if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
@@ -307,6 +310,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     WfArgs a{};
     a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
     a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_ray = (float4 *)w.q_ray; a.q_mat = (uint32_t *)w.q_mat;
+    a.q_shadow = (uint32_t *)w.q_shadow; a.r_shadow = (float4 *)w.r_shadow; a.occ = (uint8_t *)w.occ;
     a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
     a.G = G; a.seg = seg;
@@ -327,7 +331,8 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             a.n_seg = (Pcur + G - 1) / G;
             a.seg_live = (uint32_t *)w.counts;
             a.seg_mat = (uint32_t *)w.counts + (size_t)2 * a.n_seg;
-            uint32_t *live_total = (uint32_t *)w.counts + (size_t)(2 + kWfKeys) * a.n_seg;
+            a.seg_shadow = (uint32_t *)w.counts + (size_t)(2 + kWfKeys) * a.n_seg;
+            uint32_t *live_total = (uint32_t *)w.counts + (size_t)(3 + kWfKeys) * a.n_seg;
             a.live_total = unbounded ? live_total : nullptr;
             const int grid = (int)std::min<uint32_t>(a.n_seg, (uint32_t)grid_full);
             const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
@@ -337,8 +342,15 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             uint32_t depth = 0;
             while (depth < max_depth) {
                 if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
+                a.trace_any = 0u;
                 HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));                   // closest hit + material lists
-                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));                   // shade + compaction
+                if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
+                    HIP_TRY(c, launch_wf(a, cfg, 4, grid, c->stream));               // shadow rays of the emitter samples
+                    a.trace_any = 1u;
+                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));               // their occlusion
+                    *n_trace += 2;
+                }
+                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));                   // shade (+ inline shadow rays when the scene is in LDS) + compaction
                 *n_trace += 2;
                 a.parity ^= 1u;
                 ++depth;

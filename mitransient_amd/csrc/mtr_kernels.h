@@ -68,6 +68,11 @@ struct WfArgs {
     float4 *q_ray;                       // [2][n_slots][2] the rays of the live lists IN LIST ORDER: (o, tmax) (d, eta)
     uint32_t *seg_live;                  // [2][n_seg]   their lengths
     uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit lists, same segmentation
+    uint32_t *q_shadow;                  // [n_slots] slots whose vertex emits a shadow ray this bounce, same segmentation
+    float4 *r_shadow;                    // [n_slots][2] those shadow rays, in list order: (o, tmax) (d, -)
+    uint32_t *seg_shadow;                // [n_seg] their counts
+    uint8_t *occ;                        // [n_slots] shadow-ray result per slot: 1 = occluded
+    uint32_t trace_any;                  // k_wf_trace: 0 closest hits of the live lists, 1 occlusion of the shadow lists
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths
     uint32_t *live_total;                // optional: number of survivors of this bounce (unbounded-depth renders)
     uint4 *rec;                          // [P][rec_cap] time-bin records (bin, r, g, b)
@@ -82,7 +87,8 @@ struct WfConfig { int stack; bool scene_lds; size_t lds_bytes; };
 
 size_t wf_planes_bytes(uint32_t n_slots);
 bool wf_plan(const SceneDev &sc, WfConfig &cfg);
-// which: 0 raygen, 1 trace (closest hit + material-sorted queues), 2 shade, 3 time-bin scatter-add
+// which: 0 raygen, 1 trace (closest hit + material-sorted queues, or occlusion when a.trace_any), 2 shade,
+// 3 time-bin scatter-add, 4 shadow-ray generation
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream);
 
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,

@@ -265,19 +265,21 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 #ifdef MTR_PROFILE_SIMT
     unsigned long long prof[4] = { 0, 0, 0, 0 };      // node iterations, lanes in them, leaf iterations, lanes in them
 #endif
+    const bool any_hit = a.trace_any != 0u;         // occlusion of this bounce's shadow rays instead of closest hits
     for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
-        const uint32_t n_live = a.seg_live[(size_t)par * a.n_seg + sg];
+        const uint32_t n_live = any_hit ? a.seg_shadow[sg] : a.seg_live[(size_t)par * a.n_seg + sg];
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
         if (tid == 0) *s_fetch = 0u;
         __syncthreads();
-        const uint32_t *q = a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+        const uint32_t *q = any_hit ? a.q_shadow + (size_t)sg * a.seg : a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
 
         Trav tr;
         tr.cur = kTravDone; tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1; tr.best_orig = 0xffffffffu;
         tr.o = mk(0, 0, 0); tr.d = mk(0, 0, 1); tr.id = mk(0, 0, 0); tr.noid = mk(0, 0, 0); tr.tmax = 0.0f; tr.tbest = 0.0f;
         uint32_t slot = 0, pos = 0;
         bool pending = false;                                   // a finished ray whose result is not written yet
-        const float4 *qr = a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);   // rays in list order
+        const float4 *qr = any_hit ? a.r_shadow + 2 * (size_t)sg * a.seg
+                                   : a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);   // rays in list order
         st.reset();
         for (;;) {
             const bool idle = tr.cur == kTravDone;
@@ -285,10 +287,13 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
             const uint32_t n_idle = (uint32_t)__popcll(m_idle);
             if (n_idle >= MTR_WF_REFILL_MIN) {
                 if (idle && pending) {
-                    P.q(Q_HIT, slot) = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
-                    uint32_t key = 4u;                          // miss
-                    if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
-                    s_key[pos] = (uint8_t)key;
+                    if (any_hit) a.occ[slot] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
+                    else {
+                        P.q(Q_HIT, slot) = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
+                        uint32_t key = 4u;                      // miss
+                        if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
+                        s_key[pos] = (uint8_t)key;
+                    }
                     pending = false;
                 }
                 const int leader = __ffsll((long long)m_idle) - 1;
@@ -310,11 +315,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
             if (lane_id == 0) { if (n_node >= n_leaf) { prof[0] += 1; prof[1] += n_node; } else { prof[2] += 1; prof[3] += n_leaf; } }
 #endif
             if (n_node >= n_leaf) { if (at_node) trav_node_step(tr, sv, st); }
-            else { if (at_leaf) trav_leaf_step(tr, sv, st, false); }
+            else { if (at_leaf) trav_leaf_step(tr, sv, st, any_hit); }
         }
         __syncthreads();
         // material lists in list order
-        const uint32_t n_round = (n_live + 63u) & ~63u;                    // whole waves stay in the loop (ballots)
+        const uint32_t n_round = any_hit ? 0u : (n_live + 63u) & ~63u;     // whole waves stay in the loop (ballots)
         for (uint32_t i = tid; i < n_round; i += kBlock) {
             const bool on = i < n_live;
             const uint32_t key = on ? (uint32_t)s_key[i] : kWfKeys;
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
             }
         }
         __syncthreads();
-        if (tid < (int)kWfKeys) a.seg_mat[(size_t)sg * kWfKeys + tid] = s_cnt[tid];
+        if (!any_hit && tid < (int)kWfKeys) a.seg_mat[(size_t)sg * kWfKeys + tid] = s_cnt[tid];
         __syncthreads();
     }
 #ifdef MTR_PROFILE_SIMT
@@ -338,6 +343,63 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
         atomicAdd(&a.counters->r1, (prof[2] << 32) | (prof[3] >> 6));
     }
 #endif
+}
+
+// shadow rays of this bounce: shade_hit (emitter sampling, transientpath.py:185-218) is re-run on the diffuse list with
+// a null sink, only to learn which vertices emit a shadow ray and which; the rays go, in list order, to the segment's
+// shadow list for k_wf_trace (occlusion), and k_wf_shade re-runs shade_hit for real with the answer in `occ`.
+// (Shadow rays traced inside k_wf_shade, one traverse<true>() per lane, were 83 % of that kernel on the staircase —
+// 169 of 204 ms — for the same reason as closest hits: lanes waiting for the slowest ray of their wave.)
+template <int STACK, bool SCENE_LDS>
+__global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_tail = (uint32_t *)smem;
+    const int tid = threadIdx.x;
+    SceneView sv; WStack<STACK> st; uint32_t off;
+    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    const Planes P{ (float4 *)a.planes, a.n_slots };
+    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+        if (tid == 0) *s_tail = 0u;
+        __syncthreads();
+        const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
+        const uint32_t *q = a.q_mat + (size_t)sg * a.seg;
+        uint32_t *q_out = a.q_shadow + (size_t)sg * a.seg;
+        float4 *r_out = a.r_shadow + 2 * (size_t)sg * a.seg;
+        const uint32_t n_round = (n_k + 63u) & ~63u;
+        for (uint32_t i = tid; i < n_round; i += kBlock) {
+            bool want = false;
+            uint32_t slot = 0;
+            Ray shadow;
+            shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
+            if (i < n_k) {
+                slot = q[i];
+                uint32_t pixel, s, pl;
+                slot_to_lane(a, slot, pixel, s, pl);
+                Path p;
+                load_state(P, slot, p);
+                const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                Hit h;
+                { const float4 hq = P.q(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
+                NullSink sink;
+                Pending pd;
+                shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                want = pd.has_shadow != 0u;
+            }
+            if (__ballot(want) != 0ull) {
+                const uint32_t pos = wave_append(s_tail, want);
+                if (want) {
+                    q_out[pos] = slot;
+                    r_out[2 * (size_t)pos] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.tmax);
+                    r_out[2 * (size_t)pos + 1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) a.seg_shadow[sg] = *s_tail;
+        __syncthreads();
+    }
 }
 
 // shade the material-sorted lists of every segment; survivors form the next live list
@@ -397,8 +459,10 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
-                        Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
-                        occluded = sh.prim >= 0;
+                        if (SCENE_LDS) {                  // short rays out of LDS: tracing them right here is cheaper (config 2: 168 vs 243 ms)
+                            Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                            occluded = sh.prim >= 0;
+                        } else occluded = a.occ[slot] != 0;   // traced by k_wf_trace from the list k_wf_shadow_gen wrote (staircase: 360 vs 300 ms)
                     }
                     alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
@@ -556,7 +620,8 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
 template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
-    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL> : k_wf_shade<STACK, SL>;
+    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
+                            : which == 4 ? k_wf_shadow_gen<STACK, SL> : k_wf_shade<STACK, SL>;
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -579,7 +644,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
     return true;
 }
 
-// which: 0 raygen, 1 trace, 2 shade, 3 scatter
+// which: 0 raygen, 1 trace, 2 shade, 3 scatter, 4 shadow-ray generation
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
 {
     if (which == 3) {
