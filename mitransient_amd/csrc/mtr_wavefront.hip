@@ -59,7 +59,9 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     // all LDS scratch lives in the dynamic region, every carve offset a multiple of 16 (a static
     // __shared__ in front of it would shift the base and mis-align the ds_read_b128 node fetches)
     off = 64;                                                   // smem[0..63]: workgroup counters
-    int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
+    // the traversal stack holds at most bvh_depth entries per lane (+1: push_if writes before it counts); sized exactly,
+    // not by the STACK class, so that a depth-27 tree leaves room for 5 workgroups per CU instead of 4
+    int32_t *s_stack = (int32_t *)(smem + off); off += (sc.bvh_depth + 1u) * kBlock * 4u;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     if (SCENE_LDS) {
@@ -640,7 +642,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
     uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_slots / 2 * sizeof(TriPair)) + al16(sc.n_slots * sizeof(TriShade)) +
                        al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
     cfg.scene_lds = scene_b <= 64u * 1024u;
-    cfg.lds_bytes = 64 + (size_t)(cfg.stack + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
+    cfg.lds_bytes = 64 + (size_t)(sc.bvh_depth + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
     return true;
 }
 

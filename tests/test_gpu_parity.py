@@ -493,3 +493,23 @@ def test_staircase_config5_geometry(oracle, mode):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("max_depth,rr_depth,unwarp", [(1, 5, False), (2, 5, True), (3, 1, False), (-1, 2, True)])
+def test_hbm_scene_wavefront_depths(oracle, max_depth, rr_depth, unwarp):
+    """the wavefront pipeline of scenes in HBM/L2 (k_wf_trace closest -> k_wf_shadow_gen -> k_wf_trace any-hit ->
+    k_wf_shade) at the depth edge cases: no emitter sampling at all (max_depth 1), one bounce, early Russian
+    roulette, unbounded depth (host polls the live count); ragged film so that the last segment is partial"""
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scenes import staircase_like
+    d = staircase_like(n_steps=12, balusters=2, tiles=6, width=37, height=23, temporal_bins=48, spp=6, max_depth=max_depth)
+    d["integrator"].update(amd_mode="wavefront", rr_depth=rr_depth, camera_unwarp=unwarp)
+    scene = mi.load_dict(d)
+    s_gpu, t_gpu = gpu_render(scene, 6, seed=3)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 6, seed=3)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+    if max_depth == 1:
+        assert cnt["rays_shadow"] == 0
