@@ -388,7 +388,7 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
         const f2 uv = add2(u, v);
         {
             const bool hit = (u.x >= 0.0f) && (u.x <= 1.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= 0.0f) && (t.x <= tr.tmax);
-            const bool closer = (t.x < tr.h.t) || ((t.x == tr.h.t) && (orig_a < tr.best_orig));
+            const bool closer = (t.x < tr.h.t) | ((t.x == tr.h.t) & (orig_a < tr.best_orig));      // bitwise: no branches for three compares
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;
             tr.h.t = better ? t.x : tr.h.t; tr.h.u = better ? u.x : tr.h.u; tr.h.v = better ? v.x : tr.h.v;
@@ -397,7 +397,7 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
         }
         {
             const bool hit = two && (u.y >= 0.0f) && (u.y <= 1.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= 0.0f) && (t.y <= tr.tmax);
-            const bool closer = (t.y < tr.h.t) || ((t.y == tr.h.t) && (orig_b < tr.best_orig));
+            const bool closer = (t.y < tr.h.t) | ((t.y == tr.h.t) & (orig_b < tr.best_orig));
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;
             tr.h.t = better ? t.y : tr.h.t; tr.h.u = better ? u.y : tr.h.u; tr.h.v = better ? v.y : tr.h.v;
