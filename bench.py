@@ -85,7 +85,7 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
 
 def traffic_from_profiles(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools_profile.sh: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    tools/profile.sh: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no profile of this kernel is committed: bench.py itself cannot collect PMC counters."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_ab.sh lib1.so lib2.so ... — A/B the config-2 render time of kernel variants on the GPU box
+# tools/ab.sh lib1.so lib2.so ... — A/B the config-2 render time of kernel variants on the GPU box
 for lib in "$@"; do
   MITRANSIENT_AMD_LIB=$(pwd)/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json

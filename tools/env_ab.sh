@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_env_ab.sh VAR v1 v2 ... : A/B an environment knob
+# tools/env_ab.sh VAR v1 v2 ... : A/B an environment knob
 VAR=$1; shift
 for v in "$@"; do
   env $VAR=$v python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_pmc.sh <lib.so> <tag>: quick SQ counter pass for the path kernel
+# tools/pmc.sh <lib.so> <tag>: quick SQ counter pass for the path kernel
 LIB=$(pwd)/$1; TAG=$2; shift; shift; EXTRA="$@"; REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $EXTRA"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_profile.sh <tag> [bench args...] — kernel-trace stats + PMC passes for bench.py on the GPU box.
+# tools/profile.sh <tag> [bench args...] — kernel-trace stats + PMC passes for bench.py on the GPU box.
 # Outputs summaries under gpurun_out/prof_<tag>/ (copy what should be judged into profiles/).
 TAG=$1; shift
 REPO=$(pwd)
