@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 4
+#define MTR_ABI_VERSION 5
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -88,6 +88,13 @@ typedef struct mtr_film_desc {
      * the tensor H x W x laser_scan_height x laser_scan_width x T x 4 with the reference's flat index
      * ((((y*W + x)*laser_scan_width + laser_x)*laser_scan_height + laser_y)*T + t)*4; 0/0 = plain H x W x T x 4 */
     uint32_t laser_scan_width, laser_scan_height;
+    /* `phasor_hdr_film` (mitransient/films/phasor_hdr_film.py:125-139, render/phasor_image_block.py:42-67): n_frequencies > 0
+     * makes the tensor H x W x (2F + 1) — per frequency the real and imaginary part of sum(value * exp(i * phase)),
+     * phase = fmod(-2 pi f (opl - start_opl), 2 pi), then the weight channel — instead of time bins; every finite optical
+     * path length counts (temporal_bins / bin_width_opl only choose the frequencies, on the host).  Monochromatic: the
+     * value is channel 0 of the contribution.  frequencies: host pointer, read during the call that takes the desc. */
+    uint32_t n_frequencies;
+    const float *frequencies;
 } mtr_film_desc;
 
 /* ---- NLOS tier: `transient_nlos_path` + `nlos_capture_meter` + `projector` ---------------

@@ -11,7 +11,7 @@ from .utils import speed_of_light, cornell_box       # noqa: F401
 from . import mi, vis, nlos                          # noqa: F401
 from . import integrators, films, render, sensors    # noqa: F401
 from .integrators import TransientADIntegrator, TransientPath, TransientNLOSPath   # noqa: F401
-from .films import TransientHDRFilm                  # noqa: F401
+from .films import TransientHDRFilm, PhasorHDRFilm   # noqa: F401
 from .render import TransientImageBlock              # noqa: F401
 from .mi import load_dict                            # noqa: F401
 from .mi import render as render_scene               # noqa: F401

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 4
+MTR_ABI_VERSION = 5
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -46,7 +46,8 @@ class mtr_film_desc(C.Structure):
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("temporal_bins", C.c_uint32),
                 ("start_opl", C.c_float), ("bin_width_opl", C.c_float),
-                ("laser_scan_width", C.c_uint32), ("laser_scan_height", C.c_uint32)]
+                ("laser_scan_width", C.c_uint32), ("laser_scan_height", C.c_uint32),
+                ("n_frequencies", C.c_uint32), ("frequencies", C.POINTER(C.c_float))]
 
 
 MTR_CAPTURE_SINGLE, MTR_CAPTURE_CONFOCAL, MTR_CAPTURE_EXHAUSTIVE = 1, 2, 3

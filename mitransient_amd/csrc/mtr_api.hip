@@ -27,6 +27,7 @@ struct mtr_ctx {
     std::string err;
     DevCounters *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
@@ -52,6 +53,8 @@ struct mtr_scene {
     Camera cam{};
     Film film{};
     mtr_film_desc film_desc{};
+    float *d_freq = nullptr;               // phasor film: device copy of film_desc.frequencies
+    std::vector<float> h_freq;
     uint32_t n_leaves = 0;
     std::vector<void *> allocs;
     SplatLog log{ nullptr, 0, nullptr };
@@ -105,6 +108,7 @@ void mtr_ctx_destroy(mtr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_freq) (void)hipFree(c->d_freq);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -127,6 +131,10 @@ static int check_film(mtr_ctx *c, const mtr_film_desc &d)
         d.crop_offset_y + d.crop_height > d.height)
         return fail(c, MTR_ERR_INVALID, "film: invalid crop window");
     if (!(d.bin_width_opl > 0.0f)) return fail(c, MTR_ERR_INVALID, "film: bin_width_opl must be > 0");
+    if (d.n_frequencies && !d.frequencies) return fail(c, MTR_ERR_INVALID, "film: n_frequencies > 0 but frequencies is NULL");
+    if (d.n_frequencies && (d.laser_scan_width || d.laser_scan_height))
+        return fail(c, MTR_ERR_INVALID, "film: a phasor film cannot be an exhaustive_scan film");
+    if (d.n_frequencies > (1u << 20)) return fail(c, MTR_ERR_INVALID, "film: too many frequencies");
     if ((d.laser_scan_width == 0) != (d.laser_scan_height == 0))
         return fail(c, MTR_ERR_INVALID, "film: laser_scan_width and laser_scan_height must both be set (exhaustive_scan) or both be 0");
     if ((uint64_t)d.temporal_bins * (d.laser_scan_width ? d.laser_scan_width : 1u) * (d.laser_scan_height ? d.laser_scan_height : 1u) > 0x7fffffffull)
@@ -150,6 +158,8 @@ static int upload(mtr_scene *s, const std::vector<T> &v, const T **out)
 
 extern "C" {
 
+static int scene_take_film(mtr_scene *s, const mtr_film_desc &f);
+
 int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 {
     if (!c || !d || !out) return fail(c, MTR_ERR_INVALID, "mtr_scene_create: NULL argument");
@@ -162,7 +172,9 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 
     mtr_scene *s = new mtr_scene();
     s->ctx = c;
-    s->film = hs.film; s->cam = hs.cam; s->film_desc = d->film;
+    s->cam = hs.cam;
+    rc = scene_take_film(s, d->film);
+    if (rc) { delete s; return rc; }
 
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
@@ -229,9 +241,30 @@ void mtr_scene_destroy(mtr_scene *s)
     void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
-    void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets };
+    void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets, s->d_freq };
     for (void *p : nl) if (p) (void)hipFree(p);
     delete s;
+}
+
+// the scene keeps its own host + device copy of a phasor film's frequencies (the caller's array need not outlive the call)
+static int scene_take_film(mtr_scene *s, const mtr_film_desc &f)
+{
+    mtr_ctx *c = s->ctx;
+    s->film = film_from_desc(f);
+    s->film_desc = f;
+    s->film.freq = nullptr; s->film_desc.frequencies = nullptr;
+    if (f.n_frequencies) {
+        const std::vector<float> nf(f.frequencies, f.frequencies + f.n_frequencies);
+        if (nf != s->h_freq || !s->d_freq) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            if (s->d_freq) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipFree(s->d_freq); s->d_freq = nullptr; }
+            HIP_TRY(c, hipMalloc((void **)&s->d_freq, nf.size() * 4));
+            HIP_TRY(c, hipMemcpy(s->d_freq, nf.data(), nf.size() * 4, hipMemcpyHostToDevice));
+            s->h_freq = nf;
+        }
+        s->film.freq = s->d_freq; s->film_desc.frequencies = s->h_freq.data();
+    }
+    return MTR_OK;
 }
 
 int mtr_scene_set_film(mtr_scene *s, const mtr_film_desc *f)
@@ -239,9 +272,7 @@ int mtr_scene_set_film(mtr_scene *s, const mtr_film_desc *f)
     if (!s || !f) return fail(s ? s->ctx : nullptr, MTR_ERR_INVALID, "mtr_scene_set_film: NULL argument");
     int rc = check_film(s->ctx, *f);
     if (rc) return rc;
-    s->film = film_from_desc(*f);
-    s->film_desc = *f;
-    return MTR_OK;
+    return scene_take_film(s, *f);
 }
 
 int mtr_scene_bvh_info(const mtr_scene *s, uint32_t *n_nodes, uint32_t *max_depth, uint32_t *n_leaves)
@@ -391,7 +422,9 @@ int mtr_film_clear(mtr_ctx *c, const mtr_film_desc *f, float *t4, float *s4)
     if (!c || !f) return fail(c, MTR_ERR_INVALID, "mtr_film_clear: NULL argument");
     HIP_TRY(c, hipSetDevice(c->device));
     size_t npix = (size_t)f->width * f->height;
-    if (t4) HIP_TRY(c, hipMemsetAsync(t4, 0, npix * f->temporal_bins * 4 * sizeof(float), c->stream));
+    const Film fm = film_from_desc(*f);
+    const size_t per_pixel = fm.n_freq ? (size_t)2 * fm.n_freq + 1 : (size_t)fm.bins * 4;   // (2F+1) | [lasers][T][4]
+    if (t4) HIP_TRY(c, hipMemsetAsync(t4, 0, npix * per_pixel * sizeof(float), c->stream));
     if (s4) HIP_TRY(c, hipMemsetAsync(s4, 0, npix * 4 * sizeof(float), c->stream));
     return MTR_OK;
 }
@@ -443,6 +476,11 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             if (mode == MTR_MODE_WAVEFRONT)
                 return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: the NLOS tier runs in the fused kernel only");
             mode = MTR_MODE_FUSED;
+        }
+        if (f.n_freq) {                      // phasor film: contributions are kept as (opl, value) records -> wavefront pipeline
+            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
+            if (mode == MTR_MODE_FUSED) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film runs in the wavefront pipeline only");
+            mode = MTR_MODE_WAVEFRONT;
         }
         if (mode == MTR_MODE_AUTO) {
             FusedArgs probe = a; FusedConfig pc{};
@@ -503,8 +541,20 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
     if (s->n && (!s->pixel || !s->opl || !s->r || !s->g || !s->b))
         return fail(c, MTR_ERR_INVALID, "mtr_splat_add: NULL splat array");
     HIP_TRY(c, hipSetDevice(c->device));
+    Film fm = film_from_desc(*fd);
+    if (fm.n_freq) {
+        if (c->freq_cap < fm.n_freq) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->d_freq) (void)hipFree(c->d_freq);
+            c->d_freq = nullptr; c->freq_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_freq, (size_t)fm.n_freq * 4));
+            c->freq_cap = fm.n_freq;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_freq, fd->frequencies, (size_t)fm.n_freq * 4, hipMemcpyHostToDevice, c->stream));
+        fm.freq = c->d_freq;
+    }
     if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, launch_splat_add(variant, *s, film_from_desc(*fd), t4, nullptr, c->stream));
+    HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, c->stream));
     if (elapsed_ms) {
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -111,6 +111,23 @@ MTR_HD void sincos_quarter(float x, float &s, float &c)   // |x| <= pi/4
     float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
     c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
 }
+// One frequency of a phasor-film contribution (phasor_image_block.py:49-56): phase = fmod(-2 pi f opl, 2 pi) with
+// fmod(x, y) = x - y * floor(x / y), all f32; cos / sin by reduction to a multiple of pi/2 (two-constant Cody-Waite)
+// and the quarter-range polynomials above (numerics contract; Dr.Jit's own sincos is not reproducible bit for bit).
+MTR_HD void phasor_term(float freq, float opl, float &c, float &s)
+{
+    const float x = (-6.283185307179586f * freq) * opl, y = 6.283185307179586f;
+    const float phase = x - y * floorf(x / y);
+    const float k = floorf(fmaf(phase, 0.6366197723675814f, 0.5f));          // nearest multiple of pi/2
+    float r = fmaf(-k, 1.5707962512969971f, phase);                             // pi/2 = hi + lo
+    r = fmaf(-k, 7.549789415861596e-08f, r);
+    float sq, cq;
+    sincos_quarter(r, sq, cq);
+    const uint32_t q = (uint32_t)(int32_t)k & 3u;
+    s = (q == 0u) ? sq : (q == 1u) ? cq : (q == 2u) ? -sq : -cq;
+    c = (q == 0u) ? cq : (q == 1u) ? -sq : (q == 2u) ? -cq : sq;
+}
+
 MTR_HD f3 cosine_hemisphere(float u1, float u2)
 {
     float x = fmaf(2.0f, u1, -1.0f), y = fmaf(2.0f, u2, -1.0f);
@@ -205,6 +222,8 @@ struct Film {
     float start_opl, bin_width;
     uint32_t tbins;      // T: the time bins of one (pixel, laser) histogram
     uint32_t lasers;     // Lw*Lh (1 without exhaustive_scan)
+    uint32_t n_freq;     // phasor_hdr_film: F > 0, the tensor is H x W x (2F + 1) and `bins` / `tbins` are 1
+    const float *freq;   // [F]
 };
 
 struct SceneView {
@@ -464,6 +483,7 @@ MTR_HD Ray camera_ray(const Camera &c, const RenderConst &rc, uint32_t px, uint3
 // returns the time bin or -1 (transient_hdr_film.py:263-265)
 MTR_HD int32_t film_bin(const Film &f, float opl)
 {
+    if (f.n_freq) return (fabsf(opl) <= 3.402823466e+38f) ? 0 : -1;      // phasor film: active &= isfinite(opl) (phasor_image_block.py:47)
     float pos = (opl - f.start_opl) / f.bin_width;
     if (!(pos >= 0.0f && pos < (float)f.tbins)) return -1;
     return (int32_t)(uint32_t)floorf(pos);

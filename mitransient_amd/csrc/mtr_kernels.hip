@@ -497,10 +497,18 @@ __global__ void __launch_bounds__(kBlock) k_splat_sorted(mtr_splat_soa s, Film f
     if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
 }
 
+__global__ void k_splat_phasor(mtr_splat_soa s, Film film, float *out, DevCounters *cnt);
+
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
                             DevCounters *counters, hipStream_t stream)
 {
     if (s.n == 0) return hipSuccess;
+    if (film.n_freq) {
+        uint64_t blocks = (s.n + kBlock - 1) / kBlock;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_splat_phasor, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters);
+        return hipGetLastError();
+    }
     if (variant == 0 || (size_t)film.bins * 12u > 150u * 1024u) {
         uint64_t blocks = (s.n + kBlock - 1) / kBlock;
         if (blocks > 256 * 16) blocks = 256 * 16;
@@ -550,9 +558,46 @@ __global__ void __launch_bounds__(kBlock) k_develop_steady(const float4 *__restr
     }
 }
 
+// phasor film from Python (add_transient_data): one thread per contribution, 2F atomics
+__global__ void __launch_bounds__(kBlock) k_splat_phasor(mtr_splat_soa s, Film film, float *out, DevCounters *cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t npix = film.width * film.height, F = film.n_freq;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < s.n; i += stride) {
+        const uint32_t pixel = s.pixel[i];
+        const float opl = s.opl[i];
+        if (pixel >= npix || film_bin(film, opl) < 0) continue;
+        const float rel = opl - film.start_opl, v = s.r[i];
+        float *dst = out + (size_t)pixel * (2u * F + 1u);
+        for (uint32_t f = 0; f < F; ++f) {
+            float c, sn;
+            phasor_term(film.freq[f], rel, c, sn);
+            unsafeAtomicAdd(dst + 2 * f, v * c); unsafeAtomicAdd(dst + 2 * f + 1, v * sn);
+        }
+        ++mine;
+    }
+    if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
+}
+
+// develop_phasors_ (phasor_hdr_film.py:216-238): (H,W,2F+1) -> (H,W,F,2), values / (weight == 0 ? 1 : weight)
+__global__ void __launch_bounds__(kBlock) k_develop_phasor(const float *in, float *out, uint64_t n_pix, uint32_t F)
+{
+    const uint64_t n = n_pix * 2u * F, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t px = i / (2u * F);
+        const float w = in[px * (2u * F + 1u) + 2u * F];
+        out[i] = in[px * (2u * F + 1u) + (i - px * 2u * F)] / (w == 0.0f ? 1.0f : w);
+    }
+}
+
 hipError_t launch_develop(const Film &film, const float *t4, float *t3, const float *s4, float *s3, hipStream_t stream)
 {
-    if (t4 && t3) {
+    if (t4 && t3 && film.n_freq) {
+        const uint64_t npx = (uint64_t)film.width * film.height;
+        uint64_t blocks = (npx * 2u * film.n_freq + kBlock - 1) / kBlock; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_develop_phasor, dim3((unsigned)blocks), dim3(kBlock), 0, stream, t4, t3, npx, film.n_freq);
+    } else if (t4 && t3) {
         uint64_t n = (uint64_t)film.width * film.height * film.bins;
         uint64_t blocks = (n / 4 + kBlock - 1) / kBlock; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_develop_transient, dim3((unsigned)blocks), dim3(kBlock), 0, stream, (const float4 *)t4, t3, n);

@@ -13,6 +13,8 @@ Film film_from_desc(const mtr_film_desc &d)
     f.lasers = (d.laser_scan_width && d.laser_scan_height) ? d.laser_scan_width * d.laser_scan_height : 1u;
     f.bins = f.tbins * f.lasers;
     f.start_opl = d.start_opl; f.bin_width = d.bin_width_opl;
+    f.n_freq = d.n_frequencies; f.freq = d.frequencies;         // host pointer; the API layer swaps in its device copy
+    if (f.n_freq) { f.tbins = 1; f.lasers = 1; f.bins = 1; }
     return f;
 }
 

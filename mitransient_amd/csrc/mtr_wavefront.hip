@@ -156,6 +156,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
 struct RecordSink {
     uint4 *rec; uint32_t *s_rec_count; uint32_t rec_cap;    // s_rec_count: LDS, indexed by pixel within the segment
     float *film; uint32_t film_w, bins;
+    uint32_t n_freq; const float *freq; float start_opl;    // phasor film: records keep the optical path length instead of a bin
     uint32_t p_local, p_seg, lane;                          // pixel within the tile / within the segment
     uint32_t n_splats, n_overflow;
     SplatLog log;
@@ -182,7 +183,17 @@ struct RecordSink {
         }
         ++n_splats;
         if (idx < rec_cap) {
-            rec[(size_t)p_local * rec_cap + idx] = make_uint4(bin, __float_as_uint(r), __float_as_uint(g), __float_as_uint(b));
+            rec[(size_t)p_local * rec_cap + idx] = make_uint4(n_freq ? __float_as_uint(opl) : bin, __float_as_uint(r),
+                                                              __float_as_uint(g), __float_as_uint(b));
+        } else if (n_freq) {
+            ++n_overflow;
+            float *dst = film + ((size_t)fy * film_w + fx) * (2u * n_freq + 1u);
+            const float rel = opl - start_opl;                                 // phasor_hdr_film.py:249
+            for (uint32_t f = 0; f < n_freq; ++f) {
+                float c, sn;
+                phasor_term(freq[f], rel, c, sn);
+                unsafeAtomicAdd(dst + 2 * f, r * c); unsafeAtomicAdd(dst + 2 * f + 1, r * sn);
+            }
         } else {
             ++n_overflow;
             size_t o = (((size_t)fy * film_w + fx) * bins + bin) * 4u;
@@ -453,6 +464,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                     RecordSink sink;
                     sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
                     sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
+                    sink.n_freq = a.film.n_freq; sink.freq = a.film.freq; sink.start_opl = a.film.start_opl;
                     sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = p.lane;
                     sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
                     Pending pd; Ray shadow;
@@ -619,6 +631,61 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
     }
 }
 
+// phasor_hdr_film: the frequency-domain counterpart of k_wf_scatter (phasor_image_block.py:42-67).  One workgroup per
+// pixel; threads are arranged as (record lane) x (frequency): a chunk of the pixel's (opl, value) records is staged in
+// LDS, every thread walks its share of the chunk for ITS frequency and keeps the complex sum in registers — no atomics
+// per record (ds_add_f32 costs 3 clocks per lane) — and the record lanes are folded once per pixel.
+constexpr uint32_t kPhasorChunk = 1024;
+__global__ void __launch_bounds__(kBlock) k_wf_phasor_scatter(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *s_rec = (float2 *)(smem + 64);                          // [kPhasorChunk] (opl - start_opl, value)
+    float2 *s_part = (float2 *)(smem + 64 + kPhasorChunk * 8u);     // [kBlock] partial sums of the threads
+    const uint32_t F = a.film.n_freq;
+    const int tid = threadIdx.x;
+    for (uint32_t pl = blockIdx.x; pl < a.P; pl += gridDim.x) {
+        const uint32_t pixel = a.pix0 + pl;
+        const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;
+        const bool in_film = (cx < a.film.width) & (cy < a.film.height);
+        const uint32_t n = min(a.rec_count[pl], a.rec_cap);
+        const uint4 *rec = a.rec + (size_t)pl * a.rec_cap;
+        float *dst = a.film_out + ((size_t)cy * a.film.width + cx) * (2u * F + 1u);
+        for (uint32_t f0 = 0; f0 < F; f0 += kBlock) {              // frequency chunks (one for F <= 256)
+            const uint32_t fc = min(F - f0, (uint32_t)kBlock);
+            const uint32_t lanes = kBlock / fc;                    // record lanes per frequency
+            const uint32_t f = (uint32_t)tid % fc, rl = (uint32_t)tid / fc;
+            const bool on = rl < lanes;
+            const float freq = a.film.freq[f0 + f];
+            float re = 0.0f, im = 0.0f;
+            for (uint32_t base = 0; base < n; base += kPhasorChunk) {
+                const uint32_t m = min(n - base, kPhasorChunk);
+                __syncthreads();
+                for (uint32_t i = tid; i < m; i += kBlock) {
+                    const uint4 r = rec[base + i];
+                    s_rec[i] = make_float2(__uint_as_float(r.x) - a.film.start_opl, __uint_as_float(r.y));   // phasor_hdr_film.py:249
+                }
+                __syncthreads();
+                if (on)
+                    for (uint32_t i = rl; i < m; i += lanes) {
+                        const float2 r = s_rec[i];
+                        float c, sn;
+                        phasor_term(freq, r.x, c, sn);
+                        re += r.y * c; im += r.y * sn;
+                    }
+            }
+            __syncthreads();
+            s_part[tid] = make_float2(re, im);
+            __syncthreads();
+            if ((uint32_t)tid < fc && in_film) {
+                float sr = 0.0f, si = 0.0f;
+                for (uint32_t l = 0; l < lanes; ++l) { const float2 v = s_part[l * fc + tid]; sr += v.x; si += v.y; }
+                if (sr != 0.0f || si != 0.0f) { dst[2 * (f0 + tid)] += sr; dst[2 * (f0 + tid) + 1] += si; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
@@ -649,6 +716,11 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 // which: 0 raygen, 1 trace, 2 shade, 3 scatter, 4 shadow-ray generation
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
 {
+    if (which == 3 && a.film.n_freq) {
+        const size_t lds = 64 + kPhasorChunk * 8u + kBlock * 8u;
+        hipLaunchKernelGGL(k_wf_phasor_scatter, dim3(grid), dim3(kBlock), lds, stream, a);
+        return hipGetLastError();
+    }
     if (which == 3) {
         // fixed-point rows need 24 B per bin; fall back to f32 rows (12 B) when that does not leave 2 workgroups per CU
         const bool fixed = a.rec_cap && (size_t)a.film.bins * 24u <= 72u * 1024u;

@@ -12,7 +12,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .. import _cabi
+from .. import _cabi, variant
 from ..render.transient_image_block import TransientImageBlock
 from ..runtime import get_context, require_gpu
 from ..scene import Properties, film_desc_from
@@ -77,6 +77,9 @@ class TransientHDRFilm:
     def prepare(self, aovs: Sequence[str] = ()):
         if aovs:
             raise NotImplementedError("AOVs are not part of the transient_path hot path")
+        if variant.is_monochromatic() and type(self) is TransientHDRFilm:
+            raise NotImplementedError("the monochromatic variants are implemented for phasor_hdr_film only "
+                                      "(transient_hdr_film's two-channel 'LW' layout is not built)")
         torch = require_gpu()
         W, H = self.size_
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -154,10 +157,16 @@ class TransientHDRFilm:
     # -- develop -------------------------------------------------------------
     def develop(self, raw: bool = False):
         transient_image = self.develop_transient_(raw=raw)
-        torch = require_gpu()
-        W, H = self.size_
         if self.exhaustive_scan:            # transient_hdr_film.py:213-214: dr.mean(transient_image, axis=-1)
             return TensorXf(transient_image.torch().mean(dim=-1)), transient_image
+        return self._develop_steady(raw)[0], transient_image
+
+    def _develop_steady(self, raw: bool = False):
+        """``self.steady.develop(raw)`` of the reference: (H,W,3) (one channel in the monochromatic variants), or the
+        raw (H,W,4) accumulator"""
+        torch = require_gpu()
+        W, H = self.size_
+        transient_image = None
         ctx = get_context(self._device.index)
         ctx.bind_current_stream()
         if raw:
@@ -168,6 +177,8 @@ class TransientHDRFilm:
             ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), None, None,
                                                C.c_void_p(self._steady_accum.data_ptr()),
                                                C.c_void_p(steady.data_ptr())), "mtr_film_develop")
+            if variant.is_monochromatic():
+                steady = steady[..., :1].contiguous()        # pixel_format 'luminance' (:141)
         return TensorXf(steady), transient_image
 
     def develop_transient_(self, raw: bool = False):

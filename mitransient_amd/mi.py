@@ -15,27 +15,30 @@ import os
 from typing import Any, Dict
 
 from . import _cabi, plugins
+from . import variant as _variant_mod
 from .scene import Properties, flatten_scene, film_desc_from
 from .sensors import IndependentSampler, PerspectiveSensor
 from .transform import ScalarTransform4f
 from .tensor import TensorXf
 
 Transform4f = ScalarTransform4f
-_variant = None
 
 
 def variant():
-    return _variant
+    return _variant_mod.get()
 
 
 def set_variant(*names):
-    """Only the unpolarized RGB variants have a counterpart here."""
-    global _variant
+    """The unpolarized ``*_ad_rgb`` variants, and ``*_ad_mono`` (needed by ``phasor_hdr_film``): monochromatic rendering
+    = every colour replaced by its luminance, one output channel."""
     for n in names:
-        if n.endswith("_rgb") and "polarized" not in n and not n.startswith("scalar"):
-            _variant = n
+        if (n.endswith("_rgb") or n.endswith("_mono")) and "polarized" not in n and not n.startswith("scalar"):
+            _variant_mod.set(n)
             return
-    raise ValueError(f"unsupported variant(s) {names}: mitransient_amd implements the *_ad_rgb path only")
+    raise ValueError(f"unsupported variant(s) {names}: mitransient_amd implements the *_ad_rgb / *_ad_mono paths only")
+
+
+is_monochromatic = _variant_mod.is_monochromatic
 
 
 def ScalarColor3d(*v):

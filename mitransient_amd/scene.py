@@ -20,6 +20,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from . import _cabi
+from . import variant as _variant
 from .transform import ScalarTransform4f, to_transform
 
 
@@ -89,6 +90,10 @@ def _color3(v, what="color", approx_base=None):
         a = np.repeat(a, 3)
     if a.size != 3:
         raise ValueError(f"{what}: expected a scalar or an RGB triple")
+    if _variant.is_monochromatic():              # [mitsuba3: luminance(Color3f)], f32 like the srgb spectrum plugin in mono mode
+        c = a.astype(np.float32)
+        lum = (c[0] * np.float32(0.212671) + c[1] * np.float32(0.715160)) + c[2] * np.float32(0.072169)
+        a = np.repeat(np.float64(lum), 3)
     return a
 
 
@@ -496,6 +501,11 @@ def film_desc_from(film) -> _cabi.mtr_film_desc:
     f.bin_width_opl = np.float32(film.bin_width_opl)
     if getattr(film, "exhaustive_scan", False):
         f.laser_scan_width, f.laser_scan_height = int(film.laser_scan_width), int(film.laser_scan_height)
+    fr = getattr(film, "frequencies_f32", None)                 # phasor_hdr_film
+    if fr is not None:
+        f.n_frequencies = int(fr.size)
+        f.frequencies = fr.ctypes.data_as(C.POINTER(C.c_float))
+        f._keepalive = fr
     return f
 
 

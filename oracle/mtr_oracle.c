@@ -139,6 +139,25 @@ static void sincos_q(float x, float *s, float *c)
 }
 void orc_sincos_q(float x, float *s, float *c) { sincos_q(x, s, c); }
 
+/* One frequency of a phasor_hdr_film contribution (mitransient/render/phasor_image_block.py:49-56):
+ *   phase = fmod(-2 pi f opl, 2 pi), fmod(x, y) = x - y * floor(x / y); values spec * cos(phase), spec * sin(phase).
+ * All f32.  Dr.Jit's sincos cannot be reproduced bit for bit; the contract here: reduce to a multiple of pi/2 with the
+ * two-constant Cody-Waite split (fma), then the quarter-range polynomials above. */
+static void phasor_term(float freq, float opl, float *c, float *s)
+{
+    const float x = (-6.283185307179586f * freq) * opl, y = 6.283185307179586f;
+    const float phase = x - y * floorf(x / y);
+    const float k = floorf(fmaf(phase, 0.6366197723675814f, 0.5f));
+    float r = fmaf(-k, 1.5707962512969971f, phase);
+    r = fmaf(-k, 7.549789415861596e-08f, r);
+    float sq, cq;
+    sincos_q(r, &sq, &cq);
+    const uint32_t q = (uint32_t)(int32_t)k & 3u;
+    *s = (q == 0u) ? sq : (q == 1u) ? cq : (q == 2u) ? -sq : -cq;
+    *c = (q == 0u) ? cq : (q == 1u) ? -sq : (q == 2u) ? -cq : sq;
+}
+void orc_phasor_term(float freq, float opl, float *c, float *s) { phasor_term(freq, opl, c, s); }
+
 #define ORC_PI       3.14159265358979323846f
 #define ORC_INV_PI   0.31830988618379067154f
 #define ORC_RAY_EPS  (1500.0f * 5.9604644775390625e-8f)          /* [mitsuba3: math::RayEpsilon = Epsilon*1500, Epsilon<float> = 2^-24] */
@@ -557,6 +576,25 @@ static void add_transient_l(film_t *F, uint32_t px, uint32_t py, float distance,
     const mtr_film_desc *f = F->f;
     /* common.py:417-421: spec * sample_scale, then * ray_weight (== 1) */
     float val[3] = { spec[0] * sample_scale, spec[1] * sample_scale, spec[2] * sample_scale };
+    if (f->n_frequencies) {                        /* phasor_hdr_film.add_transient_data (:240-262) + PhasorImageBlock.put (:42-67) */
+        if (!isfinite(distance)) return;                                    /* active &= isfinite(opl) :47 */
+        uint32_t x = px - f->crop_offset_x, y = py - f->crop_offset_y;
+        if (!(x < f->width && y < f->height)) return;
+        if (val[0] == 0.0f) return;                                         /* spec.x (monochromatic); adding +0 is a no-op */
+        const float rel = distance - f->start_opl;                          /* :249 */
+        float *dst = F->transient + ((size_t)y * f->width + x) * (2u * (size_t)f->n_frequencies + 1u);
+        for (uint32_t k = 0; k < f->n_frequencies; ++k) {
+            float c, sn;
+            phasor_term(f->frequencies[k], rel, &c, &sn);
+            const float re = val[0] * c, im = val[0] * sn;
+#pragma omp atomic
+            dst[2 * k] += re;
+#pragma omp atomic
+            dst[2 * k + 1] += im;
+        }
+        C->splats += 1;
+        return;
+    }
     int bin = orc_bin_index(distance, f->start_opl, f->bin_width_opl, f->temporal_bins);
     if (bin < 0) return;
     /* p = floor(pos) - offset (transient_image_block.py:132); pos carries the crop offset */
@@ -1259,6 +1297,16 @@ void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *tra
                  const float *steady_hw4, float *steady_hw3)
 {
     size_t npt = film_cells(f);
+    if (f->n_frequencies) {                        /* develop_phasors_ (phasor_hdr_film.py:216-238): (H,W,2F+1) -> (H,W,F,2) */
+        const size_t np_ = (size_t)f->width * f->height, F2 = 2u * (size_t)f->n_frequencies;
+        if (transient_hwt4 && transient_hwt3)
+            for (size_t i = 0; i < np_; ++i) {
+                float w = transient_hwt4[i * (F2 + 1) + F2];
+                float dv = (w == 0.0f) ? 1.0f : w;
+                for (size_t k = 0; k < F2; ++k) transient_hwt3[i * F2 + k] = transient_hwt4[i * (F2 + 1) + k] / dv;
+            }
+        transient_hwt4 = NULL;
+    }
     if (transient_hwt4 && transient_hwt3)
         for (size_t i = 0; i < npt; ++i) {
             float w = transient_hwt4[4 * i + 3];
@@ -1279,6 +1327,16 @@ void orc_splat_add(const mtr_film_desc *f, uint64_t n, const uint32_t *pixel, co
                    const uint32_t *laser_x, const uint32_t *laser_y)
 {
     for (uint64_t i = 0; i < n; ++i) {
+        if (f->n_frequencies) {
+            if (!isfinite(opl[i]) || pixel[i] >= f->width * f->height) continue;
+            float *dst = transient_hwt4 + (size_t)pixel[i] * (2u * (size_t)f->n_frequencies + 1u);
+            for (uint32_t k = 0; k < f->n_frequencies; ++k) {
+                float c, sn;
+                phasor_term(f->frequencies[k], opl[i] - f->start_opl, &c, &sn);
+                dst[2 * k] += r[i] * c; dst[2 * k + 1] += r[i] * sn;
+            }
+            continue;
+        }
         int bin = orc_bin_index(opl[i], f->start_opl, f->bin_width_opl, f->temporal_bins);
         if (bin < 0) continue;
         if (pixel[i] >= f->width * f->height) continue;

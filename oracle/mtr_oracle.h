@@ -20,6 +20,7 @@ int  orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *tran
                 orc_splat_rec *log, uint64_t log_cap, uint64_t *log_n);
 void orc_develop(const mtr_film_desc *f, const float *transient_hwt4, float *transient_hwt3,
                  const float *steady_hw4, float *steady_hw3);
+void orc_phasor_term(float freq, float opl, float *c, float *s);
 void orc_splat_add(const mtr_film_desc *f, uint64_t n, const uint32_t *pixel, const float *opl,
                    const float *r, const float *g, const float *b, float *transient_hwt4,
                    const uint32_t *laser_x, const uint32_t *laser_y);

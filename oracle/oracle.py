@@ -62,6 +62,8 @@ def lib():
         L.orc_square_to_cos_hemi.argtypes = [C.c_float, C.c_float, fp]
         L.orc_square_to_cos_hemi.restype = None
         L.orc_num_threads.restype = C.c_int
+        L.orc_phasor_term.argtypes = [C.c_float, C.c_float, fp, fp]
+        L.orc_phasor_term.restype = None
         _lib = L
     return _lib
 
@@ -72,6 +74,8 @@ def _fp(a):
 
 def film_shape(f):
     """raw tensor shape: (H,W,T,4), or (H,W,Lh,Lw,T,4) for an exhaustive_scan film (transient_image_block.py:63-68)"""
+    if f.n_frequencies:                         # phasor_hdr_film: (H, W, 2F+1)
+        return (f.height, f.width, 2 * f.n_frequencies + 1)
     if f.laser_scan_width and f.laser_scan_height:
         return (f.height, f.width, f.laser_scan_height, f.laser_scan_width, f.temporal_bins, 4)
     return (f.height, f.width, f.temporal_bins, 4)
@@ -112,7 +116,9 @@ def render(scene_data, params: _cabi.mtr_render_params, n_threads=0, use_bvh=Fal
 
 def develop(film_desc, t4=None, s4=None):
     t3 = s3 = None
-    if t4 is not None:
+    if t4 is not None and film_desc.n_frequencies:
+        t3 = np.empty(t4.shape[:-1] + (film_desc.n_frequencies, 2), np.float32)
+    elif t4 is not None:
         t3 = np.empty(t4.shape[:-1] + (3,), np.float32)
     if s4 is not None:
         s3 = np.empty(s4.shape[:-1] + (3,), np.float32)
@@ -129,6 +135,12 @@ def splat_add(film_desc, pixel, opl, r, g, b, t4, laser_x=None, laser_y=None):
     ly = np.ascontiguousarray(laser_y, np.uint32) if laser_y is not None else None
     lib().orc_splat_add(C.byref(film_desc), len(pixel), pixel.ctypes.data_as(up), *[_fp(a) for a in arrs], _fp(t4),
                         lx.ctypes.data_as(up) if lx is not None else None, ly.ctypes.data_as(up) if ly is not None else None)
+
+
+def phasor_term(freq, opl):
+    c, s = C.c_float(0), C.c_float(0)
+    lib().orc_phasor_term(np.float32(freq), np.float32(opl), C.byref(c), C.byref(s))
+    return c.value, s.value
 
 
 def bin_index(distance, start, width, T):

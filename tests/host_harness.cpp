@@ -24,8 +24,20 @@ struct ArrStack {
 };
 struct HostSink {
     float *film; uint32_t W, T; uint64_t n;
-    void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b, float, uint32_t, uint32_t)
+    Film fm;
+    void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b, float opl, uint32_t, uint32_t)
     {
+        if (fm.n_freq) {                        // phasor film: the arithmetic of k_wf_phasor_scatter, contribution by contribution
+            float *dst = film + ((size_t)fy * W + fx) * (2u * fm.n_freq + 1u);
+            const float rel = opl - fm.start_opl;
+            for (uint32_t f = 0; f < fm.n_freq; ++f) {
+                float c, s;
+                phasor_term(fm.freq[f], rel, c, s);
+                dst[2 * f] += r * c; dst[2 * f + 1] += r * s;
+            }
+            ++n;
+            return;
+        }
         size_t idx = (((size_t)fy * W + fx) * T + bin) * 4u;
         film[idx] += r; film[idx + 1] += g; film[idx + 2] += b; ++n;
     }
@@ -47,7 +59,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
-    HostSink sink{ t4, hs.film.width, hs.film.bins, 0 };
+    HostSink sink{ t4, hs.film.width, hs.film.bins, 0, hs.film };
     ArrStack st; st.sp = 0;
     uint64_t closest = 0, shadow = 0, bounces = 0, paths = 0;
     // NLOS tier: tables + scanned points (the product computes the latter in k_nlos_prepare)

@@ -1,0 +1,87 @@
+"""phasor_hdr_film on the GPU: wavefront records -> k_wf_phasor_scatter, through the C-ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from test_phasor import phasor_cornell, mono  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _render(scene, spp, seed=0):
+    import torch
+    integ = scene.integrator()
+    integ.collect_stats = True
+    steady, phasors = integ.render(scene, seed=seed, spp=spp)
+    torch.cuda.synchronize()
+    return np.array(steady), np.array(phasors)
+
+
+def _oracle(oracle, scene, spp, seed=0):
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), seed, spp)
+    t, s4, cnt = oracle.render(sd, p, use_bvh=True)
+    ph, s3 = oracle.develop(sd.film, t, s4)
+    return s3, ph, t, cnt
+
+
+@pytest.mark.parametrize("res,spp,film", [(16, 64, {}), (9, 300, {"wl_mean": 1.0, "wl_sigma": 0.2}),
+                                          (24, 2, {})])           # 2 spp: 8-record lists overflow -> the atomic fallback
+def test_phasor_render_matches_oracle(mono, oracle, res, spp, film):
+    scene = phasor_cornell(mono, res=res, **film)
+    F = len(scene.sensors()[0].film().frequencies)
+    s_gpu, p_gpu = _render(scene, spp, seed=2)
+    s_ref, p_ref, raw_ref, cnt = _oracle(oracle, scene, spp, seed=2)
+    assert p_gpu.shape == (res, res, F, 2) and s_gpu.shape == (res, res, 1)
+    assert rel_l2(p_gpu, p_ref) <= TOL and rel_l2(s_gpu[..., 0], s_ref[..., 0]) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+    if spp == 2:
+        assert got["splats_overflow"] > 0
+    _, raw = scene.sensors()[0].film().develop(raw=True)
+    raw = np.array(raw)
+    assert raw.shape == (res, res, 2 * F + 1) and not raw[..., -1].any() and rel_l2(raw, raw_ref) <= TOL
+    # the zero frequency would be the steady image; here: |phasor| never exceeds the total energy of the pixel
+    assert np.all(np.hypot(p_gpu[..., 0], p_gpu[..., 1]).max(axis=2) <= s_gpu[..., 0] * (1 + 1e-3) + 1e-6)
+
+
+def test_phasor_add_transient_data_and_errors(mono, oracle):
+    import torch
+    import mitransient_amd as mitr
+    from mitransient_amd.scene import Properties
+    film = mitr.PhasorHDRFilm(Properties("phasor_hdr_film", {"width": 6, "height": 5, "wl_mean": 4.0, "wl_sigma": 2.0,
+                                                              "temporal_bins": 256, "bin_width_opl": 0.1, "start_opl": 1.5,
+                                                              "rfilter": {"type": "box"}}))
+    film.prepare([])
+    rng = np.random.default_rng(11)
+    n = 5000
+    pos = rng.uniform([-0.5, -0.5], [6.5, 5.5], size=(n, 2)).astype(np.float32)
+    dist = rng.uniform(0.0, 30.0, n).astype(np.float32)
+    dist[:5] = np.inf
+    spec = rng.uniform(0, 1, n).astype(np.float32)
+    film.add_transient_data(pos, dist, None, spec, 1.0, None)
+    torch.cuda.synchronize()
+    _, raw = film.develop(raw=True)
+    raw = np.array(raw)
+    px, py = np.floor(pos[:, 0]).astype(np.int64), np.floor(pos[:, 1]).astype(np.int64)
+    ok = (px >= 0) & (px < 6) & (py >= 0) & (py < 5)
+    ref = np.zeros_like(raw)
+    oracle.splat_add(film.desc(), (py * 6 + px)[ok], dist[ok], spec[ok], spec[ok], spec[ok], ref)
+    assert np.count_nonzero(ref) > 1000 and np.allclose(raw, ref, rtol=1e-4, atol=1e-5)
+    # errors: rgb variant, fused mode
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    with pytest.raises(RuntimeError, match="monochromatic"):
+        sc = phasor_cornell(mi)
+        sc.integrator().render(sc, spp=1)
+    mi.set_variant("llvm_ad_mono")
+    sc = phasor_cornell(mi)
+    sc.integrator().mode = 1
+    with pytest.raises(RuntimeError, match="wavefront"):
+        sc.integrator().render(sc, spp=1)
+    with pytest.raises(NotImplementedError, match="phasor_hdr_film only"):
+        d = mitr.cornell_box()
+        sc = mi.load_dict(d)
+        sc.integrator().render(sc, spp=1)
