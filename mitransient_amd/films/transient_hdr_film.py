@@ -77,9 +77,6 @@ class TransientHDRFilm:
     def prepare(self, aovs: Sequence[str] = ()):
         if aovs:
             raise NotImplementedError("AOVs are not part of the transient_path hot path")
-        if variant.is_monochromatic() and type(self) is TransientHDRFilm:
-            raise NotImplementedError("the monochromatic variants are implemented for phasor_hdr_film only "
-                                      "(transient_hdr_film's two-channel 'LW' layout is not built)")
         torch = require_gpu()
         W, H = self.size_
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -92,7 +89,9 @@ class TransientHDRFilm:
         return self.prepare_transient_(aovs)
 
     def prepare_transient_(self, aovs: Sequence[str] = ()):
-        self.channels = list("RGBW") + list(aovs)          # Film base flags carry no Alpha -> "RGBW"
+        # Film base flags carry no Alpha -> "RGBW"; "LW" in the monochromatic variants (:177-179).  The accumulator in HBM is
+        # RGBW either way: mono renders run three equal channels (variant.py) and the outputs below keep channel 0
+        self.channels = list("LW" if variant.is_monochromatic() else "RGBW") + list(aovs)
         self.crop_offset_xyt = (self.crop_offset_[0], self.crop_offset_[1], 0)
         self.crop_size_xyt = (self.size_[0], self.size_[1], self.temporal_bins)
         self.transient_storage = self.create_block()
@@ -100,6 +99,7 @@ class TransientHDRFilm:
         return len(self.channels)
 
     def create_block(self):
+        n_ch = 4                                            # storage channels (see prepare_transient_)
         if (self.transient_storage is not None and self.transient_storage.size_xyt == self.crop_size_xyt
                 and self.transient_storage.torch_tensor().device == self._device
                 and tuple(self.transient_storage.torch_tensor().shape) == self.raw_shape()):
@@ -108,7 +108,7 @@ class TransientHDRFilm:
         return TransientImageBlock(size_xyt=self.crop_size_xyt, offset_xyt=self.crop_offset_xyt,
                                    exhaustive_scan=self.exhaustive_scan, laser_scan_width=self.laser_scan_width,
                                    laser_scan_height=self.laser_scan_height,
-                                   channel_count=len(self.channels), rfilter=self.rfilter_, device=self._device)
+                                   channel_count=n_ch, rfilter=self.rfilter_, device=self._device)
 
     def raw_shape(self):
         W, H = self.size_
@@ -136,6 +136,8 @@ class TransientHDRFilm:
         pos = torch.as_tensor(pos, dtype=torch.float32, device=dev)
         distance = torch.as_tensor(distance, dtype=torch.float32, device=dev)
         spec = torch.as_tensor(spec, dtype=torch.float32, device=dev) * ray_weight
+        if spec.dim() == 1 or spec.shape[1] == 1:           # monochromatic: one value per contribution
+            spec = spec.reshape(-1, 1).expand(-1, 3)
         px = torch.floor(pos[:, 0]).to(torch.int64) - self.crop_offset_[0]
         py = torch.floor(pos[:, 1]).to(torch.int64) - self.crop_offset_[1]
         W, H = self.size_
@@ -184,9 +186,12 @@ class TransientHDRFilm:
     def develop_transient_(self, raw: bool = False):
         if not self.transient_storage:
             raise RuntimeError("No transient storage allocated, was prepare_transient_() called first?")
+        torch = require_gpu()
+        if raw and variant.is_monochromatic():
+            t = self.transient_storage.torch_tensor()
+            return TensorXf(torch.stack((t[..., 0], t[..., 3]), dim=-1))          # "LW"
         if raw:
             return self.transient_storage.tensor
-        torch = require_gpu()
         W, H = self.size_
         data = self.transient_storage.torch_tensor()
         out = torch.empty(self.raw_shape()[:-1] + (3,), dtype=torch.float32, device=data.device)
@@ -195,6 +200,8 @@ class TransientHDRFilm:
         fd = self.desc()
         ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), C.c_void_p(data.data_ptr()),
                                            C.c_void_p(out.data_ptr()), None, None), "mtr_film_develop")
+        if variant.is_monochromatic():
+            out = out[..., :1].contiguous()
         return TensorXf(out)
 
     def develop_slab(self, raw_t, raw_s):

@@ -81,7 +81,24 @@ def test_phasor_add_transient_data_and_errors(mono, oracle):
     sc.integrator().mode = 1
     with pytest.raises(RuntimeError, match="wavefront"):
         sc.integrator().render(sc, spp=1)
-    with pytest.raises(NotImplementedError, match="phasor_hdr_film only"):
-        d = mitr.cornell_box()
-        sc = mi.load_dict(d)
-        sc.integrator().render(sc, spp=1)
+
+
+def test_mono_transient_film(mono, oracle):
+    """llvm_ad_mono with transient_hdr_film (the variant of the reference's NLOS notebooks): one colour channel,
+    raw layout "LW"; equals the luminance-coloured RGB run"""
+    import mitransient_amd as mitr
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=16, height=16, temporal_bins=64, bin_width_opl=6.0 / 64)
+    sc = mono.load_dict(d)
+    steady, transient = sc.integrator().render(sc, spp=8)
+    steady, transient = np.array(steady), np.array(transient)
+    assert transient.shape == (16, 16, 64, 1) and steady.shape == (16, 16, 1)
+    _, raw = sc.sensors()[0].film().develop(raw=True)
+    raw = np.array(raw)
+    assert raw.shape == (16, 16, 64, 2) and not raw[..., 1].any() and sc.sensors()[0].film().channels == ["L", "W"]
+    sd = sc.data()
+    p = sc.integrator().render_params(sc.sensors()[0].film(), 0, 8)
+    t4, s4, _ = oracle.render(sd, p, use_bvh=True)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
+    assert np.array_equal(t3[..., 0], t3[..., 1]) and np.array_equal(t3[..., 0], t3[..., 2])      # channels never mix
+    assert rel_l2(transient[..., 0], t3[..., 0]) <= TOL and rel_l2(steady[..., 0], s3[..., 0]) <= TOL
