@@ -41,6 +41,26 @@ def set_variant(*names):
 is_monochromatic = _variant_mod.is_monochromatic
 
 
+__version__ = "3.7.0-mitransient_amd"       # the Mitsuba generation whose plugin semantics are mirrored (reference: >=3.6,<3.9)
+
+
+def ScalarPoint3f(*v):
+    return [float(x) for x in (v[0] if len(v) == 1 else v)]
+
+
+Point3f = ScalarPoint3f = ScalarPoint3f
+
+
+class util:                                 # namespace, like mitsuba.util
+    @staticmethod
+    def convert_to_bitmap(data, uint8_srgb=True):
+        """``mi.util.convert_to_bitmap``: array -> displayable image (uint8 sRGB by default)"""
+        import numpy as np
+        from .vis import to_srgb_uint8
+        a = np.array(data)
+        return to_srgb_uint8(a) if uint8_srgb else a
+
+
 def ScalarColor3d(*v):
     return [float(x) for x in (v[0] if len(v) == 1 else v)]
 
