@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 5
+#define MTR_ABI_VERSION 6
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -116,9 +116,12 @@ typedef struct mtr_shape {          /* one scene shape = a contiguous triangle r
     float    center[3], du[3], dv[3];   /* rectangle only: to_world*(0,0,0), half edges */
 } mtr_shape;
 
+#define MTR_NLOS_NO_RELAY 0xffffffffu
 typedef struct mtr_nlos_desc {
     float    sensor_origin[3];      /* nlos_capture_meter.sensor_origin (nloscapturemeter.py:103-105)     */
-    uint32_t relay_shape;           /* index into shapes[]: the rectangle the sensor is attached to        */
+    uint32_t relay_shape;           /* index into shapes[]: the rectangle the nlos_capture_meter is attached to;
+                                       MTR_NLOS_NO_RELAY: the sensor is the scene's `perspective` camera
+                                       (mtr_scene_desc.camera), as in examples/transient-nlos/nlos-z-simple.xml      */
     float    laser_to_world[16];    /* projector world transform, row-major (after nlos.focus_emitter_*)   */
     float    laser_fov;             /* degrees, along x                                                    */
     float    laser_irradiance[3];   /* constant `irradiance` texture                                       */
@@ -141,7 +144,7 @@ typedef struct mtr_scene_desc {
     const mtr_material *materials; /* host                                              */
     uint32_t        n_emitters;
     const mtr_emitter  *emitters;  /* host                                              */
-    mtr_camera      camera;         /* ignored when nlos != NULL                                      */
+    mtr_camera      camera;         /* with nlos != NULL: used only when nlos->relay_shape == MTR_NLOS_NO_RELAY */
     mtr_film_desc   film;
     const mtr_nlos_desc *nlos;      /* NULL: `perspective` sensor + `transient_path`; else the NLOS tier */
 } mtr_scene_desc;

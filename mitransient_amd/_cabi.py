@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 5
+MTR_ABI_VERSION = 6
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -52,6 +52,7 @@ class mtr_film_desc(C.Structure):
 
 MTR_CAPTURE_SINGLE, MTR_CAPTURE_CONFOCAL, MTR_CAPTURE_EXHAUSTIVE = 1, 2, 3
 MTR_NLOS_FORCE_EQUAL_GRIDS = 64
+MTR_NLOS_NO_RELAY = 0xFFFFFFFF
 MTR_NLOS_LASER_SAMPLING, MTR_NLOS_HG_SAMPLING, MTR_NLOS_HG_RROULETTE = 1, 2, 4
 MTR_NLOS_HG_INCLUDES_WALL, MTR_NLOS_ACCOUNT_FIRST_LAST, MTR_NLOS_DISCARD_DIRECT = 8, 16, 32
 

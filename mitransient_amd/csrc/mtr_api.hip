@@ -203,6 +203,9 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     mtr_scene_desc d{};
     d.n_tris = (uint32_t)(s->tri_verts.size() / 9); d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
     d.film = s->film_desc;
+    memcpy(d.camera.sample_to_camera, s->cam.s2c, sizeof s->cam.s2c);
+    memcpy(d.camera.to_world, s->cam.tw, sizeof s->cam.tw);
+    d.camera.near_clip = s->cam.near_clip; d.camera.far_clip = s->cam.far_clip;
     d.nlos = n;
     HostNlos hn;
     if (const char *msg = derive_nlos(d, hn)) return fail(c, MTR_ERR_INVALID, std::string("mtr_scene_set_nlos: ") + msg);

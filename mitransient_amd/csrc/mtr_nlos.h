@@ -42,6 +42,9 @@ struct NlosConst {
     uint32_t laser_w, laser_h;         // Exhaustive: illumination grid (film.laser_scan_width / _height), else 0
     float illum_tan;                   // Exhaustive without FORCE_EQUAL_GRIDS: tan(illumination_scan_fov / 2)
     float l_rot[9];                    // rows of the laser's local -> world rotation
+    uint32_t camera_sensor;            // 1: the sensor is the scene's perspective camera (no nlos_capture_meter / relay wall)
+    Camera cam;                        // ... that camera
+    float inv_w, inv_h;                // 1 / film size (film sample of a pixel corner)
 };
 
 MTR_HD uint32_t nlos_target_count(const NlosConst &nc) { return nc.film_w * nc.film_h + 1u + nc.laser_w * nc.laser_h; }
@@ -80,6 +83,18 @@ MTR_HD Ray nlos_sensor_ray(const NlosConst &nc, float sx, float sy)
     return r;
 }
 
+// sensor.sample_ray at the film sample of pixel (x, y)'s corner (:296-308): the capture meter snaps it to the pixel centre
+// (nloscapturemeter.py:146-149), a perspective camera shoots through it
+MTR_HD Ray nlos_scan_ray(const NlosConst &nc, uint32_t x, uint32_t y)
+{
+    if (nc.camera_sensor) {
+        RenderConst rc{};
+        rc.inv_crop_w = nc.inv_w; rc.inv_crop_h = nc.inv_h; rc.off_x = 0.0f; rc.off_y = 0.0f;
+        return camera_ray(nc.cam, rc, x, y, 0.0f, 0.0f);
+    }
+    return nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);
+}
+
 // the rays of TransientNLOSPath.prepare (:295-381) in the order of NlosConst::targets
 MTR_HD Ray nlos_prepare_ray(const NlosConst &nc, uint32_t i)
 {
@@ -87,13 +102,13 @@ MTR_HD Ray nlos_prepare_ray(const NlosConst &nc, uint32_t i)
     Ray r;
     if (i < n) {                                                           // linspace(0,1,res,endpoint=False), meshgrid 'xy'
         const uint32_t y = i / nc.film_w, x = i - y * nc.film_w;
-        return nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);
+        return nlos_scan_ray(nc, x, y);
     }
     if (i == n) { r.o = nc.l_origin; r.d = nc.l_forward; r.tmax = kInf; return r; }
     const uint32_t j = i - n - 1u;
     if (nc.flags & MTR_NLOS_FORCE_EQUAL_GRIDS) {                           // laser_targets = sensor_targets (:344-346)
         const uint32_t y = j / nc.film_w, x = j - y * nc.film_w;
-        return nlos_sensor_ray(nc, (float)x / (float)nc.film_w, (float)y / (float)nc.film_h);
+        return nlos_scan_ray(nc, x, y);
     }
     // dummy projector with illumination_scan_fov, one ray per grid point [mitsuba3: Projector::sample_ray with a
     // constant irradiance: uv = sample; near_p = sample_to_camera * (u, v, 0); d = to_world * normalize(near_p)]
@@ -116,7 +131,7 @@ MTR_HD void nlos_begin(Path &p, const NlosConst &nc, const Film &f, const Render
     p.rng = rng_seed(rc.seed, lane);
     const float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
     const float sx = fmaf((float)p.px + j1, rc.inv_crop_w, rc.off_x), sy = fmaf((float)p.py + j2, rc.inv_crop_h, rc.off_y);
-    p.ray = nlos_sensor_ray(nc, sx, sy);
+    p.ray = nc.camera_sensor ? camera_ray(nc.cam, rc, p.px, p.py, j1, j2) : nlos_sensor_ray(nc, sx, sy);
     p.beta = mk(1, 1, 1); p.L = mk(0, 0, 0); p.prev_p = mk(0, 0, 0);
     p.eta = 1.0f; p.dist = 0.0f; p.prev_pdf = 1.0f; p.depth = 0; p.prev_delta = 1;       // distance = ray.time = 0 (:718)
 }

@@ -128,8 +128,11 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
     if (exhaustive && (n->flags & MTR_NLOS_FORCE_EQUAL_GRIDS) &&
         (d.film.laser_scan_width != d.film.width || d.film.laser_scan_height != d.film.height))
         return "Sensor and laser scan resolution must be equal if force_equal_illumination_scanning is set to True";
-    if (!n->shapes || n->n_shapes == 0 || n->relay_shape >= n->n_shapes) return "NLOS: bad shape table";
-    if (!n->shapes[n->relay_shape].is_rectangle) return "NLOS: the relay wall must be a rectangle";
+    const bool camera_sensor = n->relay_shape == MTR_NLOS_NO_RELAY;
+    if (camera_sensor && (d.film.crop_width != d.film.width || d.film.crop_height != d.film.height))
+        return "NLOS with a perspective sensor: crop windows are not supported";
+    if (!n->shapes || n->n_shapes == 0 || (!camera_sensor && n->relay_shape >= n->n_shapes)) return "NLOS: bad shape table";
+    if (!camera_sensor && !n->shapes[n->relay_shape].is_rectangle) return "NLOS: the relay wall must be a rectangle";
     if (d.n_emitters != 0) return "NLOS: area emitters are not supported next to the projector";
     uint32_t covered = 0;
     for (uint32_t s = 0; s < n->n_shapes; ++s) {
@@ -139,8 +142,15 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
     if (covered != d.n_tris) return "NLOS: shapes must cover every triangle";
     NlosConst &k = o.k;
     k.sensor_origin = mk(n->sensor_origin[0], n->sensor_origin[1], n->sensor_origin[2]);
-    const mtr_shape &rw = n->shapes[n->relay_shape];
-    k.w_center = ld3(rw.center); k.w_du = ld3(rw.du); k.w_dv = ld3(rw.dv);
+    k.camera_sensor = camera_sensor ? 1u : 0u;
+    memcpy(k.cam.s2c, d.camera.sample_to_camera, sizeof k.cam.s2c);
+    memcpy(k.cam.tw, d.camera.to_world, sizeof k.cam.tw);
+    k.cam.near_clip = d.camera.near_clip; k.cam.far_clip = d.camera.far_clip;
+    k.inv_w = 1.0f / (float)d.film.width; k.inv_h = 1.0f / (float)d.film.height;
+    if (!camera_sensor) {
+        const mtr_shape &rw = n->shapes[n->relay_shape];
+        k.w_center = ld3(rw.center); k.w_du = ld3(rw.du); k.w_dv = ld3(rw.dv);
+    } else { k.w_center = mk(0, 0, 0); k.w_du = mk(1, 0, 0); k.w_dv = mk(0, 1, 0); }
     const float *T = n->laser_to_world;
     k.l_origin = mk(T[3], T[7], T[11]);
     k.l_forward = mk(T[2], T[6], T[10]);

@@ -53,8 +53,9 @@ class TransientNLOSPath(TransientADIntegrator):
         from ..sensors.nloscapturemeter import NLOSCaptureMeter
         if isinstance(sensor, int):
             sensor = scene.sensors()[sensor]
-        if not isinstance(sensor, NLOSCaptureMeter):
-            raise AssertionError("transient_nlos_path needs a nlos_capture_meter sensor")
+        from ..sensors import PerspectiveSensor
+        if not isinstance(sensor, (NLOSCaptureMeter, PerspectiveSensor)):
+            raise AssertionError("transient_nlos_path needs a nlos_capture_meter or a perspective sensor")
         film = sensor.film()
         if self.capture_type == 3:
             if not getattr(film, "exhaustive_scan", False):

@@ -173,7 +173,10 @@ class Scene:
                                             self.relay_names_.get(key), self.approximate_materials, self.geometry_)
         sd = self._data[key]
         sd.film = film_desc_from(sensor.film())
-        if key in self.relay_names_:                                    # NLOS tier: rebuilt from the live objects
+        from .integrators.transientnlospath import TransientNLOSPath
+        # NLOS tier (rebuilt from the live objects): a nlos_capture_meter on its relay wall, or — as in the reference's
+        # examples/transient-nlos/nlos-z-*.xml — transient_nlos_path behind an ordinary perspective camera
+        if key in self.relay_names_ or isinstance(self.integrator_, TransientNLOSPath):
             from .scene import nlos_desc_from
             if len(self.emitters_) != 1:
                 raise AssertionError(f"You have defined multiple ({len(self.emitters_)}) emitters in the scene with a "

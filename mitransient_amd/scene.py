@@ -512,10 +512,11 @@ def film_desc_from(film) -> _cabi.mtr_film_desc:
 def nlos_desc_from(integrator, sensor, emitter, relay_shape: int) -> _cabi.mtr_nlos_desc:
     """mtr_nlos_desc from the live plugin objects (so that nlos.focus_emitter_* edits are picked up)."""
     n = _cabi.mtr_nlos_desc()
+    origin = getattr(sensor, "sensor_origin", (0.0, 0.0, 0.0))       # perspective sensor: unused
     for k in range(3):
-        n.sensor_origin[k] = np.float32(sensor.sensor_origin[k])
+        n.sensor_origin[k] = np.float32(origin[k])
         n.laser_irradiance[k] = np.float32(emitter.irradiance[k])
-    n.relay_shape = relay_shape
+    n.relay_shape = relay_shape if relay_shape >= 0 else _cabi.MTR_NLOS_NO_RELAY
     m = emitter.world_transform().matrix.reshape(-1)
     for i in range(16):
         n.laser_to_world[i] = np.float32(m[i])

@@ -90,9 +90,10 @@ def _transform(el, ctx) -> ScalarTransform4f:
 
 
 def _bool(s: str) -> bool:
-    if s not in ("true", "false"):
+    v = s.strip().lower()                      # the reference's own nlos-z-simple.xml writes "False"
+    if v not in ("true", "false"):
         raise ValueError(f"XML: boolean value must be 'true' or 'false', got '{s}'")
-    return s == "true"
+    return v == "true"
 
 
 def _property(el, ctx):

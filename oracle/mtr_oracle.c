@@ -930,7 +930,8 @@ static void nlos_build(nlos_scene *N, const orc_scene *sc, int use_bvh)
     float inv[12] = { T[0], T[4], T[8], 0, T[1], T[5], T[9], 0, T[2], T[6], T[10], 0 };
     memcpy(N->l_inv, inv, sizeof inv);
     N->l_cot = (float)(1.0 / tan(0.5 * (double)n->laser_fov * 3.14159265358979323846 / 180.0));
-    const mtr_shape *rw = &n->shapes[n->relay_shape];
+    static const mtr_shape no_wall = { 0, 0, 1, { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 } };
+    const mtr_shape *rw = n->relay_shape == MTR_NLOS_NO_RELAY ? &no_wall : &n->shapes[n->relay_shape];   /* perspective camera: no relay wall */
     N->w_center = V(rw->center[0], rw->center[1], rw->center[2]);
     N->w_du = V(rw->du[0], rw->du[1], rw->du[2]); N->w_dv = V(rw->dv[0], rw->dv[1], rw->dv[2]);
     uint32_t ns = n->n_shapes;
@@ -973,7 +974,9 @@ static void nlos_build(nlos_scene *N, const orc_scene *sc, int use_bvh)
     N->sensor_targets = calloc((size_t)f->width * f->height, sizeof(v3));
     for (uint32_t y = 0; y < f->height; ++y)
         for (uint32_t x = 0; x < f->width; ++x) {
-            ray3 r = nlos_sensor_ray(N, f, (float)x / (float)f->width, (float)y / (float)f->height);
+            /* sensor.sample_ray at the film sample (x / W, y / H) (:296-308): nlos_capture_meter, or the scene's camera */
+            ray3 r = n->relay_shape == MTR_NLOS_NO_RELAY ? sample_ray(d, x, y, 0.0f, 0.0f)
+                                                         : nlos_sensor_ray(N, f, (float)x / (float)f->width, (float)y / (float)f->height);
             hit_t h = intersect(sc, &r, use_bvh);
             sinter si = make_si(sc, &r, h);
             N->sensor_targets[(size_t)y * f->width + x] = si.p;          /* (0,0,0) on a miss, like zeros(si) */
@@ -1159,7 +1162,7 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
     /* sample_rays: pos_adjusted = (pos + jitter) * (1/crop) + offset, then the sensor snaps it to the pixel centre */
     float scx = 1.0f / (float)f->crop_width, scy = 1.0f / (float)f->crop_height;
     float sx = fmaf((float)px + j1, scx, -(float)f->crop_offset_x * scx), sy = fmaf((float)py + j2, scy, -(float)f->crop_offset_y * scy);
-    ray3 ray = nlos_sensor_ray(N, f, sx, sy);
+    ray3 ray = n->relay_shape == MTR_NLOS_NO_RELAY ? sample_ray(d, px, py, j1, j2) : nlos_sensor_ray(N, f, sx, sy);
 
     uint32_t depth = 0; float L[3] = { 0, 0, 0 }, beta[3] = { 1, 1, 1 };
     float eta = 1.0f, distance = 0.0f;                                  /* distance = ray.time = 0 (:718) */

@@ -101,3 +101,26 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
     scene = mi.load_dict(d)
     mitr.nlos.focus_emitter_at_relay_wall_pixel((sx / 2, sy / 2), relay, laser)
     return scene
+
+
+def make_nlos_camera(res=16, bins=100, capture="single", spp=8, laser_fov=0.2, **integ):
+    """transient_nlos_path behind an ordinary perspective camera (examples/transient-nlos/nlos-z-simple.xml /
+    2-complex-nlos-scenes.ipynb): camera and projector at (-2, 0, 2) looking at a 2x2 wall in the z = 0 plane, a hidden
+    quad at z = 1; no nlos_capture_meter, so no shape is excluded from hidden-geometry sampling."""
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    pose = T().look_at(origin=[-2.0, 0.0, 2.0], target=[0.0, 0.0, 0.0], up=[0, 1, 0])
+    white = {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.9, 0.9, 0.9]}}}
+    idict = {"type": "transient_nlos_path", "max_depth": 5, "nlos_laser_sampling": True, "nlos_hidden_geometry_sampling": True,
+             "capture_type": capture, "temporal_filter": "box"}
+    idict.update(integ)
+    return mi.load_dict({
+        "type": "scene", "integrator": idict,
+        "sensor": {"type": "perspective", "fov": 40.0, "fov_axis": "x", "near_clip": 0.1, "far_clip": 100.0, "to_world": pose,
+                   "sampler": {"type": "independent", "sample_count": spp},
+                   "film": {"type": "transient_hdr_film", "width": res, "height": res, "temporal_bins": bins,
+                            "bin_width_opl": 0.04, "start_opl": 1.0, "rfilter": {"type": "box"}}},
+        "laser": {"type": "projector", "to_world": pose, "fov": laser_fov, "irradiance": {"type": "rgb", "value": [100.0, 100.0, 100.0]}},
+        "wall": {"type": "rectangle", "bsdf": white},
+        "hidden": {"type": "rectangle", "to_world": T().translate([0.5, 0, 1]).rotate([0, 1, 0], 180).scale(0.5), "bsdf": white},
+    })

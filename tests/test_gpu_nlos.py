@@ -136,3 +136,21 @@ def test_exhaustive_film_add_transient_data(oracle, variant, sort):
     i = int(np.argmax(ok & (dist > 1.0) & (dist < 4.2)))
     b = int(np.floor((np.float32(dist[i]) - np.float32(1.0)) / np.float32(0.1)))
     assert flat[py[i], px[i], lx[i], ly[i], b, 0] > 0
+
+
+from test_nlos import CAMERA_NLOS  # noqa: E402
+from conftest import make_nlos_camera  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg", CAMERA_NLOS)
+def test_camera_nlos_matches_oracle(oracle, cfg):
+    """transient_nlos_path with a perspective camera instead of a nlos_capture_meter (nlos-z-simple.xml)"""
+    scene = make_nlos_camera(res=20, **cfg)
+    s_gpu, t_gpu = _gpu(scene, 48)
+    s_ref, t_ref, cnt = _oracle(oracle, scene, 48)
+    assert t_gpu.shape == (20, 20, 100, 3)
+    assert rel_l2(t_gpu, t_ref) <= TOL
+    assert np.linalg.norm(s_ref) == 0 or rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

@@ -176,3 +176,57 @@ def test_exhaustive_needs_matching_film():
     with pytest.raises(AssertionError, match="must be equal"):
         sc = exhaustive_scene(sx=4, sy=4, lw=2, lh=2, equal=True)
         sc.integrator().check_transient_(sc, 0)
+
+
+# ---- transient_nlos_path behind a perspective camera (examples/transient-nlos/nlos-z-*.xml) --------------------
+from conftest import make_nlos_camera  # noqa: E402
+
+CAMERA_NLOS = [dict(), dict(capture="confocal", max_depth=4), dict(nlos_laser_sampling=False, nlos_hidden_geometry_sampling=False, laser_fov=60.0, max_depth=4),
+               dict(nlos_hidden_geometry_sampling=False, max_depth=-1, rr_depth=2)]
+
+
+@pytest.mark.parametrize("cfg", CAMERA_NLOS)
+def test_camera_nlos_host_harness_matches_oracle(oracle, host_harness, cfg):
+    scene = make_nlos_camera(**cfg)
+    sd = scene.data()
+    assert sd.nlos is not None and sd.nlos.relay_shape == 0xFFFFFFFF
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 24)
+    t4, s4, c = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert hc[k] == c[k], k
+    assert np.count_nonzero(t4) > 100
+
+
+def test_camera_nlos_three_bounce_arrival(oracle):
+    """Single capture through a camera: the laser spot is where the projector's axis meets the wall (the origin);
+    the three-bounce signal of a wall pixel starts at |spot - h| + |h - pixel point| minimised over the hidden quad
+    (camera -> wall is not counted: account_first_and_last_bounces = False)"""
+    scene = make_nlos_camera(res=8, bins=200, max_depth=3, spp=1)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 600)
+    t4, s4, _ = oracle.render(sd, p)
+    prof = t4[..., 0].sum(axis=(0, 1))
+    first = int(np.argmax(prof > 0))
+    # hidden quad: x in [0, 1], y in [-0.5, 0.5], z = 1; closest approach for wall points near the spot is straight up
+    # the z axis at x = 0 (the quad's edge): 2 * 1 = 2 for the pixel that sees the spot itself
+    assert abs((1.0 + first * 0.04) - 2.0) < 0.09
+    assert prof.sum() > 0 and not np.isnan(prof).any()
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/examples/transient-nlos"), reason="reference examples not present")
+def test_reference_nlos_xml_scenes(oracle, host_harness):
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_mono")
+    try:
+        for name, n_tris in (("nlos-z-simple.xml", 8), ("nlos-z-room.xml", 18)):
+            sc = mi.load_file("/root/reference/examples/transient-nlos/" + name)
+            sd = sc.data()
+            assert sd.tri_verts.shape[0] == n_tris and sc.integrator().laser_sampling and sc.integrator().hg_sampling
+            p = sc.integrator().render_params(sc.sensors()[0].film(), 0, 32)
+            t4, s4, c = oracle.render(sd, p, use_bvh=True)
+            ht, hs, hc = hh_render(host_harness, sd, p)
+            assert np.array_equal(t4, ht) and hc["bounces"] == c["bounces"] and np.count_nonzero(t4) > 500
+    finally:
+        mi.set_variant("llvm_ad_rgb")
