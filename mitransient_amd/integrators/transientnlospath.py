@@ -5,8 +5,16 @@ sampling (:637-670) — and the Single / Confocal / Exhaustive capture types (Ex
 in the HIP kernels (``nlos_bounce`` in csrc/mtr_nlos.h)."""
 from __future__ import annotations
 
+import enum
+
 from .. import _cabi
 from .common import TransientADIntegrator
+
+
+class CaptureType(enum.IntEnum):                  # transientnlospath.py:12-13
+    Single = 1
+    Confocal = 2
+    Exhaustive = 3
 
 
 class TransientNLOSPath(TransientADIntegrator):

@@ -48,7 +48,8 @@ def ScalarPoint3f(*v):
     return [float(x) for x in (v[0] if len(v) == 1 else v)]
 
 
-Point3f = ScalarPoint3f = ScalarPoint3f
+Point3f = ScalarPoint3f
+Point2f = ScalarPoint2f = ScalarPoint3f        # plain float lists, any length
 
 
 class util:                                 # namespace, like mitsuba.util
@@ -71,11 +72,25 @@ ScalarColor3f = ScalarColor3d
 _SHAPE_TYPES = ("rectangle", "cube", "obj", "ply", "sphere", "disk", "cylinder")
 
 
+def _nested(d, pred_dict, pred_obj):
+    """the first nested plugin of a dictionary that matches: keys are arbitrary (the notebooks write 'transient_film',
+    'nlos_sensor', ...), values are dictionaries or objects that mi.load_dict returned earlier"""
+    for v in d.values():
+        if isinstance(v, dict) and pred_dict(v):
+            return v
+        if not isinstance(v, dict) and pred_obj(v):
+            return v
+    return None
+
+
 def _make_sensor(sd, shape_obj=None):
-    fd = sd.get("film")
+    from . import films as _f  # noqa: F401  (registers the film plugins)
+    from .films.transient_hdr_film import TransientHDRFilm
+    fd = _nested(sd, lambda v: str(v.get("type", "")).endswith("_film") or v.get("type") == "hdrfilm",
+                 lambda v: isinstance(v, TransientHDRFilm))
     if fd is None:
         raise ValueError("sensor: a 'film' is required")
-    film = plugins.create_film(fd["type"], Properties(fd["type"], fd))
+    film = fd if isinstance(fd, TransientHDRFilm) else plugins.create_film(fd["type"], Properties(fd["type"], fd))
     smp = sd.get("sampler", {"type": "independent"})
     if smp.get("type") != "independent":
         raise ValueError(f"failed to instantiate unknown plugin of type \"{smp.get('type')}\" (supported samplers: independent)")
@@ -94,11 +109,15 @@ def _make_sensor(sd, shape_obj=None):
 def _load_shape(d):
     """a shape dictionary -> Shape object; a nested nlos_capture_meter becomes its sensor"""
     from .shapes import Shape
+    from .sensors.nloscapturemeter import NLOSCaptureMeter
     sh = Shape(d)
     for k, v in d.items():
         if isinstance(v, dict) and v.get("type") == "nlos_capture_meter":
             sh.sensor_ = _make_sensor(v, sh)
             sh.sensor_key = k
+        elif isinstance(v, NLOSCaptureMeter):              # a sensor object loaded on its own (1-simple-nlos-scenes.ipynb)
+            sh.sensor_, sh.sensor_key = v, k
+            v.shape_ = sh
     return sh
 
 
@@ -132,12 +151,14 @@ class Scene:
             else:
                 flat[k] = v
         self.dict_ = flat
-        integ = [v for v in flat.values() if isinstance(v, dict) and
-                 (str(v.get("type", "")).startswith("transient") or v.get("type") in ("path", "direct"))]
+        from .integrators.common import TransientADIntegrator
+        integ = [v for v in flat.values() if isinstance(v, TransientADIntegrator) or (isinstance(v, dict) and
+                 (str(v.get("type", "")).startswith("transient") or v.get("type") in ("path", "direct")))]
         if len(integ) != 1:
             raise ValueError("load_dict(): exactly one integrator is required")
         idict = integ[0]
-        self.integrator_ = plugins.create_integrator(idict["type"], Properties(idict["type"], idict))
+        self.integrator_ = idict if isinstance(idict, TransientADIntegrator) else \
+            plugins.create_integrator(idict["type"], Properties(idict["type"], idict))
         for k, v in flat.items():
             if isinstance(v, dict) and v.get("type") == "perspective":
                 self.sensors_.append(_make_sensor(v))
@@ -224,6 +245,13 @@ def load_dict(d: Dict[str, Any], base_dir: str = ".", approximate_materials: boo
         e = Projector(Properties("projector", d))
         e.dict_ = d
         return e
+    from . import integrators as _i, films as _f  # noqa: F401  (registers the plugins)
+    if str(t).endswith("_film"):                                # stand-alone plugins, as 1-simple-nlos-scenes.ipynb builds them
+        return plugins.create_film(t, Properties(t, d))
+    if t in ("nlos_capture_meter", "perspective"):
+        return _make_sensor(d)
+    if str(t).startswith("transient"):
+        return plugins.create_integrator(t, Properties(t, d))
     raise ValueError(f"load_dict(): unsupported top-level plugin type \"{t}\"")
 
 

@@ -230,3 +230,58 @@ def test_reference_nlos_xml_scenes(oracle, host_harness):
             assert np.array_equal(t4, ht) and hc["bounces"] == c["bounces"] and np.count_nonzero(t4) > 500
     finally:
         mi.set_variant("llvm_ad_rgb")
+
+
+def notebook_scene(tmp_path, capture, film_extra=None, spp=16):
+    """the scene of examples/transient-nlos/1-simple-nlos-scenes.ipynb, built the way the notebook builds it: every
+    plugin loaded on its own with mi.load_dict and then assembled (Z.obj comes from the committed geometry fixture)"""
+    import os
+    import mitransient_amd.mi as mi
+    from mitransient_amd.integrators.transientnlospath import CaptureType
+    tris = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nlos_Z_geometry.npz"))["tris"]
+    lines = [f"v {v[0]} {v[1]} {v[2]}" for v in tris.reshape(-1, 3)] + [f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}" for i in range(len(tris))]
+    (tmp_path / "Z.obj").write_text("\n".join(lines) + "\n")
+    geometry = mi.load_dict({"type": "obj", "filename": str(tmp_path / "Z.obj"),
+                             "to_world": mi.ScalarTransform4f().translate([0.0, 0.0, 1.0]),
+                             "bsdf": {"type": "diffuse", "reflectance": 1.0}})
+    emitter = mi.load_dict({"type": "projector", "irradiance": 100.0, "fov": 0.2,
+                            "to_world": mi.ScalarTransform4f().translate([-0.5, 0.0, 0.25])})
+    fd = {"type": "transient_hdr_film", "width": 8, "height": 8, "temporal_bins": 300, "bin_width_opl": 0.006,
+          "start_opl": 1.85, "rfilter": {"type": "box"}}
+    fd.update(film_extra or {})
+    transient_film = mi.load_dict(fd)
+    nlos_sensor = mi.load_dict({"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp},
+                                "sensor_origin": mi.ScalarPoint3f(-0.5, 0.0, 0.25), "transient_film": transient_film})
+    relay_wall = mi.load_dict({"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": 1.0}, "nlos_sensor": nlos_sensor})
+    integrator = mi.load_dict({"type": "transient_nlos_path", "nlos_laser_sampling": True, "nlos_hidden_geometry_sampling": True,
+                               "nlos_hidden_geometry_sampling_do_rroulette": False,
+                               "nlos_hidden_geometry_sampling_includes_relay_wall": False, "discard_direct_paths": False,
+                               "account_first_and_last_bounces": False,
+                               "capture_type": {"single": CaptureType.Single, "confocal": CaptureType.Confocal,
+                                                "exhaustive": CaptureType.Exhaustive}[capture],
+                               "temporal_filter": "box"})
+    scene = mi.load_dict({"type": "scene", "geometry": geometry, "emitter": emitter, "relay_wall": relay_wall,
+                          "integrator": integrator})
+    return scene, relay_wall, emitter, transient_film, nlos_sensor
+
+
+def test_notebook_style_assembly(tmp_path, oracle, host_harness):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_mono")
+    try:
+        scene, relay_wall, emitter, film, sensor = notebook_scene(tmp_path, "single")
+        assert scene.sensors()[0] is sensor and sensor.film() is film and scene.emitters()[0] is emitter
+        assert sensor.get_shape() is relay_wall and isinstance(scene.integrator(), mitr.TransientNLOSPath)
+        mitr.nlos.focus_emitter_at_relay_wall_pixel(mi.Point2f(4, 4), relay_wall, emitter)
+        sd = scene.data()
+        assert sd.tri_verts.shape[0] == 2 + 6 and sd.nlos.capture_type == 1 and sd.nlos.laser_irradiance[0] == 100.0
+        p = scene.integrator().render_params(film, 0, 16)
+        t4, s4, c = oracle.render(sd, p, n_threads=1)
+        ht, hs, hc = hh_render(host_harness, sd, p)
+        assert np.array_equal(t4, ht) and hc["bounces"] == c["bounces"] and np.count_nonzero(t4) > 50
+        scene, *_ = notebook_scene(tmp_path, "exhaustive", {"exhaustive_scan": True, "laser_scan_width": 8, "laser_scan_height": 8}, spp=4)
+        sd = scene.data()
+        assert sd.nlos.capture_type == 3 and sd.film.laser_scan_width == 8
+    finally:
+        mi.set_variant("llvm_ad_rgb")
