@@ -20,6 +20,18 @@ from ..tensor import TensorXf
 from .transient_hdr_film import TransientHDRFilm
 
 
+class _Float(float):
+    """a frequency as the reference exposes it: a one-lane Dr.Jit Float — the notebooks read it as ``f[0]``"""
+
+    def __getitem__(self, i):
+        if i not in (0, -1):
+            raise IndexError(i)
+        return float(self)
+
+    def __len__(self):
+        return 1
+
+
 class PhasorImageBlock:
     """(H, W, 2F+1) float32 accumulator in HBM (render/phasor_image_block.py)."""
 
@@ -75,7 +87,7 @@ class PhasorHDRFilm(TransientHDRFilm):
             np.fft.fftfreq(nt, d=self.bin_width_opl)[freq_min_idx:freq_max_idx + 1].astype(np.float32))
         if self.frequencies_f32.size == 0:
             raise ValueError("PhasorHDRFilm: wl_mean / wl_sigma select no frequency")
-        self.frequencies = [float(f) for f in self.frequencies_f32]
+        self.frequencies = [_Float(f) for f in self.frequencies_f32]
         self.phasors = None
 
     # -- lifecycle -------------------------------------------------------------
