@@ -67,19 +67,8 @@ __device__ __forceinline__ void log_splat(const SplatLog &lg, uint32_t lane, uin
     }
 }
 
-// 64-bit fixed-point accumulation (see mtr_wavefront.hip: ds_add_u64 is 13x faster than ds_add_f32)
-constexpr float kFixScale = 4398046511104.0f, kFixInv = 2.2737367544323206e-13f;     // 2^42, 2^-42
-__device__ __forceinline__ unsigned long long to_fixed(float v)
-{
-    long long q = __float2ll_rn(v * kFixScale);
-    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;
-    return (unsigned long long)q;
-}
 #ifndef MTR_FUSED_SEG_LANES
 #define MTR_FUSED_SEG_LANES 2048u      // lanes per segment the planner aims for (1024: 148 ms, 2048: 143 ms)
-#endif
-#ifndef MTR_FUSED_FIXED
-#define MTR_FUSED_FIXED 0
 #endif
 
 // private per-segment histogram in LDS: planes [3][G*T]
@@ -93,13 +82,8 @@ struct LdsHistSink {
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
-#if MTR_FUSED_FIXED
-        unsigned long long *p = (unsigned long long *)hist + row + bin;
-        atomicAdd(p, to_fixed(r)); atomicAdd(p + plane, to_fixed(g)); atomicAdd(p + 2 * plane, to_fixed(b));
-#else
         float *p = hist + row + bin;
         lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b);
-#endif
         ++n_splats;
         if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
     }
@@ -169,7 +153,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     const uint32_t plane = a.G * T;
 
     if (tid < 6) s_cnt[tid] = 0ull;
-    if (HIST_LDS) for (uint32_t i = tid; i < 3 * plane * (MTR_FUSED_FIXED ? 2 : 1); i += kBlock) s_hist[i] = 0.0f;
+    if (HIST_LDS) for (uint32_t i = tid; i < 3 * plane; i += kBlock) s_hist[i] = 0.0f;
 
     LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
@@ -256,21 +240,10 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
             const size_t fpix = (size_t)cy * a.film.width + cx;
             if (HIST_LDS) {
                 float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
-#if MTR_FUSED_FIXED
-                unsigned long long *h = (unsigned long long *)s_hist + gg * T;
-#else
                 float *h = s_hist + gg * T;
-#endif
                 for (uint32_t t = tid; t < T; t += kBlock) {
-#if MTR_FUSED_FIXED
-                    const unsigned long long qr = h[t], qg = h[t + plane], qb = h[t + 2 * plane];
-                    float r = __ll2float_rn((long long)qr) * kFixInv, gc = __ll2float_rn((long long)qg) * kFixInv,
-                          b = __ll2float_rn((long long)qb) * kFixInv;
-                    if ((qr | qg | qb) != 0ull) {
-#else
                     float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
                     if (r != 0.0f || gc != 0.0f || b != 0.0f) {
-#endif
                         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];     // accumulate onto earlier passes
                         v.x += r; v.y += gc; v.z += b;
@@ -332,7 +305,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     cfg.scene_lds = scene_b <= 64u * 1024u;
     if (cfg.scene_lds) fixed += scene_b;
     // pixels per segment: enough lanes to keep 256 persistent threads busy, rows must fit in LDS
-    const uint32_t row_bytes = film.bins * (MTR_FUSED_FIXED ? 24u : 12u);
+    const uint32_t row_bytes = film.bins * 12u;
     const uint32_t hist_budget = 48u * 1024u;
     uint32_t g_want = (MTR_FUSED_SEG_LANES + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
     if (g_want < 1) g_want = 1;

@@ -539,10 +539,10 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
 // ---- the time-bin scatter-add: one workgroup per pixel of the tile ------------------------------
 // LDS float atomics (ds_add_f32) retire at a fixed 3 clocks per LANE on gfx950 whatever the address
 // pattern (204 G adds/s for the whole chip, measured), 64-bit integer LDS atomics at 2.7 T/s.  The row
-// is therefore accumulated in signed 2^-kFixShift fixed point with ds_add_u64 and converted back to
+// is therefore accumulated in signed 2^-42 fixed point with ds_add_u64 and converted back to
 // f32 once per (pixel, bin) at the flush: 13x faster, order-independent (deterministic) sums, and an
 // absolute rounding error of 2^-43 per contribution — below the f32 rounding of any bin sum > 1e-5.
-constexpr int kFixShift = 42;                       // resolution 2.3e-13, range +-2^21 per bin
+// resolution 2.3e-13, range +-2^21 per bin
 __device__ __forceinline__ unsigned long long to_fixed(float v)
 {
     long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42, exact scaling
