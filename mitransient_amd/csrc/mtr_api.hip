@@ -28,6 +28,7 @@ struct mtr_ctx {
     DevCounters *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
+    void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
@@ -109,6 +110,7 @@ void mtr_ctx_destroy(mtr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_freq) (void)hipFree(c->d_freq);
+    if (c->d_runs) (void)hipFree(c->d_runs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -549,6 +551,7 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
         if (c->freq_cap < fm.n_freq) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->d_freq) (void)hipFree(c->d_freq);
+    if (c->d_runs) (void)hipFree(c->d_runs);
             c->d_freq = nullptr; c->freq_cap = 0;
             HIP_TRY(c, hipMalloc((void **)&c->d_freq, (size_t)fm.n_freq * 4));
             c->freq_cap = fm.n_freq;
@@ -556,8 +559,20 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
         HIP_TRY(c, hipMemcpyAsync(c->d_freq, fd->frequencies, (size_t)fm.n_freq * 4, hipMemcpyHostToDevice, c->stream));
         fm.freq = c->d_freq;
     }
+    void *scratch = nullptr;
+    if (variant == 1 && !fm.n_freq) {
+        const size_t need = 8u * ((size_t)fm.width * fm.height + 2u);
+        if (c->runs_cap < need) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->d_runs) (void)hipFree(c->d_runs);
+            c->d_runs = nullptr; c->runs_cap = 0;
+            HIP_TRY(c, hipMalloc(&c->d_runs, need));
+            c->runs_cap = need;
+        }
+        scratch = c->d_runs;
+    }
     if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, c->stream));
+    HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, scratch, c->stream));
     if (elapsed_ms) {
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -91,8 +91,9 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg);
 // 3 time-bin scatter-add, 4 shadow-ray generation
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream);
 
+// scratch (variant 1): device buffer of >= 8 * (width * height + 2) bytes for the run table; NULL forces the atomics
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
-                            DevCounters *counters, hipStream_t stream);
+                            DevCounters *counters, void *scratch, hipStream_t stream);
 hipError_t launch_develop(const Film &film, const float *t4, float *t3, const float *s4, float *s3, hipStream_t stream);
 
 } // namespace mtr

@@ -399,8 +399,10 @@ hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream
 // ------------------------------------------------------------------ stand-alone time-bin scatter-add
 // variant 0: one f32 atomic per channel straight into HBM (the contract form of
 // transient_image_block.py:148-149)
-__global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film film, float *out, DevCounters *cnt)
+__global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film film, float *out, DevCounters *cnt,
+                                                         const uint32_t *only_if)
 {
+    if (only_if && *only_if == 0u) return;          // the fallback of variant 1: runs only when the input was not sorted
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint32_t npix = film.width * film.height;
     uint32_t mine = 0;
@@ -415,57 +417,75 @@ __global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film f
     if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
 }
 
-// variant 1: splats sorted by pixel.  A workgroup takes a contiguous chunk, walks its pixel runs,
-// accumulates each run in an LDS row (T x 3) and adds the touched bins to HBM once per run.
-constexpr uint32_t kSplatChunk = 8192;
-__global__ void __launch_bounds__(kBlock) k_splat_sorted(mtr_splat_soa s, Film film, float *out, DevCounters *cnt)
+// variant 1: contributions sorted by pixel.  k_splat_runs finds where each pixel's run starts (and whether the input is
+// sorted at all); k_splat_rows then works like k_wf_scatter: one workgroup per pixel streams the run into an LDS row —
+// 64-bit fixed point, ds_add_u64 (ds_add_f32 retires at 3 clocks per lane on gfx950) — and adds the touched bins to the
+// film with plain 16-byte read-modify-writes, because the pixel is its own.  Unsorted input falls back to the atomics.
+__global__ void __launch_bounds__(kBlock) k_splat_runs(const uint32_t *pixel, uint64_t n, uint32_t npix,
+                                                       unsigned long long *starts, uint32_t *unsorted)
 {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t cur = min(pixel[i], npix);                    // ids >= npix (dropped contributions) sort to the end
+        const int64_t prev = i ? (int64_t)min(pixel[i - 1], npix) : -1;
+        if ((int64_t)cur < prev) *unsorted = 1u;
+        for (int64_t q = prev + 1; q <= (int64_t)cur; ++q) starts[q] = i;                   // pixels prev+1 .. cur start here
+        if (i == n - 1) for (uint32_t q = cur + 1; q <= npix; ++q) starts[q] = n;
+    }
+}
+
+__device__ __forceinline__ unsigned long long splat_to_fixed(float v)
+{
+    long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42
+    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;
+    return (unsigned long long)q;
+}
+
+template <bool FIXED>
+__global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film film, float *out, const unsigned long long *starts,
+                                                       const uint32_t *unsorted, DevCounters *cnt)
+{
+    if (*unsorted) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *row = (float *)smem;                    // [3][T]
-    __shared__ uint32_t s_pix, s_end;
+    float *row = (float *)smem;                                      // [3][T] f32 ...
+    unsigned long long *row64 = (unsigned long long *)smem;          // ... or [3][T] 2^-42 fixed point
     const uint32_t T = film.bins, npix = film.width * film.height;
     const int tid = threadIdx.x;
-    for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
+    for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
+    __syncthreads();
     uint32_t mine = 0;
-    const uint64_t n_chunks = (s.n + kSplatChunk - 1) / kSplatChunk;
-    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const uint64_t c0 = c * kSplatChunk, c1 = min((unsigned long long)s.n, (unsigned long long)(c0 + kSplatChunk));
-        uint64_t cur = c0;
-        while (cur < c1) {
-            __syncthreads();
-            if (tid == 0) {                                  // run of equal pixel ids starting at cur
-                uint32_t px = s.pixel[cur];
-                s_pix = px;
+    for (uint32_t px = blockIdx.x; px < npix; px += gridDim.x) {
+        const uint64_t lo = starts[px], hi = starts[px + 1];
+        if (lo == hi) continue;                                      // (uniform across the workgroup)
+        for (uint64_t i = lo + tid; i < hi; i += kBlock) {
+            const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
+            if (bin < 0) continue;
+            if (FIXED) {
+                unsigned long long *p = row64 + bin;
+                atomicAdd(p, splat_to_fixed(s.r[i])); atomicAdd(p + T, splat_to_fixed(s.g[i])); atomicAdd(p + 2 * T, splat_to_fixed(s.b[i]));
+            } else {
+                lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
             }
-            __syncthreads();
-            const uint32_t px = s_pix;
-            // all threads scan forward cooperatively for the end of the run
-            if (tid == 0) s_end = (uint32_t)(c1 - cur);
-            __syncthreads();
-            for (uint64_t i = cur + tid; i < c1; i += kBlock)
-                if (s.pixel[i] != px) { atomicMin(&s_end, (uint32_t)(i - cur)); break; }
-            __syncthreads();
-            const uint64_t run_end = cur + s_end;
-            if (px < npix) {
-                for (uint64_t i = cur + tid; i < run_end; i += kBlock) {
-                    const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
-                    if (bin < 0) continue;
-                    lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
-                    ++mine;
-                }
-                __syncthreads();
-                float *dst = out + (size_t)px * T * 4u;
-                for (uint32_t t = tid; t < T; t += kBlock) {
-                    float r = row[t], g = row[T + t], b = row[2 * T + t];
-                    if (r != 0.0f || g != 0.0f || b != 0.0f) {
-                        // a pixel's run may continue in the neighbouring chunk -> atomics, once per touched bin
-                        unsafeAtomicAdd(dst + 4 * t, r); unsafeAtomicAdd(dst + 4 * t + 1, g); unsafeAtomicAdd(dst + 4 * t + 2, b);
-                        row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f;
-                    }
-                }
-            }
-            cur = run_end;
+            ++mine;
         }
+        __syncthreads();
+        float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
+        for (uint32_t t = tid; t < T; t += kBlock) {
+            float r, g, b; bool nz;
+            if (FIXED) {
+                const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
+                nz = (qr | qg | qb) != 0ull;
+                r = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; g = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;
+                b = __ll2float_rn((long long)qb) * 2.2737367544323206e-13f;
+                if (nz) { row64[t] = 0ull; row64[T + t] = 0ull; row64[2 * T + t] = 0ull; }
+            } else {
+                r = row[t]; g = row[T + t]; b = row[2 * T + t];
+                nz = r != 0.0f || g != 0.0f || b != 0.0f;
+                if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
+            }
+            if (nz) { float4 v = dst[t]; v.x += r; v.y += g; v.z += b; dst[t] = v; }
+        }
+        __syncthreads();
     }
     if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
 }
@@ -473,7 +493,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_sorted(mtr_splat_soa s, Film f
 __global__ void k_splat_phasor(mtr_splat_soa s, Film film, float *out, DevCounters *cnt);
 
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
-                            DevCounters *counters, hipStream_t stream)
+                            DevCounters *counters, void *scratch, hipStream_t stream)
 {
     if (s.n == 0) return hipSuccess;
     if (film.n_freq) {
@@ -482,18 +502,27 @@ hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &fil
         hipLaunchKernelGGL(k_splat_phasor, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters);
         return hipGetLastError();
     }
-    if (variant == 0 || (size_t)film.bins * 12u > 150u * 1024u) {
-        uint64_t blocks = (s.n + kBlock - 1) / kBlock;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters);
+    uint64_t blocks = (s.n + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (variant == 0 || (size_t)film.bins * 12u > 150u * 1024u || !scratch) {
+        hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters, nullptr);
     } else {
-        uint64_t chunks = (s.n + kSplatChunk - 1) / kSplatChunk;
-        size_t lds = (size_t)film.bins * 12u;
-        int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
-        uint64_t blocks = chunks < (uint64_t)(256 * per_cu) ? chunks : (uint64_t)(256 * per_cu);
-        hipError_t e = hipFuncSetAttribute((const void *)k_splat_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const uint32_t npix = film.width * film.height;
+        uint32_t *unsorted = (uint32_t *)scratch;                                    // [0]: flag; [2..]: run starts (u64[npix + 1])
+        unsigned long long *starts = (unsigned long long *)scratch + 1;
+        hipError_t e = hipMemsetAsync(unsorted, 0, 8, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_splat_sorted, dim3((unsigned)blocks), dim3(kBlock), lds, stream, s, film, film_out, counters);
+        hipLaunchKernelGGL(k_splat_runs, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s.pixel, (uint64_t)s.n, npix, starts, unsorted);
+        const bool fixed = (size_t)film.bins * 24u <= 72u * 1024u;
+        const size_t lds = (size_t)film.bins * (fixed ? 24u : 12u);
+        int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+        const unsigned grid = npix < (uint32_t)(256 * per_cu) ? npix : (unsigned)(256 * per_cu);
+        void (*k)(mtr_splat_soa, Film, float *, const unsigned long long *, const uint32_t *, DevCounters *) =
+            fixed ? k_splat_rows<true> : k_splat_rows<false>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, s, film, film_out, starts, unsorted, counters);
+        hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters, unsorted);
     }
     return hipGetLastError();
 }

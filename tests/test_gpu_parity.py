@@ -235,7 +235,7 @@ def _splats(n, npix, T, seed=1234, sorted_by_pixel=False):
     return pixel, opl, r, g, b
 
 
-@pytest.mark.parametrize("variant,sorted_by_pixel", [(0, False), (0, True), (1, True)])
+@pytest.mark.parametrize("variant,sorted_by_pixel", [(0, False), (0, True), (1, True), (1, False)])      # (1, False): unsorted input -> atomics fallback
 def test_splat_add_matches_oracle(oracle, variant, sorted_by_pixel):
     import torch
     scene = make_cornell(width=32, height=16, bins=256)
