@@ -21,69 +21,52 @@ def indent(obj, amount=2):
 
 
 def cornell_box():
-    '''
-    Returns a dictionary containing a description of the Cornell Box scene for Transient Rendering.
-    (Values of mitransient/utils.py:78-220.)
-    '''
+    """Dictionary description of the Cornell box for transient rendering; same objects, ids and values as the
+    reference helper (mitransient/utils.py:78-220), assembled here from small tables."""
     T = ScalarTransform4f
-    white = {'type': 'ref', 'id': 'white'}
+    X, Y = [1, 0, 0], [0, 1, 0]
 
-    def rgb(r, g, b):
-        return {'type': 'rgb', 'value': [r, g, b]}
+    def rgb(*v):
+        return dict(type="rgb", value=list(v))
 
-    def wall(to_world, bsdf_id):
-        return {'type': 'rectangle', 'to_world': to_world, 'bsdf': {'type': 'ref', 'id': bsdf_id}}
+    def ref(name):
+        return dict(type="ref", id=name)
 
-    return {
-        'type': 'scene',
-        'integrator': {
-            'type': 'transient_path',
-            'camera_unwarp': False,
-            'max_depth': 8,
-            'temporal_filter': 'box',
-            'gaussian_stddev': 2.0,
-        },
-        'sensor': {
-            'type': 'perspective',
-            'fov_axis': 'smaller',
-            'near_clip': 0.001,
-            'far_clip': 100.0,
-            'focus_distance': 1000,
-            'fov': 39.3077,
-            'to_world': T().look_at(origin=[0, 0, 3.90], target=[0, 0, 0], up=[0, 1, 0]),
-            'sampler': {'type': 'independent', 'sample_count': 256},
-            'film': {
-                'type': 'transient_hdr_film',
-                'width': 256,
-                'height': 256,
-                'rfilter': {'type': 'box'},
-                'temporal_bins': 300,
-                'start_opl': 3.5,
-                'bin_width_opl': 0.02,
-            },
-        },
-        'white': {'type': 'diffuse', 'reflectance': rgb(0.885809, 0.698859, 0.666422)},
-        'green': {'type': 'diffuse', 'reflectance': rgb(0.105421, 0.37798, 0.076425)},
-        'red': {'type': 'diffuse', 'reflectance': rgb(0.570068, 0.0430135, 0.0443706)},
-        'light': {
-            'type': 'rectangle',
-            'to_world': T().translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19]),
-            'bsdf': white,
-            'emitter': {'type': 'area', 'radiance': rgb(18.387, 13.9873, 6.75357)},
-        },
-        'floor': wall(T().translate([0.0, -1.0, 0.0]).rotate([1, 0, 0], -90), 'white'),
-        'ceiling': wall(T().translate([0.0, 1.0, 0.0]).rotate([1, 0, 0], 90), 'white'),
-        'back': wall(T().translate([0.0, 0.0, -1.0]), 'white'),
-        'green-wall': wall(T().translate([1.0, 0.0, 0.0]).rotate([0, 1, 0], -90), 'green'),
-        'red-wall': wall(T().translate([-1.0, 0.0, 0.0]).rotate([0, 1, 0], 90), 'red'),
-        'small-box': {
-            'type': 'cube',
-            'to_world': T().translate([0.335, -0.7, 0.38]).rotate([0, 1, 0], -17).scale(0.3),
-            'bsdf': white,
-        },
-        'large-box': {
-            'type': 'cube',
-            'to_world': T().translate([-0.33, -0.4, -0.28]).rotate([0, 1, 0], 18.25).scale([0.3, 0.61, 0.3]),
-            'bsdf': white,
-        },
-    }
+    def place(at, axis=None, deg=0.0, scale=None):
+        t = T().translate(at)
+        if axis is not None:
+            t = t.rotate(axis, deg)
+        return t if scale is None else t.scale(scale)
+
+    scene = dict(type="scene")
+    scene["integrator"] = dict(type="transient_path", camera_unwarp=False, max_depth=8,
+                               temporal_filter="box", gaussian_stddev=2.0)
+    film = dict(type="transient_hdr_film", width=256, height=256, rfilter=dict(type="box"),
+                temporal_bins=300, start_opl=3.5, bin_width_opl=0.02)
+    scene["sensor"] = dict(type="perspective", fov_axis="smaller", near_clip=0.001, far_clip=100.0,
+                           focus_distance=1000, fov=39.3077,
+                           to_world=T().look_at(origin=[0, 0, 3.90], target=[0, 0, 0], up=Y),
+                           sampler=dict(type="independent", sample_count=256), film=film)
+
+    albedo = {"white": (0.885809, 0.698859, 0.666422),
+              "green": (0.105421, 0.37798, 0.076425),
+              "red": (0.570068, 0.0430135, 0.0443706)}
+    for name, value in albedo.items():
+        scene[name] = dict(type="diffuse", reflectance=rgb(*value))
+
+    scene["light"] = dict(type="rectangle", to_world=place([0.0, 0.99, 0.01], X, 90, [0.23, 0.19, 0.19]),
+                          bsdf=ref("white"), emitter=dict(type="area", radiance=rgb(18.387, 13.9873, 6.75357)))
+
+    walls = [("floor", [0.0, -1.0, 0.0], X, -90, "white"),
+             ("ceiling", [0.0, 1.0, 0.0], X, 90, "white"),
+             ("back", [0.0, 0.0, -1.0], None, 0, "white"),
+             ("green-wall", [1.0, 0.0, 0.0], Y, -90, "green"),
+             ("red-wall", [-1.0, 0.0, 0.0], Y, 90, "red")]
+    for name, at, axis, deg, material in walls:
+        scene[name] = dict(type="rectangle", to_world=place(at, axis, deg), bsdf=ref(material))
+
+    boxes = [("small-box", [0.335, -0.7, 0.38], -17, 0.3),
+             ("large-box", [-0.33, -0.4, -0.28], 18.25, [0.3, 0.61, 0.3])]
+    for name, at, deg, scale in boxes:
+        scene[name] = dict(type="cube", to_world=place(at, Y, deg, scale), bsdf=ref("white"))
+    return scene
