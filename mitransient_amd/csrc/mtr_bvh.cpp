@@ -172,4 +172,81 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
     }
 }
 
+namespace {
+
+struct WChild { float lo[3], hi[3]; int32_t ref; };
+size_t g_wide_width = kWide;
+
+void packet_children(const Node &n, std::vector<WChild> &out)
+{
+    const float *f = &n.q[0].x;
+    for (int c = 0; c < 2; ++c) {
+        WChild w;
+        for (int k = 0; k < 3; ++k) { w.lo[k] = f[4 * k + c]; w.hi[k] = f[4 * k + 2 + c]; }
+        w.ref = (int32_t)fbits(f[12 + c]);
+        if (w.lo[0] <= w.hi[0]) out.push_back(w);          // an absent child has an inverted box
+    }
+}
+float half_area(const WChild &w)
+{
+    const float dx = w.hi[0] - w.lo[0], dy = w.hi[1] - w.lo[1], dz = w.hi[2] - w.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNode> &wide, uint32_t level, uint32_t &levels)
+{
+    levels = std::max(levels, level);
+    const uint32_t me = (uint32_t)wide.size();
+    wide.emplace_back();
+    std::vector<WChild> ch;
+    packet_children(bvh.nodes[packet], ch);
+    for (;;) {
+        int best = -1; float best_a = -1.0f;
+        for (size_t i = 0; i < ch.size(); ++i)
+            if (ch[i].ref >= 0 && half_area(ch[i]) > best_a) { best = (int)i; best_a = half_area(ch[i]); }
+        if (best < 0) break;
+        std::vector<WChild> sub;
+        packet_children(bvh.nodes[ch[best].ref], sub);
+        if (ch.size() - 1 + sub.size() > g_wide_width) break;
+        ch.erase(ch.begin() + best);
+        ch.insert(ch.end(), sub.begin(), sub.end());
+    }
+    // walk order: by centroid along the axis on which the centroids spread most
+    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (const WChild &w : ch)
+        for (int k = 0; k < 3; ++k) { const float c = 0.5f * (w.lo[k] + w.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    std::stable_sort(ch.begin(), ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
+
+    WNode nd{};
+    float *f = &nd.box[0].x;
+    for (int c = 0; c < (int)kWide; ++c) {
+        const int j = c >> 1, h = c & 1;
+        for (int k = 0; k < 3; ++k) {
+            f[4 * (3 * j + k) + h] = c < (int)ch.size() ? ch[c].lo[k] : INFINITY;
+            f[4 * (3 * j + k) + 2 + h] = c < (int)ch.size() ? ch[c].hi[k] : -INFINITY;
+        }
+        nd.ref[c] = 0;
+    }
+    nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.leaves = 0u;
+    for (size_t c = 0; c < ch.size(); ++c) if (ch[c].ref < 0) nd.leaves |= 1u << c;
+    for (size_t c = 0; c < ch.size(); ++c)
+        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec(bvh, ch[c].ref, wide, level + 1, levels) : ch[c].ref;
+    wide[me] = nd;
+    return me;
+}
+
+} // namespace
+
+uint32_t build_wide(const BvhBuild &bvh, std::vector<WNode> &wide)
+{
+    wide.clear();
+    if (bvh.nodes.empty()) return 0;
+    if (const char *e = getenv("MTR_WIDE_WIDTH")) { int w = atoi(e); g_wide_width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
+    uint32_t levels = 0;
+    wide_rec(bvh, 0, wide, 1, levels);
+    return levels;
+}
+
 } // namespace mtr

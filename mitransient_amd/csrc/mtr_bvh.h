@@ -20,4 +20,9 @@ struct BvhBuild {
 // verts: n*9 floats (p0 p1 p2 per triangle, world space)
 void build_bvh(const float *verts, uint32_t n, BvhBuild &out);
 
+// Collapses the BVH2 into a tree of up to 8-wide nodes (WNode, mtr_core.h) over the SAME leaves and (padded) boxes:
+// starting from a packet's two children, the inner child with the largest surface area is replaced by its own children
+// until eight are held or only leaves remain.  wide[0] is the root; returns the number of levels.
+uint32_t build_wide(const BvhBuild &bvh, std::vector<WNode> &wide);
+
 } // namespace mtr

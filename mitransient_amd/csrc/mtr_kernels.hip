@@ -1,12 +1,13 @@
 // mtr_kernels.hip — CDNA4 (gfx950) kernels of the transient path tracer.
 //
-// k_fused        MTR_MODE_FUSED: one workgroup owns a segment of G pixels (all their samples).
+// k_fused        MTR_MODE_FUSED: one workgroup owns every gridDim-th pixel (all their samples), G of them at a time.
 //                The whole scene (BVH2 node packets + triangles + materials) is staged in LDS,
 //                paths are generated, traced and shaded by persistent lanes that refill
-//                themselves from an LDS work counter (no idle lanes while the segment has work),
-//                every OPL -> time-bin contribution is an LDS float atomic into the segment's
-//                private (G, T, 3) histogram, and each film row is added to HBM exactly once,
-//                coalesced, by the owning workgroup: no global atomics, no splat traffic.
+//                themselves from an LDS work counter (no idle lanes while the workgroup has work),
+//                every OPL -> time-bin contribution is an LDS float atomic into the pixel's slot of a
+//                private (G, T, 3) ring of row histograms, and each film row is added to HBM exactly
+//                once, coalesced, by the wave that ended the pixel's last path: no global atomics, no
+//                splat traffic, no workgroup barrier between pixels.
 // k_splat_*      the stand-alone time-bin scatter-add (add_transient_data + put_ + accum).
 // k_develop_*    TransientHDRFilm.develop.
 #include "mtr_kernels.h"
@@ -131,29 +132,41 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
     sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf;
     if (SCENE_LDS) {
-        Node *n = (Node *)(smem + off); off += align16(a.sc.n_nodes * sizeof(Node));
+        // a scene staged in LDS is walked through its 8-wide tree (fused_plan); the BVH2 packets stay in HBM, unused
+        const uint32_t tree_bytes = a.sc.n_wnodes * (uint32_t)sizeof(WNode);
+        WNode *n = (WNode *)(smem + off); off += align16(tree_bytes);
         TriPair *tg = (TriPair *)(smem + off); off += align16(a.sc.n_slots / 2 * sizeof(TriPair));
         TriShade *ts = (TriShade *)(smem + off); off += align16(a.sc.n_slots * sizeof(TriShade));
         mtr_material *mm = (mtr_material *)(smem + off); off += align16(a.sc.n_mats * sizeof(mtr_material));
         Emitter *ee = (Emitter *)(smem + off); off += align16(a.sc.n_ems * sizeof(Emitter));
-        copy16(n, a.sc.nodes, align16(a.sc.n_nodes * sizeof(Node)), tid);
+        copy16(n, a.sc.wnodes, align16(tree_bytes), tid);
         copy16(tg, a.sc.tpairs, align16(a.sc.n_slots / 2 * sizeof(TriPair)), tid);
         copy16(ts, a.sc.tshade, align16(a.sc.n_slots * sizeof(TriShade)), tid);
         copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = nullptr; sv.wnodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
     } else {
         sv.nodes = a.sc.nodes; sv.tpairs = a.sc.tpairs; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
+        sv.wnodes = nullptr;
         sv.node_pairs = false;
     }
-    float *s_steady = (float *)(smem + off); off += align16(a.G * 16);
+    // ---- pixel ring: K = a.G row slots; the workgroup's q-th pixel (pixel_begin + blockIdx + q * gridDim) lives in
+    // slot q % K from its first sample until its last path has ended, then the wave that ended it flushes the row
+    // and hands the slot to pixel q + K.  No segment boundaries: lanes of pixel q + 1 start while pixel q drains.
+    const uint32_t K = a.G;
+    float *s_steady = (float *)(smem + off); off += align16(K * 16);
+    uint32_t *s_owner = (uint32_t *)(smem + off); off += align16(K * 4);      // pixel ordinal that may use the slot
+    uint32_t *s_done = (uint32_t *)(smem + off); off += align16(K * 4);       // paths of that pixel that have ended
     float *s_hist = (float *)(smem + off);
     const uint32_t T = a.film.bins;
-    const uint32_t plane = a.G * T;
+    const uint32_t plane = K * T;
 
     if (tid < 6) s_cnt[tid] = 0ull;
-    if (HIST_LDS) for (uint32_t i = tid; i < 3 * plane; i += kBlock) s_hist[i] = 0.0f;
+    if (tid == 0) *s_next = kBlock;
+    for (uint32_t k = tid; k < K; k += kBlock) { s_owner[k] = k; s_done[k] = 0u; }
+    for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady[k] = 0.0f;
+    if (HIST_LDS) for (uint32_t k = tid; k < 3 * plane; k += kBlock) s_hist[k] = 0.0f;
 
     LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
@@ -165,100 +178,116 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
 #endif
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_paths = 0, n_splats = 0;
 
-    for (uint32_t seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
-        const uint32_t pix0 = a.pixel_begin + seg * a.G;
-        const uint32_t npx = min(a.G, a.pixel_end - pix0);
-        const uint32_t n_lanes = npx * a.spp_chunk;
-        for (uint32_t i = tid; i < a.G * 4; i += kBlock) s_steady[i] = 0.0f;
-        if (tid == 0) *s_next = kBlock;
-        __syncthreads();
-        st.prof_mark(5);       // (experiment builds) segment tail + flush + barrier time ends here
+    const uint32_t n_px_all = a.pixel_end - a.pixel_begin;
+    const uint32_t Q = blockIdx.x < n_px_all ? (n_px_all - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+    const uint32_t n_lanes = Q * a.spp_chunk;           // fused_plan keeps this below 2^32 - kBlock
+    __syncthreads();
+    st.prof_mark(5);
 
-        // ---- persistent lanes: refill from the LDS work counter when a path ends ----
-        // The two __ballot()s are convergent operations: they pin this loop to ONE wave-synchronous
-        // iteration = (refill dead lanes) + (one bounce for every live lane).  Without them the
-        // compiler threads `alive` through the back edge and nests a per-path inner loop, i.e. dead
-        // lanes wait for the longest path of their wave instead of refilling (measured: 1/3 of the time).
-        // (A finer-grained wave scheduler — node / leaf / shade blocks picked by lane-count ballots —
-        // was measured too: 2.6x SLOWER; see DESIGN.md "what did not work".)
-        uint32_t i = tid;
-        bool alive = false;
-        Path p;
-        uint32_t g = 0;
-        for (;;) {
-            if (__ballot(!alive) != 0ull) {
-                if (!alive && i < n_lanes) {
-                    g = i / a.spp_chunk;
-                    const uint32_t s = a.spp_begin + (i - g * a.spp_chunk);
-                    if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pix0 + g, s);
-                    else path_begin(p, a.cam, a.film, a.rc, pix0 + g, s);
+    // ---- persistent lanes: refill from the LDS work counter when a path ends ----
+    // The __ballot()s are convergent operations: they pin this loop to ONE wave-synchronous
+    // iteration = (start waiting lanes) + (one bounce for every live lane) + (flush finished rows).  Without
+    // them the compiler threads `alive` through the back edge and nests a per-path inner loop, i.e. dead
+    // lanes wait for the longest path of their wave instead of refilling (measured: 1/3 of the time).
+    // (A finer-grained wave scheduler — node / leaf / shade blocks picked by lane-count ballots —
+    // was measured too: 2.6x SLOWER; see DESIGN.md "what did not work".)
+    uint32_t i = tid;
+    bool alive = false;
+    bool waiting = i < n_lanes;          // holds a sample index whose path has not started yet
+    Path p;
+    uint32_t q = 0, slot = 0;
+    for (;;) {
+        if (__ballot(waiting) != 0ull) {
+            if (waiting) {
+                q = i / a.spp_chunk;
+                slot = q % K;
+                if (__hip_atomic_load(s_owner + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == q) {
+                    const uint32_t s = a.spp_begin + (i - q * a.spp_chunk);
+                    const uint32_t pixel = a.pixel_begin + blockIdx.x + q * gridDim.x;
+                    if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
+                    else path_begin(p, a.cam, a.film, a.rc, pixel, s);
                     ++n_paths;
                     if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
                         Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
                         ++n_closest;
                         if (h0.prim >= 0) p.dist = -h0.t;
                     }
-                    alive = true;
+                    alive = true; waiting = false;
                     st.prof_mark(2);
                 }
             }
-            if (__ballot(alive) == 0ull) break;           // the whole wave is out of work
-            if (alive) {
-                BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
-                if (HIST_LDS) {
-                    LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = g * T;
-                    sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                    alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                                 : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                    n_splats += sink.n_splats;
-                } else {
-                    GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
-                    sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                    alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                                 : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                    n_splats += sink.n_splats;
-                }
-                n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
-                if (!alive) {
-                    // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
-                    const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
-                    if (fx < a.film.width && fy < a.film.height) {
-                        float *sp = s_steady + 4 * g;
-                        lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
-                    }
-                    i = atomicAdd(s_next, 1u);
-                }
-            }
         }
-        __syncthreads();
-
-        // ---- flush: each film row is touched once, by its owner, coalesced (16 B / lane) ----
-        for (uint32_t gg = 0; gg < npx; ++gg) {
-            const uint32_t pixel = pix0 + gg;
-            const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;   // == film coords
-            if (cx >= a.film.width || cy >= a.film.height) continue;
-            const size_t fpix = (size_t)cy * a.film.width + cx;
+        if (__ballot(alive) == 0ull) {
+            if (__ballot(waiting) == 0ull) break;        // the whole wave is out of work
+            __builtin_amdgcn_s_sleep(8);                 // every lane waits for a row another wave is about to flush
+            continue;
+        }
+        bool closes = false;
+        if (alive) {
+            BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
             if (HIST_LDS) {
-                float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
-                float *h = s_hist + gg * T;
-                for (uint32_t t = tid; t < T; t += kBlock) {
-                    float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
-                    if (r != 0.0f || gc != 0.0f || b != 0.0f) {
-                        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];     // accumulate onto earlier passes
-                        v.x += r; v.y += gc; v.z += b;
-                        row[t] = v;
-                        h[t] = 0; h[t + plane] = 0; h[t + 2 * plane] = 0;
-                    }
-                }
+                LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
+                sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                             : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                n_splats += sink.n_splats;
+            } else {
+                GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
+                sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                             : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                n_splats += sink.n_splats;
             }
-            if (tid < 4) {
-                float v = s_steady[4 * gg + tid];
-                if (v != 0.0f) a.steady_out[fpix * 4u + tid] += v;
+            n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
+            if (!alive) {
+                // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+                const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
+                if (fx < a.film.width && fy < a.film.height) {
+                    float *sp = s_steady + 4 * slot;
+                    lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                }
+                // acq_rel: this lane's row / steady adds are performed before the count that may release the row
+                closes = __hip_atomic_fetch_add(s_done + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == a.spp_chunk;
+                i = atomicAdd(s_next, 1u);
+                waiting = i < n_lanes;
             }
         }
-        __syncthreads();
+        // ---- flush: each film row is touched once, by the wave that ended its last path, coalesced (16 B / lane) ----
+        for (unsigned long long cm = __ballot(closes); cm != 0ull; cm &= cm - 1ull) {
+            const int src = __ffsll((long long)cm) - 1;
+            const uint32_t fq = __builtin_amdgcn_readlane(q, src), fs = __builtin_amdgcn_readlane(slot, src);
+            const uint32_t pixel = a.pixel_begin + blockIdx.x + fq * gridDim.x;
+            const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;   // == film coords
+            const uint32_t wl = tid & 63u;
+            if (cx < a.film.width && cy < a.film.height) {
+                const size_t fpix = (size_t)cy * a.film.width + cx;
+                if (HIST_LDS) {
+                    float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
+                    float *h = s_hist + fs * T;
+                    for (uint32_t t = wl; t < T; t += 64u) {
+                        float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
+                        if (r != 0.0f || gc != 0.0f || b != 0.0f) {
+                            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];     // accumulate onto earlier passes
+                            v.x += r; v.y += gc; v.z += b;
+                            row[t] = v;
+                            h[t] = 0; h[t + plane] = 0; h[t + 2 * plane] = 0;
+                        }
+                    }
+                }
+                if (wl < 4) {
+                    float v = s_steady[4 * fs + wl];
+                    if (v != 0.0f) a.steady_out[fpix * 4u + wl] += v;
+                    s_steady[4 * fs + wl] = 0.0f;
+                }
+            }
+            if (wl == 0) {
+                s_done[fs] = 0u;
+                __hip_atomic_store(s_owner + fs, fq + K, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
+    __syncthreads();
 
     // ---- counters: LDS reduction, then one set of global atomics per workgroup ----
     atomicAdd(&s_cnt[0], (unsigned long long)n_paths);
@@ -289,7 +318,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
 
 static uint32_t scene_lds_bytes(const SceneDev &sc)
 {
-    return align16(sc.n_nodes * sizeof(Node)) + align16(sc.n_slots / 2 * sizeof(TriPair)) +
+    return align16(sc.n_wnodes * sizeof(WNode)) + align16(sc.n_slots / 2 * sizeof(TriPair)) +
            align16(sc.n_slots * sizeof(TriShade)) + align16(sc.n_mats * sizeof(mtr_material)) +
            align16(sc.n_ems * sizeof(Emitter));
 }
@@ -302,9 +331,9 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (sc.bvh_depth > 64) return false;
     uint32_t fixed = (stack + 1) * kBlock * 4 + 64;
     uint32_t scene_b = scene_lds_bytes(sc);
-    cfg.scene_lds = scene_b <= 64u * 1024u;
+    cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
     if (cfg.scene_lds) fixed += scene_b;
-    // pixels per segment: enough lanes to keep 256 persistent threads busy, rows must fit in LDS
+    // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
     const uint32_t row_bytes = film.bins * 12u;
     const uint32_t hist_budget = 48u * 1024u;
     uint32_t g_want = (MTR_FUSED_SEG_LANES + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
@@ -320,15 +349,21 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     args.G = G;
     args.nseg = (n_pixels + G - 1) / G;
     cfg.stack = stack;
-    cfg.lds_bytes = fixed + align16(G * 16) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
+    cfg.lds_bytes = fixed + align16(G * 16) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
     if (cfg.lds_bytes > kLdsMax) return false;
-    // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), never more than segments
+    // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), each with at least g_want pixels
     int per_cu = (int)(kLdsMax / cfg.lds_bytes);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     long grid = (long)n_cu * per_cu;
-    if (grid > (long)args.nseg) grid = args.nseg;
+    uint32_t g_blk = g_want;                       // small renders: rather more workgroups than long pixel queues
+    while (g_blk > 1 && ((long)n_pixels + g_blk - 1) / g_blk < n_cu && (unsigned long long)g_blk * spp_chunk > 512ull) g_blk = (g_blk + 1) / 2;
+    const long max_blocks = ((long)n_pixels + g_blk - 1) / g_blk;
+    if (grid > max_blocks) grid = max_blocks;
     if (grid < 1) grid = 1;
+    // the per-workgroup sample counter is 32 bits wide
+    const unsigned long long q_max = ((unsigned long long)n_pixels + grid - 1) / grid;
+    if (q_max * spp_chunk > 0xffff0000ull) return false;
     cfg.grid = (int)grid;
     return true;
 }
@@ -354,6 +389,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
     sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+    sv.wnodes = nullptr;
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;

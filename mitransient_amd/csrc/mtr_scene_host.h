@@ -12,6 +12,7 @@ namespace mtr {
 
 struct HostScene {
     std::vector<Node> nodes;
+    std::vector<WNode> wnodes;                 // 8-wide collapse of `nodes` (small scenes only: the fused kernel walks it in LDS)
     std::vector<TriPair> tpairs;               // [n_slots / 2]
     std::vector<TriShade> tshade;              // [n_slots]
     std::vector<uint32_t> slot_orig;           // [n_slots] original triangle index (pad slots: the triangle they repeat)

@@ -76,10 +76,12 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
         cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
         cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
         sv.nodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.wnodes = nullptr;
         sv.node_pairs = false;        // measured: the 6 offset registers cost k_wf_trace more than the selects (+2.5 %)
         __syncthreads();
     } else {
         sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
+        sv.wnodes = nullptr;
         sv.node_pairs = false;
     }
     st.base = s_stack + tid; st.sp = 0;

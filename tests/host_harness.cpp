@@ -7,6 +7,7 @@
 #include "../mitransient_amd/csrc/mtr_scene_host.h"
 #include "../mitransient_amd/csrc/mtr_nlos.h"
 
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -47,6 +48,9 @@ struct HostSink {
 // both plane-fetch forms of trav_node_step (selects / sign-dependent offsets) are run through the CPU tests
 static bool g_node_pairs = false;
 extern "C" void hh_set_node_pairs(int on) { g_node_pairs = on != 0; }
+// ... and so is the 8-wide tree the fused kernel walks in LDS
+static bool g_wide = false;
+extern "C" void hh_set_wide(int on) { g_wide = on != 0; }
 
 extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, float *t4, float *s4, mtr_counters *out)
 {
@@ -55,6 +59,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
+    sv.wnodes = (g_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -144,6 +149,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
+    sv.wnodes = (g_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -155,6 +161,24 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
         t_out[i] = h.t; prim_out[i] = h.prim >= 0 ? (int32_t)hs.slot_orig[h.prim] : -1;
         Hit a = traverse<true>(sv, o, dd, mt, st);
         occ_out[i] = a.prim >= 0;
+    }
+    return 0;
+}
+
+// debugging aid: prints the 8-wide tree of a scene (child counts, leaf / inner refs, walk axis)
+extern "C" int hh_print_wide(const mtr_scene_desc *d)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    printf("bvh2 packets %zu, wide nodes %zu, slots %zu\n", hs.nodes.size(), hs.wnodes.size(), hs.tshade.size());
+    for (size_t i = 0; i < hs.wnodes.size(); ++i) {
+        const WNode &w = hs.wnodes[i];
+        printf("  wnode %zu axis %u count %u:", i, w.axis, w.count);
+        for (uint32_t c = 0; c < w.count; ++c) {
+            if (w.ref[c] >= 0) printf(" N%d", w.ref[c]);
+            else { uint32_t code = ~(uint32_t)w.ref[c]; printf(" L%u(%u)", code >> 2, (code & 3u) + 1u); }
+        }
+        printf("\n");
     }
     return 0;
 }

@@ -236,12 +236,16 @@ def test_ior_scales_optical_path(oracle):
     assert abs((b1 - b0) * 0.005 - 0.5) < 0.011
 
 
-@pytest.fixture(params=[0, 1], ids=["plane-selects", "plane-offsets"])
+@pytest.fixture(params=[(0, 0), (1, 0), (1, 1)], ids=["plane-selects", "plane-offsets", "wide-tree"])
 def node_pairs(request, host_harness):
-    """both forms of the node step's entry / exit plane fetch (selects for HBM scenes, sign-dependent offsets in LDS)"""
-    host_harness.hh_set_node_pairs(request.param)
+    """the forms of the traversal: BVH2 with the node step's entry / exit planes fetched by selects (HBM scenes) or by
+    sign-dependent offsets (LDS), and the 8-wide tree the fused kernel walks when the scene is staged in LDS"""
+    pairs, wide = request.param
+    host_harness.hh_set_node_pairs(pairs)
+    host_harness.hh_set_wide(wide)
     yield request.param
     host_harness.hh_set_node_pairs(0)
+    host_harness.hh_set_wide(0)
 
 
 def test_host_harness_matches_oracle_bit_for_bit(oracle, host_harness, cornell_c1, node_pairs):

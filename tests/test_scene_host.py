@@ -127,13 +127,15 @@ def _hh_intersect(lib, sd, o, d, maxt=None):
     return t, prim, occ
 
 
-@pytest.mark.parametrize("pairs", [0, 1])
-def test_product_bvh_equals_brute_force(oracle, host_harness, pairs):
+@pytest.mark.parametrize("pairs,wide", [(0, 0), (1, 0), (1, 1)], ids=["plane-selects", "plane-offsets", "wide-tree"])
+def test_product_bvh_equals_brute_force(oracle, host_harness, pairs, wide):
     host_harness.hh_set_node_pairs(pairs)
+    host_harness.hh_set_wide(wide)
     try:
         _bvh_equals_brute_force(oracle, host_harness)
     finally:
         host_harness.hh_set_node_pairs(0)
+        host_harness.hh_set_wide(0)
 
 
 def _bvh_equals_brute_force(oracle, host_harness):
