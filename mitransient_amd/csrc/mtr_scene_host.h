@@ -12,7 +12,8 @@ namespace mtr {
 
 struct HostScene {
     std::vector<Node> nodes;
-    std::vector<WNode> wnodes;                 // 8-wide collapse of `nodes` (small scenes only: the fused kernel walks it in LDS)
+    std::vector<WNode> wnodes;                 // 8-wide collapse of `nodes` (small scenes only: walked in LDS)
+    bool has_wide = false;                     // wnodes is valid (possibly empty: a scene without triangles)
     std::vector<TriPair> tpairs;               // [n_slots / 2]
     std::vector<TriShade> tshade;              // [n_slots]
     std::vector<uint32_t> slot_orig;           // [n_slots] original triangle index (pad slots: the triangle they repeat)

@@ -65,19 +65,19 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     if (SCENE_LDS) {
-        Node *n = (Node *)(smem + off); off += al16(sc.n_nodes * sizeof(Node));
+        // a scene staged in LDS is walked through its 8-wide tree (wf_plan), as in k_fused
+        WNode *n = (WNode *)(smem + off); off += al16(sc.n_wnodes * sizeof(WNode));
         TriPair *tg = (TriPair *)(smem + off); off += al16(sc.n_slots / 2 * sizeof(TriPair));
         TriShade *ts = (TriShade *)(smem + off); off += al16(sc.n_slots * sizeof(TriShade));
         mtr_material *mm = (mtr_material *)(smem + off); off += al16(sc.n_mats * sizeof(mtr_material));
         Emitter *ee = (Emitter *)(smem + off); off += al16(sc.n_ems * sizeof(Emitter));
-        cp16(n, sc.nodes, al16(sc.n_nodes * sizeof(Node)), tid);
+        cp16(n, sc.wnodes, al16(sc.n_wnodes * sizeof(WNode)), tid);
         cp16(tg, sc.tpairs, al16(sc.n_slots / 2 * sizeof(TriPair)), tid);
         cp16(ts, sc.tshade, al16(sc.n_slots * sizeof(TriShade)), tid);
         cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
         cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
-        sv.wnodes = nullptr;
-        sv.node_pairs = false;        // measured: the 6 offset registers cost k_wf_trace more than the selects (+2.5 %)
+        sv.nodes = nullptr; sv.wnodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.node_pairs = true;
         __syncthreads();
     } else {
         sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
@@ -329,8 +329,13 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 #ifdef MTR_PROFILE_SIMT
             if (lane_id == 0) { if (n_node >= n_leaf) { prof[0] += 1; prof[1] += n_node; } else { prof[2] += 1; prof[3] += n_leaf; } }
 #endif
-            if (n_node >= n_leaf) { if (at_node) trav_node_step(tr, sv, st); }
-            else { if (at_leaf) trav_leaf_step(tr, sv, st, any_hit); }
+            if (SCENE_LDS) {
+                if (n_node >= n_leaf) { if (at_node) wide_node_step(tr, sv, st); }
+                else { if (at_leaf) wide_leaf_step(tr, sv, st, any_hit); }
+            } else {
+                if (n_node >= n_leaf) { if (at_node) trav_node_step(tr, sv, st); }
+                else { if (at_leaf) trav_leaf_step(tr, sv, st, any_hit); }
+            }
         }
         __syncthreads();
         // material lists in list order
@@ -708,9 +713,9 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 {
     if (sc.bvh_depth > 64) return false;
     cfg.stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
-    uint32_t scene_b = al16(sc.n_nodes * sizeof(Node)) + al16(sc.n_slots / 2 * sizeof(TriPair)) + al16(sc.n_slots * sizeof(TriShade)) +
+    uint32_t scene_b = al16(sc.n_wnodes * sizeof(WNode)) + al16(sc.n_slots / 2 * sizeof(TriPair)) + al16(sc.n_slots * sizeof(TriShade)) +
                        al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
-    cfg.scene_lds = scene_b <= 64u * 1024u;
+    cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
     cfg.lds_bytes = 64 + (size_t)(sc.bvh_depth + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
     return true;
 }

@@ -59,7 +59,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
-    sv.wnodes = (g_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes = (g_wide && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -149,7 +149,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
-    sv.wnodes = (g_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes = (g_wide && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
