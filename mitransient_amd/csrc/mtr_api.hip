@@ -184,6 +184,8 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr;
     s->dev.wnodes = nullptr; s->dev.n_wnodes = (uint32_t)hs.wnodes.size();
     if (hs.has_wide) UP(hs.wnodes, wnodes);
+    s->dev.wnodes4 = nullptr; s->dev.n_wnodes4 = (uint32_t)hs.wnodes4.size();
+    UP(hs.wnodes4, wnodes4);
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
 #undef UP
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();

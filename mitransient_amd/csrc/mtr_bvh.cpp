@@ -175,7 +175,6 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
 namespace {
 
 struct WChild { float lo[3], hi[3]; int32_t ref; };
-size_t g_wide_width = kWide;
 
 void packet_children(const Node &n, std::vector<WChild> &out)
 {
@@ -193,7 +192,8 @@ float half_area(const WChild &w)
     return dx * dy + dy * dz + dz * dx;
 }
 
-uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNode> &wide, uint32_t level, uint32_t &levels)
+template <uint32_t W>
+uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNodeT<W>> &wide, uint32_t level, uint32_t &levels, size_t width)
 {
     levels = std::max(levels, level);
     const uint32_t me = (uint32_t)wide.size();
@@ -207,7 +207,7 @@ uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNode> &wide,
         if (best < 0) break;
         std::vector<WChild> sub;
         packet_children(bvh.nodes[ch[best].ref], sub);
-        if (ch.size() - 1 + sub.size() > g_wide_width) break;
+        if (ch.size() - 1 + sub.size() > width) break;
         ch.erase(ch.begin() + best);
         ch.insert(ch.end(), sub.begin(), sub.end());
     }
@@ -219,9 +219,9 @@ uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNode> &wide,
     for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
     std::stable_sort(ch.begin(), ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
 
-    WNode nd{};
+    WNodeT<W> nd{};
     float *f = &nd.box[0].x;
-    for (int c = 0; c < (int)kWide; ++c) {
+    for (int c = 0; c < (int)W; ++c) {
         const int j = c >> 1, h = c & 1;
         for (int k = 0; k < 3; ++k) {
             f[4 * (3 * j + k) + h] = c < (int)ch.size() ? ch[c].lo[k] : INFINITY;
@@ -232,7 +232,7 @@ uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNode> &wide,
     nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.leaves = 0u;
     for (size_t c = 0; c < ch.size(); ++c) if (ch[c].ref < 0) nd.leaves |= 1u << c;
     for (size_t c = 0; c < ch.size(); ++c)
-        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec(bvh, ch[c].ref, wide, level + 1, levels) : ch[c].ref;
+        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, ch[c].ref, wide, level + 1, levels, width) : ch[c].ref;
     wide[me] = nd;
     return me;
 }
@@ -243,9 +243,59 @@ uint32_t build_wide(const BvhBuild &bvh, std::vector<WNode> &wide)
 {
     wide.clear();
     if (bvh.nodes.empty()) return 0;
-    if (const char *e = getenv("MTR_WIDE_WIDTH")) { int w = atoi(e); g_wide_width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
+    size_t width = kWide;
+    if (const char *e = getenv("MTR_WIDE_WIDTH")) { int w = atoi(e); width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
     uint32_t levels = 0;
-    wide_rec(bvh, 0, wide, 1, levels);
+    wide_rec<kWide>(bvh, 0, wide, 1, levels, width);
+    return levels;
+}
+uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
+{
+    wide.clear();
+    if (bvh.nodes.empty()) return 0;
+    uint32_t levels = 0;
+    std::vector<WNodeT<4>> full;
+    wide_rec<4>(bvh, 0, full, 1, levels, 4);
+    wide.resize(full.size());
+    for (size_t i = 0; i < full.size(); ++i) {
+        const WNodeT<4> &w = full[i];
+        const float *f = &w.box[0].x;
+        auto lo = [&](uint32_t c, int k) { return f[4 * (3 * (c >> 1) + k) + (c & 1)]; };
+        auto hi = [&](uint32_t c, int k) { return f[4 * (3 * (c >> 1) + k) + 2 + (c & 1)]; };
+        QNode4 q{};
+        float *org = &q.q[0].x;
+        uint32_t meta = (w.axis << 24) | (w.count << 26);
+        uint32_t plo[3] = { 0, 0, 0 }, phi[3] = { 0, 0, 0 };
+        for (int k = 0; k < 3; ++k) {
+            float o = INFINITY, top = -INFINITY;
+            for (uint32_t c = 0; c < w.count; ++c) { o = std::min(o, lo(c, k)); top = std::max(top, hi(c, k)); }
+            org[k] = o;
+            // smallest power-of-two step whose 255 multiples cover the extent; every plane rounds outwards (checked in f64)
+            int e = -100;
+            const double ext = (double)top - (double)o;
+            if (ext > 0.0) e = std::max(-100, (int)std::ceil(std::log2(ext / 255.0)));
+            for (;; ++e) {
+                const double step = std::ldexp(1.0, e);
+                bool ok = true;
+                uint32_t wl = 0, wh = 0;
+                for (uint32_t c = 0; c < w.count && ok; ++c) {
+                    long ql = (long)std::floor(((double)lo(c, k) - (double)o) / step), qh = (long)std::ceil(((double)hi(c, k) - (double)o) / step);
+                    while (ql > 0 && (double)o + (double)ql * step > (double)lo(c, k)) --ql;
+                    while ((double)o + (double)qh * step < (double)hi(c, k)) ++qh;
+                    if (ql < 0) ql = 0;
+                    if (qh > 255) { ok = false; break; }
+                    wl |= (uint32_t)ql << (8 * c); wh |= (uint32_t)qh << (8 * c);
+                }
+                if (ok) { plo[k] = wl; phi[k] = wh; break; }
+            }
+            meta |= (uint32_t)(e + 127) << (8 * k);
+        }
+        q.q[0].w = bitsf(meta);
+        for (int c = 0; c < 4; ++c) (&q.q[1].x)[c] = bitsf((uint32_t)w.ref[c]);
+        q.q[2] = q4{ bitsf(plo[0]), bitsf(plo[1]), bitsf(plo[2]), bitsf(phi[0]) };
+        q.q[3] = q4{ bitsf(phi[1]), bitsf(phi[2]), 0.0f, 0.0f };
+        wide[i] = q;
+    }
     return levels;
 }
 

@@ -24,5 +24,7 @@ void build_bvh(const float *verts, uint32_t n, BvhBuild &out);
 // starting from a packet's two children, the inner child with the largest surface area is replaced by its own children
 // until eight are held or only leaves remain.  wide[0] is the root; returns the number of levels.
 uint32_t build_wide(const BvhBuild &bvh, std::vector<WNode> &wide);
+// the same, 4 wide (one node per 128-byte line): scenes walked in HBM
+uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide);
 
 } // namespace mtr

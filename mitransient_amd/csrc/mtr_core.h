@@ -203,14 +203,26 @@ MTR_HD void node_set_child(Node &n, int c, const float *lo, const float *hi, int
 // A BVH2 over a few large quads (the walls of a room) cannot separate them — every ray visits all their ancestors;
 // one 8-wide step replaces up to seven of those dependent 2-wide steps and, more important on a 64-lane wave, brings the
 // per-ray step count of different lanes close together (Cornell box: wave-steps at 19 % lane utilisation with BVH2).
-constexpr uint32_t kWide = MTR_WIDE;
-struct alignas(16) WNode {
-    q4 box[3 * kWide / 2];
-    int32_t ref[kWide];
+template <uint32_t W>
+struct alignas(16) WNodeT {
+    q4 box[3 * W / 2];
+    int32_t ref[W];
     uint32_t axis, count, leaves, pad1;       // leaves: bit c set = child c is a leaf
+    static constexpr uint32_t kBytes = 28u * W + 16u, kRefOff = 24u * W, kHdrOff = 28u * W;
+    static constexpr uint32_t kMask = (1u << W) - 1u, kRevBit = 1u << W, kNodeShift = W + 1u;
 };
-constexpr uint32_t kWNodeBytes = 24u * kWide + 4u * kWide + 16u, kWRefOff = 24u * kWide, kWHdrOff = 28u * kWide;
-constexpr uint32_t kWMask = (1u << kWide) - 1u, kWRevBit = 1u << kWide, kWNodeShift = kWide + 1u;
+constexpr uint32_t kWide = MTR_WIDE;
+typedef WNodeT<kWide> WNode;
+// Scenes walked in HBM: 4-wide nodes with the children's boxes quantised to 8 bits per plane on the node's own grid
+// (origin = the node's lower corner, one power-of-two step per axis) — 64 bytes, the size of a BVH2 packet, for twice the
+// fan-out.  The trace kernel is bound by the number of 16-byte-per-lane loads it issues (divergent addresses: 0.6 - 0.8
+// per clock per CU, profiles/r01_divergent_load_microbench.txt), not by the bytes behind them, so this halves its load
+// count per ray; an uncompressed 4-wide node (128 B) halved the steps and doubled the loads per step — no gain (measured).
+// Quantisation rounds lo down and hi up, so culling stays conservative; hits are decided by the triangle test alone.
+//   q[0] = (org.x, org.y, org.z, meta)   meta = ex | ey << 8 | ez << 16 | axis << 24 | count << 26  (e*: biased exponents)
+//   q[1] = refs   q[2] = (lo.x, lo.y, lo.z, hi.x)   q[3] = (hi.y, hi.z, -, -)     byte c of a plane word = child c
+struct alignas(16) QNode4 { q4 q[4]; };
+static_assert(sizeof(QNode4) == 64, "quantised 4-wide node");
 // triangles, split by use and stored by SLOT: every leaf starts on an even slot and owns ceil(count / 2) pairs of slots
 // (an odd leaf repeats its last triangle in the pad slot; the pad is never reported as a hit).
 // Intersection record = one PAIR of slots with the two triangles interleaved, so that one 16-byte read delivers two
@@ -248,6 +260,7 @@ struct SceneView {
     bool node_pairs;          // scene staged in LDS: fetch the entry / exit planes of a node by sign-dependent OFFSETS
     const Node *nodes;
     const WNode *wnodes;      // non-null: traverse the wide tree instead of `nodes` (scene staged in LDS)
+    const QNode4 *wnodes4;    // non-null (and wnodes null): traverse the quantised 4-wide tree (scene in HBM)
     const TriPair *tpairs;    // [n_slots / 2]
     const TriShade *tshade;
     const mtr_material *mats;
@@ -455,37 +468,49 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     else tr.cur = st.empty() ? kTravDone : st.pop();
 }
 
-// ---- wide tree (SceneView::wnodes) ----
+// ---- wide trees (SceneView::wnodes / wnodes4) ----
 // next child of the current group (or of the group on top of the stack): sets tr.cur
-template <class Stack>
-MTR_HD void wide_advance(Trav &tr, const SceneView &sc, Stack &st, uint32_t g)
+template <uint32_t W, class Stack>
+MTR_HD void wide_advance(Trav &tr, const void *nodes, Stack &st, uint32_t g)
 {
-    if ((g & kWMask) == 0u) g = st.empty() ? 0u : (uint32_t)st.pop();
-    const uint32_t mask = g & kWMask;
+    typedef WNodeT<W> N;
+    if ((g & N::kMask) == 0u) g = st.empty() ? 0u : (uint32_t)st.pop();
+    const uint32_t mask = g & N::kMask;
     if (mask == 0u) { tr.grp = 0u; tr.cur = kTravDone; return; }
-    const uint32_t k = (g & kWRevBit) ? 31u - (uint32_t)__builtin_clz(mask) : (uint32_t)__builtin_ctz(mask);
+    const uint32_t k = (g & N::kRevBit) ? 31u - (uint32_t)__builtin_clz(mask) : (uint32_t)__builtin_ctz(mask);
     g &= ~(1u << k);
     tr.grp = g;
-    tr.cur = *(const int32_t *)((const char *)sc.wnodes + (size_t)(g >> kWNodeShift) * kWNodeBytes + kWRefOff + 4u * k);
+    tr.cur = *(const int32_t *)((const char *)nodes + (size_t)(g >> N::kNodeShift) * N::kBytes + N::kRefOff + 4u * k);
 }
-// one wide-node step: up to four packed pairs of slab tests -> mask of the children the ray enters
-template <class Stack>
-MTR_HD void wide_node_step(Trav &tr, const SceneView &sc, Stack &st)
+// one wide-node step: packed pairs of slab tests -> mask of the children the ray enters.
+// OFFS: entry / exit planes fetched at sign-dependent byte offsets (LDS) instead of whole quads + selects (HBM).
+template <uint32_t W, bool OFFS, class Stack>
+MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
 {
+    typedef WNodeT<W> N;
     st.count(0);
     const f3 id = tr.id, noid = tr.noid;
-    const char *nb = (const char *)sc.wnodes + (size_t)(uint32_t)tr.cur * kWNodeBytes;
-    const uint32_t axis = *(const uint32_t *)(nb + kWHdrOff), count = *(const uint32_t *)(nb + kWHdrOff + 4u);
+    const char *nb = (const char *)nodes + (size_t)(uint32_t)tr.cur * N::kBytes;
+    const uint32_t axis = *(const uint32_t *)(nb + N::kHdrOff), count = *(const uint32_t *)(nb + N::kHdrOff + 4u);
+    const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
     uint32_t m = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (uint32_t j = 0; j < kWide / 2u; ++j) {
-        if (2u * j < count) {
+    for (uint32_t j = 0; j < W / 2u; ++j) {
+        if (OFFS ? (2u * j < count) : true) {
             const char *pb = nb + 48u * j;
-            const f2 nx = fma2(*(const f2 *)(pb + tr.sel[0]), id.x, noid.x), fx = fma2(*(const f2 *)(pb + tr.sel[1]), id.x, noid.x);
-            const f2 ny = fma2(*(const f2 *)(pb + tr.sel[2]), id.y, noid.y), fy = fma2(*(const f2 *)(pb + tr.sel[3]), id.y, noid.y);
-            const f2 nz = fma2(*(const f2 *)(pb + tr.sel[4]), id.z, noid.z), fz = fma2(*(const f2 *)(pb + tr.sel[5]), id.z, noid.z);
+            f2 nx, fx, ny, fy, nz, fz;
+            if (OFFS) {
+                nx = fma2(*(const f2 *)(pb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(pb + tr.sel[1]), id.x, noid.x);
+                ny = fma2(*(const f2 *)(pb + tr.sel[2]), id.y, noid.y); fy = fma2(*(const f2 *)(pb + tr.sel[3]), id.y, noid.y);
+                nz = fma2(*(const f2 *)(pb + tr.sel[4]), id.z, noid.z); fz = fma2(*(const f2 *)(pb + tr.sel[5]), id.z, noid.z);
+            } else {
+                const q4 X = *(const q4 *)pb, Y = *(const q4 *)(pb + 16), Z = *(const q4 *)(pb + 32);
+                nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x); fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
+                ny = fma2(sy ? f2{ Y.z, Y.w } : f2{ Y.x, Y.y }, id.y, noid.y); fy = fma2(sy ? f2{ Y.x, Y.y } : f2{ Y.z, Y.w }, id.y, noid.y);
+                nz = fma2(sz ? f2{ Z.z, Z.w } : f2{ Z.x, Z.y }, id.z, noid.z); fz = fma2(sz ? f2{ Z.x, Z.y } : f2{ Z.z, Z.w }, id.z, noid.z);
+            }
             const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
             const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
             const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
@@ -496,19 +521,79 @@ MTR_HD void wide_node_step(Trav &tr, const SceneView &sc, Stack &st)
     }
     uint32_t g = tr.grp;
     if (m != 0u) {
-        st.push_if((g & kWMask) != 0u, (int32_t)g);
+        st.push_if((g & N::kMask) != 0u, (int32_t)g);
         // walk order of this node's children: reversed when the direction is negative on the node's sort axis
-        const uint32_t neg = axis == 0u ? tr.sel[0] : (axis == 1u ? tr.sel[2] : tr.sel[4]);      // bit 3 = sign (trav_init)
-        g = ((uint32_t)tr.cur << kWNodeShift) | ((neg & 8u) ? kWRevBit : 0u) | m;
+        const bool neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
+        g = ((uint32_t)tr.cur << N::kNodeShift) | (neg ? N::kRevBit : 0u) | m;
     }
-    wide_advance(tr, sc, st, g);
+    wide_advance<W>(tr, nodes, st, g);
 }
-template <class Stack>
-MTR_HD void wide_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
+template <uint32_t W, class Stack>
+MTR_HD void wide_leaf_step(Trav &tr, const SceneView &sc, const void *nodes, Stack &st, bool any_hit)
 {
     const bool found = trav_leaf_test(tr, sc, st, any_hit);
     if (any_hit & found) tr.cur = kTravDone;
-    else wide_advance(tr, sc, st, tr.grp);
+    else wide_advance<W>(tr, nodes, st, tr.grp);
+}
+
+// ---- quantised 4-wide tree (SceneView::wnodes4) ----
+template <class Stack>
+MTR_HD void qwide_advance(Trav &tr, const QNode4 *nodes, Stack &st, uint32_t g)
+{
+    if ((g & 0xfu) == 0u) g = st.empty() ? 0u : (uint32_t)st.pop();
+    const uint32_t mask = g & 0xfu;
+    if (mask == 0u) { tr.grp = 0u; tr.cur = kTravDone; return; }
+    const uint32_t k = (g & 0x10u) ? 31u - (uint32_t)__builtin_clz(mask) : (uint32_t)__builtin_ctz(mask);
+    g &= ~(1u << k);
+    tr.grp = g;
+    tr.cur = *((const int32_t *)&nodes[g >> 5].q[1] + k);
+}
+MTR_HD float qbyte(uint32_t w, uint32_t c) { return (float)((w >> (8u * c)) & 0xffu); }     // v_cvt_f32_ubyte<c>
+template <class Stack>
+MTR_HD void qwide_node_step(Trav &tr, const QNode4 *nodes, Stack &st)
+{
+    st.count(0);
+    const QNode4 &n = nodes[tr.cur];
+    const q4 A = n.q[0], P = n.q[2], Q = n.q[3];
+    const uint32_t meta = fbits(A.w);
+    const f3 id = tr.id;
+    // plane distance = (org + q * step) * id + noid, evaluated as q * (step * id) + (org * id + noid)
+    const float kx = bitsf((meta & 0xffu) << 23) * id.x, ky = bitsf(((meta >> 8) & 0xffu) << 23) * id.y, kz = bitsf(((meta >> 16) & 0xffu) << 23) * id.z;
+    const float bx = fmaf(A.x, id.x, tr.noid.x), by = fmaf(A.y, id.y, tr.noid.y), bz = fmaf(A.z, id.z, tr.noid.z);
+    const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
+    const uint32_t lox = fbits(P.x), loy = fbits(P.y), loz = fbits(P.z), hix = fbits(P.w), hiy = fbits(Q.x), hiz = fbits(Q.y);
+    const uint32_t nxw = sx ? hix : lox, fxw = sx ? lox : hix, nyw = sy ? hiy : loy, fyw = sy ? loy : hiy, nzw = sz ? hiz : loz, fzw = sz ? loz : hiz;
+    uint32_t m = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t c = 0; c < 4u; c += 2u) {
+        const f2 nx = fma2(f2{ qbyte(nxw, c), qbyte(nxw, c + 1u) }, kx, bx), fx = fma2(f2{ qbyte(fxw, c), qbyte(fxw, c + 1u) }, kx, bx);
+        const f2 ny = fma2(f2{ qbyte(nyw, c), qbyte(nyw, c + 1u) }, ky, by), fy = fma2(f2{ qbyte(fyw, c), qbyte(fyw, c + 1u) }, ky, by);
+        const f2 nz = fma2(f2{ qbyte(nzw, c), qbyte(nzw, c + 1u) }, kz, bz), fz = fma2(f2{ qbyte(fzw, c), qbyte(fzw, c + 1u) }, kz, bz);
+        const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
+        const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
+        const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
+        const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
+        m |= (tn0 <= tf0 ? 1u : 0u) << c;
+        m |= (tn1 <= tf1 ? 2u : 0u) << c;
+    }
+    m &= (1u << (meta >> 26)) - 1u;                       // absent children
+    uint32_t g = tr.grp;
+    if (m != 0u) {
+        st.push_if((g & 0xfu) != 0u, (int32_t)g);
+        const uint32_t axis = (meta >> 24) & 3u;
+        const bool neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
+        g = ((uint32_t)tr.cur << 5) | (neg ? 0x10u : 0u) | m;
+    }
+    qwide_advance(tr, nodes, st, g);
+}
+template <class Stack>
+MTR_HD void qwide_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
+{
+    const bool found = trav_leaf_test(tr, sc, st, any_hit);
+    if (any_hit & found) tr.cur = kTravDone;
+    else qwide_advance(tr, sc.wnodes4, st, tr.grp);
 }
 
 // run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
@@ -522,25 +607,20 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
     uint32_t my_nodes = 0;
 #endif
     if (sc.wnodes) {
-#if defined(MTR_WIDE_VOTE) && defined(__HIP_DEVICE_COMPILE__)
-        for (;;) {
-            const bool at_node = tr.cur >= 0, at_leaf = tr.cur < 0 && tr.cur != kTravDone;
-            const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
-            if (n_node + n_leaf == 0) break;
-            if (n_node >= n_leaf) { if (at_node) wide_node_step(tr, sc, st); }
-            else { if (at_leaf) wide_leaf_step(tr, sc, st, ANY_HIT); }
-        }
-#else
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) {
-                wide_node_step(tr, sc, st);
+                wide_node_step<kWide, true>(tr, sc.wnodes, st);
 #ifdef MTR_PROFILE_SIMT
                 ++my_nodes;
 #endif
             }
-            if (tr.cur != kTravDone) wide_leaf_step(tr, sc, st, ANY_HIT);
+            if (tr.cur != kTravDone) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
         }
-#endif
+    } else if (sc.wnodes4) {
+        while (tr.cur != kTravDone) {
+            while (tr.cur >= 0) qwide_node_step(tr, sc.wnodes4, st);
+            if (tr.cur != kTravDone) qwide_leaf_step(tr, sc, st, ANY_HIT);
+        }
     } else
     while (tr.cur != kTravDone) {
         while (tr.cur >= 0) {

@@ -15,6 +15,7 @@ struct DevCounters {                 // device mirror of mtr_counters (u64 atomi
 struct SceneDev {
     const Node *nodes; uint32_t n_nodes;
     const WNode *wnodes; uint32_t n_wnodes;                            // 8-wide tree over the same leaves (null for large scenes)
+    const QNode4 *wnodes4; uint32_t n_wnodes4;                         // quantised 4-wide tree (always present)
     const TriPair *tpairs; const TriShade *tshade; uint32_t n_slots;   // triangle slots (even), see mtr_core.h
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;

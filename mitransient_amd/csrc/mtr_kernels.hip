@@ -144,11 +144,11 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
         copy16(ts, a.sc.tshade, align16(a.sc.n_slots * sizeof(TriShade)), tid);
         copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = nullptr; sv.wnodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
     } else {
         sv.nodes = a.sc.nodes; sv.tpairs = a.sc.tpairs; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
-        sv.wnodes = nullptr;
+        sv.wnodes = nullptr; sv.wnodes4 = a.sc.wnodes4;
         sv.node_pairs = false;
     }
     // ---- pixel ring: K = a.G row slots; the workgroup's q-th pixel (pixel_begin + blockIdx + q * gridDim) lives in
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
     sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
-    sv.wnodes = nullptr;
+    sv.wnodes = nullptr; sv.wnodes4 = nullptr;
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;

@@ -69,6 +69,8 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     s.wnodes.clear();
     s.has_wide = bvh.nodes.size() <= 2048;
     if (s.has_wide) build_wide(bvh, s.wnodes);
+    s.wnodes4.clear();
+    build_wide4(bvh, s.wnodes4);
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
     for (uint32_t slot = 0; slot < n_slots; ++slot) {

@@ -13,6 +13,7 @@ namespace mtr {
 struct HostScene {
     std::vector<Node> nodes;
     std::vector<WNode> wnodes;                 // 8-wide collapse of `nodes` (small scenes only: walked in LDS)
+    std::vector<QNode4> wnodes4;               // quantised 4-wide collapse of `nodes` (walked in HBM by the wavefront kernels)
     bool has_wide = false;                     // wnodes is valid (possibly empty: a scene without triangles)
     std::vector<TriPair> tpairs;               // [n_slots / 2]
     std::vector<TriShade> tshade;              // [n_slots]

@@ -76,12 +76,12 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
         cp16(ts, sc.tshade, al16(sc.n_slots * sizeof(TriShade)), tid);
         cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
         cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = nullptr; sv.wnodes = n; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
         __syncthreads();
     } else {
         sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
-        sv.wnodes = nullptr;
+        sv.wnodes = nullptr; sv.wnodes4 = sc.wnodes4;
         sv.node_pairs = false;
     }
     st.base = s_stack + tid; st.sp = 0;
@@ -330,11 +330,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
             if (lane_id == 0) { if (n_node >= n_leaf) { prof[0] += 1; prof[1] += n_node; } else { prof[2] += 1; prof[3] += n_leaf; } }
 #endif
             if (SCENE_LDS) {
-                if (n_node >= n_leaf) { if (at_node) wide_node_step(tr, sv, st); }
-                else { if (at_leaf) wide_leaf_step(tr, sv, st, any_hit); }
+                if (n_node >= n_leaf) { if (at_node) wide_node_step<kWide, true>(tr, sv.wnodes, st); }
+                else { if (at_leaf) wide_leaf_step<kWide>(tr, sv, sv.wnodes, st, any_hit); }
             } else {
-                if (n_node >= n_leaf) { if (at_node) trav_node_step(tr, sv, st); }
-                else { if (at_leaf) trav_leaf_step(tr, sv, st, any_hit); }
+                if (n_node >= n_leaf) { if (at_node) qwide_node_step(tr, sv.wnodes4, st); }
+                else { if (at_leaf) qwide_leaf_step(tr, sv, st, any_hit); }
             }
         }
         __syncthreads();

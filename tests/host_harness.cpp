@@ -49,8 +49,8 @@ struct HostSink {
 static bool g_node_pairs = false;
 extern "C" void hh_set_node_pairs(int on) { g_node_pairs = on != 0; }
 // ... and so is the 8-wide tree the fused kernel walks in LDS
-static bool g_wide = false;
-extern "C" void hh_set_wide(int on) { g_wide = on != 0; }
+static int g_wide = 0;       // 1: 8-wide (LDS form), 2: 4-wide (HBM form; scenes with more than 256 BVH2 packets)
+extern "C" void hh_set_wide(int on) { g_wide = on; }
 
 extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, float *t4, float *s4, mtr_counters *out)
 {
@@ -59,7 +59,8 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
-    sv.wnodes = (g_wide && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes = (g_wide == 1 && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes4 = (g_wide == 2 && !hs.wnodes4.empty()) ? hs.wnodes4.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -149,7 +150,8 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     SceneView sv;
     sv.nodes = hs.nodes.data(); sv.tpairs = hs.tpairs.data(); sv.tshade = hs.tshade.data();
     sv.node_pairs = g_node_pairs;
-    sv.wnodes = (g_wide && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes = (g_wide == 1 && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
+    sv.wnodes4 = (g_wide == 2 && !hs.wnodes4.empty()) ? hs.wnodes4.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();

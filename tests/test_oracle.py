@@ -283,9 +283,19 @@ def test_host_harness_specular_and_flags(oracle, host_harness, node_pairs):
     assert np.count_nonzero(t4) > 1000
 
 
-def test_host_harness_staircase_like(oracle, host_harness):
+@pytest.mark.parametrize("wide", [0, 1, 2], ids=["bvh2", "wide-8", "wide-4"])
+def test_host_harness_staircase_like(oracle, host_harness, wide):
     """BASELINE config-5 stand-in (procedural stair flight: conductor / dielectric / twosided mix, 852 triangles,
-    BVH depth 13, max_depth 65, camera_unwarp): product arithmetic == oracle, bit for bit."""
+    BVH depth 13, max_depth 65, camera_unwarp): product arithmetic == oracle, bit for bit — through the BVH2, the
+    8-wide tree (scenes staged in LDS) and the 4-wide tree (scenes walked in HBM)."""
+    host_harness.hh_set_wide(wide)
+    try:
+        _staircase_like_bit_for_bit(oracle, host_harness)
+    finally:
+        host_harness.hh_set_wide(0)
+
+
+def _staircase_like_bit_for_bit(oracle, host_harness):
     import mitransient_amd.mi as mi
     from mitransient_amd.scenes import staircase_like
     mi.set_variant("llvm_ad_rgb")
