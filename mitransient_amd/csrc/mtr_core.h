@@ -336,18 +336,18 @@ constexpr int32_t kTravDone = (int32_t)0x80000000;
 
 struct Trav {
     f3 o, d, id, noid;
-    float tmax, tbest;
+    float tmax;          // culling bound of a node step = min(tmax, h.t): the closest hit so far (h.t stays inf for shadow rays)
     int32_t cur;
     Hit h;
     uint32_t best_orig;
-    uint32_t sel[6];      // node_pairs: byte offsets of the (entry, exit) plane pairs of x, y, z inside a node packet
+    uint32_t sel[3];      // node_pairs / wide tree: byte offsets of the ENTRY plane pairs of x, y, z inside a node packet (exit = entry ^ 8)
     uint32_t grp;         // wide tree: (node << 9) | (reverse << 8) | mask of the children of `node` still to be visited
 };
 
 template <class Stack>
 MTR_HD void trav_init(Trav &tr, const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
-    tr.o = o; tr.d = d; tr.tmax = tmax; tr.tbest = tmax;
+    tr.o = o; tr.d = d; tr.tmax = tmax;
     // reciprocal direction kept finite so that fma(lo, id, -o*id) never meets inf - inf (axis-parallel rays)
     tr.id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     tr.noid = mk(-(o.x * tr.id.x), -(o.y * tr.id.y), -(o.z * tr.id.z));
@@ -356,7 +356,7 @@ MTR_HD void trav_init(Trav &tr, const SceneView &sc, f3 o, f3 d, float tmax, Sta
     tr.grp = 0u;
     if (sc.node_pairs || sc.wnodes) {
         const uint32_t sx = tr.id.x < 0.0f ? 8u : 0u, sy = tr.id.y < 0.0f ? 8u : 0u, sz = tr.id.z < 0.0f ? 8u : 0u;
-        tr.sel[0] = sx; tr.sel[1] = 8u - sx; tr.sel[2] = 16u + sy; tr.sel[3] = 24u - sy; tr.sel[4] = 32u + sz; tr.sel[5] = 40u - sz;
+        tr.sel[0] = sx; tr.sel[1] = 16u + sy; tr.sel[2] = 32u + sz;
     }
     tr.cur = sc.n_slots ? 0 : kTravDone;
     st.reset();
@@ -369,6 +369,7 @@ MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
 {
     st.count(0);
     const f3 id = tr.id, noid = tr.noid;
+    const float tb = fminf(tr.tmax, tr.h.t);
     // slab planes of both children as packed pairs (.x child 0, .y child 1).  The reciprocal direction is finite
     // (safe_rcp), so fma(p, id, noid) is monotonic in p: the entry plane is `lo` when id >= 0 and `hi` otherwise —
     // selecting it by the sign gives bit for bit what min/max of the two plane distances gives, in fewer instructions.
@@ -376,9 +377,9 @@ MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
     int32_t c0, c1;
     if (sc.node_pairs) {      // LDS: six 8-byte reads at per-ray offsets (one address computation each) instead of selects
         const char *nb = (const char *)sc.nodes + ((size_t)(uint32_t)tr.cur << 6);
-        nx = fma2(*(const f2 *)(nb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(nb + tr.sel[1]), id.x, noid.x);
-        ny = fma2(*(const f2 *)(nb + tr.sel[2]), id.y, noid.y); fy = fma2(*(const f2 *)(nb + tr.sel[3]), id.y, noid.y);
-        nz = fma2(*(const f2 *)(nb + tr.sel[4]), id.z, noid.z); fz = fma2(*(const f2 *)(nb + tr.sel[5]), id.z, noid.z);
+        nx = fma2(*(const f2 *)(nb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(nb + (tr.sel[0] ^ 8u)), id.x, noid.x);
+        ny = fma2(*(const f2 *)(nb + tr.sel[1]), id.y, noid.y); fy = fma2(*(const f2 *)(nb + (tr.sel[1] ^ 8u)), id.y, noid.y);
+        nz = fma2(*(const f2 *)(nb + tr.sel[2]), id.z, noid.z); fz = fma2(*(const f2 *)(nb + (tr.sel[2] ^ 8u)), id.z, noid.z);
         const f2 cc = *(const f2 *)(nb + 48);
         c0 = (int32_t)fbits(cc.x); c1 = (int32_t)fbits(cc.y);
     } else {
@@ -391,9 +392,9 @@ MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
         c0 = (int32_t)fbits(C.x); c1 = (int32_t)fbits(C.y);
     }
     const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
-    const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
+    const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
     const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
-    const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
+    const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const bool near0 = tn0 <= tn1;
     const bool both = h0 && h1;
@@ -446,7 +447,6 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
             found = found || hit;
             tr.h.t = better ? t.x : tr.h.t; tr.h.u = better ? u.x : tr.h.u; tr.h.v = better ? v.x : tr.h.v;
             tr.h.prim = better ? pa : tr.h.prim; tr.best_orig = better ? orig_a : tr.best_orig;
-            tr.tbest = (better && !any_hit) ? t.x : tr.tbest;
         }
         {
             const bool hit = two && (u.y >= 0.0f) && (u.y <= 1.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= 0.0f) && (t.y <= tr.tmax);
@@ -455,7 +455,6 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
             found = found || hit;
             tr.h.t = better ? t.y : tr.h.t; tr.h.u = better ? u.y : tr.h.u; tr.h.v = better ? v.y : tr.h.v;
             tr.h.prim = better ? pb : tr.h.prim; tr.best_orig = better ? orig_b : tr.best_orig;
-            tr.tbest = (better && !any_hit) ? t.y : tr.tbest;
         }
     }
     return found;
@@ -490,6 +489,7 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
     typedef WNodeT<W> N;
     st.count(0);
     const f3 id = tr.id, noid = tr.noid;
+    const float tb = fminf(tr.tmax, tr.h.t);
     const char *nb = (const char *)nodes + (size_t)(uint32_t)tr.cur * N::kBytes;
     const uint32_t axis = *(const uint32_t *)(nb + N::kHdrOff), count = *(const uint32_t *)(nb + N::kHdrOff + 4u);
     const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
@@ -502,9 +502,9 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
             const char *pb = nb + 48u * j;
             f2 nx, fx, ny, fy, nz, fz;
             if (OFFS) {
-                nx = fma2(*(const f2 *)(pb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(pb + tr.sel[1]), id.x, noid.x);
-                ny = fma2(*(const f2 *)(pb + tr.sel[2]), id.y, noid.y); fy = fma2(*(const f2 *)(pb + tr.sel[3]), id.y, noid.y);
-                nz = fma2(*(const f2 *)(pb + tr.sel[4]), id.z, noid.z); fz = fma2(*(const f2 *)(pb + tr.sel[5]), id.z, noid.z);
+                nx = fma2(*(const f2 *)(pb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(pb + (tr.sel[0] ^ 8u)), id.x, noid.x);
+                ny = fma2(*(const f2 *)(pb + tr.sel[1]), id.y, noid.y); fy = fma2(*(const f2 *)(pb + (tr.sel[1] ^ 8u)), id.y, noid.y);
+                nz = fma2(*(const f2 *)(pb + tr.sel[2]), id.z, noid.z); fz = fma2(*(const f2 *)(pb + (tr.sel[2] ^ 8u)), id.z, noid.z);
             } else {
                 const q4 X = *(const q4 *)pb, Y = *(const q4 *)(pb + 16), Z = *(const q4 *)(pb + 32);
                 nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x); fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
@@ -512,9 +512,9 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
                 nz = fma2(sz ? f2{ Z.z, Z.w } : f2{ Z.x, Z.y }, id.z, noid.z); fz = fma2(sz ? f2{ Z.x, Z.y } : f2{ Z.z, Z.w }, id.z, noid.z);
             }
             const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
-            const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
+            const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
             const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
-            const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
+            const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
             m |= (tn0 <= tf0 ? 1u : 0u) << (2u * j);
             m |= (tn1 <= tf1 ? 2u : 0u) << (2u * j);
         }
@@ -523,7 +523,9 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
     if (m != 0u) {
         st.push_if((g & N::kMask) != 0u, (int32_t)g);
         // walk order of this node's children: reversed when the direction is negative on the node's sort axis
-        const bool neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
+        bool neg;
+        if (OFFS) neg = ((axis == 0u ? tr.sel[0] : (axis == 1u ? tr.sel[1] : tr.sel[2])) & 8u) != 0u;      // bit 3 = sign (trav_init)
+        else neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
         g = ((uint32_t)tr.cur << N::kNodeShift) | (neg ? N::kRevBit : 0u) | m;
     }
     wide_advance<W>(tr, nodes, st, g);
@@ -557,6 +559,7 @@ MTR_HD void qwide_node_step(Trav &tr, const QNode4 *nodes, Stack &st)
     const q4 A = n.q[0], P = n.q[2], Q = n.q[3];
     const uint32_t meta = fbits(A.w);
     const f3 id = tr.id;
+    const float tb = fminf(tr.tmax, tr.h.t);
     // plane distance = (org + q * step) * id + noid, evaluated as q * (step * id) + (org * id + noid)
     const float kx = bitsf((meta & 0xffu) << 23) * id.x, ky = bitsf(((meta >> 8) & 0xffu) << 23) * id.y, kz = bitsf(((meta >> 16) & 0xffu) << 23) * id.z;
     const float bx = fmaf(A.x, id.x, tr.noid.x), by = fmaf(A.y, id.y, tr.noid.y), bz = fmaf(A.z, id.z, tr.noid.z);
@@ -572,9 +575,9 @@ MTR_HD void qwide_node_step(Trav &tr, const QNode4 *nodes, Stack &st)
         const f2 ny = fma2(f2{ qbyte(nyw, c), qbyte(nyw, c + 1u) }, ky, by), fy = fma2(f2{ qbyte(fyw, c), qbyte(fyw, c + 1u) }, ky, by);
         const f2 nz = fma2(f2{ qbyte(nzw, c), qbyte(nzw, c + 1u) }, kz, bz), fz = fma2(f2{ qbyte(fzw, c), qbyte(fzw, c + 1u) }, kz, bz);
         const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
-        const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tr.tbest));
+        const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
         const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
-        const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tr.tbest));
+        const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
         m |= (tn0 <= tf0 ? 1u : 0u) << c;
         m |= (tn1 <= tf1 ? 2u : 0u) << c;
     }

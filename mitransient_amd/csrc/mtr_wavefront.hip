@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
 
         Trav tr;
         tr.cur = kTravDone; tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1; tr.best_orig = 0xffffffffu;
-        tr.o = mk(0, 0, 0); tr.d = mk(0, 0, 1); tr.id = mk(0, 0, 0); tr.noid = mk(0, 0, 0); tr.tmax = 0.0f; tr.tbest = 0.0f;
+        tr.o = mk(0, 0, 0); tr.d = mk(0, 0, 1); tr.id = mk(0, 0, 0); tr.noid = mk(0, 0, 0); tr.tmax = 0.0f;
         uint32_t slot = 0, pos = 0;
         bool pending = false;                                   // a finished ray whose result is not written yet
         const float4 *qr = any_hit ? a.r_shadow + 2 * (size_t)sg * a.seg
