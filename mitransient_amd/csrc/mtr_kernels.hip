@@ -176,7 +176,11 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     for (int k = 0; k < 6; ++k) st.cyc[k] = 0;
     st.t0 = __builtin_readcyclecounter();
 #endif
-    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_paths = 0, n_splats = 0;
+    // Counters are kept per WAVE, summed from ballots (scalar registers, scalar adds): five per-lane counters would be
+    // five vector registers live across every traversal of a kernel that already spills.  The NLOS loop can trace many
+    // shadow rays per bounce (one per illuminated point), so that variant counts per lane.
+    unsigned long long w_closest = 0, w_shadow = 0, w_bounce = 0, w_paths = 0, w_splats = 0;
+    uint32_t n_closest = 0, n_shadow = 0, n_splats = 0;          // NLOS only
 
     const uint32_t n_px_all = a.pixel_end - a.pixel_begin;
     const uint32_t Q = blockIdx.x < n_px_all ? (n_px_all - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
@@ -198,6 +202,7 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     uint32_t q = 0, slot = 0;
     for (;;) {
         if (__ballot(waiting) != 0ull) {
+            bool started = false;
             if (waiting) {
                 q = i / a.spp_chunk;
                 slot = q % K;
@@ -206,16 +211,17 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                     const uint32_t pixel = a.pixel_begin + blockIdx.x + q * gridDim.x;
                     if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
                     else path_begin(p, a.cam, a.film, a.rc, pixel, s);
-                    ++n_paths;
                     if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
                         Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
-                        ++n_closest;
                         if (h0.prim >= 0) p.dist = -h0.t;
                     }
-                    alive = true; waiting = false;
+                    alive = true; waiting = false; started = true;
                     st.prof_mark(2);
                 }
             }
+            const uint32_t n_started = (uint32_t)__popcll(__ballot(started));
+            w_paths += n_started;
+            if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) w_closest += n_started;
         }
         if (__ballot(alive) == 0ull) {
             if (__ballot(waiting) == 0ull) break;        // the whole wave is out of work
@@ -223,6 +229,8 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
             continue;
         }
         bool closes = false;
+        w_bounce += (uint32_t)__popcll(__ballot(alive));
+        uint32_t did_shadow = 0u, did_splats = 0u;                 // this iteration's per-lane counts (0..1, 0..2)
         if (alive) {
             BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
             if (HIST_LDS) {
@@ -230,15 +238,15 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
                              : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                n_splats += sink.n_splats;
+                if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
                              : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
-                n_splats += sink.n_splats;
+                if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
-            n_closest += bstat.closest; n_shadow += bstat.shadow; ++n_bounce;
+            if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
             if (!alive) {
                 // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
                 const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
@@ -251,6 +259,10 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 i = atomicAdd(s_next, 1u);
                 waiting = i < n_lanes;
             }
+        }
+        if (!NLOS) {          // one closest-hit ray per live lane (counted with w_bounce), at most one shadow ray, at most two contributions
+            w_shadow += (uint32_t)__popcll(__ballot(did_shadow != 0u));
+            w_splats += (uint32_t)__popcll(__ballot((did_splats & 1u) != 0u)) + 2u * (uint32_t)__popcll(__ballot((did_splats & 2u) != 0u));
         }
         // ---- flush: each film row is touched once, by the wave that ended its last path, coalesced (16 B / lane) ----
         for (unsigned long long cm = __ballot(closes); cm != 0ull; cm &= cm - 1ull) {
@@ -290,11 +302,18 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
     __syncthreads();
 
     // ---- counters: LDS reduction, then one set of global atomics per workgroup ----
-    atomicAdd(&s_cnt[0], (unsigned long long)n_paths);
-    atomicAdd(&s_cnt[1], (unsigned long long)n_closest);
-    atomicAdd(&s_cnt[2], (unsigned long long)n_shadow);
-    atomicAdd(&s_cnt[3], (unsigned long long)n_splats);
-    atomicAdd(&s_cnt[4], (unsigned long long)n_bounce);
+    if (NLOS) {
+        atomicAdd(&s_cnt[1], (unsigned long long)n_closest);
+        atomicAdd(&s_cnt[2], (unsigned long long)n_shadow);
+        atomicAdd(&s_cnt[3], (unsigned long long)n_splats);
+    } else w_closest += w_bounce;
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_cnt[0], w_paths);
+        atomicAdd(&s_cnt[1], w_closest);
+        atomicAdd(&s_cnt[2], w_shadow);
+        atomicAdd(&s_cnt[3], w_splats);
+        atomicAdd(&s_cnt[4], w_bounce);
+    }
     __syncthreads();
     if (tid < 5 && a.counters) atomicAdd(&a.counters->paths + tid, s_cnt[tid]);
 #ifdef MTR_PROFILE_SIMT
