@@ -117,8 +117,10 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 #ifndef MTR_FUSED_MIN_WAVES
 #define MTR_FUSED_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
-template <int STACK, bool SCENE_LDS, bool HIST_LDS, bool NLOS>
-__global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const FusedArgs a)
+// MINW: waves per SIMD the register allocator must leave room for.  4 when four workgroups fit a CU; long rows (one
+// 48 KB histogram per workgroup: three per CU) get the 168-register budget of 3 waves per SIMD instead of spilling.
+template <int STACK, bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES>
+__global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -276,7 +278,31 @@ __global__ void __launch_bounds__(kBlock, MTR_FUSED_MIN_WAVES) k_fused(const Fus
                 if (HIST_LDS) {
                     float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
                     float *h = s_hist + fs * T;
-                    for (uint32_t t = wl; t < T; t += 64u) {
+                    // four bins per lane and pass (16-byte LDS reads, 64 contiguous bytes of film per lane); rows and planes
+                    // are 16-byte aligned when T is a multiple of 4, the tail (or an odd T) goes bin by bin
+                    // (only in the 3-waves instantiation, whose rows are long: in the 128-register one the extra live values
+                    // of this block shift spills into the traversal loop, config 2 +5 %)
+                    const uint32_t T4 = (MINW < 4 && (T & 3u) == 0u) ? T : 0u;
+                    for (uint32_t t = 4u * wl; t < T4; t += 256u) {
+                        const float4 r4 = *(const float4 *)(h + t), g4 = *(const float4 *)(h + t + plane), b4 = *(const float4 *)(h + t + 2 * plane);
+                        const float rr[4] = { r4.x, r4.y, r4.z, r4.w }, gg[4] = { g4.x, g4.y, g4.z, g4.w }, bb[4] = { b4.x, b4.y, b4.z, b4.w };
+                        bool any = false;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (rr[k] != 0.0f || gg[k] != 0.0f || bb[k] != 0.0f) {
+                                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t + k];     // accumulate onto earlier passes
+                                v.x += rr[k]; v.y += gg[k]; v.z += bb[k];
+                                row[t + k] = v;
+                                any = true;
+                            }
+                        }
+                        if (any) {
+                            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            *(float4 *)(h + t) = z; *(float4 *)(h + t + plane) = z; *(float4 *)(h + t + 2 * plane) = z;
+                        }
+                    }
+                    for (uint32_t t = T4 + wl; t < T; t += 64u) {
                         float r = h[t], gc = h[t + plane], b = h[t + 2 * plane];
                         if (r != 0.0f || gc != 0.0f || b != 0.0f) {
                             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -374,6 +400,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     int per_cu = (int)(kLdsMax / cfg.lds_bytes);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
+    cfg.per_cu = per_cu;
     long grid = (long)n_cu * per_cu;
     uint32_t g_blk = g_want;                       // small renders: rather more workgroups than long pixel queues
     while (g_blk > 1 && ((long)n_pixels + g_blk - 1) / g_blk < n_cu && (unsigned long long)g_blk * spp_chunk > 512ull) g_blk = (g_blk + 1) / 2;
@@ -391,7 +418,7 @@ template <int STACK, bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
-    if (cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, true, true, NLOS>;
+    if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<STACK, true, true, NLOS, 3> : k_fused<STACK, true, true, NLOS>;
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<STACK, true, false, NLOS>;
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true, NLOS>;
     else k = k_fused<STACK, false, false, NLOS>;
