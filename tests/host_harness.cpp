@@ -7,6 +7,8 @@
 #include "../mitransient_amd/csrc/mtr_scene_host.h"
 #include "../mitransient_amd/csrc/mtr_nlos.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -181,6 +183,114 @@ extern "C" int hh_print_wide(const mtr_scene_desc *d)
             else { uint32_t code = ~(uint32_t)w.ref[c]; printf(" L%u(%u)", code >> 2, (code & 3u) + 1u); }
         }
         printf("\n");
+    }
+    return 0;
+}
+
+// structural checks of the collapsed trees (tests/test_scene_host.py): every BVH2 leaf is referenced exactly once by the
+// 8-wide and by the quantised 4-wide tree, every wide node is reachable exactly once, and each quantised child box
+// contains the (padded) BVH2 box it was made from.  Returns 0 or a negative code naming the first violation.
+namespace {
+void bvh2_leaves(const std::vector<Node> &nodes, std::vector<int32_t> &out)
+{
+    if (nodes.empty()) return;
+    std::vector<int32_t> st{ 0 };
+    while (!st.empty()) {
+        const int32_t n = st.back(); st.pop_back();
+        const float *f = &nodes[n].q[0].x;
+        for (int c = 0; c < 2; ++c) {
+            if (!(f[c] <= f[2 + c])) continue;                       // absent child
+            const int32_t ref = (int32_t)fbits(f[12 + c]);
+            if (ref >= 0) st.push_back(ref); else out.push_back(ref);
+        }
+    }
+}
+}
+extern "C" int hh_check_wide(const mtr_scene_desc *d, uint32_t *n_wide8, uint32_t *n_wide4)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    std::vector<int32_t> want;
+    bvh2_leaves(hs.nodes, want);
+    std::sort(want.begin(), want.end());
+    if (n_wide8) *n_wide8 = (uint32_t)hs.wnodes.size();
+    if (n_wide4) *n_wide4 = (uint32_t)hs.wnodes4.size();
+    if (hs.has_wide) {
+        std::vector<int32_t> got; std::vector<int> seen(hs.wnodes.size(), 0);
+        std::vector<int32_t> st; if (!hs.wnodes.empty()) { st.push_back(0); seen[0] = 1; }
+        while (!st.empty()) {
+            const WNode &w = hs.wnodes[st.back()]; st.pop_back();
+            if (w.count < 1 || w.count > kWide || w.axis > 2) return -2;
+            for (uint32_t c = 0; c < w.count; ++c) {
+                if (((w.leaves >> c) & 1u) != (w.ref[c] < 0 ? 1u : 0u)) return -3;
+                if (w.ref[c] < 0) got.push_back(w.ref[c]);
+                else { if ((size_t)w.ref[c] >= seen.size() || seen[w.ref[c]]++) return -4; st.push_back(w.ref[c]); }
+            }
+        }
+        std::sort(got.begin(), got.end());
+        if (got != want) return -5;
+        for (int v : seen) if (v != 1) return -6;
+    }
+    {
+        std::vector<int32_t> got; std::vector<int> seen(hs.wnodes4.size(), 0);
+        struct Item { int32_t node; };
+        std::vector<int32_t> st; if (!hs.wnodes4.empty()) { st.push_back(0); seen[0] = 1; }
+        while (!st.empty()) {
+            const QNode4 &q = hs.wnodes4[st.back()]; st.pop_back();
+            const uint32_t meta = fbits(q.q[0].w), count = meta >> 26;
+            if (count < 1 || count > 4 || ((meta >> 24) & 3u) > 2) return -12;
+            for (uint32_t c = 0; c < count; ++c) {
+                const int32_t ref = (int32_t)fbits((&q.q[1].x)[c]);
+                if (ref < 0) got.push_back(ref);
+                else { if ((size_t)ref >= seen.size() || seen[ref]++) return -14; st.push_back(ref); }
+            }
+        }
+        std::sort(got.begin(), got.end());
+        if (got != want) return -15;
+        for (int v : seen) if (v != 1) return -16;
+    }
+    // containment: walk BVH2 and the 4-wide tree together is not possible (different shapes); instead check, for every
+    // 4-wide node, that each decoded child box contains the union of the leaf boxes below it — cheap proxy: it must contain
+    // the decoded boxes of that child's own children (inner) — and that the root's children cover every triangle vertex.
+    if (!hs.wnodes4.empty()) {
+        auto decode = [&](const QNode4 &q, uint32_t c, double lo[3], double hi[3]) {
+            const uint32_t meta = fbits(q.q[0].w);
+            const float org[3] = { q.q[0].x, q.q[0].y, q.q[0].z };
+            const uint32_t wl[3] = { fbits(q.q[2].x), fbits(q.q[2].y), fbits(q.q[2].z) }, wh[3] = { fbits(q.q[2].w), fbits(q.q[3].x), fbits(q.q[3].y) };
+            for (int k = 0; k < 3; ++k) {
+                const double step = std::ldexp(1.0, (int)((meta >> (8 * k)) & 0xffu) - 127);
+                lo[k] = (double)org[k] + (double)((wl[k] >> (8 * c)) & 0xffu) * step;
+                hi[k] = (double)org[k] + (double)((wh[k] >> (8 * c)) & 0xffu) * step;
+            }
+        };
+        for (size_t i = 0; i < hs.wnodes4.size(); ++i) {
+            const QNode4 &q = hs.wnodes4[i];
+            const uint32_t count = fbits(q.q[0].w) >> 26;
+            for (uint32_t c = 0; c < count; ++c) {
+                double lo[3], hi[3]; decode(q, c, lo, hi);
+                const int32_t ref = (int32_t)fbits((&q.q[1].x)[c]);
+                if (ref >= 0) {
+                    const QNode4 &ch = hs.wnodes4[ref];
+                    const uint32_t cc = fbits(ch.q[0].w) >> 26;
+                    for (uint32_t k = 0; k < cc; ++k) {
+                        double l2[3], h2[3]; decode(ch, k, l2, h2);
+                        // planes round outwards on the child's own grid: allow one step of that grid (plus the box padding) as slack
+                        const uint32_t cm = fbits(ch.q[0].w);
+                        for (int a = 0; a < 3; ++a) {
+                            const double slack = std::ldexp(1.0, (int)((cm >> (8 * a)) & 0xffu) - 127) + 1e-4 * (1.0 + std::fabs(hi[a]));
+                            if (l2[a] < lo[a] - slack || h2[a] > hi[a] + slack) return -20;
+                        }
+                    }
+                } else {
+                    const uint32_t code = ~(uint32_t)ref, first = code >> 2, cnt = (code & 3u) + 1u;
+                    for (uint32_t t = 0; t < cnt; ++t) {
+                        const float *v = d->tri_verts + 9 * (size_t)hs.slot_orig[first + t];
+                        for (int p = 0; p < 3; ++p) for (int a = 0; a < 3; ++a)
+                            if ((double)v[3 * p + a] < lo[a] || (double)v[3 * p + a] > hi[a]) return -21;      // a triangle pokes out of its quantised leaf box
+                    }
+                }
+            }
+        }
     }
     return 0;
 }

@@ -204,3 +204,24 @@ def test_obj_loader(tmp_path):
     t = load_obj(str(p))
     assert t.shape == (3, 3, 3)
     assert np.allclose(t[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
+
+
+@pytest.mark.parametrize("which", ["cornell", "staircase_like"])
+def test_collapsed_trees_cover_the_bvh2(host_harness, which):
+    """The 8-wide tree (LDS scenes) and the quantised 4-wide tree (HBM scenes) are collapses of the BVH2: every leaf
+    referenced exactly once, every node reachable exactly once, every triangle inside its quantised leaf box, child boxes
+    inside their parent's."""
+    import mitransient_amd.mi as mi
+    if which == "cornell":
+        scene = make_cornell()
+    else:
+        from mitransient_amd.scenes import staircase_like
+        mi.set_variant("llvm_ad_rgb")
+        scene = mi.load_dict(staircase_like(n_steps=12, balusters=2, tiles=6, width=16, height=16, temporal_bins=16, spp=1))
+    sd = scene.data()
+    desc = sd.desc()
+    n8, n4 = C.c_uint32(0), C.c_uint32(0)
+    assert host_harness.hh_check_wide(C.byref(desc), C.byref(n8), C.byref(n4)) == 0
+    assert n8.value >= 1 and n4.value >= 1
+    if which == "cornell":
+        assert n8.value == 3            # walls + light under the root, one node per box
