@@ -191,6 +191,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
+    s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
     s->n_emitters_area = d->n_emitters;
     if (d->nlos) {

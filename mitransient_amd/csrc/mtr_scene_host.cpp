@@ -68,9 +68,9 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     s.nodes = bvh.nodes; s.bvh_depth = bvh.max_depth; s.n_leaves = bvh.n_leaves;
     s.wnodes.clear();
     s.has_wide = bvh.nodes.size() <= 2048;
-    if (s.has_wide) build_wide(bvh, s.wnodes);
+    s.wide_levels = s.has_wide ? build_wide(bvh, s.wnodes) : 0;
     s.wnodes4.clear();
-    build_wide4(bvh, s.wnodes4);
+    s.wide4_levels = build_wide4(bvh, s.wnodes4);
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
     for (uint32_t slot = 0; slot < n_slots; ++slot) {

@@ -23,6 +23,7 @@ struct HostScene {
     std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView
     std::vector<float> face_pmf, face_cdf;
     uint32_t bvh_depth = 0, n_leaves = 0;
+    uint32_t wide_levels = 0, wide4_levels = 0;        // levels of the collapsed trees (= their traversal stack bound)
     Camera cam{};
     Film film{};
 };

@@ -52,6 +52,8 @@ __device__ __forceinline__ void cp16(void *dst, const void *src, uint32_t bytes,
 }
 
 // stage the scene in LDS (or point at HBM) and carve the traversal stack
+__host__ __device__ inline uint32_t wf_stack_rows(const SceneDev &sc, bool scene_lds) { return (scene_lds ? sc.wide_levels : sc.wide4_levels) + 1u; }
+
 template <int STACK, bool SCENE_LDS>
 __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem, int tid, SceneView &sv, WStack<STACK> &st,
                                          uint32_t &off)
@@ -59,9 +61,10 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     // all LDS scratch lives in the dynamic region, every carve offset a multiple of 16 (a static
     // __shared__ in front of it would shift the base and mis-align the ds_read_b128 node fetches)
     off = 64;                                                   // smem[0..63]: workgroup counters
-    // the traversal stack holds at most bvh_depth entries per lane (+1: push_if writes before it counts); sized exactly,
+    // the traversal stack holds at most one group per level of the tree that is walked (8-wide in LDS, quantised 4-wide in
+    // HBM; +1: push_if writes before it counts) — 15 rows instead of the BVH2's 28 for the staircase; sized exactly,
     // not by the STACK class, so that a depth-27 tree leaves room for 5 workgroups per CU instead of 4
-    int32_t *s_stack = (int32_t *)(smem + off); off += (sc.bvh_depth + 1u) * kBlock * 4u;
+    int32_t *s_stack = (int32_t *)(smem + off); off += wf_stack_rows(sc, SCENE_LDS) * kBlock * 4u;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
     if (SCENE_LDS) {
@@ -264,8 +267,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 #ifndef MTR_WF_REFILL_MIN
 #define MTR_WF_REFILL_MIN 16
 #endif
+#ifndef MTR_WF_TRACE_WAVES
+#define MTR_WF_TRACE_WAVES 6          // scenes in HBM: the walk waits on loads, 6 waves per SIMD (80 registers, 6 spilled) beat 5 and 8 (measured)
+#endif
 template <int STACK, bool SCENE_LDS>
-__global__ void __launch_bounds__(kBlock) k_wf_trace(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_cnt = (uint32_t *)smem;                         // [kWfKeys] list tails of the segment
@@ -716,7 +722,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
     uint32_t scene_b = al16(sc.n_wnodes * sizeof(WNode)) + al16(sc.n_slots / 2 * sizeof(TriPair)) + al16(sc.n_slots * sizeof(TriShade)) +
                        al16(sc.n_mats * sizeof(mtr_material)) + al16(sc.n_ems * sizeof(Emitter));
     cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
-    cfg.lds_bytes = 64 + (size_t)(sc.bvh_depth + 1) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
+    cfg.lds_bytes = 64 + (size_t)wf_stack_rows(sc, cfg.scene_lds) * kBlock * 4 + (cfg.scene_lds ? scene_b : 0) + 16;
     return true;
 }
 
