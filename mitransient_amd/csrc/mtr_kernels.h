@@ -34,8 +34,7 @@ struct FusedArgs {
     RenderConst rc;
     uint32_t pixel_begin, pixel_end;     // crop-window pixels
     uint32_t spp_begin, spp_chunk;       // samples [spp_begin, spp_begin + spp_chunk)
-    uint32_t G;                          // pixels per segment (one workgroup owns a segment)
-    uint32_t nseg;
+    uint32_t G;                          // row slots of a workgroup's pixel ring (k_fused)
     float *film_out;                     // (H, W, T, 4)
     float *steady_out;                   // (H, W, 4)
     DevCounters *counters;

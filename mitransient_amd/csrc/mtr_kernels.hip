@@ -392,7 +392,6 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
-    args.nseg = (n_pixels + G - 1) / G;
     cfg.stack = stack;
     cfg.lds_bytes = fixed + align16(G * 16) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
     if (cfg.lds_bytes > kLdsMax) return false;
