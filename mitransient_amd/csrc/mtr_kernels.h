@@ -35,6 +35,7 @@ struct FusedArgs {
     uint32_t pixel_begin, pixel_end;     // crop-window pixels
     uint32_t spp_begin, spp_chunk;       // samples [spp_begin, spp_begin + spp_chunk)
     uint32_t G;                          // row slots of a workgroup's pixel ring (k_fused)
+    uint32_t rot;                        // rotation of the workgroup -> pixel assignment from one stripe of gridDim pixels to the next
     float *film_out;                     // (H, W, T, 4)
     float *steady_out;                   // (H, W, 4)
     DevCounters *counters;

@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
+#ifdef MTR_PROFILE_TAIL
+    const unsigned long long t0_wall = wall_clock64();
+#endif
 
     // ---- LDS carve-up (all offsets multiples of 16) ----
     uint32_t off = 0;
@@ -187,6 +190,15 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     const uint32_t n_px_all = a.pixel_end - a.pixel_begin;
     const uint32_t Q = blockIdx.x < n_px_all ? (n_px_all - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
     const uint32_t n_lanes = Q * a.spp_chunk;           // fused_plan keeps this below 2^32 - kBlock
+    // The q-th pixel of workgroup b: stripe q of gridDim pixels, position (b + q * rot) mod gridDim inside it.  Without the
+    // rotation a power-of-two grid over a power-of-two image width pins every workgroup to ONE image column, and columns
+    // differ in cost by more than 10x (the Cornell box's image has empty margins): the cheapest workgroup of config 2
+    // finished after 6 ms, the dearest after 102.  The last, partial stripe is not rotated (every pixel keeps one owner).
+    const uint32_t n_full = n_px_all / gridDim.x;
+    auto pixel_of = [&](uint32_t qq) -> uint32_t {
+        const uint32_t r = qq < n_full ? (blockIdx.x + qq * a.rot) % gridDim.x : blockIdx.x;
+        return a.pixel_begin + qq * gridDim.x + r;
+    };
     __syncthreads();
     st.prof_mark(5);
 
@@ -210,7 +222,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 slot = q % K;
                 if (__hip_atomic_load(s_owner + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == q) {
                     const uint32_t s = a.spp_begin + (i - q * a.spp_chunk);
-                    const uint32_t pixel = a.pixel_begin + blockIdx.x + q * gridDim.x;
+                    const uint32_t pixel = pixel_of(q);
                     if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
                     else path_begin(p, a.cam, a.film, a.rc, pixel, s);
                     if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
@@ -270,7 +282,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         for (unsigned long long cm = __ballot(closes); cm != 0ull; cm &= cm - 1ull) {
             const int src = __ffsll((long long)cm) - 1;
             const uint32_t fq = __builtin_amdgcn_readlane(q, src), fs = __builtin_amdgcn_readlane(slot, src);
-            const uint32_t pixel = a.pixel_begin + blockIdx.x + fq * gridDim.x;
+            const uint32_t pixel = pixel_of(fq);
             const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;   // == film coords
             const uint32_t wl = tid & 63u;
             if (cx < a.film.width && cy < a.film.height) {
@@ -342,6 +354,14 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     }
     __syncthreads();
     if (tid < 5 && a.counters) atomicAdd(&a.counters->paths + tid, s_cnt[tid]);
+#ifdef MTR_PROFILE_TAIL       // experiment build: when does the first / the last workgroup finish (100 MHz wall clock)
+    if (tid == 0 && a.counters) {
+        const unsigned long long t = wall_clock64();
+        atomicMax(&a.counters->r0, ~(t - t0_wall));           // shortest workgroup (counters start at 0: minimum kept as the maximum of the complement)
+        atomicMax(&a.counters->r1, t - t0_wall);              // longest workgroup
+        atomicAdd(&a.counters->splats_overflow, t - t0_wall); // sum over workgroups
+    }
+#endif
 #ifdef MTR_PROFILE_SIMT
     if (a.counters) {
         unsigned long long *c = &a.counters->splats_overflow;
@@ -411,6 +431,10 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const unsigned long long q_max = ((unsigned long long)n_pixels + grid - 1) / grid;
     if (q_max * spp_chunk > 0xffff0000ull) return false;
     cfg.grid = (int)grid;
+    // rotation step of the pixel stripes (k_fused): odd, about 0.38 of the grid
+    args.rot = (uint32_t)(((unsigned long long)grid * 3819ull / 10000ull) | 1ull);
+    if (args.rot >= (uint32_t)grid) args.rot = 1u;
+    if (const char *e = getenv("MTR_FUSED_ROT")) args.rot = (uint32_t)atoi(e);     // experiments (0 = one column of stripes per workgroup)
     return true;
 }
 
