@@ -26,6 +26,7 @@ struct mtr_ctx {
     int n_cu = 256;
     std::string err;
     DevCounters *d_counters = nullptr;
+    uint32_t *d_ticket = nullptr;          // k_fused work-ticket counter
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
     void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
@@ -98,6 +99,7 @@ int mtr_ctx_create(int device_ordinal, mtr_ctx **out)
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(nullptr, hipMalloc((void **)&c->d_counters, sizeof(DevCounters)));
+    HIP_TRY(nullptr, hipMalloc((void **)&c->d_ticket, 16));
     HIP_TRY(nullptr, hipEventCreate(&c->ev0));
     HIP_TRY(nullptr, hipEventCreate(&c->ev1));
     *out = c;
@@ -109,6 +111,7 @@ void mtr_ctx_destroy(mtr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_freq) (void)hipFree(c->d_freq);
     if (c->d_runs) (void)hipFree(c->d_runs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -505,6 +508,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             FusedConfig cfg{};
             if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, a, cfg))
                 return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
+            a.ticket = c->d_ticket;
             HIP_TRY(c, launch_fused(a, cfg, c->stream));
             launches = 1;
         }

@@ -35,7 +35,8 @@ struct FusedArgs {
     uint32_t pixel_begin, pixel_end;     // crop-window pixels
     uint32_t spp_begin, spp_chunk;       // samples [spp_begin, spp_begin + spp_chunk)
     uint32_t G;                          // row slots of a workgroup's pixel ring (k_fused)
-    uint32_t rot;                        // rotation of the workgroup -> pixel assignment from one stripe of gridDim pixels to the next
+    uint32_t chunk, n_chunks;            // consecutive pixels per work ticket, number of tickets of this launch
+    uint32_t *ticket;                    // device counter, zeroed before the launch (launch_fused)
     float *film_out;                     // (H, W, T, 4)
     float *steady_out;                   // (H, W, 4)
     DevCounters *counters;

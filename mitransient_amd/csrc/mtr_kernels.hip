@@ -156,9 +156,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         sv.wnodes = nullptr; sv.wnodes4 = a.sc.wnodes4;
         sv.node_pairs = false;
     }
-    // ---- pixel ring: K = a.G row slots; the workgroup's q-th pixel (pixel_begin + blockIdx + q * gridDim) lives in
-    // slot q % K from its first sample until its last path has ended, then the wave that ended it flushes the row
-    // and hands the slot to pixel q + K.  No segment boundaries: lanes of pixel q + 1 start while pixel q drains.
+    // ---- work distribution: workgroups draw CHUNKS of a.chunk consecutive pixels from a global ticket counter (pixels
+    // differ in cost by more than 10x — the Cornell box's image has empty margins — and a static assignment left the
+    // cheapest workgroup of config 2 idle after 6 of 102 ms; rotating the assignment still left a 52 .. 90 ms spread).
+    // ---- pixel ring inside a chunk: K = a.G row slots; the chunk's q-th pixel lives in slot q % K from its first sample
+    // until its last path has ended, then the wave that ended it flushes the row and hands the slot to pixel q + K:
+    // lanes of pixel q + 1 start while pixel q drains; the only workgroup barrier is the one between chunks.
     const uint32_t K = a.G;
     float *s_steady = (float *)(smem + off); off += align16(K * 16);
     uint32_t *s_owner = (uint32_t *)(smem + off); off += align16(K * 4);      // pixel ordinal that may use the slot
@@ -168,8 +171,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     const uint32_t plane = K * T;
 
     if (tid < 6) s_cnt[tid] = 0ull;
-    if (tid == 0) *s_next = kBlock;
-    for (uint32_t k = tid; k < K; k += kBlock) { s_owner[k] = k; s_done[k] = 0u; }
+    for (uint32_t k = tid; k < K; k += kBlock) s_done[k] = 0u;
     for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady[k] = 0.0f;
     if (HIST_LDS) for (uint32_t k = tid; k < 3 * plane; k += kBlock) s_hist[k] = 0.0f;
 
@@ -187,19 +189,18 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     unsigned long long w_closest = 0, w_shadow = 0, w_bounce = 0, w_paths = 0, w_splats = 0;
     uint32_t n_closest = 0, n_shadow = 0, n_splats = 0;          // NLOS only
 
-    const uint32_t n_px_all = a.pixel_end - a.pixel_begin;
-    const uint32_t Q = blockIdx.x < n_px_all ? (n_px_all - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
-    const uint32_t n_lanes = Q * a.spp_chunk;           // fused_plan keeps this below 2^32 - kBlock
-    // The q-th pixel of workgroup b: stripe q of gridDim pixels, position (b + q * rot) mod gridDim inside it.  Without the
-    // rotation a power-of-two grid over a power-of-two image width pins every workgroup to ONE image column, and columns
-    // differ in cost by more than 10x (the Cornell box's image has empty margins): the cheapest workgroup of config 2
-    // finished after 6 ms, the dearest after 102.  The last, partial stripe is not rotated (every pixel keeps one owner).
-    const uint32_t n_full = n_px_all / gridDim.x;
-    auto pixel_of = [&](uint32_t qq) -> uint32_t {
-        const uint32_t r = qq < n_full ? (blockIdx.x + qq * a.rot) % gridDim.x : blockIdx.x;
-        return a.pixel_begin + qq * gridDim.x + r;
-    };
+    uint32_t *s_chunk = s_next + 1;
+    for (;;) {
+    // every wave has left the previous chunk (all its rows are flushed): draw the next one, reset the ring
     __syncthreads();
+    if (tid == 0) { *s_chunk = atomicAdd(a.ticket, 1u); *s_next = kBlock; }
+    for (uint32_t k = tid; k < K; k += kBlock) s_owner[k] = k;
+    __syncthreads();
+    const uint32_t chunk = *s_chunk;
+    if (chunk >= a.n_chunks) break;
+    const uint32_t pix0 = a.pixel_begin + chunk * a.chunk;
+    const uint32_t n_lanes = min(a.chunk, a.pixel_end - pix0) * a.spp_chunk;
+    auto pixel_of = [&](uint32_t qq) -> uint32_t { return pix0 + qq; };
     st.prof_mark(5);
 
     // ---- persistent lanes: refill from the LDS work counter when a path ends ----
@@ -337,6 +338,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             }
         }
     }
+    }       // chunks
     __syncthreads();
 
     // ---- counters: LDS reduction, then one set of global atomics per workgroup ----
@@ -427,14 +429,18 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const long max_blocks = ((long)n_pixels + g_blk - 1) / g_blk;
     if (grid > max_blocks) grid = max_blocks;
     if (grid < 1) grid = 1;
-    // the per-workgroup sample counter is 32 bits wide
-    const unsigned long long q_max = ((unsigned long long)n_pixels + grid - 1) / grid;
-    if (q_max * spp_chunk > 0xffff0000ull) return false;
+    // chunk of consecutive pixels per ticket: about 8192 samples (amortises the drain at the chunk's end), but at least
+    // 8 chunks per workgroup (so that the last chunks level the workgroups out)
+    uint32_t chunk = (8192u + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
+    const uint32_t c_bal = (uint32_t)((unsigned long long)n_pixels / (8ull * (unsigned long long)grid));
+    if (chunk > c_bal) chunk = c_bal;
+    if (chunk < 1u) chunk = 1u;
+    if (const char *e = getenv("MTR_FUSED_CHUNK")) { const int v = atoi(e); if (v >= 1) chunk = (uint32_t)v; }     // experiments
+    if ((unsigned long long)chunk * spp_chunk > 0xffff0000ull) return false;     // the per-chunk sample counter is 32 bits wide
+    args.chunk = chunk;
+    args.n_chunks = (n_pixels + chunk - 1u) / chunk;
+    if (grid > (long)args.n_chunks) grid = args.n_chunks;
     cfg.grid = (int)grid;
-    // rotation step of the pixel stripes (k_fused): odd, about 0.38 of the grid
-    args.rot = (uint32_t)(((unsigned long long)grid * 3819ull / 10000ull) | 1ull);
-    if (args.rot >= (uint32_t)grid) args.rot = 1u;
-    if (const char *e = getenv("MTR_FUSED_ROT")) args.rot = (uint32_t)atoi(e);     // experiments (0 = one column of stripes per workgroup)
     return true;
 }
 
@@ -447,6 +453,8 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true, NLOS>;
     else k = k_fused<STACK, false, false, NLOS>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(args.ticket, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, stream, args);
     return hipGetLastError();
