@@ -382,19 +382,21 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
             HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
             a.parity = 0;
+            a.ticket = c->d_ticket + 1; a.ticket_cur = 0u;                           // segment tickets (k_wf_trace / shadow_gen / shade)
+            HIP_TRY(c, hipMemsetAsync(a.ticket, 0, 2 * sizeof(uint32_t), c->stream));
             HIP_TRY(c, launch_wf(a, cfg, 0, grid_gen, c->stream));                   // raygen (writes live list 0)
             uint32_t depth = 0;
             while (depth < max_depth) {
                 if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
                 a.trace_any = 0u;
-                HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));                   // closest hit + material lists
+                HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream)); a.ticket_cur ^= 1u;  // closest hit + material lists
                 if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
-                    HIP_TRY(c, launch_wf(a, cfg, 4, grid, c->stream));               // shadow rays of the emitter samples
+                    HIP_TRY(c, launch_wf(a, cfg, 4, grid, c->stream)); a.ticket_cur ^= 1u;   // shadow rays of the emitter samples
                     a.trace_any = 1u;
-                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream));               // their occlusion
+                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream)); a.ticket_cur ^= 1u;   // their occlusion
                     *n_trace += 2;
                 }
-                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream));                   // shade (+ inline shadow rays when the scene is in LDS) + compaction
+                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream)); a.ticket_cur ^= 1u;  // shade (+ inline shadow rays when the scene is in LDS) + compaction
                 *n_trace += 2;
                 a.parity ^= 1u;
                 ++depth;

@@ -67,6 +67,7 @@ struct WfArgs {
     uint32_t n_slots;                    // P * S
     uint32_t G, seg, n_seg;              // segment = G whole pixels = G * S slots, owned by one workgroup per launch
     uint32_t parity;                     // which of the two live lists this bounce reads
+    uint32_t *ticket; uint32_t ticket_cur;   // segment tickets: two counters alternating between consecutive launches
     float *planes;                       // SoA state, PL_COUNT planes of n_slots
     uint32_t *q_live;                    // [2][n_slots] ping-pong live lists (slot indices), segment sg at sg * seg
     float4 *q_ray;                       // [2][n_slots][2] the rays of the live lists IN LIST ORDER: (o, tmax) (d, eta)

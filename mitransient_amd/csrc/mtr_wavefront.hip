@@ -90,6 +90,22 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     st.base = s_stack + tid; st.sp = 0;
 }
 
+// Segments are drawn from a ticket counter, not strided over the grid: their live counts differ, and every launch of a
+// bounce ends with its slowest workgroup.  Two counters alternate between consecutive launches of the stream: a launch
+// draws from a.ticket[a.ticket_cur] and zeroes the other one for its successor.
+__device__ __forceinline__ void wf_ticket_begin(const WfArgs &a, int tid)
+{
+    if (blockIdx.x == 0 && tid == 0) a.ticket[a.ticket_cur ^ 1u] = 0u;
+}
+__device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned char *smem, int tid)
+{
+    uint32_t *s_sg = (uint32_t *)smem + 15;
+    __syncthreads();                      // the previous segment's LDS state is no longer in use
+    if (tid == 0) *s_sg = atomicAdd(a.ticket + a.ticket_cur, 1u);
+    __syncthreads();
+    return *s_sg;
+}
+
 // ---- SoA-of-quads state: 7 planes of float4 (16 B per lane per access, the coalescing sweet spot;
 // also what keeps the gathers through the slot queues efficient) ----------------------------------
 //   Q_RAY0 (o.xyz, tmax)   Q_RAY1 (d.xyz, eta)      Q_BETA (beta.xyz, dist)   Q_RAD (L.xyz, prev_pdf)
@@ -287,7 +303,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
     unsigned long long prof[4] = { 0, 0, 0, 0 };      // node iterations, lanes in them, leaf iterations, lanes in them
 #endif
     const bool any_hit = a.trace_any != 0u;         // occlusion of this bounce's shadow rays instead of closest hits
-    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+    wf_ticket_begin(a, tid);
+    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
         const uint32_t n_live = any_hit ? a.seg_shadow[sg] : a.seg_live[(size_t)par * a.n_seg + sg];
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
         if (tid == 0) *s_fetch = 0u;
@@ -385,7 +402,8 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     const Planes P{ (float4 *)a.planes, a.n_slots };
-    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+    wf_ticket_begin(a, tid);
+    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
         if (tid == 0) *s_tail = 0u;
         __syncthreads();
         const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
@@ -445,7 +463,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     const Planes P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
-    for (uint32_t sg = blockIdx.x; sg < a.n_seg; sg += gridDim.x) {
+    wf_ticket_begin(a, tid);
+    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
         const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
         const uint32_t npx = min(a.G, a.P - pl0);
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
