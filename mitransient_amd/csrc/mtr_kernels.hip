@@ -189,17 +189,27 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     unsigned long long w_closest = 0, w_shadow = 0, w_bounce = 0, w_paths = 0, w_splats = 0;
     uint32_t n_closest = 0, n_shadow = 0, n_splats = 0;          // NLOS only
 
-    uint32_t *s_chunk = s_next + 1;
+    uint32_t *s_chunk = s_next + 1;                  // [2]: first pixel of the ticket, pixels in it
+    const uint32_t n_px_all = a.pixel_end - a.pixel_begin;
     for (;;) {
     // every wave has left the previous chunk (all its rows are flushed): draw the next one, reset the ring
     __syncthreads();
-    if (tid == 0) { *s_chunk = atomicAdd(a.ticket, 1u); *s_next = kBlock; }
+    if (tid == 0) {
+        // guided: a.chunk pixels per ticket, fewer as the launch runs out (about half a share of what is left), so that the
+        // workgroups finish within one pixel of each other — a launch per row band (multi-GPU pipeline) ends 8 times per render
+        const uint32_t seen = __hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t left = seen < n_px_all ? n_px_all - seen : 0u;
+        uint32_t want = left / (2u * gridDim.x);
+        want = want < 1u ? 1u : (want > a.chunk ? a.chunk : want);
+        s_chunk[0] = atomicAdd(a.ticket, want); s_chunk[1] = want;
+        *s_next = kBlock;
+    }
     for (uint32_t k = tid; k < K; k += kBlock) s_owner[k] = k;
     __syncthreads();
-    const uint32_t chunk = *s_chunk;
-    if (chunk >= a.n_chunks) break;
-    const uint32_t pix0 = a.pixel_begin + chunk * a.chunk;
-    const uint32_t n_lanes = min(a.chunk, a.pixel_end - pix0) * a.spp_chunk;
+    const uint32_t first = s_chunk[0];
+    if (first >= n_px_all) break;
+    const uint32_t pix0 = a.pixel_begin + first;
+    const uint32_t n_lanes = min(s_chunk[1], n_px_all - first) * a.spp_chunk;
     auto pixel_of = [&](uint32_t qq) -> uint32_t { return pix0 + qq; };
     st.prof_mark(5);
 
