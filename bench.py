@@ -135,7 +135,18 @@ def main():
     torch.cuda.set_device(device_index)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            # RCCL's kernels on a HIGH-PRIORITY stream: k_fused is persistent and fills every CU's LDS, so the film
+            # reduction of band b can only get onto the chip at the boundary between the kernels of bands b and b+1 —
+            # where, with equal priority, the next path kernel would take every slot first and the communication of all
+            # bands would pile up behind the last one.  (The path kernel does not mind starting a few workgroups late:
+            # its work is drawn from a ticket counter.)
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:
+                opts = None
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), pg_options=opts)
         else:
             dist.init_process_group(backend)
 

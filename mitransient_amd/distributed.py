@@ -170,7 +170,9 @@ class DistributedRenderer:
         main = torch.cuda.current_stream(dev)
         side = getattr(self, "_side_stream", None)
         if side is None:
-            side = self._side_stream = torch.cuda.Stream(device=dev)
+            # high priority: its kernels (develop, copies; RCCL's own stream takes the process group's priority option) must
+            # get onto the chip at the boundary between two persistent path kernels, which otherwise fill every CU first
+            side = self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
         gloo = dist.get_backend(self.group) == "gloo"
         for b in range(nb):
             r0, r1 = b * rows_b, (b + 1) * rows_b
