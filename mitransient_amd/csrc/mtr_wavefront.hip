@@ -97,11 +97,14 @@ __device__ __forceinline__ void wf_ticket_begin(const WfArgs &a, int tid)
 {
     if (blockIdx.x == 0 && tid == 0) a.ticket[a.ticket_cur ^ 1u] = 0u;
 }
-__device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned char *smem, int tid)
+// A workgroup's FIRST segment is its own index (no atomic: 2048 workgroups hitting one counter at launch cost a launch of
+// a late, nearly empty bounce 90 us), the following ones come from the counter, which therefore counts from gridDim.
+__device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned char *smem, int tid, bool first)
 {
+    if (first) return blockIdx.x;
     uint32_t *s_sg = (uint32_t *)smem + 15;
     __syncthreads();                      // the previous segment's LDS state is no longer in use
-    if (tid == 0) *s_sg = atomicAdd(a.ticket + a.ticket_cur, 1u);
+    if (tid == 0) *s_sg = gridDim.x + atomicAdd(a.ticket + a.ticket_cur, 1u);
     __syncthreads();
     return *s_sg;
 }
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
 #endif
     const bool any_hit = a.trace_any != 0u;         // occlusion of this bounce's shadow rays instead of closest hits
     wf_ticket_begin(a, tid);
-    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
+    for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t n_live = any_hit ? a.seg_shadow[sg] : a.seg_live[(size_t)par * a.n_seg + sg];
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
         if (tid == 0) *s_fetch = 0u;
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     const Planes P{ (float4 *)a.planes, a.n_slots };
     wf_ticket_begin(a, tid);
-    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
+    for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         if (tid == 0) *s_tail = 0u;
         __syncthreads();
         const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
     wf_ticket_begin(a, tid);
-    for (uint32_t sg = wf_next_segment(a, smem, tid); sg < a.n_seg; sg = wf_next_segment(a, smem, tid)) {
+    for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
         const uint32_t npx = min(a.G, a.P - pl0);
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
