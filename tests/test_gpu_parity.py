@@ -513,3 +513,30 @@ def test_hbm_scene_wavefront_depths(oracle, max_depth, rr_depth, unwarp):
         assert got[k] == cnt[k], k
     if max_depth == 1:
         assert cnt["rays_shadow"] == 0
+
+
+@pytest.mark.parametrize("bins,spp", [(1024, 40), (2048, 300), (4096, 520), (4100, 64), (12000, 33)])
+def test_fused_row_ring_sizes(oracle, bins, spp):
+    """k_fused's ring of row histograms at every depth the LDS budget produces: 4 / 2 / 1 slots (T = 1024 / 2048 / 4096:
+    the last one runs the 3-waves-per-SIMD instantiation with the 4-bins-per-lane flush), a row that is not a multiple of
+    four bins, and the longest row that still fits a CU on its own (T = 12000); samples per pixel below, around and above
+    the 256 lanes of a workgroup; a second pass accumulated onto the first (read-modify-write flush)."""
+    import torch
+    scene = make_cornell(width=12, height=10, bins=bins, start=3.0, window=9.0, amd_mode="fused")
+    s_gpu, t_gpu = gpu_render(scene, spp)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, spp)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+    # two half passes accumulated into one film == one pass over all samples (the second pass finds a non-zero film)
+    integ = scene.integrator()
+    sens = scene.sensors()[0]
+    film = sens.film()
+    passes = integ.prepare(scene, sens, 0, spp, integ.aov_names())
+    half = spp // 2
+    integ.accumulate(scene, sens, passes, spp, spp_range=(0, half))
+    integ.accumulate(scene, sens, passes, spp, spp_range=(half, spp))
+    s2, t2 = film.develop()
+    torch.cuda.synchronize()
+    assert rel_l2(np.array(t2), t_ref) <= TOL and rel_l2(np.array(s2), s_ref) <= TOL
