@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
                     nz = r != 0.0f || g != 0.0f || b != 0.0f;
                     if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
                 }
-                if (nz && in_film) {
+                if ((nz || store_only) && in_film) {          // store_only: whole lines, zeros included (the row is contiguous)
                     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (!store_only) v = dst[t];                  // accumulate onto earlier passes / overflow atomics
                     v.x += r; v.y += g; v.z += b;
