@@ -69,10 +69,10 @@ __device__ __forceinline__ void log_splat(const SplatLog &lg, uint32_t lane, uin
 }
 
 #ifndef MTR_FUSED_SEG_LANES
-#define MTR_FUSED_SEG_LANES 2048u      // lanes per segment the planner aims for (1024: 148 ms, 2048: 143 ms)
+#define MTR_FUSED_SEG_LANES 2048u      // samples in flight per workgroup the ring of row slots is sized for (1024 / 4096 measured worse)
 #endif
 
-// private per-segment histogram in LDS: planes [3][G*T]
+// the workgroup's ring of row histograms in LDS: planes [3][G*T]
 struct LdsHistSink {
     float *hist; uint32_t plane;       // plane = G * T
     uint32_t row;                      // (local pixel) * T, set per path
