@@ -306,6 +306,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     WfWorkspace &w = s->wf;
     if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= n_seg && w.planes) return MTR_OK;
     void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.q_shadow, &w.r_shadow, &w.occ, &w.counts, &w.rec, &w.rec_count };
+    w.n_slots = 0; w.P = 0; w.rec_cap = 0; w.rows = 0;          // sizes are valid only once every buffer below exists
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
@@ -562,7 +563,6 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
         if (c->freq_cap < fm.n_freq) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->d_freq) (void)hipFree(c->d_freq);
-    if (c->d_runs) (void)hipFree(c->d_runs);
             c->d_freq = nullptr; c->freq_cap = 0;
             HIP_TRY(c, hipMalloc((void **)&c->d_freq, (size_t)fm.n_freq * 4));
             c->freq_cap = fm.n_freq;

@@ -91,6 +91,7 @@ class DistributedRenderer:
         if partition not in ("spp", "rows"):
             raise ValueError("partition must be 'spp' or 'rows'")
         self.scene, self.partition, self.group, self.gather, self.bands = scene, partition, group, gather, int(bands)
+        self.last_path = None            # "single" | "pipelined" | "spp" | "rows": which code path the last render took
 
     def render(self, spp: int, seed: int = 0, sensor: int = 0):
         import torch
@@ -108,12 +109,19 @@ class DistributedRenderer:
         W, H = film.size()
         cw, ch = film.crop_size()
         if world == 1:
+            self.last_path = "single"
             integ.accumulate(scene, sens, passes, total_spp)
             return film.develop()
+        self.last_path = self.partition
+        # reject what the slab develop cannot do BEFORE any rendering (a phasor film has no time rows to scatter;
+        # an exhaustive film's "steady" image is a mean over channels of the gathered tensor)
+        if getattr(film, "frequencies_f32", None) is not None:
+            raise NotImplementedError("DistributedRenderer: phasor_hdr_film is single-GPU only")
         if self.partition == "spp":
             my_spp = shard_range(total_spp, world, rank)
             nb = self.bands
             if self.gather and nb > 1 and ch == H and cw == W and H % (nb * world) == 0:
+                self.last_path = "pipelined"
                 return self._render_pipelined(integ, sens, film, passes, total_spp, my_spp, nb, world)
             integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp)
         else:
@@ -129,10 +137,12 @@ class DistributedRenderer:
             lo, hi = shard_range(ch, world, rank)
             slab_t, slab_s = raw_t[lo:hi], raw_s[lo:hi]
         dev_t, dev_s = film.develop_slab(slab_t, slab_s)
+        exh = film.exhaustive_scan                # its "steady" is mean(transient, axis=-1) (transient_hdr_film.py:213-214)
         if not self.gather:
-            return TensorXf(dev_s), TensorXf(dev_t)
+            return TensorXf(dev_t.mean(dim=-1) if exh else dev_s), TensorXf(dev_t)
         if self.partition == "spp":
-            return (TensorXf(all_gather_rows(dev_s, H, self.group)), TensorXf(all_gather_rows(dev_t, H, self.group)))
+            full_t = all_gather_rows(dev_t, H, self.group)
+            return (TensorXf(full_t.mean(dim=-1) if exh else all_gather_rows(dev_s, H, self.group)), TensorXf(full_t))
         # rows: uneven slabs are padded to the largest before the gather
         per = (ch + world - 1) // world
 
@@ -151,7 +161,7 @@ class DistributedRenderer:
         if full_t.shape[0] < H:
             full_t = torch.cat([full_t, torch.zeros((H - full_t.shape[0],) + tuple(full_t.shape[1:]), dtype=full_t.dtype, device=full_t.device)])
             full_s = torch.cat([full_s, torch.zeros((H - full_s.shape[0],) + tuple(full_s.shape[1:]), dtype=full_s.dtype, device=full_s.device)])
-        return TensorXf(full_s), TensorXf(full_t)
+        return TensorXf(full_t.mean(dim=-1) if exh else full_s), TensorXf(full_t)
 
     def _render_pipelined(self, integ, sens, film, passes, total_spp, my_spp, nb, world):
         """bands of rows: render band b | reduce-scatter + develop + all-gather band b-1 on a side stream"""
@@ -164,7 +174,7 @@ class DistributedRenderer:
         raw_t = film.transient_storage.torch_tensor()
         raw_s = film.steady_accum()
         dev = raw_t.device
-        out_t = torch.empty((H, W, T, 3), dtype=torch.float32, device=dev)
+        out_t = torch.empty(tuple(film.raw_shape()[:-1]) + (3,), dtype=torch.float32, device=dev)
         out_s = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         rows_b = H // nb
         main = torch.cuda.current_stream(dev)
@@ -191,4 +201,6 @@ class DistributedRenderer:
                 out_t[r0:r1].copy_(got_t)
                 out_s[r0:r1].copy_(got_s)
         main.wait_stream(side)
+        if film.exhaustive_scan:                 # transient_hdr_film.py:213-214
+            return TensorXf(out_t.mean(dim=-1)), TensorXf(out_t)
         return TensorXf(out_s), TensorXf(out_t)

@@ -181,6 +181,12 @@ class TransientHDRFilm:
                                                C.c_void_p(steady.data_ptr())), "mtr_film_develop")
             if variant.is_monochromatic():
                 steady = steady[..., :1].contiguous()        # pixel_format 'luminance' (:141)
+        # the reference builds its steady hdrfilm WITH the crop window (:131-144), so steady.develop() is
+        # (crop_h, crop_w, C); only the transient block spans the full size (crop_size_xyt = size, :185-187).  The
+        # accumulator here is full-size with the window at the top-left corner (positions carry the crop offset).
+        cw, ch = self.crop_size_
+        if (cw, ch) != (W, H):
+            steady = steady[:ch, :cw].contiguous()
         return TensorXf(steady), transient_image
 
     def develop_transient_(self, raw: bool = False):

@@ -171,6 +171,7 @@ class Scene:
             raise ValueError("load_dict(): at least one sensor is required")
         self._data = {}
         self._handles = {}
+        self._nlos_fp = {}
 
     def sensors(self):
         return self.sensors_
@@ -219,8 +220,16 @@ class Scene:
         fd = sd.film
         ctx.check(ctx.lib.mtr_scene_set_film(h, C.byref(fd)), "mtr_scene_set_film")
         if sd.nlos is not None:
+            # TransientNLOSPath.prepare re-derives its tables on every render; here only when the description changed
+            # (laser moved by nlos.focus_emitter_*, integrator property, film size): mtr_scene_set_nlos reallocates
+            # four device tables and retraces the scanned points, which is not free per pass / per band
             d = sd.desc()
-            ctx.check(ctx.lib.mtr_scene_set_nlos(h, d.nlos), "mtr_scene_set_nlos")
+            n = sd.nlos
+            fp = (bytes(memoryview(n))[:C.sizeof(type(n)) - C.sizeof(C.c_void_p)], bytes(memoryview(sd.shapes)),
+                  int(fd.width), int(fd.height), int(fd.laser_scan_width), int(fd.laser_scan_height))
+            if self._nlos_fp.get(key) != fp:
+                ctx.check(ctx.lib.mtr_scene_set_nlos(h, d.nlos), "mtr_scene_set_nlos")
+                self._nlos_fp[key] = fp
         return h
 
     def __del__(self):

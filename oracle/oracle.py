@@ -124,6 +124,11 @@ def develop(film_desc, t4=None, s4=None):
         s3 = np.empty(s4.shape[:-1] + (3,), np.float32)
     lib().orc_develop(C.byref(film_desc), _fp(t4) if t4 is not None else None, _fp(t3) if t3 is not None else None,
                       _fp(s4) if s4 is not None else None, _fp(s3) if s3 is not None else None)
+    # the reference's steady hdrfilm carries the crop window (transient_hdr_film.py:131-144): steady.develop() is
+    # (crop_h, crop_w, 3); the accumulator is full-size with the window at its top-left corner
+    if s3 is not None and (film_desc.crop_width, film_desc.crop_height) != (film_desc.width, film_desc.height) \
+            and s3.shape[:2] == (film_desc.height, film_desc.width):
+        s3 = np.ascontiguousarray(s3[:film_desc.crop_height, :film_desc.crop_width])
     return t3, s3
 
 

@@ -124,3 +124,39 @@ def make_nlos_camera(res=16, bins=100, capture="single", spp=8, laser_fov=0.2, *
         "wall": {"type": "rectangle", "bsdf": white},
         "hidden": {"type": "rectangle", "to_world": T().translate([0.5, 0, 1]).rotate([0, 1, 0], 180).scale(0.5), "bsdf": white},
     })
+
+
+def make_nlos_z(tmp_path, sx=32, sy=32, bins=4096, bin_width=2.0 ** -11, start=1.85, capture="confocal", spp=64,
+                irradiance=1.0, **integ):
+    """BASELINE config 4's scene: examples/transient-nlos/nlos_Z.xml / tests/integration/test_nlos.py:1-78 — the reference's
+    Z.obj (6 triangles; committed as the data fixture tests/golden/nlos_Z_geometry.npz and written back to an .obj here, so
+    that it goes through the `obj` shape plugin) at z = 1, a 2 x 2 relay `rectangle` at the origin carrying a
+    nlos_capture_meter, projector + sensor origin at (-0.5, 0, 0.25), fov 0.2, laser + hidden-geometry sampling on,
+    account_first_and_last_bounces off, max_depth -1 / rr_depth 5."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    tris = np.load(os.path.join(ROOT, "tests", "golden", "nlos_Z_geometry.npz"))["tris"]
+    lines = [f"v {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}" for v in tris.reshape(-1, 3)]
+    lines += [f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}" for i in range(len(tris))]
+    obj = os.path.join(str(tmp_path), "Z.obj")
+    with open(obj, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
+    relay = mi.load_dict({
+        "type": "rectangle", "bsdf": white,
+        "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
+                        "sensor_origin": [-0.5, 0.0, 0.25],
+                        "film": {"type": "transient_hdr_film", "width": sx, "height": sy, "temporal_bins": bins,
+                                 "bin_width_opl": bin_width, "start_opl": start, "rfilter": {"type": "box"}}}})
+    laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
+                          "irradiance": {"type": "rgb", "value": [irradiance] * 3}, "fov": 0.2})
+    idict = {"type": "transient_nlos_path", "max_depth": -1, "rr_depth": 5, "nlos_laser_sampling": True,
+             "nlos_hidden_geometry_sampling": True, "account_first_and_last_bounces": False,
+             "capture_type": capture, "temporal_filter": "box"}
+    idict.update(integ)
+    scene = mi.load_dict({"type": "scene", "integrator": idict, "laser": laser, "relay_wall": relay,
+                          "Z": {"type": "obj", "filename": obj, "to_world": T().translate([0.0, 0.0, 1.0]), "bsdf": white}})
+    mitr.nlos.focus_emitter_at_relay_wall_pixel((sx / 2, sy / 2), relay, laser)
+    return scene

@@ -1,0 +1,246 @@
+"""BASELINE.json configs at their STATED sizes / geometry, on the GPU (task 1).
+
+  config 2: Cornell 512x512, 1024 bins, 1024 spp — the whole film is rendered once; three pixel strips (centre,
+            light, left margin) are compared with the CPU oracle (<= 1e-5, identical counters), the whole image
+            against the same render sharded into 8 row bands (counters == sum of shards), energy bound.
+  config 3: the same film (512x512x1024) through the 2-rank band-pipelined reduce-scatter / develop / all-gather
+            path (gloo: the box has one GPU) against the single-process film, samples sharded.
+  config 4: NLOS confocal on the reference's examples/transient-nlos/Z.obj geometry (fixture), T = 4096 bins of
+            2^-11, reduced pixels / samples — GPU vs oracle, and the same scene through the 2-rank DistributedRenderer.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import make_cornell, make_nlos_z, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COUNTERS = ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+def test_config2_full_size_strips_match_oracle(oracle):
+    import torch
+    W = H = 512
+    T, SPP = 1024, 1024
+    scene = make_cornell(width=W, height=H, bins=T)             # start_opl 3.5, bin width 6/1024: BASELINE config 2
+    integ = scene.integrator()
+    integ.collect_stats = True
+    sens = scene.sensors()[0]
+    film = sens.film()
+    steady, transient = integ.render(scene, seed=0, spp=SPP)
+    torch.cuda.synchronize()
+    t_full = transient.torch()
+    s_full = steady.torch()
+    whole = dict(integ.total_counters)
+    assert tuple(t_full.shape) == (H, W, T, 3) and whole["paths"] == W * H * SPP
+    # energy: the 3.5 .. 9.5 window holds a subset of every pixel's contributions
+    tsum = t_full.sum(dim=2)
+    assert bool((tsum <= s_full * (1 + 1e-4) + 1e-6).all())
+    assert float(tsum.sum() / s_full.sum()) > 0.5
+
+    # strips of 64 pixels x all 1024 samples against the oracle (same lanes: lane = pixel * spp + s)
+    strips = {"centre": (256, 224), "light": (30, 224), "left margin": (256, 0)}
+    sd = scene.data()
+    for name, (row, c0) in strips.items():
+        p0 = row * W + c0
+        params = integ.render_params(film, 0, SPP, 0, SPP, p0, p0 + 64)
+        t4, s4, cnt = oracle.render(sd, params, use_bvh=True)
+        fd = type(sd.film).from_buffer_copy(sd.film)            # develop only the strip: a 64 x 1 film of the same rows
+        fd.width, fd.height, fd.crop_width, fd.crop_height = 64, 1, 64, 1
+        t_ref, s_ref = oracle.develop(fd, np.ascontiguousarray(t4[row, c0:c0 + 64]).reshape(1, 64, T, 4),
+                                      np.ascontiguousarray(s4[row, c0:c0 + 64]).reshape(1, 64, 4))
+        del t4, s4
+        got_t = t_full[row, c0:c0 + 64].cpu().numpy()
+        got_s = s_full[row, c0:c0 + 64].cpu().numpy()
+        assert np.linalg.norm(t_ref) > 0, name
+        assert rel_l2(got_t, t_ref[0]) <= TOL, name
+        assert rel_l2(got_s, s_ref[0]) <= TOL, name
+        assert np.array_equal(got_t != 0, t_ref[0] != 0), name
+        # the strip alone on the GPU: identical counters
+        passes = integ.prepare(scene, sens, 0, SPP, [])
+        integ.accumulate(scene, sens, passes, SPP, pixel_range=(p0, p0 + 64))
+        for k in COUNTERS:
+            assert integ.total_counters[k] == cnt[k], (name, k)
+    keep_t = t_full.clone()
+    keep_s = s_full.clone()
+    del t_full, s_full, transient, steady
+
+    # the same render as 8 row bands: counters add up, the film is the same up to f32 summation order
+    passes = integ.prepare(scene, sens, 0, SPP, [])
+    rows = H // 8
+    for b in range(8):
+        integ.accumulate(scene, sens, passes, SPP, pixel_range=(b * rows * W, (b + 1) * rows * W))
+    for k in COUNTERS:
+        assert integ.total_counters[k] == whole[k], k
+    s2, t2 = film.develop()
+    torch.cuda.synchronize()
+    d = (t2.torch() - keep_t).double().norm() / keep_t.double().norm()
+    assert float(d) <= 1e-6
+    assert float((s2.torch() - keep_s).double().norm() / keep_s.double().norm()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+def _c3_worker(rank, world, port, tmp, backend):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_cornell
+        from mitransient_amd import distributed as md
+        spp = 8
+        scene = make_cornell(width=512, height=512, bins=1024)
+        r = md.DistributedRenderer(scene, partition="spp", gather=True, bands=8)
+        steady, transient = r.render(spp=spp, seed=0)
+        torch.cuda.synchronize()
+        got_t, got_s = transient.torch().clone(), steady.torch().clone()
+        assert r.last_path == "pipelined" and tuple(got_t.shape) == (512, 512, 1024, 3)
+        # single-process film of the same lanes
+        s_ref, t_ref = scene.integrator().render(scene, seed=0, spp=spp)
+        torch.cuda.synchronize()
+        et = float((got_t - t_ref.torch()).double().norm() / t_ref.torch().double().norm())
+        es = float((got_s - s_ref.torch()).double().norm() / s_ref.torch().double().norm())
+        same_cells = bool(((got_t != 0) == (t_ref.torch() != 0)).all())
+        with open(os.path.join(tmp, f"ok{rank}"), "w") as fh:
+            fh.write(f"{et} {es} {int(same_cells)}")
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_c3(tmp_path, backend):
+    import torch.multiprocessing as mp
+    mp.spawn(_c3_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
+    for r in range(2):
+        et, es, same = (tmp_path / f"ok{r}").read_text().split()
+        assert float(et) <= 1e-6 and float(es) <= 1e-6 and int(same) == 1, (r, et, es, same)
+
+
+def test_config3_film_size_two_rank_pipelined(tmp_path):
+    """config 3's film (512 x 512 x 1024 bins = 4 GiB raw per rank) through the band-pipelined multi-GPU path with 2
+    ranks sharing the box's GPU (gloo); every rank ends with the full developed tensor == the single-process render."""
+    _run_c3(tmp_path, "gloo")
+
+
+def test_config3_film_size_two_rank_rccl(tmp_path):
+    """the same over RCCL, one device per rank: runs wherever >= 2 GPUs are visible (the driver's 8-GPU node)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL: one device per rank)")
+    _run_c3(tmp_path, "nccl")
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+C4 = dict(sx=32, sy=32, bins=4096, bin_width=2.0 ** -11, start=1.85, capture="confocal", spp=96)
+
+
+def test_config4_z_obj_matches_oracle(tmp_path, oracle):
+    import torch
+    scene = make_nlos_z(tmp_path, **C4)
+    integ = scene.integrator()
+    integ.collect_stats = True
+    assert integ.max_depth == 0xFFFFFFFF and integ.rr_depth == 5          # tests/integration/test_nlos.py:1-10
+    sd = scene.data()
+    assert sd.tri_verts.shape[0] == 2 + 6                                  # relay wall + Z.obj
+    s, t = integ.render(scene, seed=0, spp=C4["spp"])
+    torch.cuda.synchronize()
+    t_gpu, s_gpu = np.array(t), np.array(s)
+    p = integ.render_params(scene.sensors()[0].film(), 0, C4["spp"])
+    t4, s4, cnt = oracle.render(sd, p, use_bvh=True)
+    t_ref, s_ref = oracle.develop(sd.film, t4, s4)
+    assert t_gpu.shape == (32, 32, 4096, 3) and np.count_nonzero(t_ref) > 10000
+    assert rel_l2(t_gpu, t_ref) <= TOL
+    assert rel_l2(s_gpu, s_ref) <= TOL
+    assert np.array_equal(t_gpu != 0, t_ref != 0)
+    for k in COUNTERS:
+        assert integ.last_counters[k] == cnt[k], k
+    # three-bounce geometry: nothing arrives before 2 x (distance wall -> Z plane = 1 - 0.004)
+    first_bin = int(np.nonzero(t_gpu.sum(axis=(0, 1, 3)))[0][0])
+    assert 1.85 + (first_bin + 1) * 2.0 ** -11 >= 2 * 0.996
+
+
+def _c4_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import pathlib
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_nlos_z
+        from mitransient_amd import distributed as md
+        wd = pathlib.Path(tmp) / f"rank{rank}"
+        wd.mkdir()
+        scene = make_nlos_z(wd, **C4)
+        r = md.DistributedRenderer(scene, partition="spp", gather=True, bands=8)
+        steady, transient = r.render(spp=C4["spp"], seed=0)
+        torch.cuda.synchronize()
+        assert r.last_path == "pipelined"
+        np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
+        np.save(os.path.join(tmp, f"s{rank}.npy"), np.array(steady))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_z_obj_two_rank(tmp_path, oracle):
+    import torch
+    import torch.multiprocessing as mp
+    scene = make_nlos_z(tmp_path, **C4)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, C4["spp"])
+    t4, s4, _ = oracle.render(sd, p, use_bvh=True)
+    t_ref, s_ref = oracle.develop(sd.film, t4, s4)
+    mp.spawn(_c4_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        assert t.shape == t_ref.shape
+        assert rel_l2(t, t_ref) <= TOL and rel_l2(s, s_ref) <= TOL
+
+
+def test_config4_full_row_length_properties(tmp_path):
+    """256 x 256 x 4096 bins (the 4 GiB film of config 4) on one GPU at 16 spp: the 48 KB-row instantiation of the
+    fused kernel over the whole film — energy identity with a window covering every path and self-consistency of two
+    sample shards."""
+    import torch
+    scene = make_nlos_z(tmp_path, sx=256, sy=256, bins=4096, bin_width=8.0 / 4096, start=0.0, capture="confocal", spp=16,
+                        max_depth=6)
+    integ = scene.integrator()
+    integ.collect_stats = True
+    s, t = integ.render(scene, seed=0, spp=16)
+    torch.cuda.synchronize()
+    tt, ss = t.torch(), s.torch()
+    assert tuple(tt.shape) == (256, 256, 4096, 3) and integ.last_counters["paths"] == 256 * 256 * 16
+    assert float((tt.sum(dim=2) - ss).double().norm() / ss.double().norm()) <= 1e-5
+    keep = tt.clone()
+    del tt, t
+    sens = scene.sensors()[0]
+    passes = integ.prepare(scene, sens, 0, 16, [])
+    integ.accumulate(scene, sens, passes, 16, spp_range=(0, 5))
+    integ.accumulate(scene, sens, passes, 16, spp_range=(5, 16))
+    s2, t2 = sens.film().develop()
+    assert float((t2.torch() - keep).double().norm() / keep.double().norm()) <= 1e-6

@@ -102,3 +102,41 @@ def test_mono_transient_film(mono, oracle):
     t3, s3 = oracle.develop(sd.film, t4, s4)
     assert np.array_equal(t3[..., 0], t3[..., 1]) and np.array_equal(t3[..., 0], t3[..., 2])      # channels never mix
     assert rel_l2(transient[..., 0], t3[..., 0]) <= TOL and rel_l2(steady[..., 0], s3[..., 0]) <= TOL
+
+
+def test_variant1_scratch_survives_a_phasor_splat(mono, oracle):
+    """a phasor splat that grows the ctx's frequency buffer once also freed the variant-1 run table without
+    resetting it — the next sorted-by-pixel splat then wrote through a dangling pointer.  Sequence: variant 1 on a
+    transient film, a phasor splat with more frequencies than ever before, variant 1 again; both must match the oracle."""
+    import torch
+    import mitransient_amd as mitr
+    from mitransient_amd.scene import Properties
+    rng = np.random.default_rng(5)
+
+    def sorted_splat():
+        film = mitr.TransientHDRFilm(Properties("transient_hdr_film", {"width": 16, "height": 8, "temporal_bins": 128,
+                                                                        "bin_width_opl": 0.05, "start_opl": 1.0,
+                                                                        "rfilter": {"type": "box"}}))
+        film.prepare([])
+        n = 30000
+        pix = np.sort(rng.integers(0, 16 * 8, n)).astype(np.int64)
+        pos = np.stack([(pix % 16) + 0.5, (pix // 16) + 0.5], axis=1).astype(np.float32)
+        dist = rng.uniform(0.9, 7.6, n).astype(np.float32)
+        spec = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        film.add_transient_data(pos, dist, None, spec, 1.0, None, variant=1)
+        torch.cuda.synchronize()
+        raw = np.array(film.develop(raw=True)[1])
+        ref = np.zeros_like(raw)
+        oracle.splat_add(film.desc(), pix, dist, spec[:, 0], spec[:, 1], spec[:, 2], ref)
+        assert np.count_nonzero(ref) > 1000 and rel_l2(raw, ref) <= TOL
+
+    sorted_splat()
+    for sigma in (1.0, 3.0):                     # the second film has more frequencies: the ctx buffer grows again
+        ph = mitr.PhasorHDRFilm(Properties("phasor_hdr_film", {"width": 4, "height": 4, "wl_mean": 4.0, "wl_sigma": sigma,
+                                                                "temporal_bins": 512, "bin_width_opl": 0.1, "start_opl": 0.0,
+                                                                "rfilter": {"type": "box"}}))
+        ph.prepare([])
+        ph.add_transient_data(np.full((64, 2), 1.5, np.float32), rng.uniform(0, 9, 64).astype(np.float32), None,
+                              np.ones(64, np.float32), 1.0, None)
+        torch.cuda.synchronize()
+        sorted_splat()
