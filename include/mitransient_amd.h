@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 6
+#define MTR_ABI_VERSION 7
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -112,8 +112,14 @@ enum { MTR_NLOS_LASER_SAMPLING = 1u,          /* nlos_laser_sampling            
 
 typedef struct mtr_shape {          /* one scene shape = a contiguous triangle range */
     uint32_t first_tri, n_tris;
-    uint32_t is_rectangle;          /* analytic `rectangle` (sample_position by to_world) vs triangle mesh */
-    float    center[3], du[3], dv[3];   /* rectangle only: to_world*(0,0,0), half edges */
+    uint32_t is_rectangle;          /* analytic `rectangle`: the shape is ONE primitive — mitsuba's Rectangle::ray_intersect
+                                       (ray to object space, t = -o.z/d.z, |x|,|y| <= 1), one shading frame, sample_position by
+                                       to_world.  Its two triangles (0,1,2) (0,2,3) of the corners (-1,-1) (1,-1) (1,1) (-1,1)
+                                       only CARRY the material / emitter / index of the primitive (hits report the first one). */
+    float    center[3], du[3], dv[3];   /* rectangle only: to_world*(0,0,0), half edges to_world*(1,0,0) - center, to_world*(0,1,0) - center */
+    uint32_t has_to_world;          /* meshes: to_world below is the shape's object -> world transform (cube: of [-1,1]^3; obj / ply:
+                                       of the file's coordinates).  Only an acceleration hint (oriented bounds); 0 = unknown */
+    float    to_world[12];          /* row-major 3 x 4 affine */
 } mtr_shape;
 
 #define MTR_NLOS_NO_RELAY 0xffffffffu
@@ -147,6 +153,16 @@ typedef struct mtr_scene_desc {
     mtr_camera      camera;         /* with nlos != NULL: used only when nlos->relay_shape == MTR_NLOS_NO_RELAY */
     mtr_film_desc   film;
     const mtr_nlos_desc *nlos;      /* NULL: `perspective` sensor + `transient_path`; else the NLOS tier */
+    /* Shape table (host; optional): shapes tile the triangle array in order.  Needed for analytic rectangles
+     * (mtr_shape.is_rectangle); without it every triangle is a plain mesh triangle.  With nlos != NULL it must be the
+     * same table as nlos->shapes. */
+    uint32_t        n_shapes;
+    const mtr_shape *shapes;
+    /* Per-corner texture coordinates (host, n_tris*6 floats: uv0 uv1 uv2; optional).  They only fix the tangent of the
+     * shading frame, as in mitsuba's Mesh::compute_surface_interaction: dp_du from the UV parameterisation when it is
+     * not degenerate, coordinate_system(n) otherwise (and for every triangle when this is NULL); then
+     * SurfaceInteraction::initialize_sh_frame: s = normalize(dp_du - n * dot(n, dp_du)), t = n x s. */
+    const float    *tri_uv;
 } mtr_scene_desc;
 
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 6
+MTR_ABI_VERSION = 7
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_MAT_TWOSIDED = 1
@@ -59,7 +59,7 @@ MTR_NLOS_HG_INCLUDES_WALL, MTR_NLOS_ACCOUNT_FIRST_LAST, MTR_NLOS_DISCARD_DIRECT 
 
 class mtr_shape(C.Structure):
     _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("is_rectangle", C.c_uint32),
-                ("center", _f3), ("du", _f3), ("dv", _f3)]
+                ("center", _f3), ("du", _f3), ("dv", _f3), ("has_to_world", C.c_uint32), ("to_world", C.c_float * 12)]
 
 
 class mtr_nlos_desc(C.Structure):
@@ -80,7 +80,10 @@ class mtr_scene_desc(C.Structure):
                 ("emitters", C.POINTER(mtr_emitter)),
                 ("camera", mtr_camera),
                 ("film", mtr_film_desc),
-                ("nlos", C.POINTER(mtr_nlos_desc))]
+                ("nlos", C.POINTER(mtr_nlos_desc)),
+                ("n_shapes", C.c_uint32),
+                ("shapes", C.POINTER(mtr_shape)),
+                ("tri_uv", C.POINTER(C.c_float))]
 
 
 class mtr_render_params(C.Structure):

@@ -1,6 +1,11 @@
 // mtr_bvh.cpp — binned-SAH BVH2 over triangles, flattened to "node packets": one record per
 // inner node holding BOTH children's (padded) boxes and references, so a traversal step is one
 // 64-byte fetch (4 x ds_read_b128 from LDS, or one cache line from L2) and two slab tests.
+//
+// Build primitives ("items"): a mesh triangle; an analytic RECTANGLE (its two carrier triangles, always alone in its
+// leaf); an OBJECT — a small mesh shape with a known object -> world transform, kept together in one subtree whose
+// splits are chosen in the shape's OBJECT space (where the faces of a rotated cube are flat: coplanar triangles end up in
+// the same leaf) and which the 8-wide collapse turns into one object node with object-space boxes (mtr_core.h, WNodeT).
 #include "mtr_bvh.h"
 
 #include <algorithm>
@@ -24,31 +29,95 @@ struct Box {
     }
 };
 
-struct Tmp { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+enum : uint8_t { kItemTri = 0, kItemQuad = 1, kItemObject = 2 };
+struct Item { uint32_t first_tri, n_tris; uint8_t type; int32_t object; };
+
+// world box of a triangle / its image under a 3 x 4 affine map (f64, then outward-rounded to f32 by the caller's padding)
+Box tri_box(const float *v, const float *xf)
+{
+    Box b; b.reset();
+    for (int k = 0; k < 3; ++k) {
+        const float *p = v + 3 * k;
+        if (!xf) { b.grow(p); continue; }
+        float q[3];
+        for (int r = 0; r < 3; ++r)
+            q[r] = (float)((double)xf[4 * r] * p[0] + (double)xf[4 * r + 1] * p[1] + (double)xf[4 * r + 2] * p[2] + (double)xf[4 * r + 3]);
+        b.grow(q);
+    }
+    return b;
+}
+
+struct Tmp { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; bool quad = false; int32_t object = -1; };
+
+struct Shared {                       // what every (sub-)builder appends to
+    const float *verts = nullptr;
+    std::vector<Tmp> tmp;
+    std::vector<uint32_t> leaf_tris;  // Tmp leaves: triangles [first, first + count) of this array
+};
 
 struct Builder {
-    const float *verts;
-    std::vector<Box> tbox;
-    std::vector<float> cent;       // 3 per triangle
+    Shared &S;
+    std::vector<Item> items;
+    std::vector<Box> sbox;            // boxes the SPLITS are chosen on (object space inside an object, world otherwise)
+    std::vector<Box> wbox;            // world boxes (what the nodes store)
+    std::vector<float> cent;          // 3 per item, of sbox
     std::vector<uint32_t> order;
-    std::vector<Tmp> tmp;
+    const BvhPrims *prims = nullptr;
 
     static constexpr int kBins = 16;
     uint32_t kLeafTarget = 2, kLeafMax = 4;
 
+    explicit Builder(Shared &s) : S(s) {}
+
+    void add_item(const Item &it, const float *xf)
+    {
+        Box sb, wb; sb.reset(); wb.reset();
+        for (uint32_t t = 0; t < it.n_tris; ++t) {
+            const float *v = S.verts + 9 * (size_t)(it.first_tri + t);
+            wb.grow(tri_box(v, nullptr));
+            sb.grow(tri_box(v, xf));
+        }
+        items.push_back(it); sbox.push_back(sb); wbox.push_back(wb);
+        for (int k = 0; k < 3; ++k) cent.push_back(0.5f * (sb.lo[k] + sb.hi[k]));
+        order.push_back((uint32_t)items.size() - 1u);
+    }
+
+    int make_leaf(uint32_t first, uint32_t count)
+    {
+        Tmp t; t.box.reset(); t.first = (uint32_t)S.leaf_tris.size();
+        for (uint32_t i = first; i < first + count; ++i) {
+            const Item &it = items[order[i]];
+            t.box.grow(wbox[order[i]]);
+            t.quad = it.type == kItemQuad;
+            for (uint32_t k = 0; k < it.n_tris; ++k) S.leaf_tris.push_back(it.first_tri + k);
+        }
+        t.count = (uint32_t)S.leaf_tris.size() - t.first;
+        S.tmp.push_back(t);
+        return (int)S.tmp.size() - 1;
+    }
+
+    // an object: its own sub-tree, splits chosen on object-space boxes
+    int build_object(const Item &it)
+    {
+        const float *xf = prims->object_xf + 12 * (size_t)it.object;
+        Builder B(S);
+        B.kLeafTarget = kLeafTarget; B.kLeafMax = 2;           // object-space leaves: at most one coplanar pair
+        for (uint32_t t = 0; t < it.n_tris; ++t) B.add_item(Item{ it.first_tri + t, 1u, kItemTri, -1 }, xf);
+        const int root = B.build(0, it.n_tris);
+        S.tmp[root].object = it.object;
+        return root;
+    }
+
     int build(uint32_t first, uint32_t count)
     {
-        int idx = (int)tmp.size();
-        tmp.emplace_back();
-        Box b; b.reset();
-        Box cb; cb.reset();
-        for (uint32_t i = first; i < first + count; ++i) {
-            b.grow(tbox[order[i]]);
-            cb.grow(&cent[3 * (size_t)order[i]]);
-        }
-        tmp[idx].box = b; tmp[idx].first = first; tmp[idx].count = count;
-        if (count <= kLeafTarget) return idx;
+        bool special = false;
+        uint32_t n_tris = 0;
+        for (uint32_t i = first; i < first + count; ++i) { special |= items[order[i]].type != kItemTri; n_tris += items[order[i]].n_tris; }
+        if (count == 1 && items[order[first]].type == kItemObject) return build_object(items[order[first]]);
+        if (count == 1 || (!special && count <= kLeafTarget)) return make_leaf(first, count);
 
+        Box b, cb; b.reset(); cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) { b.grow(sbox[order[i]]); cb.grow(&cent[3 * (size_t)order[i]]); }
         // binned SAH over the three axes
         float best_cost = FLT_MAX; int best_axis = -1, best_split = -1;
         for (int ax = 0; ax < 3; ++ax) {
@@ -60,7 +129,7 @@ struct Builder {
             for (uint32_t i = first; i < first + count; ++i) {
                 uint32_t t = order[i];
                 int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + ax] - cb.lo[ax]) * scale)));
-                bins[k].grow(tbox[t]); cnt[k]++;
+                bins[k].grow(sbox[t]); cnt[k] += items[t].n_tris;
             }
             float right_area[kBins]; uint32_t right_cnt[kBins];
             Box acc; acc.reset(); uint32_t c = 0;
@@ -75,8 +144,8 @@ struct Builder {
         }
         uint32_t mid = first;
         if (best_axis >= 0) {
-            float leaf_cost = b.area() * (float)count;
-            if (count <= kLeafMax && best_cost >= leaf_cost) return idx;          // a leaf is cheaper
+            float leaf_cost = b.area() * (float)n_tris;
+            if (!special && n_tris <= kLeafMax && best_cost >= leaf_cost) return make_leaf(first, count);   // a leaf is cheaper
             float ext = cb.hi[best_axis] - cb.lo[best_axis];
             float scale = (float)kBins / ext;
             auto it = std::stable_partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
@@ -86,21 +155,22 @@ struct Builder {
             mid = (uint32_t)(it - order.begin());
         }
         if (mid == first || mid == first + count) {
-            if (count <= kLeafMax) return idx;
+            if (!special && n_tris <= kLeafMax) return make_leaf(first, count);
             mid = first + count / 2;                                              // degenerate: split by index
         }
-        int l = build(first, mid - first);
-        int r = build(mid, first + count - mid);
-        tmp[idx].left = l; tmp[idx].right = r; tmp[idx].count = 0;
-        return idx;
+        const int l = build(first, mid - first);
+        const int r = build(mid, first + count - mid);
+        Tmp t; t.box = S.tmp[l].box; t.box.grow(S.tmp[r].box); t.left = l; t.right = r;
+        S.tmp.push_back(t);
+        return (int)S.tmp.size() - 1;
     }
 };
 
-void padded(const Box &b, float *lo, float *hi)
+void padded(const Box &b, float *lo, float *hi, float rel = 2e-5f)
 {
     float m = 0.0f;
     for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
-    float pad = 2e-5f * (1.0f + m);        // culling must stay conservative under f32 rounding
+    float pad = rel * (1.0f + m);        // culling must stay conservative under f32 rounding
     for (int k = 0; k < 3; ++k) { lo[k] = b.lo[k] - pad; hi[k] = b.hi[k] + pad; }
 }
 void set_child(Node &n, int c, const Box &b, int32_t ref)
@@ -117,55 +187,61 @@ void set_empty_child(Node &n, int c, int32_t ref)
 
 } // namespace
 
-void build_bvh(const float *verts, uint32_t n, BvhBuild &out)
+void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &out)
 {
-    out.nodes.clear(); out.order.clear(); out.max_depth = 0; out.n_leaves = 0;
+    out.nodes.clear(); out.order.clear(); out.max_depth = 0; out.n_leaves = 0; out.packet_object.clear();
     if (n == 0) return;
-    Builder B; B.verts = verts;
+    Shared S; S.verts = verts;
+    Builder B(S); B.prims = prims;
     if (const char *e = getenv("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
-    B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        Box b; b.reset();
-        for (int k = 0; k < 3; ++k) b.grow(verts + 9 * (size_t)i + 3 * k);
-        B.tbox[i] = b;
-        for (int k = 0; k < 3; ++k) B.cent[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
-        B.order[i] = i;
+    S.tmp.reserve(2 * (size_t)n);
+    for (uint32_t i = 0; i < n;) {
+        const uint8_t kind = prims && prims->kind ? prims->kind[i] : 0;
+        const int32_t obj = prims && prims->object ? prims->object[i] : -1;
+        if (kind == 1 && i + 1 < n) { B.add_item(Item{ i, 2u, kItemQuad, -1 }, nullptr); i += 2; continue; }
+        if (obj >= 0) {
+            uint32_t j = i;
+            while (j < n && prims->object[j] == obj) ++j;
+            B.add_item(Item{ i, j - i, kItemObject, obj }, nullptr);
+            i = j; continue;
+        }
+        B.add_item(Item{ i, 1u, kItemTri, -1 }, nullptr);
+        ++i;
     }
-    B.tmp.reserve(2 * (size_t)n);
-    int root = B.build(0, n);
+    const int root = B.build(0, (uint32_t)B.items.size());
 
     // flatten: one packet per inner Tmp node
     // leaves are laid out in slot space: each starts on an even slot, odd leaves get a pad slot
-    out.order.clear();
     auto leaf_ref = [&](const Tmp &t) -> int32_t {
         const uint32_t first = (uint32_t)out.order.size();
-        for (uint32_t k = 0; k < t.count; ++k) out.order.push_back(B.order[t.first + k]);
+        for (uint32_t k = 0; k < t.count; ++k) out.order.push_back(S.leaf_tris[t.first + k]);
         if (t.count & 1u) out.order.push_back(kPadSlot);
         uint32_t code = (first << 2) | (t.count - 1u);
+        if (t.quad) code |= kLeafQuadBit;
         return (int32_t)~code;
     };
-    struct Item { int tmp; int packet; uint32_t depth; };
-    std::vector<Item> stack;
-    const Tmp &R = B.tmp[root];
+    struct Entry { int tmp; int packet; uint32_t depth; };
+    std::vector<Entry> stack;
+    const Tmp &R = S.tmp[root];
     if (R.left < 0) {                        // the whole scene is one leaf
         Node nd{};
         const int32_t ref = leaf_ref(R);
         set_child(nd, 0, R.box, ref); set_empty_child(nd, 1, ref);
-        out.nodes.push_back(nd); out.max_depth = 1; out.n_leaves = 1;
+        out.nodes.push_back(nd); out.packet_object.push_back(-1); out.max_depth = 1; out.n_leaves = 1;
     } else {
-        out.nodes.emplace_back();
+        out.nodes.emplace_back(); out.packet_object.push_back(R.object);
         stack.push_back({ root, 0, 1 });
         while (!stack.empty()) {
-            Item it = stack.back(); stack.pop_back();
+            Entry it = stack.back(); stack.pop_back();
             out.max_depth = std::max(out.max_depth, it.depth);
-            const Tmp &t = B.tmp[it.tmp];
-            const Tmp &L = B.tmp[t.left], &Rr = B.tmp[t.right];
+            const Tmp &t = S.tmp[it.tmp];
+            const Tmp &L = S.tmp[t.left], &Rr = S.tmp[t.right];
             Node nd{};
             int32_t c0, c1;
             if (L.left < 0) { c0 = leaf_ref(L); out.n_leaves++; }
-            else { c0 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.left, c0, it.depth + 1 }); }
+            else { c0 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); out.packet_object.push_back(L.object); stack.push_back({ t.left, c0, it.depth + 1 }); }
             if (Rr.left < 0) { c1 = leaf_ref(Rr); out.n_leaves++; }
-            else { c1 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); stack.push_back({ t.right, c1, it.depth + 1 }); }
+            else { c1 = (int32_t)out.nodes.size(); out.nodes.emplace_back(); out.packet_object.push_back(Rr.object); stack.push_back({ t.right, c1, it.depth + 1 }); }
             set_child(nd, 0, L.box, c0); set_child(nd, 1, Rr.box, c1);
             out.nodes[it.packet] = nd;
         }
@@ -192,32 +268,66 @@ float half_area(const WChild &w)
     return dx * dy + dy * dz + dz * dx;
 }
 
+bool is_quad_ref(int32_t ref) { return ref < 0 && ((~(uint32_t)ref) & kLeafQuadBit) != 0u; }
+
+// every leaf below a BVH2 packet
+void subtree_leaves(const BvhBuild &bvh, int32_t packet, std::vector<int32_t> &out)
+{
+    std::vector<WChild> ch;
+    packet_children(bvh.nodes[packet], ch);
+    for (const WChild &w : ch) { if (w.ref < 0) out.push_back(w.ref); else subtree_leaves(bvh, w.ref, out); }
+}
+
 template <uint32_t W>
-uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNodeT<W>> &wide, uint32_t level, uint32_t &levels, size_t width)
+uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts, int32_t packet, std::vector<WNodeT<W>> &wide,
+                  uint32_t level, uint32_t &levels, size_t width)
 {
     levels = std::max(levels, level);
     const uint32_t me = (uint32_t)wide.size();
     wide.emplace_back();
     std::vector<WChild> ch;
-    packet_children(bvh.nodes[packet], ch);
-    for (;;) {
-        int best = -1; float best_a = -1.0f;
-        for (size_t i = 0; i < ch.size(); ++i)
-            if (ch[i].ref >= 0 && half_area(ch[i]) > best_a) { best = (int)i; best_a = half_area(ch[i]); }
-        if (best < 0) break;
-        std::vector<WChild> sub;
-        packet_children(bvh.nodes[ch[best].ref], sub);
-        if (ch.size() - 1 + sub.size() > width) break;
-        ch.erase(ch.begin() + best);
-        ch.insert(ch.end(), sub.begin(), sub.end());
+    // an OBJECT subtree with few leaves becomes one node whose boxes live in the object's own space (8-wide tree only)
+    const float *xf = nullptr;
+    if (W == 8 && prims && prims->object_xf && verts && !getenv("MTR_NO_OBJECT_NODES")) {
+        const int32_t obj = bvh.packet_object[packet];
+        std::vector<int32_t> leaves;
+        if (obj >= 0) subtree_leaves(bvh, packet, leaves);
+        if (obj >= 0 && leaves.size() <= width) {
+            xf = prims->object_xf + 12 * (size_t)obj;
+            for (int32_t ref : leaves) {
+                const uint32_t code = ~(uint32_t)ref, first = code >> 2, cnt = (code & 3u) + 1u;
+                Box b; b.reset();
+                for (uint32_t k = 0; k < cnt; ++k) b.grow(tri_box(verts + 9 * (size_t)bvh.order[first + k], xf));
+                WChild w; w.ref = ref;
+                padded(b, w.lo, w.hi, 1e-4f);          // + the rounding of the ray's own transform in the kernel
+                ch.push_back(w);
+            }
+        }
     }
-    // walk order: by centroid along the axis on which the centroids spread most
+    if (!xf) {
+        packet_children(bvh.nodes[packet], ch);
+        for (;;) {
+            int best = -1; float best_a = -1.0f;
+            for (size_t i = 0; i < ch.size(); ++i)
+                if (ch[i].ref >= 0 && half_area(ch[i]) > best_a) { best = (int)i; best_a = half_area(ch[i]); }
+            if (best < 0) break;
+            std::vector<WChild> sub;
+            packet_children(bvh.nodes[ch[best].ref], sub);
+            if (ch.size() - 1 + sub.size() > width) break;
+            ch.erase(ch.begin() + best);
+            ch.insert(ch.end(), sub.begin(), sub.end());
+        }
+    }
+    // rectangles first (8-wide tree: the walk always visits them first, wide_advance), the others in walk order: by centroid
+    // along the axis on which their centroids spread most
+    size_t nq = 0;
+    if (W == 8) nq = (size_t)(std::stable_partition(ch.begin(), ch.end(), [](const WChild &w) { return is_quad_ref(w.ref); }) - ch.begin());
     float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (const WChild &w : ch)
-        for (int k = 0; k < 3; ++k) { const float c = 0.5f * (w.lo[k] + w.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
+    for (size_t i = nq; i < ch.size(); ++i)
+        for (int k = 0; k < 3; ++k) { const float c = 0.5f * (ch[i].lo[k] + ch[i].hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
     int axis = 0;
     for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-    std::stable_sort(ch.begin(), ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
+    std::stable_sort(ch.begin() + nq, ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
 
     WNodeT<W> nd{};
     float *f = &nd.box[0].x;
@@ -229,24 +339,24 @@ uint32_t wide_rec(const BvhBuild &bvh, int32_t packet, std::vector<WNodeT<W>> &w
         }
         nd.ref[c] = 0;
     }
-    nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.leaves = 0u;
-    for (size_t c = 0; c < ch.size(); ++c) if (ch[c].ref < 0) nd.leaves |= 1u << c;
+    nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.n_quads = (uint32_t)nq; nd.flags = xf ? 1u : 0u;
+    for (int k = 0; k < 12; ++k) nd.xf[k] = xf ? xf[k] : 0.0f;
     for (size_t c = 0; c < ch.size(); ++c)
-        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, ch[c].ref, wide, level + 1, levels, width) : ch[c].ref;
+        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, prims, verts, ch[c].ref, wide, level + 1, levels, width) : ch[c].ref;
     wide[me] = nd;
     return me;
 }
 
 } // namespace
 
-uint32_t build_wide(const BvhBuild &bvh, std::vector<WNode> &wide)
+uint32_t build_wide(const BvhBuild &bvh, const BvhPrims *prims, const float *verts, std::vector<WNode> &wide)
 {
     wide.clear();
     if (bvh.nodes.empty()) return 0;
     size_t width = kWide;
     if (const char *e = getenv("MTR_WIDE_WIDTH")) { int w = atoi(e); width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
     uint32_t levels = 0;
-    wide_rec<kWide>(bvh, 0, wide, 1, levels, width);
+    wide_rec<kWide>(bvh, prims, verts, 0, wide, 1, levels, width);
     return levels;
 }
 uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
@@ -255,7 +365,7 @@ uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
     if (bvh.nodes.empty()) return 0;
     uint32_t levels = 0;
     std::vector<WNodeT<4>> full;
-    wide_rec<4>(bvh, 0, full, 1, levels, 4);
+    wide_rec<4>(bvh, nullptr, nullptr, 0, full, 1, levels, 4);
     wide.resize(full.size());
     for (size_t i = 0; i < full.size(); ++i) {
         const WNodeT<4> &w = full[i];

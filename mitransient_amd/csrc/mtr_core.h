@@ -203,13 +203,21 @@ MTR_HD void node_set_child(Node &n, int c, const float *lo, const float *hi, int
 // A BVH2 over a few large quads (the walls of a room) cannot separate them — every ray visits all their ancestors;
 // one 8-wide step replaces up to seven of those dependent 2-wide steps and, more important on a 64-lane wave, brings the
 // per-ray step count of different lanes close together (Cornell box: wave-steps at 19 % lane utilisation with BVH2).
+// Rectangle children come first (indices 0 .. n_quads-1) and are always visited first: their test is cheap and usually
+// yields the final hit of a ray inside a room, and every lane of a wave then runs its rectangle tests at the same time.
+// OBJECT nodes (flags & 1): the children's boxes are expressed in the object space of one small mesh shape (`xf` = rows of
+// the world -> object affine map), where e.g. the faces of a rotated `cube` are flat and axis-aligned, so the slab tests
+// cull exactly instead of through fat world-space boxes.  The ray parameter t is invariant under affine maps: entry / exit
+// distances computed in object space compare directly with tmax and the closest hit.  All children of an object node are
+// leaves (their triangles are tested in WORLD space as everywhere else: the hit arithmetic never changes).
 template <uint32_t W>
 struct alignas(16) WNodeT {
     q4 box[3 * W / 2];
     int32_t ref[W];
-    uint32_t axis, count, leaves, pad1;       // leaves: bit c set = child c is a leaf
-    static constexpr uint32_t kBytes = 28u * W + 16u, kRefOff = 24u * W, kHdrOff = 28u * W;
-    static constexpr uint32_t kMask = (1u << W) - 1u, kRevBit = 1u << W, kNodeShift = W + 1u;
+    uint32_t axis, count, n_quads, flags;     // n_quads: children 0 .. n_quads-1 are rectangle leaves; flags bit 0: object node
+    float xf[12];                             // object nodes: (R | T) rows, local = R * p + T
+    static constexpr uint32_t kBytes = 28u * W + 64u, kRefOff = 24u * W, kHdrOff = 28u * W, kXfOff = 28u * W + 16u;
+    static constexpr uint32_t kMask = (1u << W) - 1u, kRevBit = 1u << W, kQuadShift = W + 1u, kNodeShift = W + 5u;
 };
 constexpr uint32_t kWide = MTR_WIDE;
 typedef WNodeT<kWide> WNode;
@@ -230,11 +238,18 @@ static_assert(sizeof(QNode4) == 64, "quantised 4-wide node");
 // subtraction Moller-Trumbore starts with):
 //   g[0] = (p0.x A,B  p0.y A,B)  g[1] = (p0.z A,B  e1.x A,B)  g[2] = (e1.y A,B  e1.z A,B)  g[3] = (e2.x A,B  e2.y A,B)
 //   g[4] = (e2.z A,B  orig A, orig B)     orig: index of the triangle in the caller's array (ties on t go to the lower one)
+// A `rectangle` (analytic primitive) owns one pair of slots; its record holds the rows of to_object instead:
+//   g[0] = (rz.x, rz.y, rz.z, tz)  g[1] = (rx.x, rx.y, rx.z, tx)  g[2] = (ry.x, ry.y, ry.z, ty)  g[4] = (-, -, orig, kQuadMark)
+// and it is alone in its leaf, whose reference carries kLeafQuadBit.
 struct alignas(16) TriPair { q4 g[5]; };
+constexpr uint32_t kQuadMark = 0xffffffffu;
+constexpr uint32_t kLeafQuadBit = 0x40000000u;      // in the leaf code ~ref = (first_slot << 2) | (count - 1)
 // shading record per slot (5 quads): flat frame, the three vertices (hit point = barycentric blend), material | emitter
 //   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, p0.x)
 //   h[4] = (p0.y, p0.z, mat_em, orig)      mat_em: material index | (emitter index + 1) << 16
+// rectangle slots: p0 := to_world * (0,0,0), p1 := du, p2 := dv (hit point = c + du * u + dv * v), orig |= kShadeQuadBit
 struct alignas(16) TriShade { q4 h[5]; };
+constexpr uint32_t kShadeQuadBit = 0x80000000u;
 struct alignas(16) Emitter {                       // 80 B
     float center[3], du[3], dv[3], n[3], radiance[3], inv_area;       // rectangle: analytic sampling
     uint32_t is_mesh, first_tri, n_tris, pad;                          // mesh: triangle range (ORIGINAL indices)
@@ -406,10 +421,37 @@ MTR_HD void trav_node_step(Trav &tr, const SceneView &sc, Stack &st)
 
 // one leaf: 1..4 Moller-Trumbore tests, then pop.  `any_hit` is a per-lane runtime flag so that
 // closest-hit and shadow rays of different lanes share one instruction stream.
+// a rectangle leaf [mitsuba3: Rectangle::ray_intersect_preliminary_impl]: ray to object space (transform_affine: the
+// translation first, then one fmadd per column), t = -o.z / d.z, local = fmadd(d, t, o), hit iff 0 <= t <= maxt and
+// |local.x|, |local.y| <= 1; (u, v) of the hit = (local.x, local.y)
+MTR_HD bool is_quad_leaf(int32_t cur) { return cur < 0 && cur != kTravDone && ((~(uint32_t)cur) & kLeafQuadBit) != 0u; }
+template <class Stack>
+MTR_HD bool trav_quad_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
+{
+    st.count(1);
+    const uint32_t first = ((~(uint32_t)tr.cur) & ~kLeafQuadBit) >> 2;
+    const TriPair &tp = sc.tpairs[first >> 1];
+    const q4 Z = tp.g[0], X = tp.g[1], Y = tp.g[2];
+    const uint32_t orig = fbits(tp.g[4].z);
+    const f3 o = tr.o, d = tr.d;
+    const float oz = fmaf(Z.z, o.z, fmaf(Z.y, o.y, fmaf(Z.x, o.x, Z.w))), dz = fmaf(Z.z, d.z, fmaf(Z.y, d.y, Z.x * d.x));
+    const float t = -oz / dz;
+    const float ox = fmaf(X.z, o.z, fmaf(X.y, o.y, fmaf(X.x, o.x, X.w))), dx = fmaf(X.z, d.z, fmaf(X.y, d.y, X.x * d.x));
+    const float oy = fmaf(Y.z, o.z, fmaf(Y.y, o.y, fmaf(Y.x, o.x, Y.w))), dy = fmaf(Y.z, d.z, fmaf(Y.y, d.y, Y.x * d.x));
+    const float lx = fmaf(dx, t, ox), ly = fmaf(dy, t, oy);
+    const bool hit = (t >= 0.0f) && (t <= tr.tmax) && (fabsf(lx) <= 1.0f) && (fabsf(ly) <= 1.0f);
+    const bool closer = (t < tr.h.t) | ((t == tr.h.t) & (orig < tr.best_orig));
+    const bool better = hit && (any_hit || closer);
+    tr.h.t = better ? t : tr.h.t; tr.h.u = better ? lx : tr.h.u; tr.h.v = better ? ly : tr.h.v;
+    tr.h.prim = better ? (int32_t)first : tr.h.prim; tr.best_orig = better ? orig : tr.best_orig;
+    return hit;
+}
+
 template <class Stack>
 MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
 {
     const uint32_t code = ~(uint32_t)tr.cur;
+    if (code & kLeafQuadBit) return trav_quad_test(tr, sc, st, any_hit);
     const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
     bool found = false;
     // Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]: pvec = cross(d, e2); inv_det = 1 / dot(e1, pvec);
@@ -476,7 +518,9 @@ MTR_HD void wide_advance(Trav &tr, const void *nodes, Stack &st, uint32_t g)
     if ((g & N::kMask) == 0u) g = st.empty() ? 0u : (uint32_t)st.pop();
     const uint32_t mask = g & N::kMask;
     if (mask == 0u) { tr.grp = 0u; tr.cur = kTravDone; return; }
-    const uint32_t k = (g & N::kRevBit) ? 31u - (uint32_t)__builtin_clz(mask) : (uint32_t)__builtin_ctz(mask);
+    const uint32_t qm = mask & ((1u << ((g >> N::kQuadShift) & 0xfu)) - 1u);          // rectangle children still to visit
+    const uint32_t k = qm ? (uint32_t)__builtin_ctz(qm)
+                          : ((g & N::kRevBit) ? 31u - (uint32_t)__builtin_clz(mask) : (uint32_t)__builtin_ctz(mask));
     g &= ~(1u << k);
     tr.grp = g;
     tr.cur = *(const int32_t *)((const char *)nodes + (size_t)(g >> N::kNodeShift) * N::kBytes + N::kRefOff + 4u * k);
@@ -488,10 +532,23 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
 {
     typedef WNodeT<W> N;
     st.count(0);
-    const f3 id = tr.id, noid = tr.noid;
+    f3 id = tr.id, noid = tr.noid;
     const float tb = fminf(tr.tmax, tr.h.t);
     const char *nb = (const char *)nodes + (size_t)(uint32_t)tr.cur * N::kBytes;
     const uint32_t axis = *(const uint32_t *)(nb + N::kHdrOff), count = *(const uint32_t *)(nb + N::kHdrOff + 4u);
+    const uint32_t n_quads = *(const uint32_t *)(nb + N::kHdrOff + 8u), flags = *(const uint32_t *)(nb + N::kHdrOff + 12u);
+    uint32_t sel0 = tr.sel[0], sel1 = tr.sel[1], sel2 = tr.sel[2];
+    if (flags & 1u) {          // object node: the ray in the shape's object space (t is invariant under the affine map)
+        const q4 A = *(const q4 *)(nb + N::kXfOff), B = *(const q4 *)(nb + N::kXfOff + 16u), C = *(const q4 *)(nb + N::kXfOff + 32u);
+        const f3 o = tr.o, d = tr.d;
+        const f3 ol = mk(fmaf(A.z, o.z, fmaf(A.y, o.y, fmaf(A.x, o.x, A.w))), fmaf(B.z, o.z, fmaf(B.y, o.y, fmaf(B.x, o.x, B.w))),
+                         fmaf(C.z, o.z, fmaf(C.y, o.y, fmaf(C.x, o.x, C.w))));
+        const f3 dl = mk(fmaf(A.z, d.z, fmaf(A.y, d.y, A.x * d.x)), fmaf(B.z, d.z, fmaf(B.y, d.y, B.x * d.x)),
+                         fmaf(C.z, d.z, fmaf(C.y, d.y, C.x * d.x)));
+        id = mk(safe_rcp(dl.x), safe_rcp(dl.y), safe_rcp(dl.z));
+        noid = mk(-(ol.x * id.x), -(ol.y * id.y), -(ol.z * id.z));
+        sel0 = id.x < 0.0f ? 8u : 0u; sel1 = 16u + (id.y < 0.0f ? 8u : 0u); sel2 = 32u + (id.z < 0.0f ? 8u : 0u);
+    }
     const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
     uint32_t m = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -502,9 +559,9 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
             const char *pb = nb + 48u * j;
             f2 nx, fx, ny, fy, nz, fz;
             if (OFFS) {
-                nx = fma2(*(const f2 *)(pb + tr.sel[0]), id.x, noid.x); fx = fma2(*(const f2 *)(pb + (tr.sel[0] ^ 8u)), id.x, noid.x);
-                ny = fma2(*(const f2 *)(pb + tr.sel[1]), id.y, noid.y); fy = fma2(*(const f2 *)(pb + (tr.sel[1] ^ 8u)), id.y, noid.y);
-                nz = fma2(*(const f2 *)(pb + tr.sel[2]), id.z, noid.z); fz = fma2(*(const f2 *)(pb + (tr.sel[2] ^ 8u)), id.z, noid.z);
+                nx = fma2(*(const f2 *)(pb + sel0), id.x, noid.x); fx = fma2(*(const f2 *)(pb + (sel0 ^ 8u)), id.x, noid.x);
+                ny = fma2(*(const f2 *)(pb + sel1), id.y, noid.y); fy = fma2(*(const f2 *)(pb + (sel1 ^ 8u)), id.y, noid.y);
+                nz = fma2(*(const f2 *)(pb + sel2), id.z, noid.z); fz = fma2(*(const f2 *)(pb + (sel2 ^ 8u)), id.z, noid.z);
             } else {
                 const q4 X = *(const q4 *)pb, Y = *(const q4 *)(pb + 16), Z = *(const q4 *)(pb + 32);
                 nx = fma2(sx ? f2{ X.z, X.w } : f2{ X.x, X.y }, id.x, noid.x); fx = fma2(sx ? f2{ X.x, X.y } : f2{ X.z, X.w }, id.x, noid.x);
@@ -524,9 +581,9 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
         st.push_if((g & N::kMask) != 0u, (int32_t)g);
         // walk order of this node's children: reversed when the direction is negative on the node's sort axis
         bool neg;
-        if (OFFS) neg = ((axis == 0u ? tr.sel[0] : (axis == 1u ? tr.sel[1] : tr.sel[2])) & 8u) != 0u;      // bit 3 = sign (trav_init)
+        if (OFFS) neg = ((axis == 0u ? sel0 : (axis == 1u ? sel1 : sel2)) & 8u) != 0u;      // bit 3 = sign (trav_init)
         else neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
-        g = ((uint32_t)tr.cur << N::kNodeShift) | (neg ? N::kRevBit : 0u) | m;
+        g = ((uint32_t)tr.cur << N::kNodeShift) | (n_quads << N::kQuadShift) | (neg ? N::kRevBit : 0u) | m;
     }
     wide_advance<W>(tr, nodes, st, g);
 }
@@ -610,6 +667,8 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
     uint32_t my_nodes = 0;
 #endif
     if (sc.wnodes) {
+        // three kinds of steps, each run by the whole wave at once: inner nodes until no lane holds one, then one
+        // rectangle test for the lanes holding a rectangle, else one triangle-leaf pass
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) {
                 wide_node_step<kWide, true>(tr, sc.wnodes, st);
@@ -617,7 +676,11 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
                 ++my_nodes;
 #endif
             }
-            if (tr.cur != kTravDone) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+            if (is_quad_leaf(tr.cur)) {
+                const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                if (ANY_HIT & found) tr.cur = kTravDone;
+                else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
+            } else if (tr.cur != kTravDone) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
         }
     } else if (sc.wnodes4) {
         while (tr.cur != kTravDone) {
@@ -799,6 +862,8 @@ MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
     c.sp = mk(fmaf(hd.w, b0, fmaf(hc.y, b1, hd.x * b2)),
               fmaf(he.x, b0, fmaf(hc.z, b1, hd.y * b2)),
               fmaf(he.y, b0, fmaf(hc.w, b1, hd.z * b2)));
+    if (fbits(he.w) & kShadeQuadBit)          // rectangle: to_world.transform_affine((u, v, 0)) = fmadd(dv, v, fmadd(du, u, c))
+        c.sp = mk(fmaf(hd.x, b2, fmaf(hc.y, b1, hd.w)), fmaf(hd.y, b2, fmaf(hc.z, b1, he.x)), fmaf(hd.z, b2, fmaf(hc.w, b1, he.y)));
     c.sn = mk(ha.x, ha.y, ha.z); c.ss = mk(ha.w, hb.x, hb.y); c.stt = mk(hb.z, hb.w, hc.x);
     const f3 md = -ray_d;
     c.wi = mk(dot(md, c.ss), dot(md, c.stt), dot(md, c.sn));

@@ -46,6 +46,66 @@ static double fill_mesh_tables(const float *tri_verts, uint32_t first, uint32_t 
     return a;
 }
 
+// [mitsuba3: coordinate_system(n)] (Duff et al. 2017), first vector: the tangent of a mesh triangle without UVs
+static f3 coordinate_system_s(f3 n)
+{
+    const float sign = copysignf(1.0f, n.z);
+    const float a = -(1.0f / (sign + n.z));
+    const float b = (n.x * n.y) * a;
+    const bool neg = sign_neg(n.z);
+    const float x = (n.x * n.x) * a, nx = -n.x;
+    return mk((neg ? -x : x) + 1.0f, neg ? -b : b, neg ? -nx : nx);
+}
+// [mitsuba3: SurfaceInteraction::initialize_sh_frame]
+static void sh_frame_from(f3 n, f3 dp_du, f3 &s, f3 &t)
+{
+    const float dn = dot(n, dp_du);
+    s = normalize(mk(fmaf(-n.x, dn, dp_du.x), fmaf(-n.y, dn, dp_du.y), fmaf(-n.z, dn, dp_du.z)));
+    t = cross(n, s);
+}
+// rows of a rectangle's to_object from (c, du, dv): the inverse of [du dv n^ | c], n^ = normalize(du x dv); f64 -> f32
+// (numerics contract: the same operations, in the same order, as the test oracle's restatement)
+static void rect_to_object(const float c[3], const float du[3], const float dv[3], float rx[4], float ry[4], float rz[4])
+{
+    const double a[3] = { du[0], du[1], du[2] }, b[3] = { dv[0], dv[1], dv[2] }, o[3] = { c[0], c[1], c[2] };
+    double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+    const double ln = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] /= ln; n[1] /= ln; n[2] /= ln;
+    const double bn[3] = { b[1] * n[2] - b[2] * n[1], b[2] * n[0] - b[0] * n[2], b[0] * n[1] - b[1] * n[0] };
+    const double na[3] = { n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0] };
+    const double da = a[0] * bn[0] + a[1] * bn[1] + a[2] * bn[2], db = b[0] * na[0] + b[1] * na[1] + b[2] * na[2];
+    const double X[3] = { bn[0] / da, bn[1] / da, bn[2] / da }, Y[3] = { na[0] / db, na[1] / db, na[2] / db };
+    for (int k = 0; k < 3; ++k) { rx[k] = (float)X[k]; ry[k] = (float)Y[k]; rz[k] = (float)n[k]; }
+    rx[3] = (float)(-(X[0] * o[0] + X[1] * o[1] + X[2] * o[2]));
+    ry[3] = (float)(-(Y[0] * o[0] + Y[1] * o[1] + Y[2] * o[2]));
+    rz[3] = (float)(-(n[0] * o[0] + n[1] * o[1] + n[2] * o[2]));
+}
+// world -> object rows (R | T) of a mesh shape's 3 x 4 to_world; false when the map is singular or axis-aligned (every
+// row of the linear part has one entry: object-space boxes would be the world boxes)
+static bool object_space_of(const float tw[12], float inv[12])
+{
+    const double m[9] = { tw[0], tw[1], tw[2], tw[4], tw[5], tw[6], tw[8], tw[9], tw[10] }, t[3] = { tw[3], tw[7], tw[11] };
+    double big = 0.0;
+    for (double x : m) big = fmax(big, fabs(x));
+    bool aligned = true;
+    for (int r = 0; r < 3; ++r) {
+        int nz = 0;
+        for (int c = 0; c < 3; ++c) nz += fabs(m[3 * r + c]) > 1e-6 * big ? 1 : 0;
+        aligned = aligned && nz <= 1;
+    }
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (aligned || !(fabs(det) > 1e-30)) return false;
+    const double c[9] = { m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+                          m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+                          m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3] };
+    for (int r = 0; r < 3; ++r) {
+        double row[3] = { c[3 * r] / det, c[3 * r + 1] / det, c[3 * r + 2] / det };
+        for (int k = 0; k < 3; ++k) inv[4 * r + k] = (float)row[k];
+        inv[4 * r + 3] = (float)(-(row[0] * t[0] + row[1] * t[1] + row[2] * t[2]));
+    }
+    return true;
+}
+
 const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
 {
     if (d.n_tris && (!d.tri_verts || !d.tri_material || !d.tri_emitter)) return "triangle arrays missing";
@@ -62,13 +122,41 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     memcpy(s.cam.tw, d.camera.to_world, sizeof s.cam.tw);
     s.cam.near_clip = d.camera.near_clip; s.cam.far_clip = d.camera.far_clip;
 
-    // BVH2 over the triangles; triangles are stored in leaf order
+    // shape table -> per-triangle annotations of the BVH build: analytic rectangles, and OBJECTS = small mesh shapes
+    // with a known, not axis-aligned object -> world transform (a rotated `cube`): their triangles get object-space
+    // bounds in the 8-wide tree (mtr_core.h, WNodeT)
+    std::vector<uint8_t> kind(d.n_tris, 0);
+    std::vector<int32_t> object(d.n_tris, -1);
+    std::vector<float> object_xf;
+    std::vector<const mtr_shape *> rect_of(d.n_tris, nullptr);
+    uint32_t covered = 0;
+    for (uint32_t k = 0; k < d.n_shapes && d.shapes; ++k) {
+        const mtr_shape &S = d.shapes[k];
+        if (S.first_tri != covered || (uint64_t)S.first_tri + S.n_tris > d.n_tris) return "shapes must tile the triangle array in order";
+        covered += S.n_tris;
+        if (S.is_rectangle) {
+            if (S.n_tris != 2) return "a rectangle shape owns exactly two carrier triangles";
+            kind[S.first_tri] = 1; kind[S.first_tri + 1] = 2;
+            rect_of[S.first_tri] = rect_of[S.first_tri + 1] = &S;
+            continue;
+        }
+        float inv[12];
+        if (S.has_to_world && S.n_tris >= 4 && S.n_tris <= 16 && object_space_of(S.to_world, inv)) {
+            for (uint32_t t = 0; t < S.n_tris; ++t) object[S.first_tri + t] = (int32_t)(object_xf.size() / 12);
+            object_xf.insert(object_xf.end(), inv, inv + 12);
+        }
+    }
+    if (d.n_shapes && d.shapes && covered != d.n_tris) return "shapes must cover every triangle";
+    BvhPrims prims;
+    prims.kind = kind.data(); prims.object = object.data(); prims.object_xf = object_xf.empty() ? nullptr : object_xf.data();
+
+    // BVH2 over the primitives; triangles are stored in leaf order
     BvhBuild bvh;
-    build_bvh(d.tri_verts, d.n_tris, bvh);
+    build_bvh(d.tri_verts, d.n_tris, &prims, bvh);
     s.nodes = bvh.nodes; s.bvh_depth = bvh.max_depth; s.n_leaves = bvh.n_leaves;
     s.wnodes.clear();
     s.has_wide = bvh.nodes.size() <= 2048;
-    s.wide_levels = s.has_wide ? build_wide(bvh, s.wnodes) : 0;
+    s.wide_levels = s.has_wide ? build_wide(bvh, &prims, d.tri_verts, s.wnodes) : 0;
     s.wnodes4.clear();
     s.wide4_levels = build_wide4(bvh, s.wnodes4);
     const uint32_t n_slots = (uint32_t)bvh.order.size();
@@ -79,9 +167,44 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         const float *v = d.tri_verts + 9 * (size_t)o;
         TriShade &h = s.tshade[slot];
         const uint32_t mat_em = d.tri_material[o] | ((uint32_t)(d.tri_emitter[o] + 1) << 16);
-        // flat frame: n = normalize(e1 x e2), s = normalize(e1), t = n x s   (f32, contract in DESIGN.md)
+        if (const mtr_shape *R = rect_of[o]) {
+            // analytic rectangle [mitsuba3: src/shapes/rectangle.cpp]: both slots of its pair describe the ONE primitive
+            // (index = its first carrier triangle)
+            const uint32_t prim = R->first_tri;
+            const f3 c = ld3(R->center), du = ld3(R->du), dv = ld3(R->dv);
+            const f3 n = normalize(cross(du, dv));                              // normalize(to_world * Normal3f(0, 0, 1))
+            f3 sdir, t;
+            sh_frame_from(n, du, sdir, t);                                      // dp_du = to_world * (2, 0, 0): same direction
+            float rx[4], ry[4], rz[4];
+            rect_to_object(R->center, R->du, R->dv, rx, ry, rz);
+            TriPair &tp = s.tpairs[slot >> 1];
+            tp.g[0] = q4{ rz[0], rz[1], rz[2], rz[3] }; tp.g[1] = q4{ rx[0], rx[1], rx[2], rx[3] }; tp.g[2] = q4{ ry[0], ry[1], ry[2], ry[3] };
+            tp.g[3] = q4{ 0, 0, 0, 0 }; tp.g[4] = q4{ 0, 0, bitsf(prim), bitsf(kQuadMark) };
+            h.h[0] = q4{ n.x, n.y, n.z, sdir.x };
+            h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
+            h.h[2] = q4{ t.z, du.x, du.y, du.z };
+            h.h[3] = q4{ dv.x, dv.y, dv.z, c.x };
+            h.h[4] = q4{ c.y, c.z, bitsf(d.tri_material[prim] | ((uint32_t)(d.tri_emitter[prim] + 1) << 16)), bitsf(prim | kShadeQuadBit) };
+            continue;
+        }
+        // flat frame [mitsuba3: Mesh::compute_surface_interaction + SurfaceInteraction::initialize_sh_frame]:
+        // n = normalize(e1 x e2); dp_du from the UV parameterisation when there is one and it is not degenerate, else
+        // coordinate_system(n); s = normalize(dp_du - n * dot(n, dp_du)), t = n x s   (f32, contract in DESIGN.md)
         f3 p0 = mk(v[0], v[1], v[2]), e1 = mk(v[3], v[4], v[5]) - p0, e2 = mk(v[6], v[7], v[8]) - p0;
-        f3 n = normalize(cross(e1, e2)), sdir = normalize(e1), t = cross(n, sdir);
+        f3 n = normalize(cross(e1, e2));
+        f3 dp_du = coordinate_system_s(n);
+        if (d.tri_uv) {
+            const float *uv = d.tri_uv + 6 * (size_t)o;
+            const float duv0x = uv[2] - uv[0], duv0y = uv[3] - uv[1], duv1x = uv[4] - uv[0], duv1y = uv[5] - uv[1];
+            const float det = fmaf(duv0x, duv1y, -(duv0y * duv1x));
+            if (det != 0.0f) {
+                const float inv_det = 1.0f / det;
+                dp_du = mk(fmaf(duv1y, e1.x, -(duv0y * e2.x)) * inv_det, fmaf(duv1y, e1.y, -(duv0y * e2.y)) * inv_det,
+                           fmaf(duv1y, e1.z, -(duv0y * e2.z)) * inv_det);
+            }
+        }
+        f3 sdir, t;
+        sh_frame_from(n, dp_du, sdir, t);
         float *g = &s.tpairs[slot >> 1].g[0].x;            // interleaved pair record: dword 2*k + half
         const float comp[9] = { p0.x, p0.y, p0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };
         const uint32_t half = slot & 1u;

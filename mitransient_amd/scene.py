@@ -128,6 +128,7 @@ class _SceneBuilder:
         self.tri_verts: List[np.ndarray] = []
         self.tri_mat: List[np.ndarray] = []
         self.tri_em: List[np.ndarray] = []
+        self.tri_uv: List[Optional[np.ndarray]] = []          # per shape: (n, 6) corner texture coordinates, or None
         self.materials: List[_cabi.mtr_material] = []
         self.mat_cache: Dict[int, int] = {}
         self.emitters: List[_cabi.mtr_emitter] = []
@@ -216,24 +217,29 @@ class _SceneBuilder:
     def add_shape(self, name: str, sd: Dict[str, Any]):
         t = sd.get("type")
         tw = to_transform(sd.get("to_world"))
+        uv = None
         if t == "rectangle":
+            # an analytic primitive (mtr_shape.is_rectangle); the two triangles carry its material / emitter / index
             corners = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float64)
             w = tw.transform_affine(corners)
             tris = np.stack([w[[0, 1, 2]], w[[0, 2, 3]]])
         elif t == "cube":
-            tris = tw.transform_affine(_cube_tris().reshape(-1, 3)).reshape(-1, 3, 3)
+            ct, uv = _cube_tris()
+            tris = tw.transform_affine(ct.reshape(-1, 3)).reshape(-1, 3, 3)
         elif t in ("obj", "ply"):
             fn = sd.get("filename")
             if not os.path.isabs(fn):
                 fn = os.path.join(self.base_dir, fn)
             if fn not in self.mesh_cache:
-                self.mesh_cache[fn] = load_obj(fn) if t == "obj" else load_ply(fn)
-            v = self.mesh_cache[fn]
+                self.mesh_cache[fn] = load_obj(fn, with_uv=True) if t == "obj" else (load_ply(fn), None)
+            v, uv = self.mesh_cache[fn]
             tris = tw.transform_affine(v.reshape(-1, 3)).reshape(-1, 3, 3)
         else:
             raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported shapes: rectangle, cube, obj, ply)")
         if sd.get("flip_normals", False):
             tris = tris[:, [0, 2, 1], :]
+            if uv is not None:
+                uv = uv.reshape(-1, 3, 2)[:, [0, 2, 1], :].reshape(-1, 6)
         bsdf, em = None, None
         for k, v in sd.items():
             # nested plugins are recognised by type, not by key (keys are arbitrary, as in mitsuba): emitter, sensor,
@@ -275,10 +281,14 @@ class _SceneBuilder:
         self.tri_verts.append(tris.astype(np.float32))
         self.tri_mat.append(np.full(n, mi_, dtype=np.uint32))
         self.tri_em.append(np.full(n, em_index, dtype=np.int32))
+        self.tri_uv.append(None if uv is None else np.asarray(uv, dtype=np.float32).reshape(n, 6))
         self.shape_names.append(name)
         self.shape_ranges.append((first, first + n))
         sh = _cabi.mtr_shape()
         sh.first_tri, sh.n_tris, sh.is_rectangle = first, n, 1 if t == "rectangle" else 0
+        sh.has_to_world = 1                       # object -> world of the mesh (an acceleration hint: oriented bounds)
+        for i, x in enumerate(np.asarray(tw.matrix, dtype=np.float64)[:3, :].reshape(-1)):
+            sh.to_world[i] = np.float32(x)
         if t == "rectangle":
             c = tw.transform_affine(np.zeros(3))
             du = tw.transform_affine(np.array([1.0, 0, 0])) - c
@@ -288,45 +298,59 @@ class _SceneBuilder:
         self.shapes.append(sh)
 
 
-def _cube_tris() -> np.ndarray:
-    """[-1,1]^3 as 12 outward-facing (CCW) triangles, shape (12,3,3)."""
-    faces = []
-    for axis in range(3):
-        for sgn in (-1.0, 1.0):
-            u, v = (axis + 1) % 3, (axis + 2) % 3
-            quad = []
-            for (a, b) in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
-                p = [0.0, 0.0, 0.0]
-                p[axis] = sgn
-                p[u] = a
-                p[v] = b
-                quad.append(p)
-            if sgn < 0:
-                quad = quad[::-1]
-            faces.append([quad[0], quad[1], quad[2]])
-            faces.append([quad[0], quad[2], quad[3]])
-    return np.asarray(faces, dtype=np.float64)
+def _cube_tris():
+    """[mitsuba3: src/shapes/cube.cpp] (upstream-unverified, from memory of the plugin's tables): [-1,1]^3 as 24 vertices
+    (4 per face, with the face's normal and the texture coordinates (0,1) (1,1) (1,0) (0,0)) and 12 triangles
+    {0,1,2} {3,0,2} per face, outward-facing.  Returns (triangles (12,3,3), corner texture coordinates (12,6))."""
+    verts = np.array([
+        [1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1],      # y = -1
+        [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, 1, 1],          # y = +1
+        [1, -1, -1], [1, 1, -1], [1, 1, 1], [1, -1, 1],          # x = +1
+        [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1],          # z = +1
+        [-1, -1, 1], [-1, 1, 1], [-1, 1, -1], [-1, -1, -1],      # x = -1
+        [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]],     # z = -1
+        dtype=np.float64)
+    uvs = np.tile(np.array([[0, 1], [1, 1], [1, 0], [0, 0]], dtype=np.float32), (6, 1))
+    idx = np.array([[4 * f + a, 4 * f + b, 4 * f + c] for f in range(6) for (a, b, c) in ((0, 1, 2), (3, 0, 2))])
+    return verts[idx], uvs[idx].reshape(-1, 6)
 
 
-def load_obj(path: str) -> np.ndarray:
-    """Wavefront OBJ -> (n,3,3) float64 triangle soup (positions only, fan-triangulated;
-    ``l``/``vn``/``vt`` and groups are ignored: faces are flat-shaded)."""
-    verts, tris = [], []
+def load_obj(path: str, with_uv: bool = False):
+    """Wavefront OBJ -> (n,3,3) float64 triangle soup (positions; fan-triangulated; ``l``/``vn`` and groups are ignored:
+    faces are flat-shaded).  ``with_uv``: also the corner texture coordinates (n,6) float32 — or None when the file has no
+    ``vt`` or some face corner lacks one — which only orient the shading frame (mtr_scene_desc.tri_uv)."""
+    verts, uvs, tris, tuv = [], [], [], []
     with open(path, "r") as fh:
         for line in fh:
             if line.startswith("v "):
                 p = line.split()
                 verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("vt "):
+                p = line.split()
+                uvs.append((float(p[1]), float(p[2]) if len(p) > 2 else 0.0))
             elif line.startswith("f "):
-                idx = []
+                idx, tix = [], []
                 for tok in line.split()[1:]:
-                    i = int(tok.split("/")[0])
+                    parts = tok.split("/")
+                    i = int(parts[0])
                     idx.append(i - 1 if i > 0 else len(verts) + i)
+                    if len(parts) > 1 and parts[1]:
+                        j = int(parts[1])
+                        tix.append(j - 1 if j > 0 else len(uvs) + j)
+                    else:
+                        tix.append(-1)
                 for k in range(1, len(idx) - 1):
                     tris.append((idx[0], idx[k], idx[k + 1]))
+                    tuv.append((tix[0], tix[k], tix[k + 1]))
     v = np.asarray(verts, dtype=np.float64)
     t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
-    return v[t]
+    if not with_uv:
+        return v[t]
+    tu = np.asarray(tuv, dtype=np.int64).reshape(-1, 3)
+    uv = None
+    if uvs and tu.size and tu.min() >= 0:
+        uv = np.asarray(uvs, dtype=np.float32)[tu].reshape(-1, 6)
+    return v[t], uv
 
 
 _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
@@ -469,6 +493,7 @@ class SceneData:
         self.shape_ranges: List[tuple] = []
         self.shapes = (_cabi.mtr_shape * 1)()
         self.n_shapes = 0
+        self.tri_uv = None               # (n_tris, 6) f32 corner texture coordinates, or None
         self.nlos = None                 # mtr_nlos_desc for the NLOS tier
 
     def desc(self) -> _cabi.mtr_scene_desc:
@@ -483,6 +508,9 @@ class SceneData:
         d.emitters = C.cast(self.emitters, C.POINTER(_cabi.mtr_emitter))
         d.camera = self.camera
         d.film = self.film
+        d.n_shapes = self.n_shapes
+        d.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape)) if self.n_shapes else None
+        d.tri_uv = self.tri_uv.ctypes.data_as(C.POINTER(C.c_float)) if self.tri_uv is not None else None
         if self.nlos is not None:
             self.nlos.n_shapes = self.n_shapes
             self.nlos.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape))
@@ -538,20 +566,27 @@ def save_geometry(sd: "SceneData", path: str, **meta):
         tri_emitter=sd.tri_emitter.astype(np.int16),
         materials=np.frombuffer(bytes(sd.materials), dtype=np.uint8)[:sd.n_materials * C.sizeof(_cabi.mtr_material)],
         emitters=np.frombuffer(bytes(sd.emitters), dtype=np.uint8)[:sd.n_emitters * C.sizeof(_cabi.mtr_emitter)],
-        layout=np.asarray([C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter)]), meta=np.asarray(json.dumps(meta)))
+        shapes=np.frombuffer(bytes(sd.shapes), dtype=np.uint8)[:sd.n_shapes * C.sizeof(_cabi.mtr_shape)],
+        tri_uv=sd.tri_uv if sd.tri_uv is not None else np.zeros((0, 6), np.float32),
+        layout=np.asarray([C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]),
+        meta=np.asarray(json.dumps(meta)))
 
 
 def load_geometry(path: str) -> Dict[str, Any]:
     import json
     z = np.load(path)
-    if list(z["layout"]) != [C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter)]:
+    if list(z["layout"]) != [C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]:
         raise ValueError(f"{path}: material / emitter record sizes {list(z['layout'])} do not match this C-ABI; "
                          "regenerate with tests/golden/make_golden.py")
     nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
     ne = z["emitters"].size // C.sizeof(_cabi.mtr_emitter)
     mats = (_cabi.mtr_material * max(1, nm)).from_buffer_copy(z["materials"].tobytes().ljust(C.sizeof(_cabi.mtr_material), b"\0"))
     ems = (_cabi.mtr_emitter * max(1, ne)).from_buffer_copy(z["emitters"].tobytes().ljust(C.sizeof(_cabi.mtr_emitter), b"\0"))
-    return {"tri_verts": np.ascontiguousarray(z["tri_verts"], dtype=np.float32),
+    ns = z["shapes"].size // C.sizeof(_cabi.mtr_shape)
+    shapes = (_cabi.mtr_shape * max(1, ns)).from_buffer_copy(z["shapes"].tobytes().ljust(C.sizeof(_cabi.mtr_shape), b"\0"))
+    return {"shapes": shapes, "n_shapes": ns,
+            "tri_uv": np.ascontiguousarray(z["tri_uv"], dtype=np.float32) if z["tri_uv"].shape[0] else None,
+            "tri_verts": np.ascontiguousarray(z["tri_verts"], dtype=np.float32),
             "tri_material": np.ascontiguousarray(z["tri_material"].astype(np.uint32)),
             "tri_emitter": np.ascontiguousarray(z["tri_emitter"].astype(np.int32)),
             "materials": mats, "n_materials": nm, "emitters": ems, "n_emitters": ne,
@@ -574,10 +609,15 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
             raise ValueError("flatten_scene: pre-flattened geometry cannot be mixed with shape plugins")
         sd.tri_verts, sd.tri_material, sd.tri_emitter = geometry["tri_verts"], geometry["tri_material"], geometry["tri_emitter"]
         b.materials, b.emitters = list(geometry["materials"])[:geometry["n_materials"]], list(geometry["emitters"])[:geometry["n_emitters"]]
+        b.shapes = list(geometry["shapes"])[:geometry["n_shapes"]]
+        sd.tri_uv = geometry["tri_uv"]
     if b.tri_verts:
         sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
         sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))
         sd.tri_emitter = np.ascontiguousarray(np.concatenate(b.tri_em))
+        if any(u is not None for u in b.tri_uv):        # shapes without texture coordinates: a degenerate (all-zero) parameterisation
+            sd.tri_uv = np.ascontiguousarray(np.concatenate(
+                [u if u is not None else np.zeros((v.shape[0], 6), np.float32) for u, v in zip(b.tri_uv, b.tri_verts)]))
     sd.n_materials = len(b.materials)
     sd.materials = (_cabi.mtr_material * max(1, sd.n_materials))(*b.materials)
     sd.n_emitters = len(b.emitters)

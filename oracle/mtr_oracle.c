@@ -197,6 +197,11 @@ void orc_square_to_cos_hemi(float u1, float u2, float *out3)
 typedef struct {
     v3 p0, e1, e2;     /* [mitsuba3: Mesh::ray_intersect_triangle] */
     v3 n, s, t;        /* geometric normal == shading normal (flat); frame s,t [mitsuba3: SurfaceInteraction::initialize_sh_frame] */
+    /* analytic `rectangle` [mitsuba3: src/shapes/rectangle.cpp]: kind 1 = the primitive (first of its two carrier
+     * triangles), kind 2 = the second carrier (never intersected), kind 0 = a mesh triangle */
+    int kind;
+    v3 qc, qdu, qdv;   /* to_world * (0,0,0), to_world * (1,0,0) - c, to_world * (0,1,0) - c */
+    float rx[4], ry[4], rz[4];   /* rows of to_object (3 x 4 affine): local = R * p + T */
 } orc_tri;
 
 typedef struct { v3 lo, hi; int left, right, first, count; } orc_node;
@@ -220,6 +225,42 @@ static double orc_tri_area_d(const float *v)
 }
 static uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t n, float value, float *reused, float *pmf_out);
 
+/* [mitsuba3: coordinate_system(n)] (Duff et al. 2017), first vector only:
+ *   sign = copysign(1, n.z); a = -rcp(sign + n.z); b = n.x * n.y * a;
+ *   s = (mulsign(sqr(n.x) * a, n.z) + 1, mulsign(b, n.z), mulsign_neg(n.x, n.z)) */
+static v3 coordinate_system_s(v3 n)
+{
+    float sign = copysignf(1.0f, n.z);
+    float a = -(1.0f / (sign + n.z));
+    float b = (n.x * n.y) * a;
+    return V(mulsign((n.x * n.x) * a, n.z) + 1.0f, mulsign(b, n.z), mulsign(-n.x, n.z));
+}
+/* [mitsuba3: SurfaceInteraction::initialize_sh_frame] s = normalize(fnmadd(n, dot(n, dp_du), dp_du)); t = cross(n, s) */
+static void sh_frame_from(v3 n, v3 dp_du, v3 *s, v3 *t)
+{
+    float dn = vdot(n, dp_du);
+    *s = vnormalize(V(fmaf(-n.x, dn, dp_du.x), fmaf(-n.y, dn, dp_du.y), fmaf(-n.z, dn, dp_du.z)));
+    *t = vcross(n, *s);
+}
+/* to_object of a rectangle from (c, du, dv): the rows of the inverse of [du dv n^ | c], n^ = normalize(du x dv)
+ * (mitsuba inverts the full 4x4 to_world; the third column only scales o'.z and d'.z alike, so t = -o'.z / d'.z and the
+ * local x, y are the same up to rounding).  f64, rounded to f32 — shared numerics contract with the HIP library. */
+static void rect_to_object(const float c[3], const float du[3], const float dv[3], float rx[4], float ry[4], float rz[4])
+{
+    double a[3] = { du[0], du[1], du[2] }, b[3] = { dv[0], dv[1], dv[2] }, o[3] = { c[0], c[1], c[2] };
+    double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+    double ln = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] /= ln; n[1] /= ln; n[2] /= ln;
+    double bn[3] = { b[1] * n[2] - b[2] * n[1], b[2] * n[0] - b[0] * n[2], b[0] * n[1] - b[1] * n[0] };   /* dv x n */
+    double na[3] = { n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0] };   /* n x du */
+    double da = a[0] * bn[0] + a[1] * bn[1] + a[2] * bn[2], db = b[0] * na[0] + b[1] * na[1] + b[2] * na[2];
+    double X[3] = { bn[0] / da, bn[1] / da, bn[2] / da }, Y[3] = { na[0] / db, na[1] / db, na[2] / db };
+    for (int k = 0; k < 3; ++k) { rx[k] = (float)X[k]; ry[k] = (float)Y[k]; rz[k] = (float)n[k]; }
+    rx[3] = (float)(-(X[0] * o[0] + X[1] * o[1] + X[2] * o[2]));
+    ry[3] = (float)(-(Y[0] * o[0] + Y[1] * o[1] + Y[2] * o[2]));
+    rz[3] = (float)(-(n[0] * o[0] + n[1] * o[1] + n[2] * o[2]));
+}
+
 static void build_tris(orc_scene *sc)
 {
     const mtr_scene_desc *d = sc->d;
@@ -230,8 +271,34 @@ static void build_tris(orc_scene *sc)
         v3 p0 = V(v[0], v[1], v[2]), p1 = V(v[3], v[4], v[5]), p2 = V(v[6], v[7], v[8]);
         T->p0 = p0; T->e1 = vsub(p1, p0); T->e2 = vsub(p2, p0);
         T->n = vnormalize(vcross(T->e1, T->e2));
-        T->s = vnormalize(T->e1);
-        T->t = vcross(T->n, T->s);
+        /* [mitsuba3: Mesh::compute_surface_interaction] dp_du from the UV parameterisation when the mesh has texture
+         * coordinates and they are not degenerate, coordinate_system(n) otherwise */
+        v3 dp_du = coordinate_system_s(T->n);
+        if (d->tri_uv) {
+            const float *uv = d->tri_uv + 6 * (size_t)i;
+            float duv0x = uv[2] - uv[0], duv0y = uv[3] - uv[1], duv1x = uv[4] - uv[0], duv1y = uv[5] - uv[1];
+            float det = fmaf(duv0x, duv1y, -(duv0y * duv1x));               /* fmsub(duv0.x, duv1.y, duv0.y * duv1.x) */
+            if (det != 0.0f) {
+                float inv_det = 1.0f / det;
+                dp_du = V(fmaf(duv1y, T->e1.x, -(duv0y * T->e2.x)) * inv_det,   /* fmsub(duv1.y, dp0, duv0.y * dp1) * inv_det */
+                          fmaf(duv1y, T->e1.y, -(duv0y * T->e2.y)) * inv_det,
+                          fmaf(duv1y, T->e1.z, -(duv0y * T->e2.z)) * inv_det);
+            }
+        }
+        sh_frame_from(T->n, dp_du, &T->s, &T->t);
+    }
+    /* analytic rectangles [mitsuba3: Rectangle::update / compute_surface_interaction]: one primitive, one frame */
+    for (uint32_t k = 0; k < d->n_shapes && d->shapes; ++k) {
+        const mtr_shape *S = &d->shapes[k];
+        if (!S->is_rectangle || S->n_tris != 2 || (uint64_t)S->first_tri + 2 > d->n_tris) continue;
+        orc_tri *Q = &sc->tris[S->first_tri];
+        Q->kind = 1; sc->tris[S->first_tri + 1].kind = 2;
+        Q->qc = V(S->center[0], S->center[1], S->center[2]);
+        Q->qdu = V(S->du[0], S->du[1], S->du[2]); Q->qdv = V(S->dv[0], S->dv[1], S->dv[2]);
+        Q->n = vnormalize(vcross(Q->qdu, Q->qdv));                          /* normalize(to_world * Normal3f(0, 0, 1)) */
+        sh_frame_from(Q->n, Q->qdu, &Q->s, &Q->t);                          /* dp_du = to_world * (2, 0, 0): same direction */
+        rect_to_object(S->center, S->du, S->dv, Q->rx, Q->ry, Q->rz);
+        sc->tris[S->first_tri + 1].n = Q->n; sc->tris[S->first_tri + 1].s = Q->s; sc->tris[S->first_tri + 1].t = Q->t;
     }
     sc->em_n = (v3 *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(v3));
     sc->em_inv_area = (float *)calloc(d->n_emitters ? d->n_emitters : 1, sizeof(float));
@@ -285,7 +352,13 @@ static int build_node(orc_scene *sc, int first, int count)
     orc_node *N = &sc->nodes[idx];
     v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
     for (int i = first; i < first + count; ++i) {
-        v3 l, h; tri_bounds(sc->d->tri_verts + 9 * (size_t)sc->tri_order[i], &l, &h);
+        int p = sc->tri_order[i];
+        v3 l, h; tri_bounds(sc->d->tri_verts + 9 * (size_t)p, &l, &h);
+        if (sc->tris[p].kind == 1) {             /* a rectangle is tested where its FIRST carrier lies: bound all four corners */
+            v3 l2, h2; tri_bounds(sc->d->tri_verts + 9 * (size_t)(p + 1), &l2, &h2);
+            if (l2.x < l.x) l.x = l2.x; if (l2.y < l.y) l.y = l2.y; if (l2.z < l.z) l.z = l2.z;
+            if (h2.x > h.x) h.x = h2.x; if (h2.y > h.y) h.y = h2.y; if (h2.z > h.z) h.z = h2.z;
+        }
         if (l.x < lo.x) lo.x = l.x; if (l.y < lo.y) lo.y = l.y; if (l.z < lo.z) lo.z = l.z;
         if (h.x > hi.x) hi.x = h.x; if (h.y > hi.y) hi.y = h.y; if (h.z > hi.z) hi.z = h.z;
     }
@@ -306,6 +379,8 @@ static int build_node(orc_scene *sc, int first, int count)
 }
 static void build_bvh(orc_scene *sc)
 {
+    /* over every triangle; the leaf loop tests a rectangle when it meets its first carrier (kind 1, bounded by all
+     * four corners in build_node) and skips the second (kind 2) */
     int n = (int)sc->d->n_tris;
     sc->tri_order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
     for (int i = 0; i < n; ++i) sc->tri_order[i] = i;
@@ -340,6 +415,30 @@ static inline int tri_test(const orc_tri *T, const ray3 *r, float *t, float *u, 
     *t = tt; *u = uu; *v = vv;
     return 1;
 }
+/* [mitsuba3: Rectangle::ray_intersect_preliminary_impl]
+ *   ray = to_object.transform_affine(ray_);  t = -ray.o.z / ray.d.z;  local = ray(t);
+ *   active = t >= 0 && t <= maxt && |local.x| <= 1 && |local.y| <= 1;   prim_uv = (local.x, local.y)
+ * transform_affine(point): result = translation column, then fmadd(column_i, p[i], result) for i = 0, 1, 2;
+ * (vector): column_0 * v[0], then fmadd for i = 1, 2. */
+static inline float xf_point(const float r[4], v3 p) { return fmaf(r[2], p.z, fmaf(r[1], p.y, fmaf(r[0], p.x, r[3]))); }
+static inline float xf_vec(const float r[4], v3 v) { return fmaf(r[2], v.z, fmaf(r[1], v.y, r[0] * v.x)); }
+static inline int quad_test(const orc_tri *Q, const ray3 *r, float *t, float *u, float *v)
+{
+    float oz = xf_point(Q->rz, r->o), dz = xf_vec(Q->rz, r->d);
+    float tt = -oz / dz;
+    float lx = fmaf(xf_vec(Q->rx, r->d), tt, xf_point(Q->rx, r->o));       /* ray(t) = fmadd(d, t, o) */
+    float ly = fmaf(xf_vec(Q->ry, r->d), tt, xf_point(Q->ry, r->o));
+    if (!(tt >= 0.0f && tt <= r->maxt && fabsf(lx) <= 1.0f && fabsf(ly) <= 1.0f)) return 0;
+    *t = tt; *u = lx; *v = ly;
+    return 1;
+}
+/* one primitive: mesh triangle, rectangle (at its first carrier) or nothing (second carrier) */
+static inline int prim_test(const orc_tri *T, const ray3 *r, float *t, float *u, float *v)
+{
+    if (T->kind == 0) return tri_test(T, r, t, u, v);
+    if (T->kind == 1) return quad_test(T, r, t, u, v);
+    return 0;
+}
 /* closest hit; ties on t are broken towards the LOWER primitive index so the
  * result does not depend on traversal order (brute force == any BVH) */
 static inline void hit_update(hit_t *h, float t, float u, float v, int prim)
@@ -369,7 +468,7 @@ static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
     float t, u, v;
     if (!use_bvh) {
         for (uint32_t i = 0; i < sc->d->n_tris; ++i)
-            if (tri_test(&sc->tris[i], r, &t, &u, &v)) hit_update(&h, t, u, v, (int)i);
+            if (prim_test(&sc->tris[i], r, &t, &u, &v)) hit_update(&h, t, u, v, (int)i);
         return h;
     }
     if (!sc->n_nodes) return h;
@@ -381,7 +480,7 @@ static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
         if (N->left < 0) {
             for (int i = N->first; i < N->first + N->count; ++i) {
                 int p = sc->tri_order[i];
-                if (tri_test(&sc->tris[p], r, &t, &u, &v)) hit_update(&h, t, u, v, p);
+                if (prim_test(&sc->tris[p], r, &t, &u, &v)) hit_update(&h, t, u, v, p);
             }
         } else { stack[sp++] = N->left; stack[sp++] = N->right; }
     }
@@ -393,7 +492,7 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
     float t, u, v;
     if (!use_bvh) {
         for (uint32_t i = 0; i < sc->d->n_tris; ++i)
-            if (tri_test(&sc->tris[i], r, &t, &u, &v)) return 1;
+            if (prim_test(&sc->tris[i], r, &t, &u, &v)) return 1;
         return 0;
     }
     if (!sc->n_nodes) return 0;
@@ -404,7 +503,7 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
         if (!box_hit(N, r, inv_d, r->maxt)) continue;
         if (N->left < 0) {
             for (int i = N->first; i < N->first + N->count; ++i)
-                if (tri_test(&sc->tris[sc->tri_order[i]], r, &t, &u, &v)) return 1;
+                if (prim_test(&sc->tris[sc->tri_order[i]], r, &t, &u, &v)) return 1;
         } else { stack[sp++] = N->left; stack[sp++] = N->right; }
     }
     return 0;
@@ -429,6 +528,10 @@ static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
     si.p = V(fmaf(vv[0], b0, fmaf(vv[3], b1, vv[6] * b2)),
              fmaf(vv[1], b0, fmaf(vv[4], b1, vv[7] * b2)),
              fmaf(vv[2], b0, fmaf(vv[5], b1, vv[8] * b2)));
+    if (T->kind == 1)        /* [Rectangle::compute_surface_interaction] si.p = to_world.transform_affine((prim_uv.x, prim_uv.y, 0)) */
+        si.p = V(fmaf(T->qdv.x, h.v, fmaf(T->qdu.x, h.u, T->qc.x)),
+                 fmaf(T->qdv.y, h.v, fmaf(T->qdu.y, h.u, T->qc.y)),
+                 fmaf(T->qdv.z, h.v, fmaf(T->qdu.z, h.u, T->qc.z)));
     si.n = T->n; si.s = T->s; si.tt = T->t;
     v3 md = vneg(r->d);
     si.wi = V(vdot(md, si.s), vdot(md, si.tt), vdot(md, si.n));   /* to_local(-ray.d) */

@@ -177,10 +177,14 @@ extern "C" int hh_print_wide(const mtr_scene_desc *d)
     printf("bvh2 packets %zu, wide nodes %zu, slots %zu\n", hs.nodes.size(), hs.wnodes.size(), hs.tshade.size());
     for (size_t i = 0; i < hs.wnodes.size(); ++i) {
         const WNode &w = hs.wnodes[i];
-        printf("  wnode %zu axis %u count %u:", i, w.axis, w.count);
+        printf("  wnode %zu axis %u count %u quads %u%s:", i, w.axis, w.count, w.n_quads, (w.flags & 1u) ? " OBJECT" : "");
+        const float *f = &w.box[0].x;
         for (uint32_t c = 0; c < w.count; ++c) {
             if (w.ref[c] >= 0) printf(" N%d", w.ref[c]);
-            else { uint32_t code = ~(uint32_t)w.ref[c]; printf(" L%u(%u)", code >> 2, (code & 3u) + 1u); }
+            else { uint32_t code = ~(uint32_t)w.ref[c]; printf(" %c%u(%u)", (code & kLeafQuadBit) ? 'Q' : 'L', (code & ~kLeafQuadBit) >> 2, (code & 3u) + 1u); }
+            const int j = (int)c >> 1, hh = (int)c & 1;
+            printf("[%.2f %.2f %.2f]", f[4 * (3 * j + 0) + 2 + hh] - f[4 * (3 * j + 0) + hh], f[4 * (3 * j + 1) + 2 + hh] - f[4 * (3 * j + 1) + hh],
+                   f[4 * (3 * j + 2) + 2 + hh] - f[4 * (3 * j + 2) + hh]);
         }
         printf("\n");
     }
@@ -222,7 +226,9 @@ extern "C" int hh_check_wide(const mtr_scene_desc *d, uint32_t *n_wide8, uint32_
             const WNode &w = hs.wnodes[st.back()]; st.pop_back();
             if (w.count < 1 || w.count > kWide || w.axis > 2) return -2;
             for (uint32_t c = 0; c < w.count; ++c) {
-                if (((w.leaves >> c) & 1u) != (w.ref[c] < 0 ? 1u : 0u)) return -3;
+                const bool quad = w.ref[c] < 0 && ((~(uint32_t)w.ref[c]) & kLeafQuadBit) != 0u;
+                if (quad != (c < w.n_quads)) return -3;                  // rectangle children come first, and only they
+                if ((w.flags & 1u) && w.ref[c] >= 0) return -7;          // an object node holds leaves only
                 if (w.ref[c] < 0) got.push_back(w.ref[c]);
                 else { if ((size_t)w.ref[c] >= seen.size() || seen[w.ref[c]]++) return -4; st.push_back(w.ref[c]); }
             }
@@ -282,7 +288,7 @@ extern "C" int hh_check_wide(const mtr_scene_desc *d, uint32_t *n_wide8, uint32_
                         }
                     }
                 } else {
-                    const uint32_t code = ~(uint32_t)ref, first = code >> 2, cnt = (code & 3u) + 1u;
+                    const uint32_t code = (~(uint32_t)ref) & ~kLeafQuadBit, first = code >> 2, cnt = (code & 3u) + 1u;
                     for (uint32_t t = 0; t < cnt; ++t) {
                         const float *v = d->tri_verts + 9 * (size_t)hs.slot_orig[first + t];
                         for (int p = 0; p < 3; ++p) for (int a = 0; a < 3; ++a)
