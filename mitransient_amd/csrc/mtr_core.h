@@ -315,7 +315,30 @@ MTR_HD void mesh_sample_position(const q4 *samp_tris, const float *face_cdf, con
     n = mk(cc.y, cc.z, cc.w);
 }
 
+// exact u32 division by an invariant divisor in 5 instructions (Granlund-Montgomery, the branch-free form):
+//   q = (t + ((n - t) >> s1)) >> s2,  t = mulhi(m, n)        — the hardware has no integer divide (~35 instructions)
+struct FastDiv { uint32_t m, s1, s2, d; };
+inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f; f.d = d ? d : 1u;
+    if (f.d == 1u) { f.m = 0u; f.s1 = 0u; f.s2 = 0u; return f; }
+    uint32_t l = 0; while ((1ull << l) < f.d) ++l;                       // ceil(log2 d)
+    f.m = (uint32_t)((((1ull << l) - f.d) << 32) / f.d + 1ull);
+    f.s1 = 1u; f.s2 = l - 1u;
+    return f;
+}
+MTR_HD uint32_t fastdiv(uint32_t n, const FastDiv &f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.m, n);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct RenderConst {
+    FastDiv div_crop_w;
     uint32_t spp_total;
     uint32_t seed;
     uint32_t max_depth;      // 0xffffffff = unbounded
@@ -331,9 +354,16 @@ MTR_HD f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
 // ---------------------------------------------------------------- intersection
 struct Hit { float t, u, v; int32_t prim; };
 
+// reciprocal direction of the slab tests.  It only feeds CULLING (conservative: padded boxes, hits are decided by the
+// primitive tests alone), so the device takes the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction
+// correctly rounded division: an error of 6e-8 * t in an entry / exit distance is far inside the boxes' padding (2e-5 relative).
 MTR_HD float safe_rcp(float x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(x);
+#else
     float r = 1.0f / x;
+#endif
     return (fabsf(r) <= 1e28f) ? r : copysignf(1e28f, x);
 }
 
@@ -840,7 +870,7 @@ struct BounceStats { uint32_t closest, shadow; };
 MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderConst &rc, uint32_t pixel, uint32_t s)
 {
     uint32_t lane = pixel * rc.spp_total + s;
-    uint32_t py = pixel / f.crop_w, px = pixel - f.crop_w * py;
+    uint32_t py = fastdiv(pixel, rc.div_crop_w), px = pixel - f.crop_w * py;
     p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
     p.rng = rng_seed(rc.seed, lane);
     float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
@@ -1052,18 +1082,24 @@ template <class Stack, class Sink>
 MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
                         Stack &st, Sink &sink, BounceStats &stats)
 {
+    st.prof_mark(2);
     Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
+    st.prof_mark(0);
     stats.closest++;
     Pending pd; Ray shadow;
     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
     shade_hit(p, h, sc, film, rc, sink, pd, shadow);
+    st.prof_mark(1);
     bool occluded = false;
     if (pd.has_shadow) {
         stats.shadow++;
         Hit sh = traverse<true>(sc, shadow.o, shadow.d, shadow.tmax, st);
         occluded = sh.prim >= 0;
     }
-    return shade_finish(p, h, occluded, pd, sc, film, rc, sink);
+    st.prof_mark(0);
+    const bool an = shade_finish(p, h, occluded, pd, sc, film, rc, sink);
+    st.prof_mark(1);
+    return an;
 }
 
 } // namespace mtr

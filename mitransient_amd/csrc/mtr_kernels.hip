@@ -226,11 +226,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     Path p;
     uint32_t q = 0, slot = 0;
     for (;;) {
+        st.prof_mark(4);                 // (experiment builds) sections: 0 traversal, 1 shading, 2 path start, 3 end-of-path bookkeeping, 4 row flush, 5 idle
         if (__ballot(waiting) != 0ull) {
             bool started = false;
             if (waiting) {
-                q = i / a.spp_chunk;
-                slot = q % K;
+                q = fastdiv(i, a.div_spp);
+                slot = q - fastdiv(q, a.div_G) * K;
                 if (__hip_atomic_load(s_owner + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == q) {
                     const uint32_t s = a.spp_begin + (i - q * a.spp_chunk);
                     const uint32_t pixel = pixel_of(q);
@@ -241,16 +242,17 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                         if (h0.prim >= 0) p.dist = -h0.t;
                     }
                     alive = true; waiting = false; started = true;
-                    st.prof_mark(2);
                 }
             }
             const uint32_t n_started = (uint32_t)__popcll(__ballot(started));
             w_paths += n_started;
             if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) w_closest += n_started;
         }
+        st.prof_mark(2);
         if (__ballot(alive) == 0ull) {
             if (__ballot(waiting) == 0ull) break;        // the whole wave is out of work
             __builtin_amdgcn_s_sleep(8);                 // every lane waits for a row another wave is about to flush
+            st.prof_mark(5);
             continue;
         }
         bool closes = false;
@@ -279,7 +281,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     float *sp = s_steady + 4 * slot;
                     lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
                 }
-                // acq_rel: this lane's row / steady adds are performed before the count that may release the row
+                // acq_rel: this lane's row / steady adds are performed before the count that may release the row.
+                // (One atomic per wave for the next samples and one per (wave, slot) for the count — ballots, readlanes and a
+                // leader lane — was measured: end-of-path bookkeeping 8.0 -> 11.0 % of the wave's time; not kept.)
                 closes = __hip_atomic_fetch_add(s_done + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == a.spp_chunk;
                 i = atomicAdd(s_next, 1u);
                 waiting = i < n_lanes;
@@ -289,6 +293,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             w_shadow += (uint32_t)__popcll(__ballot(did_shadow != 0u));
             w_splats += (uint32_t)__popcll(__ballot((did_splats & 1u) != 0u)) + 2u * (uint32_t)__popcll(__ballot((did_splats & 2u) != 0u));
         }
+        st.prof_mark(3);
         // ---- flush: each film row is touched once, by the wave that ended its last path, coalesced (16 B / lane) ----
         for (unsigned long long cm = __ballot(closes); cm != 0ull; cm &= cm - 1ull) {
             const int src = __ffsll((long long)cm) - 1;
@@ -383,7 +388,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     }
 #endif
 #ifdef MTR_PROFILE_CYCLES
-    if ((tid & 63) == 0 && a.counters) {      // one lane per wave; sections: 0 closest 1 any-hit 2 regen 3 shade-A 4 shade-B 5 loop/rest
+    if ((tid & 63) == 0 && a.counters) {      // one lane per wave; sections: see the top of the persistent loop
         st.prof_mark(5);
         unsigned long long *c = &a.counters->splats_overflow;      // reuse 3 spare u64 slots: packed pairs of 32-bit Mcycles
         atomicAdd(c + 0, ((st.cyc[0] >> 10) << 32) | (st.cyc[1] >> 10));
@@ -424,6 +429,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
+    args.div_G = fastdiv_make(G); args.div_spp = fastdiv_make(spp_chunk);
     cfg.stack = stack;
     cfg.lds_bytes = fixed + align16(G * 16) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
     if (cfg.lds_bytes > kLdsMax) return false;

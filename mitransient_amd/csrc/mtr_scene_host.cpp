@@ -333,6 +333,7 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
 RenderConst make_render_const(const mtr_render_params &p, const Film &f, uint32_t n_emitters)
 {
     RenderConst rc{};
+    rc.div_crop_w = fastdiv_make(f.crop_w);
     rc.spp_total = p.spp_total; rc.seed = p.seed;
     rc.max_depth = p.max_depth < 0 ? 0xffffffffu : (uint32_t)p.max_depth;
     rc.rr_depth = (uint32_t)p.rr_depth; rc.flags = p.flags;
