@@ -23,6 +23,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SPLAT_BYTES = 24.0         # algorithmic bytes per issued time-bin contribution
+# f32 vector (VALU) roof: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-operations/s (one v_fma_f32 of a wave64 occupies its
+# SIMD for 2 cycles; x2 flops per fma = the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
 SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry)
@@ -73,26 +76,53 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
     k = int(max(1, min(spp_total - 3, target_s / dt_per_spp)))
     p = integ.render_params(film, 0, spp_total, 3, 3 + k)
     t0 = time.perf_counter()
+    bufs[0].fill(0.0)                     # TransientImageBlock.clear is part of a render
+    bufs[1].fill(0.0)
+    t_clear = time.perf_counter() - t0
     _, _, c = oracle.render(sd, p, use_bvh=use_bvh, out=bufs)
     dt = time.perf_counter() - t0
     rays = c["rays_closest"] + c["rays_shadow"]
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
             "time_bins_per_s": c["splats_issued"] / dt,
             "sample": f"{width}x{height} px, {bins} bins, samples 3..{2 + k} of {spp_total} per pixel "
-                      f"({c['paths']} paths in {dt:.1f} s; oracle {'BVH' if use_bvh else 'brute-force'} intersection, OpenMP {cores} threads, "
-                      f"film pre-faulted and not cleared inside the timed region)"}
+                      f"({c['paths']} paths in {dt:.1f} s incl. {t_clear:.1f} s film clear; oracle {'BVH' if use_bvh else 'brute-force'} "
+                      f"intersection, OpenMP {cores} threads, film pre-faulted)",
+            "note": "the build's own scalar C restatement (libm, one lane at a time, no SIMD packets): NOT Mitsuba's Embree / "
+                    "Dr.Jit-LLVM path, which is not installable here; the GPU/CPU ratio says little about kernel quality"}
 
 
-def traffic_from_profiles(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/profile.sh: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    None when no profile of this kernel is committed: bench.py itself cannot collect PMC counters."""
+def pmc_from_profiles(kernel):
+    """Counters per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/profile.sh: separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    {} when no profile of this kernel is committed: bench.py itself cannot collect PMC counters."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(kernel, {}).get("hbm_bytes_per_launch")
+            return json.load(fh).get(kernel, {}) or {}
     except Exception:
+        return {}
+
+
+def traffic_from_profiles(kernel):
+    return pmc_from_profiles(kernel).get("hbm_bytes_per_launch")
+
+
+def valu_roofline(kernel, avg_launch_ms, workload_matches):
+    """The path kernel is bound by VALU issue + SIMT divergence, not by HBM: achieved = VALU lane-operations
+    per launch (SQ_INSTS_VALU x active lanes per instruction, from the committed PMC pass of the SAME workload) / the
+    launch time measured live with HIP events; peak = the f32 vector roof."""
+    c = pmc_from_profiles(kernel)
+    if not workload_matches or "valu_insts_per_launch" not in c or avg_launch_ms <= 0:
         return None
+    lane_ops = c["valu_insts_per_launch"] * c["valu_lanes_per_inst"]
+    achieved = lane_ops / (avg_launch_ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+            "frac": achieved / VALU_PEAK_TLANEOPS,
+            "valu_issue_frac": c["valu_insts_per_launch"] * 2.0 / (1024 * avg_launch_ms * 1e-3 * 2.4e9),
+            "lanes_per_valu_inst": c["valu_lanes_per_inst"], "valu_insts_per_launch": c["valu_insts_per_launch"],
+            "traffic": c.get("hbm_bytes_per_launch"), "avg_launch_ms": avg_launch_ms,
+            "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
+                      + str(c.get("profile", "")) + ") over the launch time measured live (HIP events)"}
 
 
 def main():
@@ -126,8 +156,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node N for --gpus N")
     # dry-run hooks (single-GPU box): MTR_BENCH_DEVICE pins every rank to one device, MTR_BENCH_BACKEND=gloo
     # replaces RCCL (which needs one device per rank) so that the N>1 code path can be exercised end to end
     device_index = int(os.environ.get("MTR_BENCH_DEVICE", local_rank))
@@ -140,15 +169,19 @@ def main():
             # where, with equal priority, the next path kernel would take every slot first and the communication of all
             # bands would pile up behind the last one.  (The path kernel does not mind starting a few workgroups late:
             # its work is drawn from a ticket counter.)
-            opts = None
-            try:
-                opts = dist.ProcessGroupNCCL.Options()
-                opts.is_high_priority_stream = True
-            except Exception:
-                opts = None
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), pg_options=opts)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+
+    # the CPU baseline runs FIRST (rank 0, N = 1): the GPU legs then sit at the end of the command, where a coarse
+    # utilisation sampler cannot miss them behind ~20 s of host work
+    cpu_res = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(args.width, args.height, args.bins, args.spp, args.cpu_seconds)
 
     scene = build_scene(args.width, args.height, args.bins, mode=args.mode)
     integ = scene.integrator()
@@ -251,17 +284,30 @@ def main():
                                              else "auto (wavefront: scene in HBM)")},
             # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
             # `scatter_add` below is the stand-alone scatter-add kernel of the wavefront organisation
-            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_fused") if kname == "k_fused" else None,
-                         "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
             "counters_per_step": {k: v / args.steps for k, v in totals.items()},
         }
+        hbm_line = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_fused") if kname == "k_fused" else None,
+                    "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
+                    "algorithmic_bytes_per_launch": bytes_per_launch}
+        # the dominant kernel's bound: k_fused keeps the scatter-add in LDS, so the HBM line only says how little it moves;
+        # what bounds it is VALU issue at ~27 of 64 active lanes (PMC passes of the same workload, profiles/)
+        default_wl = (SCENE == "cornell" and (args.width, args.height, args.bins, args.spp) == dflt and world >= 1)
+        vline = valu_roofline("k_fused", avg_ms, default_wl) if fused else None
+        if vline is not None:
+            vline["launches_per_step"] = n_launch / args.steps
+            res["roofline"] = vline
+            res["roofline_hbm"] = hbm_line
+        else:
+            res["roofline"] = hbm_line
+        if world > 1:
+            res["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
+            res["comm_backend"] = backend
         if scatter:
             res["scatter_add"] = scatter
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.width, args.height, args.bins, args.spp, args.cpu_seconds)
-            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        if cpu_res is not None:
+            res["cpu_baseline"] = cpu_res
+            res["gpu_over_cpu"] = res["value"] / cpu_res["value"]
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -139,6 +139,10 @@ typedef struct mtr_nlos_desc {
                                        (transientnlospath.py:346-376); the grid is film.laser_scan_width x _height */
     uint32_t n_shapes;
     const mtr_shape *shapes;        /* host; every triangle of the scene belongs to exactly one shape      */
+    /* `is_confocal` capture meter (nloscapturemeter.py:111-119, :142): a 1 x 1 film whose every sensor ray goes to
+     * nlos_capture_meter.laser_target (set by mitransient.nlos.focus_emitter_*) instead of the pixel-centre grid */
+    uint32_t sensor_is_confocal;
+    float    sensor_target[3];
 } mtr_nlos_desc;
 
 typedef struct mtr_scene_desc {
@@ -190,7 +194,10 @@ typedef struct mtr_render_params {
     int32_t  rr_depth;
     uint32_t flags;         /* MTR_FLAG_*                                                       */
     uint32_t mode;          /* MTR_MODE_*                                                       */
-    uint32_t reserved[6];
+    uint32_t spp_scale;     /* 0, or the sample count of the WHOLE multi-pass render (common.py:56-85: above 2^32 lanes
+                               the reference renders passes of their own sampler each — lanes of a pass are indexed with
+                               spp_total = the PASS's samples — while sample_scale stays 1/total_spp, :173-175)       */
+    uint32_t reserved[5];
 } mtr_render_params;
 
 /* in-kernel counters */

@@ -66,7 +66,8 @@ class mtr_nlos_desc(C.Structure):
     _fields_ = [("sensor_origin", _f3), ("relay_shape", C.c_uint32), ("laser_to_world", _f16),
                 ("laser_fov", C.c_float), ("laser_irradiance", _f3), ("laser_scale", C.c_float),
                 ("capture_type", C.c_uint32), ("flags", C.c_uint32), ("filter_depth", C.c_int32),
-                ("illumination_scan_fov", C.c_float), ("n_shapes", C.c_uint32), ("shapes", C.POINTER(mtr_shape))]
+                ("illumination_scan_fov", C.c_float), ("n_shapes", C.c_uint32), ("shapes", C.POINTER(mtr_shape)),
+                ("sensor_is_confocal", C.c_uint32), ("sensor_target", _f3)]
 
 
 class mtr_scene_desc(C.Structure):
@@ -90,7 +91,7 @@ class mtr_render_params(C.Structure):
     _fields_ = [("spp_total", C.c_uint32), ("spp_begin", C.c_uint32), ("spp_end", C.c_uint32),
                 ("pixel_begin", C.c_uint32), ("pixel_end", C.c_uint32),
                 ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
-                ("flags", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("flags", C.c_uint32), ("mode", C.c_uint32), ("spp_scale", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class mtr_counters(C.Structure):

@@ -45,6 +45,8 @@ struct NlosConst {
     uint32_t camera_sensor;            // 1: the sensor is the scene's perspective camera (no nlos_capture_meter / relay wall)
     Camera cam;                        // ... that camera
     float inv_w, inv_h;                // 1 / film size (film sample of a pixel corner)
+    uint32_t sensor_confocal;          // is_confocal capture meter: every sensor ray goes to sensor_target (nloscapturemeter.py:142)
+    f3 sensor_target;
 };
 
 MTR_HD uint32_t nlos_target_count(const NlosConst &nc) { return nc.film_w * nc.film_h + 1u + nc.laser_w * nc.laser_h; }
@@ -76,7 +78,8 @@ MTR_HD Ray nlos_sensor_ray(const NlosConst &nc, float sx, float sy)
 {
     const float W = (float)nc.film_w, H = (float)nc.film_h;
     const float gx = (floorf(sx * W) + 0.5f) / W, gy = (floorf(sy * H) + 0.5f) / H;
-    const f3 target = rect_point(nc.w_center, nc.w_du, nc.w_dv, gx, gy);
+    f3 target = rect_point(nc.w_center, nc.w_du, nc.w_dv, gx, gy);
+    if (nc.sensor_confocal) target = nc.sensor_target;
     f3 dir = target - nc.sensor_origin;
     const float dist = sqrtf(dot(dir, dir));
     Ray r; r.o = nc.sensor_origin; r.d = dir / dist; r.tmax = kInf;

@@ -275,6 +275,10 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
     memcpy(k.cam.tw, d.camera.to_world, sizeof k.cam.tw);
     k.cam.near_clip = d.camera.near_clip; k.cam.far_clip = d.camera.far_clip;
     k.inv_w = 1.0f / (float)d.film.width; k.inv_h = 1.0f / (float)d.film.height;
+    k.sensor_confocal = n->sensor_is_confocal ? 1u : 0u;
+    k.sensor_target = ld3(n->sensor_target);
+    if (n->sensor_is_confocal && (camera_sensor || d.film.width != 1 || d.film.height != 1))
+        return "Confocal configuration requires a nlos_capture_meter with a film of size [1,1]";
     if (!camera_sensor) {
         const mtr_shape &rw = n->shapes[n->relay_shape];
         k.w_center = ld3(rw.center); k.w_du = ld3(rw.du); k.w_dv = ld3(rw.dv);
@@ -337,7 +341,7 @@ RenderConst make_render_const(const mtr_render_params &p, const Film &f, uint32_
     rc.spp_total = p.spp_total; rc.seed = p.seed;
     rc.max_depth = p.max_depth < 0 ? 0xffffffffu : (uint32_t)p.max_depth;
     rc.rr_depth = (uint32_t)p.rr_depth; rc.flags = p.flags;
-    rc.sample_scale = (float)(1.0 / (double)p.spp_total);          // common.py:173-175
+    rc.sample_scale = (float)(1.0 / (double)(p.spp_scale ? p.spp_scale : p.spp_total));          // common.py:173-175 (total_spp of all passes)
     rc.inv_crop_w = 1.0f / (float)f.crop_w; rc.inv_crop_h = 1.0f / (float)f.crop_h;
     rc.off_x = -(float)f.crop_x * rc.inv_crop_w; rc.off_y = -(float)f.crop_y * rc.inv_crop_h;
     rc.n_emitters_f = (float)n_emitters;

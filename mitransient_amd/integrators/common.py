@@ -39,6 +39,8 @@ class TransientADIntegrator:
         m = props.get("amd_mode", None)
         if m is not None:
             self.mode = {"auto": 0, "fused": 1, "wavefront": 2}[m]
+        self.max_wavefront_size = 2 ** 32          # common.py:51: lanes of one pass
+        self.pass_wavefront_size = 2 ** 26 - 1     # common.py:60: lanes per pass once the render is split
         self.last_counters = None      # counters / kernel times of the last mtr_render call ...
         self.last_times = None
         self.total_counters = None     # ... and summed over every pass since the last prepare()
@@ -58,15 +60,36 @@ class TransientADIntegrator:
         sampler.set_samples_per_wavefront(spp)
         film_size = film.crop_size()
         self.total_counters, self.total_times = None, None
-        wavefront_size = film_size[0] * film_size[1] * spp
-        if wavefront_size <= 2 ** 32:
-            film.prepare(aovs)
+        n_pixels = film_size[0] * film_size[1]
+        wavefront_size = n_pixels * spp
+        if wavefront_size > self.max_wavefront_size and int(self.pass_wavefront_size / n_pixels) == 0:
+            raise Exception("Your film is too big. Please make it smaller.")      # (before the film's storage is allocated)
+        film.prepare(aovs)
+        if wavefront_size <= self.max_wavefront_size:
             sampler.seed(seed, wavefront_size)
             return [(sampler, spp)]
-        # common.py:56-85 splits >2^32-sample renders into passes whose seeds are drawn
-        # from a seeder sampler; that multi-pass seeding is not reproduced (no config needs it).
-        raise Exception("renders above 2^32 samples (multi-pass seeding, common.py:56-85) are not supported; "
-                        "shard spp across GPUs or reduce spp")
+        # common.py:56-85: more than 2^32 samples cannot run in one pass (32-bit lane index); the reference goes down to
+        # 2^26 per pass, each pass with its own sampler whose seed is drawn from a seeder sampler
+        spp_per_pass = int(self.pass_wavefront_size / n_pixels)
+        if spp_per_pass == 0:
+            raise Exception("Your film is too big. Please make it smaller.")
+        needs_remainder = spp % spp_per_pass != 0
+        num_passes = spp // spp_per_pass + 1 * needs_remainder
+        sampler.set_sample_count(num_passes)
+        sampler.set_samples_per_wavefront(num_passes)
+        sampler.seed(seed, num_passes)
+        import numpy as np
+        seeds = (sampler.next_1d_first() * np.float32(2 ** 32)).astype(np.uint32)      # mi.UInt32(sampler.next_1d() * 2**32)
+
+        def sampler_per_pass(i):
+            spp_i = spp % spp_per_pass if (needs_remainder and i == num_passes - 1) else spp_per_pass
+            clone = sensor.sampler().clone()
+            clone.set_sample_count(spp_i)
+            clone.set_samples_per_wavefront(spp_i)
+            clone.seed(int(seeds[i]), n_pixels * spp_i)
+            return clone, spp_i
+
+        return [sampler_per_pass(i) for i in range(num_passes)]
 
     def check_transient_(self, scene, sensor):
         if isinstance(sensor, int):
@@ -88,9 +111,10 @@ class TransientADIntegrator:
         return f
 
     def render_params(self, film, seed_value, spp_total, spp_begin=0, spp_end=None,
-                      pixel_begin=0, pixel_end=None) -> _cabi.mtr_render_params:
+                      pixel_begin=0, pixel_end=None, spp_scale=0) -> _cabi.mtr_render_params:
         p = _cabi.mtr_render_params()
         p.spp_total = spp_total
+        p.spp_scale = spp_scale          # multi-pass renders: sample_scale = 1 / total_spp of all passes (common.py:173-175)
         p.spp_begin = spp_begin
         p.spp_end = spp_total if spp_end is None else spp_end
         cw, ch = film.crop_size()
@@ -126,10 +150,15 @@ class TransientADIntegrator:
         handle = scene.gpu_handle(ctx, sensor)
         tptr = C.c_void_p(film.transient_storage.torch_tensor().data_ptr())
         sptr = C.c_void_p(film.steady_accum().data_ptr())
+        multi = len(samplers_spps) > 1
+        if multi and spp_range is not None:
+            raise NotImplementedError("sample sharding of a multi-pass (> 2^32 lanes) render: shard by rows instead")
         for i, (sampler_i, spp_i) in enumerate(samplers_spps):
             s0, s1 = (0, spp_i) if spp_range is None else spp_range
             p0, p1 = (0, None) if pixel_range is None else pixel_range
-            params = self.render_params(film, sampler_i.seed_value(), total_spp, s0, s1, p0, p1)
+            # a pass of a split render indexes its lanes with ITS sample count (its own sampler) and scales by the total
+            params = self.render_params(film, sampler_i.seed_value(), spp_i if multi else total_spp, s0, s1, p0, p1,
+                                        spp_scale=total_spp if multi else 0)
             if film.film_is_zero:
                 params.flags |= _cabi.MTR_FLAG_FILM_ZERO      # first pass after clear(): row flushes may store
             film.film_is_zero = False

@@ -225,7 +225,9 @@ class Scene:
             # four device tables and retraces the scanned points, which is not free per pass / per band
             d = sd.desc()
             n = sd.nlos
-            fp = (bytes(memoryview(n))[:C.sizeof(type(n)) - C.sizeof(C.c_void_p)], bytes(memoryview(sd.shapes)),
+            n_val = type(n).from_buffer_copy(n)
+            n_val.shapes = None                       # the table is compared by value, not by address
+            fp = (bytes(n_val), bytes(memoryview(sd.shapes)),
                   int(fd.width), int(fd.height), int(fd.laser_scan_width), int(fd.laser_scan_height))
             if self._nlos_fp.get(key) != fp:
                 ctx.check(ctx.lib.mtr_scene_set_nlos(h, d.nlos), "mtr_scene_set_nlos")

@@ -50,9 +50,15 @@ class TransientImageBlock:
         shape = ((H, W, self.laser_scan_height, self.laser_scan_width, T, self.channel_count) if self.exhaustive_scan
                  else (H, W, T, self.channel_count))
         if self._tensor is None or tuple(self._tensor.shape) != shape:
-            self._tensor = torch.zeros(shape, dtype=torch.float32, device=dev)
-        else:
-            self._tensor.zero_()
+            self._tensor = torch.empty(shape, dtype=torch.float32, device=dev)
+        # TransientImageBlock.clear (transient_image_block.py:56-70) = mtr_film_clear on the context's stream
+        fd = _cabi.mtr_film_desc()
+        fd.width, fd.height, fd.crop_width, fd.crop_height = W, H, W, H
+        fd.temporal_bins, fd.bin_width_opl = T, 1.0
+        fd.laser_scan_width, fd.laser_scan_height = self.laser_scan_width, self.laser_scan_height
+        ctx = get_context(self._tensor.device.index)
+        ctx.bind_current_stream()
+        ctx.check(ctx.lib.mtr_film_clear(ctx.handle, C.byref(fd), C.c_void_p(self._tensor.data_ptr()), None), "mtr_film_clear")
 
     @property
     def tensor(self) -> TensorXf:

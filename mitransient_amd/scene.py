@@ -554,6 +554,10 @@ def nlos_desc_from(integrator, sensor, emitter, relay_shape: int) -> _cabi.mtr_n
     n.flags = int(integrator.nlos_flags())
     n.filter_depth = int(integrator.filter_depth)
     n.illumination_scan_fov = np.float32(integrator.illumination_scan_fov)
+    n.sensor_is_confocal = 1 if getattr(sensor, "is_confocal", False) else 0
+    tgt = np.asarray(getattr(sensor, "laser_target", (0.0, 0.0, 0.0)), dtype=np.float64).reshape(3)
+    for k in range(3):
+        n.sensor_target[k] = np.float32(tgt[k])
     return n
 
 

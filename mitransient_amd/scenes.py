@@ -127,13 +127,13 @@ def from_fixture(path, film=None, integrator=None, spp=None):
     return mi.Scene({"type": "scene", "integrator": integ, "sensor": sensor}, geometry=g)
 
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")       # scene data shipped with the package
 
 
 def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, **integrator):
     """BASELINE config 5: the reference's examples/diff-transient/staircase/scene.xml ('The Wooden Staircase' by
     Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles, flattened with approximate_materials=True
     (roughplastic -> diffuse, roughconductor -> conductor, bitmap -> mean colour, bump map ignored)."""
-    return from_fixture(os.path.join(GOLDEN_DIR, "staircase_geometry.npz"),
+    return from_fixture(os.path.join(DATA_DIR, "staircase_geometry.npz"),
                         film={"width": width, "height": height, "temporal_bins": temporal_bins},
                         integrator=dict(max_depth=max_depth, **integrator), spp=spp)

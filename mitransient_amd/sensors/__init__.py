@@ -35,6 +35,35 @@ class IndependentSampler:
     def seed_value(self):
         return self._seed_value
 
+    # -- the few host-side draws the plugin layer makes itself (the seeder of multi-pass renders, common.py:72-75) --
+    @staticmethod
+    def _tea(v0, v1, rounds=4):
+        M = 0xFFFFFFFF
+        s = 0
+        for _ in range(rounds):
+            s = (s + 0x9E3779B9) & M
+            v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) ^ ((v1 + s) & M) ^ ((v1 >> 5) + 0xC8013EA4))) & M
+            v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) ^ ((v0 + s) & M) ^ ((v0 >> 5) + 0x7E95761E))) & M
+        return v0, v1
+
+    def next_1d_first(self):
+        """The FIRST ``next_1d()`` of every lane of the seeded wavefront, as float32 values: lane j's PCG32 stream is
+        seeded with TEA(seed_value, j) [mitsuba3: independent.cpp seed(); drjit PCG32]; same integers as the kernels."""
+        import numpy as np
+        M64 = (1 << 64) - 1
+        out = np.empty(self._wavefront_size, np.float32)
+        for j in range(self._wavefront_size):
+            v0, v1 = self._tea(self._seed_value, j)
+            inc = ((v1 << 1) | 1) & M64
+            state = (0 * 0x5851F42D4C957F2D + inc) & M64                 # state = 0; next(); state += initstate; next()
+            state = (state + v0) & M64
+            old = state = (state * 0x5851F42D4C957F2D + inc) & M64
+            xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+            rot = old >> 59
+            u = ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+            out[j] = np.array([(u >> 9) | 0x3F800000], np.uint32).view(np.float32)[0] - np.float32(1.0)
+        return out
+
 
 class PerspectiveSensor:
     def __init__(self, sensor_dict, film, sampler):

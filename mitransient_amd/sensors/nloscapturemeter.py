@@ -17,11 +17,18 @@ class NLOSCaptureMeter:
         self.sensor_origin = np.asarray(o, dtype=np.float64).reshape(3)
         self.laser_bounce_opl = 0.0
         self.laser_target = np.zeros(3)
-        if props.get("original_film_width", None) is not None or props.get("original_film_height", None) is not None:
-            raise NotImplementedError("is_confocal sensors (1x1 film + original_film_*) are not built; "
-                                      "use capture_type='confocal' on the integrator")
-        self.film_size = (float(film.size()[0]), float(film.size()[1]))
-        self.is_confocal = False
+        # nloscapturemeter.py:111-119: a confocal meter scans one point at a time — a 1 x 1 film, the scan resolution
+        # in original_film_*, every sensor ray aimed at laser_target (:142)
+        self.original_film_width = props.get("original_film_width", None)
+        self.original_film_height = props.get("original_film_height", None)
+        if self.original_film_width is None or self.original_film_height is None:
+            self.film_size = (float(film.size()[0]), float(film.size()[1]))
+            self.is_confocal = False
+        else:
+            self.film_size = (float(self.original_film_width), float(self.original_film_height))
+            self.is_confocal = True
+            if tuple(film.size()) != (1, 1):
+                raise RuntimeError(f"Confocal configuration requires a film with size [1,1] instead of {list(film.size())}")
         self.shape_ = None
         self.dict_ = None
 

@@ -773,7 +773,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
 {
     const mtr_scene_desc *d = sc->d; const mtr_film_desc *f = &d->film;
     const uint32_t spp = P->spp_total;
-    const float sample_scale = (float)(1.0 / (double)spp);               /* common.py:173-175: python float 1.0/total_spp */
+    const float sample_scale = (float)(1.0 / (double)(P->spp_scale ? P->spp_scale : spp));               /* common.py:173-175: python float 1.0/total_spp */
     const uint32_t max_depth = P->max_depth < 0 ? 0xffffffffu : (uint32_t)P->max_depth;
     const uint32_t rr_depth = (uint32_t)P->rr_depth;
 
@@ -1015,6 +1015,8 @@ static ray3 nlos_sensor_ray(const nlos_scene *N, const mtr_film_desc *f, float s
     float W = (float)f->width, H = (float)f->height;
     float gx = (floorf(sx * W) + 0.5f) / W, gy = (floorf(sy * H) + 0.5f) / H;     /* :146-149 pixel centre */
     v3 target = rect_point(N->w_center, N->w_du, N->w_dv, gx, gy);
+    if (N->n->sensor_is_confocal)                                                  /* :142 target = self.laser_target */
+        target = V(N->n->sensor_target[0], N->n->sensor_target[1], N->n->sensor_target[2]);
     v3 o = V(N->n->sensor_origin[0], N->n->sensor_origin[1], N->n->sensor_origin[2]);
     v3 dir = vsub(target, o);
     float dist = sqrtf(vdot(dir, dir));
@@ -1254,7 +1256,7 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
 {
     const mtr_scene_desc *d = sc->d; const mtr_film_desc *f = &d->film; const mtr_nlos_desc *n = N->n;
     const uint32_t spp = P->spp_total;
-    const float sample_scale = (float)(1.0 / (double)spp);
+    const float sample_scale = (float)(1.0 / (double)(P->spp_scale ? P->spp_scale : spp));
     const uint32_t max_depth = P->max_depth < 0 ? 0xffffffffu : (uint32_t)P->max_depth;
     const uint32_t rr_depth = (uint32_t)P->rr_depth;
     uint32_t idx = lane / spp;

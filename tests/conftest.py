@@ -70,7 +70,7 @@ def hh_render(lib, sd, params):
 
 
 def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, film=None,
-              laser_fov=0.2, **integ):
+              laser_fov=0.2, sensor_extra=None, focus=None, **integ):
     """NLOS scene in the style of tests/integration/test_nlos.py:1-78 and examples/transient-nlos/nlos_Z.xml:
     2x2 relay wall at the origin with a nlos_capture_meter, projector laser and sensor at (-0.5, 0, 0.25),
     hidden geometry at z = 1 (a 0.8 x 0.8 quad, or a procedural 'Z' of 6 triangles / 3 quads)."""
@@ -81,10 +81,12 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
     fd = {"type": "transient_hdr_film", "width": sx, "height": sy, "temporal_bins": bins,
           "bin_width_opl": bin_width, "start_opl": start, "rfilter": {"type": "box"}}
     fd.update(film or {})
+    meter = {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
+             "sensor_origin": [-0.5, 0.0, 0.25], "film": fd}
+    meter.update(sensor_extra or {})
     relay = mi.load_dict({
         "type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}},
-        "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
-                        "sensor_origin": [-0.5, 0.0, 0.25], "film": fd}})
+        "nlos_sensor": meter})
     laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
                           "irradiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}, "fov": laser_fov})
     idict = {"type": "transient_nlos_path", "max_depth": -1, "nlos_laser_sampling": True,
@@ -99,7 +101,7 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
         d["z_bot"] = {"type": "cube", "to_world": T().translate([0.0, -0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}
         d["z_diag"] = {"type": "cube", "to_world": T().translate([0.0, 0.0, 1.0]).rotate([0, 0, 1], 40.0).scale([0.5, 0.05, 0.004]), "bsdf": white}
     scene = mi.load_dict(d)
-    mitr.nlos.focus_emitter_at_relay_wall_pixel((sx / 2, sy / 2), relay, laser)
+    mitr.nlos.focus_emitter_at_relay_wall_pixel(focus if focus is not None else (sx / 2, sy / 2), relay, laser)
     return scene
 
 

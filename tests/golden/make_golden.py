@@ -10,7 +10,7 @@ authoring container (no network, no wheel), and its only test holds no numeric v
                            (independent of the C oracle and of the HIP code);
   * cornell_c1_oracle.npz — a regression snapshot of the oracle on BASELINE config 1
                            (per-pixel and per-bin marginals + checksum), NOT a reference output.
-  * cbox_diffuse_scene.npz, cbox_mirror_scene.npz, nlos_Z_geometry.npz, staircase_geometry.npz —
+  * cbox_diffuse_scene.npz, cbox_mirror_scene.npz, nlos_Z_geometry.npz, ../../mitransient_amd/data/staircase_geometry.npz —
                            DATA of the reference's example scenes (examples/transient/cornell-box/*.xml,
                            examples/transient-nlos/Z.obj, examples/diff-transient/staircase/scene.xml = BASELINE
                            config 5): the triangles in world space, material / emitter tables and the sensor /
@@ -86,7 +86,7 @@ def example_scenes():
         sc = mi.load_file(f"{ref}/transient/cornell-box/{name}.xml")
         save_fixture(sc, os.path.join(HERE, f"{name}_scene.npz"), source=f"examples/transient/cornell-box/{name}.xml")
     sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials=True)
-    save_fixture(sc, os.path.join(HERE, "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
+    save_fixture(sc, os.path.join(ROOT, "mitransient_amd", "data", "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
                  approximate_materials=True)
     np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
 

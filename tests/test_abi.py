@@ -73,3 +73,36 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "libmtr_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def _build_abi_smoke():
+    """tests/abi_smoke.c: the boundary from plain C (gcc, the header, the HIP runtime's C API) — no Python, no torch"""
+    import subprocess
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "abi_smoke")
+    libdir = os.path.join(ROOT, "mitransient_amd", "csrc")
+    cmd = ["gcc", "-O1", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "abi_smoke.c"),
+           "-o", exe, "-L", libdir, "-lmitransient_amd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_c_smoke_links_against_the_header_and_fails_loudly_without_a_gpu():
+    import subprocess
+    import torch
+    exe = _build_abi_smoke()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_c_smoke_renders_on_the_gpu")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 3 and "no CPU path" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_c_smoke_renders_on_the_gpu():
+    import subprocess
+    exe = _build_abi_smoke()
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_smoke: PASS" in r.stdout, r.stdout

@@ -180,3 +180,16 @@ def test_notebook_flow(tmp_path, oracle, capture):
         assert np.linalg.norm(t3) > 0 and rel_l2(t[..., 0], t3[..., 0]) <= TOL
     finally:
         mi.set_variant("llvm_ad_rgb")
+
+
+def test_is_confocal_capture_meter_gpu(oracle):
+    """1 x 1 film + original_film_*: every sensor ray goes to the laser's focus point (nloscapturemeter.py:111-119, :142)"""
+    scene = make_nlos(sx=1, sy=1, capture="single", spp=2048, focus=(2.5, 6.5), bins=128, bin_width=0.02, hidden="z",
+                      sensor_extra={"original_film_width": 8, "original_film_height": 8}, max_depth=5)
+    s_gpu, t_gpu = _gpu(scene, 2048)
+    s_ref, t_ref, cnt = _oracle(oracle, scene, 2048)
+    assert t_gpu.shape == (1, 1, 128, 3) and np.count_nonzero(t_ref) > 20
+    assert rel_l2(t_gpu, t_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

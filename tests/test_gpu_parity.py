@@ -295,10 +295,45 @@ def test_errors_fail_loudly():
     import mitransient_amd.mi as mi
     from mitransient_amd._cabi import MitransientAMDError
     d = mitr.cornell_box()
-    d["sensor"]["film"].update(width=4096, height=4096)
+    d["sensor"]["film"].update(width=16384, height=16384, temporal_bins=4)
     scene = mi.load_dict(d)
-    with pytest.raises(Exception):
-        mi.render(scene, spp=1024)            # 2^34 lanes > 2^32 (common.py:51)
+    with pytest.raises(Exception, match="film is too big"):
+        mi.render(scene, spp=64)              # 2^34 lanes > 2^32 and 2^28 pixels > 2^26 lanes per pass (common.py:62-63)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_multi_pass_seeding(oracle, mode):
+    """common.py:56-85: a render above the single-pass lane limit is split into passes of floor((2^26-1)/(W*H)) samples, each
+    with its own sampler seeded from a seeder sampler (+ a remainder pass); the thresholds are lowered so that a 12 x 10
+    film with 11 spp splits into 4 + 4 + 3.  GPU == oracle pass by pass (same seeds, same per-pass lanes, scale 1/11)."""
+    import torch
+    scene = make_cornell(width=12, height=10, bins=32, amd_mode=mode)
+    integ = scene.integrator()
+    integ.max_wavefront_size, integ.pass_wavefront_size = 1000, 12 * 10 * 4 + 5
+    integ.collect_stats = True
+    sens = scene.sensors()[0]
+    film = sens.film()
+    progress = []
+    steady, transient = integ.render(scene, seed=3, spp=11, progress_callback=progress.append)
+    torch.cuda.synchronize()
+    passes = integ.prepare(scene, sens, 3, 11, [])
+    assert [s for _, s in passes] == [4, 4, 3] and len({p.seed_value() for p, _ in passes}) == 3
+    assert progress == [pytest.approx(1 / 3), pytest.approx(2 / 3), pytest.approx(1.0)]
+    sd = scene.data()
+    from oracle import oracle as orc
+    bufs = orc.alloc_film(sd.film)
+    tot = {k: 0 for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")}
+    for smp, spp_i in passes:
+        _, _, c = orc.render(sd, integ.render_params(film, smp.seed_value(), spp_i, spp_scale=11), use_bvh=True, out=bufs)
+        for k in tot:
+            tot[k] += c[k]
+    t_ref, s_ref = orc.develop(sd.film, bufs[0], bufs[1])
+    assert rel_l2(np.array(transient), t_ref) <= TOL and rel_l2(np.array(steady), s_ref) <= TOL
+    assert tot["paths"] == 12 * 10 * 11
+    # (counters of the GPU render were summed over its three passes)
+    steady, transient = integ.render(scene, seed=3, spp=11)
+    for k in tot:
+        assert integ.total_counters[k] == tot[k], k
 
 
 def test_wavefront_large_tile_and_overflow(oracle):
@@ -469,7 +504,8 @@ def test_reference_example_scenes(oracle, name, mode):
     """the reference's examples/transient/cornell-box/{cbox_diffuse,cbox_mirror}.xml (flattened fixtures; the
     reference's units: box 550 wide, near clip 10, 400 bins of 6.5 from OPL 1000; mesh light, conductor + glass)"""
     import os
-    from mitransient_amd.scenes import from_fixture, GOLDEN_DIR
+    from mitransient_amd.scenes import from_fixture
+    GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     scene = from_fixture(os.path.join(GOLDEN_DIR, f"{name}_scene.npz"), film={"width": 48, "height": 48},
                          integrator={"amd_mode": mode}, spp=32)
     s_gpu, t_gpu = gpu_render(scene, 32)

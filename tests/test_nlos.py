@@ -285,3 +285,32 @@ def test_notebook_style_assembly(tmp_path, oracle, host_harness):
         assert sd.nlos.capture_type == 3 and sd.film.laser_scan_width == 8
     finally:
         mi.set_variant("llvm_ad_rgb")
+
+
+def test_is_confocal_capture_meter(oracle, host_harness):
+    """nloscapturemeter.py:111-119, :142: a 1 x 1 film + original_film_width / _height = one scanned point per render;
+    every sensor ray goes to the point the laser was focused on.  Product arithmetic == oracle bit for bit; a film that
+    is not 1 x 1 is refused with the reference's message; the energy of the point equals (statistically) that of the same
+    point in a confocal capture of the whole grid."""
+    import mitransient_amd.mi as mi
+    kw = dict(bins=64, bin_width=0.03, start=1.85, hidden="quad", max_depth=4)
+    scene = make_nlos(sx=1, sy=1, capture="single", spp=4000, focus=(3.5, 5.5),
+                      sensor_extra={"original_film_width": 8, "original_film_height": 8}, **kw)
+    meter = scene.sensors()[0]
+    assert meter.is_confocal and meter.film_size == (8.0, 8.0)
+    assert np.allclose(meter.laser_target, [2.0 * 3.5 / 8 - 1.0, 2.0 * 5.5 / 8 - 1.0, 0.0])
+    sd = scene.data()
+    assert sd.nlos.sensor_is_confocal == 1
+    p = scene.integrator().render_params(meter.film(), 0, 4000)
+    t4, s4, c = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc["bounces"] == c["bounces"]
+    assert t4.shape == (1, 1, 64, 4) and np.count_nonzero(t4) > 10
+    grid = make_nlos(sx=8, sy=8, capture="confocal", spp=4000, **kw)
+    gd = grid.data()
+    gp = grid.integrator().render_params(grid.sensors()[0].film(), 0, 4000, 0, 4000, 5 * 8 + 3, 5 * 8 + 4)     # pixel (3, 5) only
+    g4, _, _ = oracle.render(gd, gp, n_threads=1)
+    a, b = float(t4[0, 0, :, 0].sum()), float(g4[5, 3, :, 0].sum())
+    assert b > 0 and abs(a - b) <= 0.1 * b
+    with pytest.raises(RuntimeError, match=r"film with size \[1,1\]"):
+        make_nlos(sx=4, sy=4, capture="single", sensor_extra={"original_film_width": 8, "original_film_height": 8})

@@ -225,3 +225,35 @@ def test_collapsed_trees_cover_the_bvh2(host_harness, which):
     assert n8.value >= 1 and n4.value >= 1
     if which == "cornell":
         assert n8.value == 3            # walls + light under the root, one node per box
+
+
+def test_multi_pass_prepare_host_logic(oracle, host_harness, monkeypatch):
+    """TransientADIntegrator.prepare above the single-pass limit (common.py:56-85): pass sizes, the remainder pass, seeds =
+    UInt32(seeder.next_1d() * 2^32) with the seeder seeded by (seed, num_passes); product arithmetic == oracle on one pass with
+    sample_scale = 1 / total_spp (mtr_render_params.spp_scale).  film.prepare needs a GPU, so it is stubbed here."""
+    from conftest import make_cornell, hh_render
+    from mitransient_amd.films.transient_hdr_film import TransientHDRFilm
+    monkeypatch.setattr(TransientHDRFilm, "prepare", lambda self, aovs=(): 4)
+    scene = make_cornell(width=12, height=10, bins=32)
+    integ = scene.integrator()
+    sens = scene.sensors()[0]
+    assert len(integ.prepare(scene, sens, 0, 16, [])) == 1                       # 1920 lanes: one pass, seed = base + seed
+    integ.max_wavefront_size, integ.pass_wavefront_size = 1000, 12 * 10 * 4 + 5
+    passes = integ.prepare(scene, sens, 3, 11, [])
+    assert [s for _, s in passes] == [4, 4, 3]
+    seeder = [oracle.sampler_stream(3, j, 1)[0] for j in range(3)]
+    want = [int(np.uint32(np.float32(f) * np.float32(2 ** 32))) for f in seeder]
+    assert [p.seed_value() for p, _ in passes] == want
+    assert [s for _, s in integ.prepare(scene, sens, 3, 12, [])] == [4, 4, 4]    # no remainder pass
+    integ.pass_wavefront_size = 100
+    with pytest.raises(Exception, match="film is too big"):
+        integ.prepare(scene, sens, 3, 11, [])
+    sd = scene.data()
+    film = sens.film()
+    p = integ.render_params(film, passes[2][0].seed_value(), 3, spp_scale=11)
+    t4, s4, c = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and c["paths"] == 12 * 10 * 3
+    p1 = integ.render_params(film, passes[2][0].seed_value(), 3)                 # the same lanes scaled by 1/3 instead of 1/11
+    t1, _, _ = oracle.render(sd, p1, n_threads=1)
+    assert np.allclose(t4 * np.float32(11.0 / 3.0), t1, rtol=2e-6, atol=0)

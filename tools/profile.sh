@@ -45,6 +45,14 @@ for k,v in agg.items():
     traffic[m.group(0)]={"fetch_size_kib_per_launch":fetch_kb,"write_size_kib_per_launch":write_kb,
         "hbm_bytes_per_launch":(2.0*fetch_kb+write_kb)*1024.0,"dispatches_profiled":nf,
         "note":"FETCH_SIZE doubled (gfx950 wide-read correction); WRITE_SIZE uncalibrated"}
+    if v.get("SQ_ACTIVE_INST_VALU"):
+        nv=cnt[(k,"SQ_INSTS_VALU")]
+        traffic[m.group(0)].update({"valu_insts_per_launch":v["SQ_INSTS_VALU"]/nv,
+            "valu_lanes_per_inst":v["SQ_THREAD_CYCLES_VALU"]/v["SQ_ACTIVE_INST_VALU"],
+            "lds_insts_per_launch":v.get("SQ_INSTS_LDS",0.0)/nv, "salu_insts_per_launch":v.get("SQ_INSTS_SALU",0.0)/nv,
+            "wait_any_frac":v.get("SQ_WAIT_ANY",0.0)/max(1.0,v.get("SQ_WAVE_CYCLES",1.0)),
+            "wait_inst_any_frac":v.get("SQ_WAIT_INST_ANY",0.0)/max(1.0,v.get("SQ_WAVE_CYCLES",1.0)),
+            "profile":"$TAG"})
 json.dump(traffic, open(out+"/traffic.json","w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY
