@@ -172,9 +172,15 @@ typedef struct mtr_scene_desc {
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */
 enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133-138 */
        MTR_FLAG_DISCARD_DIRECT_LIGHT = 2u, /* common.py:27, transientpath.py:173-176 */
-       MTR_FLAG_FILM_ZERO = 4u             /* caller guarantees that the film rows of the rendered pixels are
+       MTR_FLAG_FILM_ZERO = 4u,            /* caller guarantees that the film rows of the rendered pixels are
                                               all-zero on entry (first pass after TransientImageBlock.clear):
-                                              the row flush may store instead of read-modify-write            */ };
+                                              the row flush may store instead of read-modify-write            */
+       MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8u /* sampler seeding variant: PCG32 initseq = TEA.v1 + lane instead of TEA.v1.
+                                              drjit's PCG32::seed(size, initstate, initseq) adds arange(size) to initseq;
+                                              mitsuba's independent sampler passes size = 1 after the TEA scramble in the
+                                              versions we know [upstream-unverified, SURVEY A.9].  Kept so that ONE real
+                                              reference render decides the question without a code change
+                                              (tests/test_reference_golden.py).                                */ };
 
 /* which kernel organisation executes the path */
 enum { MTR_MODE_AUTO = 0,

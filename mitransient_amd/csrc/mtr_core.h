@@ -92,12 +92,12 @@ MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane)
     tea4(v0, v1);
     return ((uint64_t)v1 << 1u) | 1u;
 }
-MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane)
+MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane, bool seq_plus_lane = false)
 {
     uint32_t v0 = seed, v1 = lane;
     tea4(v0, v1);
     Rng r;
-    r.inc = ((uint64_t)v1 << 1u) | 1u;
+    r.inc = (((uint64_t)v1 + (seq_plus_lane ? (uint64_t)lane : 0ull)) << 1u) | 1u;      // MTR_FLAG_PCG_INITSEQ_PLUS_LANE
     r.state = 0u;
     rng_u32(r);
     r.state += (uint64_t)v0;
@@ -872,7 +872,7 @@ MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderCo
     uint32_t lane = pixel * rc.spp_total + s;
     uint32_t py = fastdiv(pixel, rc.div_crop_w), px = pixel - f.crop_w * py;
     p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
-    p.rng = rng_seed(rc.seed, lane);
+    p.rng = rng_seed(rc.seed, lane, (rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
     float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
     p.ray = camera_ray(cam, rc, p.px, p.py, j1, j2);
     p.beta = mk(1, 1, 1); p.L = mk(0, 0, 0); p.prev_p = mk(0, 0, 0);

@@ -28,6 +28,8 @@ class TransientADIntegrator:
         self.rr_depth = int(props.get("rr_depth", 5))
         if self.rr_depth <= 0:
             raise Exception("\"rr_depth\" must be set to a value greater than zero!")
+        # hide_emitters only affects environment / directly visible emitters in the camera's alpha [mitsuba3: ADIntegrator];
+        # transientpath.py never reads it and the subset has no environment emitter: parsed, kept, without effect
         self.hide_emitters = bool(props.get("hide_emitters", False))
         # common.py:25-30
         self.camera_unwarp = bool(props.get("camera_unwarp", False))
@@ -35,6 +37,8 @@ class TransientADIntegrator:
         _ = props.get("gaussian_stddev", 0.5)      # accepted and ignored, as in the reference
         _ = props.get("temporal_filter", "")
         _ = props.get("block_size", 0)
+        # sampler seeding variant (extension; see MTR_FLAG_PCG_INITSEQ_PLUS_LANE in the header): False = TEA(seed, lane) only
+        self.pcg_initseq_plus_lane = bool(props.get("amd_pcg_initseq_plus_lane", False))
         self.mode = _cabi.MTR_MODE_AUTO            # kernel organisation (extension; not a reference key)
         m = props.get("amd_mode", None)
         if m is not None:
@@ -108,6 +112,8 @@ class TransientADIntegrator:
             f |= _cabi.MTR_FLAG_CAMERA_UNWARP
         if self.discard_direct_light:
             f |= _cabi.MTR_FLAG_DISCARD_DIRECT_LIGHT
+        if self.pcg_initseq_plus_lane:
+            f |= _cabi.MTR_FLAG_PCG_INITSEQ_PLUS_LANE
         return f
 
     def render_params(self, film, seed_value, spp_total, spp_begin=0, spp_end=None,

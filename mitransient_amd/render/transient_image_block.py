@@ -83,6 +83,21 @@ class TransientImageBlock:
         n = int(pixel.numel())
         pix = pixel.to(device=self._tensor.device, dtype=torch.int32).contiguous()
         arrs = [t.to(device=self._tensor.device, dtype=torch.float32).contiguous() for t in (opl, r, g, b)]
+        if self.warn_negative or self.warn_invalid:
+            # transient_image_block.py:107-125: the checked values are the channels [r, g, b, alpha = 0, weight = 0]
+            valid = torch.ones_like(arrs[1], dtype=torch.bool)
+            for v in arrs[1:]:
+                if self.warn_negative:
+                    valid &= v >= -1e-5
+                if self.warn_invalid:
+                    valid &= torch.isfinite(v)
+            npix = self.size_xyt[0] * self.size_xyt[1]
+            bad = (~valid) & (pix.to(torch.int64) & 0xFFFFFFFF < npix)          # `active` lanes only
+            if bool(bad.any()):
+                k = int(torch.nonzero(bad)[0])
+                import logging
+                logging.getLogger("mitransient_amd").warning(
+                    "Invalid sample value: [%s, %s, %s, 0.0, 0.0]", float(arrs[1][k]), float(arrs[2][k]), float(arrs[3][k]))
         las = laser.to(device=self._tensor.device, dtype=torch.int32).contiguous() if laser is not None else None
         soa = _cabi.mtr_splat_soa(pix.data_ptr(), arrs[0].data_ptr(), arrs[1].data_ptr(),
                                   arrs[2].data_ptr(), arrs[3].data_ptr(), n, las.data_ptr() if las is not None else None)

@@ -576,3 +576,28 @@ def test_fused_row_ring_sizes(oracle, bins, spp):
     s2, t2 = film.develop()
     torch.cuda.synchronize()
     assert rel_l2(np.array(t2), t_ref) <= TOL and rel_l2(np.array(s2), s_ref) <= TOL
+
+
+def test_warn_negative_and_invalid_sample_values(caplog):
+    """TransientImageBlock.put_ (transient_image_block.py:107-125): with warn_negative / warn_invalid a bad value among the
+    active samples is logged as 'Invalid sample value: [...]' (and still accumulated, as in the reference)"""
+    import logging
+    import torch
+    from mitransient_amd.render.transient_image_block import TransientImageBlock
+    from mitransient_amd import _cabi
+    fd = _cabi.mtr_film_desc()
+    fd.width = fd.crop_width = 4
+    fd.height = fd.crop_height = 2
+    fd.temporal_bins, fd.start_opl, fd.bin_width_opl = 8, 0.0, 1.0
+    blk = TransientImageBlock(size_xyt=(4, 2, 8), warn_negative=True, warn_invalid=True)
+    pix = torch.tensor([0, 1, 2], dtype=torch.int32, device="cuda")
+    opl = torch.tensor([0.5, 1.5, 2.5], device="cuda")
+    ok = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    with caplog.at_level(logging.WARNING, logger="mitransient_amd"):
+        blk.put_opl(pix, opl, ok, ok, ok, fd)
+        assert not caplog.records
+        blk.put_opl(pix, opl, torch.tensor([1.0, -0.5, 3.0], device="cuda"), ok, ok, fd)
+        blk.put_opl(pix, opl, ok, torch.tensor([1.0, 2.0, float("nan")], device="cuda"), ok, fd)
+    assert len(caplog.records) == 2 and all("Invalid sample value" in r.getMessage() for r in caplog.records)
+    t = blk.torch_tensor().cpu().numpy()
+    assert t[0, 0, 0, 0] == 3.0 and t[0, 1, 1, 0] == 3.5

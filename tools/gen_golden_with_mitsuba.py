@@ -4,15 +4,32 @@
 Needs `mitsuba>=3.6,<3.9` and `mitransient` (the reference) importable — neither exists in the authoring
 container nor on the GPU box, which is why DESIGN.md §2 says PARITY UNPINNED.  Run once wherever they are:
 
-    python tools/gen_golden_with_mitsuba.py            # writes tests/golden/mitsuba_c1.npz (~200 KB)
+    python tools/gen_golden_with_mitsuba.py            # writes tests/golden/mitsuba_c1.npz (< 1 MB)
 
-and commit the file: tests/test_reference_golden.py then compares the oracle (CPU) and the HIP path (GPU) with
-it.  BASELINE config 1: cornell_box() at 64 x 64, 64 bins over OPL 3.5 .. 9.5, 16 spp, seed 0, llvm_ad_rgb.
+and commit the file: tests/test_reference_golden.py then holds the oracle (CPU) and the HIP path (GPU) to it and decides
+the open questions of SURVEY App. A without a code change (which PCG32 seeding the sampler uses; whether per-sample
+arithmetic lines up to 1e-5 or only statistically).
+
+Contents: BASELINE config 1 — cornell_box() at 64 x 64, 64 bins over OPL 3.5 .. 9.5, llvm_ad_rgb —
+  * `lo_*`  16 spp, seed 0: marginals in f32/f64 + 20 000 exact cells (the sample-for-sample comparison);
+  * `hi_*`  1024 spp, seed 1: per-bin / per-pixel marginals (the k-sigma statistical comparison).
+The packing is shared with the test (`pack_render`), which also uses it to build synthetic files for its self-test.
 """
 import os
 import sys
 
 import numpy as np
+
+
+def pack_render(prefix, steady, transient, n_cells=20000):
+    """the summary of one render that goes into the .npz (a full (H,W,T,3) f32 tensor would be 3 MB per render)"""
+    steady, transient = np.asarray(steady, dtype=np.float32), np.asarray(transient, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    idx = rng.choice(transient.size // 3, size=min(n_cells, transient.size // 3), replace=False)
+    return {f"{prefix}_per_bin": transient.sum(axis=(0, 1)).astype(np.float64),
+            f"{prefix}_per_pixel": transient.sum(axis=2), f"{prefix}_steady": steady,
+            f"{prefix}_sample_index": idx.astype(np.int64), f"{prefix}_sample_value": transient.reshape(-1, 3)[idx],
+            f"{prefix}_norm": np.float64(np.linalg.norm(transient.astype(np.float64)))}
 
 
 def main():
@@ -23,20 +40,17 @@ def main():
     d["sensor"]["film"].update(width=64, height=64, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
     d["integrator"].update(max_depth=8, rr_depth=5, camera_unwarp=False)
     scene = mi.load_dict(d)
-    steady, transient = mi.render(scene, spp=16, seed=0)
-    steady, transient = np.array(steady, dtype=np.float32), np.array(transient, dtype=np.float32)
-    assert transient.shape == (64, 64, 64, 3) and steady.shape == (64, 64, 3), (transient.shape, steady.shape)
+    out = {}
+    for prefix, spp, seed in (("lo", 16, 0), ("hi", 1024, 1)):
+        steady, transient = mi.render(scene, spp=spp, seed=seed)
+        steady, transient = np.array(steady, dtype=np.float32), np.array(transient, dtype=np.float32)
+        assert transient.shape == (64, 64, 64, 3) and steady.shape == (64, 64, 3), (transient.shape, steady.shape)
+        out.update(pack_render(prefix, steady, transient))
+        out[f"{prefix}_spp_seed"] = np.asarray([spp, seed])
     here = os.path.dirname(os.path.abspath(__file__))
-    out = os.path.join(os.path.dirname(here), "tests", "golden", "mitsuba_c1.npz")
-    # the full (H,W,T,3) tensor in f16 would lose the 1e-5 bar: keep f32 marginals + a sparse exact sample
-    rng = np.random.default_rng(0)
-    idx = rng.choice(transient.size // 3, size=20000, replace=False)
-    np.savez_compressed(out, per_bin=transient.sum(axis=(0, 1)).astype(np.float64),
-                        per_pixel=transient.sum(axis=2), steady=steady,
-                        sample_index=idx.astype(np.int64), sample_value=transient.reshape(-1, 3)[idx],
-                        norm=np.float64(np.linalg.norm(transient.astype(np.float64))),
-                        versions=np.asarray([f"mitsuba {mi.__version__}", f"mitransient {mitr.__version__}"]))
-    print("wrote", out, "with", transient.size, "cells summarised;", sys.version.split()[0])
+    path = os.path.join(os.path.dirname(here), "tests", "golden", "mitsuba_c1.npz")
+    np.savez_compressed(path, versions=np.asarray([f"mitsuba {mi.__version__}", f"mitransient {mitr.__version__}"]), **out)
+    print("wrote", path, ";", sys.version.split()[0])
 
 
 if __name__ == "__main__":
