@@ -107,19 +107,21 @@ def traffic_from_profiles(kernel):
     return pmc_from_profiles(kernel).get("hbm_bytes_per_launch")
 
 
-def valu_roofline(kernel, avg_launch_ms, workload_matches):
+def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1.0):
     """The path kernel is bound by VALU issue + SIMT divergence, not by HBM: achieved = VALU lane-operations
     per launch (SQ_INSTS_VALU x active lanes per instruction, from the committed PMC pass of the SAME workload) / the
     launch time measured live with HIP events; peak = the f32 vector roof."""
     c = pmc_from_profiles(kernel)
     if not workload_matches or "valu_insts_per_launch" not in c or avg_launch_ms <= 0:
         return None
-    lane_ops = c["valu_insts_per_launch"] * c["valu_lanes_per_inst"]
+    # the profile is of ONE launch per render; a multi-GPU step issues the same per-rank work as `launches_per_render` band launches
+    insts = c["valu_insts_per_launch"] / launches_per_render
+    lane_ops = insts * c["valu_lanes_per_inst"]
     achieved = lane_ops / (avg_launch_ms * 1e-3) / 1e12
     return {"kernel": kernel, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
             "frac": achieved / VALU_PEAK_TLANEOPS,
-            "valu_issue_frac": c["valu_insts_per_launch"] * 2.0 / (1024 * avg_launch_ms * 1e-3 * 2.4e9),
-            "lanes_per_valu_inst": c["valu_lanes_per_inst"], "valu_insts_per_launch": c["valu_insts_per_launch"],
+            "valu_issue_frac": insts * 2.0 / (1024 * avg_launch_ms * 1e-3 * 2.4e9),
+            "lanes_per_valu_inst": c["valu_lanes_per_inst"], "valu_insts_per_launch": insts,
             "traffic": c.get("hbm_bytes_per_launch"), "avg_launch_ms": avg_launch_ms,
             "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
                       + str(c.get("profile", "")) + ") over the launch time measured live (HIP events)"}
@@ -293,7 +295,7 @@ def main():
         # the dominant kernel's bound: k_fused keeps the scatter-add in LDS, so the HBM line only says how little it moves;
         # what bounds it is VALU issue at ~27 of 64 active lanes (PMC passes of the same workload, profiles/)
         default_wl = (SCENE == "cornell" and (args.width, args.height, args.bins, args.spp) == dflt and world >= 1)
-        vline = valu_roofline("k_fused", avg_ms, default_wl) if fused else None
+        vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps) if fused else None
         if vline is not None:
             vline["launches_per_step"] = n_launch / args.steps
             res["roofline"] = vline

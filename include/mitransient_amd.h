@@ -175,6 +175,9 @@ enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133
        MTR_FLAG_FILM_ZERO = 4u,            /* caller guarantees that the film rows of the rendered pixels are
                                               all-zero on entry (first pass after TransientImageBlock.clear):
                                               the row flush may store instead of read-modify-write            */
+       MTR_FLAG_KEEP_COUNTERS = 16u,       /* do not reset the context's device counters at the start of this call: a render
+                                              issued as several asynchronous calls (row bands on alternating streams) sums
+                                              its counters on the device; read them once with mtr_counters_read()        */
        MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8u /* sampler seeding variant: PCG32 initseq = TEA.v1 + lane instead of TEA.v1.
                                               drjit's PCG32::seed(size, initstate, initseq) adds arange(size) to initseq;
                                               mitsuba's independent sampler passes size = 1 after the TEA scramble in the
@@ -281,6 +284,10 @@ int  mtr_film_clear(mtr_ctx *, const mtr_film_desc *, float *transient_hwt4 /*de
 int  mtr_render(mtr_scene *, const mtr_render_params *,
                 float *transient_hwt4, float *steady_hw4,
                 mtr_counters *counters_out /*host*/, mtr_kernel_times *times_out /*host*/);
+
+/* The context's device counters as they stand (summed over every mtr_render since the last one without
+ * MTR_FLAG_KEEP_COUNTERS).  The caller has synchronised the streams those renders ran on. */
+int  mtr_counters_read(mtr_ctx *, mtr_counters *out /*host*/);
 
 /* TransientHDRFilm.develop / develop_transient_ (transient_hdr_film.py:210-248)
  * and steady.develop (common.py:206,212):  raw (H,W,T,4) -> (H,W,T,3) with the

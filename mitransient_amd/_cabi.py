@@ -19,6 +19,7 @@ MTR_FLAG_CAMERA_UNWARP = 1
 MTR_FLAG_DISCARD_DIRECT_LIGHT = 2
 MTR_FLAG_FILM_ZERO = 4
 MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8
+MTR_FLAG_KEEP_COUNTERS = 16
 MTR_MODE_AUTO, MTR_MODE_FUSED, MTR_MODE_WAVEFRONT = 0, 1, 2
 
 _f3 = C.c_float * 3
@@ -128,7 +129,7 @@ class mtr_kernel_times(C.Structure):
 EXPORTS = [
     "mtr_abi_version", "mtr_ctx_create", "mtr_ctx_destroy", "mtr_ctx_set_stream", "mtr_last_error",
     "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_set_nlos", "mtr_scene_bvh_info",
-    "mtr_film_clear", "mtr_render", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
+    "mtr_film_clear", "mtr_render", "mtr_counters_read", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
 ]
 
 _lib = None
@@ -166,6 +167,7 @@ def load_library() -> C.CDLL:
     lib.mtr_scene_set_film.argtypes = [vp, C.POINTER(mtr_film_desc)]
     lib.mtr_scene_set_nlos.argtypes = [vp, C.POINTER(mtr_nlos_desc)]
     lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mtr_counters_read.argtypes = [vp, C.POINTER(mtr_counters)]
     lib.mtr_film_clear.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp]
     lib.mtr_render.argtypes = [vp, C.POINTER(mtr_render_params), vp, vp,
                                C.POINTER(mtr_counters), C.POINTER(mtr_kernel_times)]

@@ -26,7 +26,9 @@ struct mtr_ctx {
     int n_cu = 256;
     std::string err;
     DevCounters *d_counters = nullptr;
-    uint32_t *d_ticket = nullptr;          // k_fused work-ticket counter
+    uint32_t *d_ticket = nullptr;          // work-ticket counters: [0, 16) k_fused launches in rotation (launches of consecutive
+                                           // row bands may overlap on two streams: each needs its own), [16, 18) wavefront segments
+    uint32_t fused_launches = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
     void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
@@ -99,7 +101,7 @@ int mtr_ctx_create(int device_ordinal, mtr_ctx **out)
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(nullptr, hipMalloc((void **)&c->d_counters, sizeof(DevCounters)));
-    HIP_TRY(nullptr, hipMalloc((void **)&c->d_ticket, 16));
+    HIP_TRY(nullptr, hipMalloc((void **)&c->d_ticket, 32 * sizeof(uint32_t)));
     HIP_TRY(nullptr, hipEventCreate(&c->ev0));
     HIP_TRY(nullptr, hipEventCreate(&c->ev1));
     *out = c;
@@ -383,7 +385,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
             HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
             a.parity = 0;
-            a.ticket = c->d_ticket + 1; a.ticket_cur = 0u;                           // segment tickets (k_wf_trace / shadow_gen / shade)
+            a.ticket = c->d_ticket + 16; a.ticket_cur = 0u;                          // segment tickets (k_wf_trace / shadow_gen / shade)
             HIP_TRY(c, hipMemsetAsync(a.ticket, 0, 2 * sizeof(uint32_t), c->stream));
             HIP_TRY(c, launch_wf(a, cfg, 0, grid_gen, c->stream));                   // raygen (writes live list 0)
             uint32_t depth = 0;
@@ -479,7 +481,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
 
     const uint32_t n_pixels = p->pixel_end - p->pixel_begin;
     const bool want_stats = counters_out || times_out;
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    if (!(p->flags & MTR_FLAG_KEEP_COUNTERS)) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     if (s->log.count) HIP_TRY(c, hipMemsetAsync(s->log.count, 0, sizeof(unsigned long long), c->stream));
     if (times_out) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     uint32_t launches = 0, scatter_launches = 0;
@@ -511,7 +513,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             FusedConfig cfg{};
             if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, a, cfg))
                 return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
-            a.ticket = c->d_ticket;
+            a.ticket = c->d_ticket + (c->fused_launches++ & 15u);
             HIP_TRY(c, launch_fused(a, cfg, c->stream));
             launches = 1;
         }
@@ -536,6 +538,19 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             times_out->trace_launches = launches; times_out->scatter_launches = scatter_launches;
         }
     }
+    return MTR_OK;
+}
+
+int mtr_counters_read(mtr_ctx *c, mtr_counters *out)
+{
+    if (!c || !out) return fail(c, MTR_ERR_INVALID, "mtr_counters_read: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevCounters h;
+    HIP_TRY(c, hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->paths = h.paths; out->rays_closest = h.rays_closest; out->rays_shadow = h.rays_shadow;
+    out->splats_issued = h.splats_issued; out->bounces = h.bounces; out->splats_overflow = h.splats_overflow;
+    out->reserved[0] = h.r0; out->reserved[1] = h.r1;
     return MTR_OK;
 }
 

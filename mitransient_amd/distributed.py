@@ -184,11 +184,29 @@ class DistributedRenderer:
             # get onto the chip at the boundary between two persistent path kernels, which otherwise fill every CU first
             side = self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
         gloo = dist.get_backend(self.group) == "gloo"
+        # consecutive bands are launched on TWO alternating streams: the path kernel is persistent, so a band's launch ends
+        # with a tail in which its workgroups run out of pixels one by one — the next band's workgroups fill those slots at
+        # once instead of waiting for the whole launch to end (8 bands on one stream: +3.8 ms per render, measured)
+        lanes = getattr(self, "_render_streams", None)
+        if lanes is None:
+            lanes = self._render_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        start = torch.cuda.Event()
+        start.record(main)
+        for st in lanes:
+            st.wait_event(start)                    # the clear of prepare() ran on the main stream
+        band_ev = []
         for b in range(nb):
             r0, r1 = b * rows_b, (b + 1) * rows_b
-            integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W))
-            ready = torch.cuda.Event()
-            ready.record(main)
+            ready = torch.cuda.Event(enable_timing=True)
+            begin = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(lanes[b & 1]):
+                begin.record(lanes[b & 1])
+                # every band owns its rows: they are still zero from prepare()'s clear when the band's only pass flushes them;
+                # no read-back per band (the launches stay asynchronous): counters sum on the device
+                integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W),
+                                 rows_are_zero=True, defer_stats="first" if b == 0 else "more")
+                ready.record(lanes[b & 1])
+            band_ev.append((begin, ready))
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 if gloo:
@@ -201,6 +219,15 @@ class DistributedRenderer:
                 out_t[r0:r1].copy_(got_t)
                 out_s[r0:r1].copy_(got_s)
         main.wait_stream(side)
+        for st in lanes:
+            main.wait_stream(st)
+        if integ.collect_stats:
+            for st in lanes:
+                st.synchronize()
+            integ.fetch_counters(film)
+            ms = [a.elapsed_time(b_) for a, b_ in band_ev]
+            integ.total_times = {"total_ms": sum(ms), "trace_ms": sum(ms), "scatter_ms": 0.0, "trace_launches": nb,
+                                 "scatter_launches": 0}
         if film.exhaustive_scan:                 # transient_hdr_film.py:213-214
             return TensorXf(out_t.mean(dim=-1)), TensorXf(out_t)
         return TensorXf(out_s), TensorXf(out_t)

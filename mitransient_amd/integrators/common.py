@@ -148,8 +148,12 @@ class TransientADIntegrator:
         return film.develop()
 
     def accumulate(self, scene, sensor, samplers_spps, total_spp, spp_range=None, pixel_range=None,
-                   progress_callback=None):
-        """The pass loop of render() (common.py:157-210) without prepare/develop: ADDS into the film."""
+                   progress_callback=None, rows_are_zero=None, defer_stats=None):
+        """The pass loop of render() (common.py:157-210) without prepare/develop: ADDS into the film.
+        ``rows_are_zero``: the caller vouches that the film rows of ``pixel_range`` are untouched since clear() (a render
+        split into disjoint row bands: every band's FIRST pass may store its rows instead of read-modify-write).
+        ``defer_stats``: "first" / "more" — the call stays asynchronous (no counters / timings are read back); the device
+        counters are reset by "first" and keep summing through "more"; read them with ``fetch_counters()``."""
         film = sensor.film()
         ctx = get_context(film._device.index)
         ctx.bind_current_stream()
@@ -165,15 +169,18 @@ class TransientADIntegrator:
             # a pass of a split render indexes its lanes with ITS sample count (its own sampler) and scales by the total
             params = self.render_params(film, sampler_i.seed_value(), spp_i if multi else total_spp, s0, s1, p0, p1,
                                         spp_scale=total_spp if multi else 0)
-            if film.film_is_zero:
+            if film.film_is_zero or (rows_are_zero and i == 0):
                 params.flags |= _cabi.MTR_FLAG_FILM_ZERO      # first pass after clear(): row flushes may store
             film.film_is_zero = False
-            cnt = _cabi.mtr_counters() if self.collect_stats else None
-            tim = _cabi.mtr_kernel_times() if self.collect_stats else None
+            stats_now = self.collect_stats and defer_stats is None
+            if defer_stats == "more" or (defer_stats == "first" and i > 0):
+                params.flags |= _cabi.MTR_FLAG_KEEP_COUNTERS
+            cnt = _cabi.mtr_counters() if stats_now else None
+            tim = _cabi.mtr_kernel_times() if stats_now else None
             ctx.check(ctx.lib.mtr_render(handle, C.byref(params), tptr, sptr,
                                          C.byref(cnt) if cnt is not None else None,
                                          C.byref(tim) if tim is not None else None), "mtr_render")
-            if self.collect_stats:
+            if stats_now:
                 self.last_counters, self.last_times = cnt.as_dict(), tim.as_dict()
                 if self.total_counters is None:
                     self.total_counters = {k: 0 for k in self.last_counters if k != "reserved"}
@@ -184,6 +191,15 @@ class TransientADIntegrator:
                     self.total_times[k] += self.last_times[k]
             if progress_callback:
                 progress_callback((i + 1) / len(samplers_spps))
+
+    def fetch_counters(self, film):
+        """counters summed on the device over the deferred calls of one render (the caller synchronised their streams)"""
+        ctx = get_context(film._device.index)
+        cnt = _cabi.mtr_counters()
+        ctx.check(ctx.lib.mtr_counters_read(ctx.handle, C.byref(cnt)), "mtr_counters_read")
+        self.last_counters = cnt.as_dict()
+        self.total_counters = {k: v for k, v in self.last_counters.items() if k != "reserved"}
+        return self.total_counters
 
     def render_forward(self, *a, **k):
         raise NotImplementedError("differentiable rendering (common.py:215-323) is outside the north-star path")
