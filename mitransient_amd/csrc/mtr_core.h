@@ -699,6 +699,26 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
     if (sc.wnodes) {
         // three kinds of steps, each run by the whole wave at once: inner nodes until no lane holds one, then one
         // rectangle test for the lanes holding a rectangle, else one triangle-leaf pass
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MTR_NODES_FIRST)
+        // PRIMITIVES FIRST: the wave runs an inner-node step only when NONE of its lanes holds a primitive (a lane at a node
+        // waits for the others' rectangle / triangle tests).  Every lane still executes its own steps in its own order;
+        // what changes is that the lanes' node steps fall into the same wave iterations: after the root, every lane that
+        // enters an object node does so in ONE step instead of whenever its own rectangles happen to be done
+        // (config 2: node wave-steps 10.9 -> 9.3 M per 64 spp, k_fused 73.2 -> 68.5 ms; -DMTR_NODES_FIRST = the former
+        // while-while order, which is also what a host build runs, lane by lane)
+        while (tr.cur != kTravDone) {
+            const bool at_prim = tr.cur < 0;
+            if (__ballot(at_prim) != 0ull) {
+                if (is_quad_leaf(tr.cur)) {
+                    const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                    if (ANY_HIT & found) tr.cur = kTravDone;
+                    else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
+                } else if (at_prim) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+            } else {
+                wide_node_step<kWide, true>(tr, sc.wnodes, st);
+            }
+        }
+#else
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) {
                 wide_node_step<kWide, true>(tr, sc.wnodes, st);
@@ -712,6 +732,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
                 else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
             } else if (tr.cur != kTravDone) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
         }
+#endif
     } else if (sc.wnodes4) {
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) qwide_node_step(tr, sc.wnodes4, st);

@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     // five vector registers live across every traversal of a kernel that already spills.  The NLOS loop can trace many
     // shadow rays per bounce (one per illuminated point), so that variant counts per lane.
     unsigned long long w_closest = 0, w_shadow = 0, w_bounce = 0, w_paths = 0, w_splats = 0;
+#ifdef MTR_PROFILE_OCC
+    unsigned long long occ_iter = 0, occ_alive = 0, occ_wait = 0;
+#endif
     uint32_t n_closest = 0, n_shadow = 0, n_splats = 0;          // NLOS only
 
     uint32_t *s_chunk = s_next + 1;                  // [2]: first pixel of the ticket, pixels in it
@@ -256,6 +259,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             continue;
         }
         bool closes = false;
+#ifdef MTR_PROFILE_OCC         // experiment build: occupancy of the persistent lanes (wave iterations, alive lanes, waiting lanes)
+        occ_iter += 1; occ_alive += (uint32_t)__popcll(__ballot(alive)); occ_wait += (uint32_t)__popcll(__ballot(waiting));
+#endif
         w_bounce += (uint32_t)__popcll(__ballot(alive));
         uint32_t did_shadow = 0u, did_splats = 0u;                 // this iteration's per-lane counts (0..1, 0..2)
         if (alive) {
@@ -371,6 +377,11 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     }
     __syncthreads();
     if (tid < 5 && a.counters) atomicAdd(&a.counters->paths + tid, s_cnt[tid]);
+#ifdef MTR_PROFILE_OCC
+    if ((tid & 63) == 0 && a.counters) {
+        atomicAdd(&a.counters->splats_overflow, occ_iter); atomicAdd(&a.counters->r0, occ_alive); atomicAdd(&a.counters->r1, occ_wait);
+    }
+#endif
 #ifdef MTR_PROFILE_TAIL       // experiment build: when does the first / the last workgroup finish (100 MHz wall clock)
     if (tid == 0 && a.counters) {
         const unsigned long long t = wall_clock64();
@@ -445,9 +456,10 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const long max_blocks = ((long)n_pixels + g_blk - 1) / g_blk;
     if (grid > max_blocks) grid = max_blocks;
     if (grid < 1) grid = 1;
-    // chunk of consecutive pixels per ticket: about 8192 samples (amortises the drain at the chunk's end), but at least
-    // 8 chunks per workgroup (so that the last chunks level the workgroups out)
-    uint32_t chunk = (8192u + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
+    // chunk of consecutive pixels per ticket: about 32768 samples (amortises the drain at the chunk's end: config 2 with
+    // 4 / 8 / 16 / 32 / 64 pixels per ticket 72.8 / 71.7 / 71.2 / 70.9 / 70.9 ms), but at least 8 chunks per workgroup (so that the
+    // last chunks level the workgroups out)
+    uint32_t chunk = (32768u + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
     const uint32_t c_bal = (uint32_t)((unsigned long long)n_pixels / (8ull * (unsigned long long)grid));
     if (chunk > c_bal) chunk = c_bal;
     if (chunk < 1u) chunk = 1u;
