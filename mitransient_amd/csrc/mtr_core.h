@@ -708,13 +708,18 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
         // while-while order, which is also what a host build runs, lane by lane)
         while (tr.cur != kTravDone) {
             const bool at_prim = tr.cur < 0;
+#ifdef MTR_STEP_VOTE          // experiment: the phase that holds more lanes (k_wf_trace's rule) instead of primitives first
+            const unsigned long long mp_ = __ballot(at_prim), mn_ = __ballot(!at_prim);
+            if (MTR_STEP_VOTE * __popcll(mp_) >= MTR_STEP_VOTE_B * __popcll(mn_)) {
+#else
             if (__ballot(at_prim) != 0ull) {
+#endif
                 if (is_quad_leaf(tr.cur)) {
                     const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
                     if (ANY_HIT & found) tr.cur = kTravDone;
                     else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
                 } else if (at_prim) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
-            } else {
+            } else if (!at_prim) {
                 wide_node_step<kWide, true>(tr, sc.wnodes, st);
             }
         }
