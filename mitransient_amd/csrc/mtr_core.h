@@ -686,6 +686,57 @@ MTR_HD void qwide_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_h
     else qwide_advance(tr, sc.wnodes4, st, tr.grp);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The walk of the 8-wide tree on the device.
+//
+// PRIMITIVES FIRST: the wave runs an inner-node step only when NONE of its lanes holds a primitive (a lane at a node waits
+// for the others' rectangle / triangle tests).  Every lane still executes its own steps in its own order; what changes is
+// that the lanes' node steps fall into the same wave iterations: after the root, every lane that enters an object node does
+// so in ONE step instead of whenever its own rectangles happen to be done (config 2: node wave-steps 10.9 -> 9.3 M per 64 spp,
+// k_fused 73.2 -> 68.5 ms; -DMTR_NODES_FIRST = the former while-while order, which is also what a host build runs).
+// Measured and not kept: majority votes between the two phases (68.9 .. 69.8 ms against 68.9), and a COOPERATIVE second
+// step — before the wave's second node step, every lane holding a node and a pending sibling handed the sibling's subtree
+// to a lane that was already done (ray over ds_bpermute, pairing through the empty LDS stack rows, results merged by the
+// (t, original index) rule; all parity tests green): 70.7 ms for closest-hit rays only against 68.2, and 92 ms with the
+// shadow rays included (the state alive across the shadow traversal left no registers: 30 -> 118 spilled).
+template <bool ANY_HIT, class Stack>
+__device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, Stack &st)
+{
+#ifndef MTR_WALK_LANE_EXIT
+    for (;;) {                          // every lane stays until the whole wave is done: ONE loop exit per wave (config 2: 67.9 ms
+                                        // against 68.8 / 70.7 ms for the per-lane exit below, same box)
+        const bool act = tr.cur != kTravDone;
+        if (__ballot(act) == 0ull) break;
+        const bool at_prim = act && tr.cur < 0;
+        if (__ballot(at_prim) != 0ull) {
+            if (at_prim) {
+                if (is_quad_leaf(tr.cur)) {
+                    const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                    if (ANY_HIT & found) tr.cur = kTravDone;
+                    else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
+                } else wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+            }
+            continue;
+        }
+        if (tr.cur >= 0) wide_node_step<kWide, true>(tr, sc.wnodes, st);
+    }
+#else
+    while (tr.cur != kTravDone) {
+        const bool at_prim = tr.cur < 0;
+        if (__ballot(at_prim) != 0ull) {
+            if (is_quad_leaf(tr.cur)) {
+                const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                if (ANY_HIT & found) tr.cur = kTravDone;
+                else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
+            } else if (at_prim) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+        } else {
+            wide_node_step<kWide, true>(tr, sc.wnodes, st);
+        }
+    }
+#endif
+}
+#endif
+
 // run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
 // intersects leaves together)
 template <bool ANY_HIT, class Stack>
@@ -700,29 +751,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
         // three kinds of steps, each run by the whole wave at once: inner nodes until no lane holds one, then one
         // rectangle test for the lanes holding a rectangle, else one triangle-leaf pass
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MTR_NODES_FIRST)
-        // PRIMITIVES FIRST: the wave runs an inner-node step only when NONE of its lanes holds a primitive (a lane at a node
-        // waits for the others' rectangle / triangle tests).  Every lane still executes its own steps in its own order;
-        // what changes is that the lanes' node steps fall into the same wave iterations: after the root, every lane that
-        // enters an object node does so in ONE step instead of whenever its own rectangles happen to be done
-        // (config 2: node wave-steps 10.9 -> 9.3 M per 64 spp, k_fused 73.2 -> 68.5 ms; -DMTR_NODES_FIRST = the former
-        // while-while order, which is also what a host build runs, lane by lane)
-        while (tr.cur != kTravDone) {
-            const bool at_prim = tr.cur < 0;
-#ifdef MTR_STEP_VOTE          // experiment: the phase that holds more lanes (k_wf_trace's rule) instead of primitives first
-            const unsigned long long mp_ = __ballot(at_prim), mn_ = __ballot(!at_prim);
-            if (MTR_STEP_VOTE * __popcll(mp_) >= MTR_STEP_VOTE_B * __popcll(mn_)) {
-#else
-            if (__ballot(at_prim) != 0ull) {
-#endif
-                if (is_quad_leaf(tr.cur)) {
-                    const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
-                    if (ANY_HIT & found) tr.cur = kTravDone;
-                    else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
-                } else if (at_prim) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
-            } else if (!at_prim) {
-                wide_node_step<kWide, true>(tr, sc.wnodes, st);
-            }
-        }
+        wide_walk_device<ANY_HIT>(tr, sc, st);
 #else
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) {

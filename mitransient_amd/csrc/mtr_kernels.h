@@ -36,6 +36,7 @@ struct FusedArgs {
     uint32_t spp_begin, spp_chunk;       // samples [spp_begin, spp_begin + spp_chunk)
     uint32_t G;                          // row slots of a workgroup's pixel ring (k_fused)
     FastDiv div_spp, div_G;              // i / spp_chunk, q / G without the ~35-instruction integer division
+    uint32_t stack_rows;                 // rows of the per-lane LDS stack columns: levels of the wide tree walked + 1 (>= 3)
     uint32_t chunk, n_chunks;            // consecutive pixels per work ticket, number of tickets of this launch
     uint32_t *ticket;                    // device counter, zeroed before the launch (launch_fused)
     float *film_out;                     // (H, W, T, 4)

@@ -13,6 +13,7 @@
 #include "mtr_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mtr {
@@ -34,13 +35,13 @@ struct LdsStack {
     __device__ __forceinline__ void prof_mark(int) {}
 #endif
 #ifdef MTR_PROFILE_SIMT        // experiment build: lane-steps vs wave-steps of node / triangle tests
-    unsigned int ls[2], ws[2], wmax;
+    unsigned int ls[2], ws[2], wmax, wcalls;
     // wave maximum of the per-lane node-step count of one traverse() call (the floor of its wave-steps)
     __device__ __forceinline__ void tail(unsigned int mine) {
         unsigned int mx = 0;
         for (int bit = 11; bit >= 0; --bit) { const unsigned int c = mx | (1u << bit); if (__ballot(mine >= c) != 0ull) mx = c; }
         unsigned long long m = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) wmax += mx;
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) { wmax += mx; wcalls += 1; }
     }
     __device__ __forceinline__ void count(int k) {
         ls[k]++;
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 
     // ---- LDS carve-up (all offsets multiples of 16) ----
     uint32_t off = 0;
-    int32_t *s_stack = (int32_t *)(smem + off); off += (STACK + 1) * kBlock * 4;
+    int32_t *s_stack = (int32_t *)(smem + off); off += a.stack_rows * kBlock * 4;
     unsigned long long *s_cnt = (unsigned long long *)(smem + off); off += 64;    // 5 counters + next
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 
     LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
-    st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0; st.wmax = 0;
+    st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0; st.wmax = 0; st.wcalls = 0;
 #endif
 #ifdef MTR_PROFILE_CYCLES
     for (int k = 0; k < 6; ++k) st.cyc[k] = 0;
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         unsigned long long *c = &a.counters->splats_overflow;
         atomicAdd(c + 0, ((unsigned long long)st.ls[0] << 32) | st.ws[0]);      // node: lane-steps | wave-steps... (per thread, summed)
         atomicAdd(c + 1, ((unsigned long long)st.ls[1] << 32) | st.ws[1]);
-        atomicAdd(c + 2, (unsigned long long)st.wmax);
+        atomicAdd(c + 2, ((unsigned long long)st.wcalls << 32) | (unsigned long long)st.wmax);     // traverse() calls of the wave | sum of their wave-maxima
     }
 #endif
 #ifdef MTR_PROFILE_CYCLES
@@ -422,9 +423,13 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const uint32_t kLdsMax = 160u * 1024u;
     int stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
     if (sc.bvh_depth > 64) return false;
-    uint32_t fixed = (stack + 1) * kBlock * 4 + 64;
     uint32_t scene_b = scene_lds_bytes(sc);
     cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
+    // the kernel walks a WIDE tree (8-wide in LDS, quantised 4-wide in HBM): one stacked group per level (+ the row the
+    // branch-free push writes before it knows whether it counts)
+    const uint32_t rows = (cfg.scene_lds ? sc.wide_levels : sc.wide4_levels) + 1u;
+    args.stack_rows = rows;
+    uint32_t fixed = rows * kBlock * 4 + 64;
     if (cfg.scene_lds) fixed += scene_b;
     // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
     const uint32_t row_bytes = film.bins * 12u;
