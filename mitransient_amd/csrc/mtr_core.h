@@ -703,6 +703,9 @@ template <bool ANY_HIT, class Stack>
 __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, Stack &st)
 {
 #ifndef MTR_WALK_LANE_EXIT
+#ifdef MTR_PROFILE_CYCLES
+    uint32_t n_phase_ = 0u;
+#endif
     for (;;) {                          // every lane stays until the whole wave is done: ONE loop exit per wave (config 2: 67.9 ms
                                         // against 68.8 / 70.7 ms for the per-lane exit below, same box)
         const bool act = tr.cur != kTravDone;
@@ -718,8 +721,14 @@ __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, 
             }
             continue;
         }
+#ifdef MTR_PROFILE_CYCLES      // experiment build: section 0 = the walk up to the wave's second node step, 5 = the rest of it
+        if (++n_phase_ == 2u) st.prof_mark(0);
+#endif
         if (tr.cur >= 0) wide_node_step<kWide, true>(tr, sc.wnodes, st);
     }
+#ifdef MTR_PROFILE_CYCLES
+    st.prof_mark(n_phase_ >= 2u ? 5 : 0);
+#endif
 #else
     while (tr.cur != kTravDone) {
         const bool at_prim = tr.cur < 0;

@@ -68,3 +68,22 @@ def test_two_rank_pipelined_band_reduction(tmp_path):
         s = np.load(tmp_path / f"s{r}.npy")
         assert t.shape == t_ref.shape == (32, 24, 48, 3)
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+
+
+def test_rccl_api_path_with_one_rank():
+    """the `nccl` (= RCCL) backend itself, on one GPU: a 1-rank process group created as bench.py creates it, the film
+    reduction helpers and the band-pipelined renderer forced through its multi-rank branch (tools/rccl_one_rank.py).
+    RCCL moves nothing with one rank, but every call, option and layout of the N > 1 path runs."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL one-rank path: OK" in r.stdout, r.stdout[-2000:]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

@@ -10,5 +10,5 @@ v = [c['splats_overflow'], c['reserved'][0], c['reserved'][1]]
 sec = []
 for x in v: sec += [x >> 32, x & 0xffffffff]
 tot = sum(sec)
-names = ['traversal (closest + any-hit)','shading (A + B)','path start (ticket, owner, path_begin)','end-of-path bookkeeping (steady, done, next)','row flush + loop top','idle (sleep) + between chunks']
+names = ['traversal up to the second node step (root, rectangles)','shading (A + B)','path start (ticket, owner, path_begin)','end-of-path bookkeeping (steady, done, next)','row flush + loop top','traversal after it (object nodes, their leaves) + idle']
 for n,x in zip(names, sec): print('%-28s %5.1f%%' % (n, 100.0*x/tot))
