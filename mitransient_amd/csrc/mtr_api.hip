@@ -361,10 +361,13 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
     a.G = G; a.seg = seg;
+    a.nlos_on = s->nlos.on ? 1u : 0u;
+    if (s->nlos.on) a.nlos = s->nlos.k;
     const int grid_full = c->n_cu * 8;
-    const bool unbounded = p->max_depth < 0 || p->max_depth > 256;
+    // NLOS paths end by the integrator's own rules (filter depth, roulette): the host polls the live count like an unbounded render
+    const bool unbounded = p->max_depth < 0 || p->max_depth > 256 || s->nlos.on;
     // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
-    const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth);
+    const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth + (s->nlos.on ? 2u : 0u));
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
 
     for (uint32_t s0 = 0; s0 < spp_chunk; s0 += S) {
@@ -391,6 +394,18 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             uint32_t depth = 0;
             while (depth < max_depth) {
                 if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
+                if (a.nlos_on) {          // NLOS tier: the whole loop iteration of transient_nlos_path in one launch per bounce
+                    HIP_TRY(c, launch_wf(a, cfg, 5, grid, c->stream)); a.ticket_cur ^= 1u;
+                    *n_trace += 1;
+                    a.parity ^= 1u;
+                    ++depth;
+                    if (unbounded && (depth & 7u) == 0) {
+                        HIP_TRY(c, hipMemcpyAsync(w.host_count, live_total, 4, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        if (*w.host_count == 0) break;
+                    }
+                    continue;
+                }
                 a.trace_any = 0u;
                 HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream)); a.ticket_cur ^= 1u;  // closest hit + material lists
                 if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
@@ -490,11 +505,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
         // MTR_MODE_AUTO: the fused kernel when the whole scene can be staged in LDS (measured 143 vs 168 ms on
         // config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
         uint32_t mode = p->mode;
-        if (s->nlos.on) {
-            if (mode == MTR_MODE_WAVEFRONT)
-                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: the NLOS tier runs in the fused kernel only");
-            mode = MTR_MODE_FUSED;
-        }
+        if (s->nlos.on && mode == MTR_MODE_AUTO) mode = MTR_MODE_FUSED;      // (wavefront = the second organisation, on request)
         if (f.n_freq) {                      // phasor film: contributions are kept as (opl, value) records -> wavefront pipeline
             if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
             if (mode == MTR_MODE_FUSED) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film runs in the wavefront pipeline only");

@@ -89,13 +89,15 @@ struct WfArgs {
     float *film_out, *steady_out;
     DevCounters *counters;
     SplatLog log;
+    uint32_t nlos_on;                    // NLOS tier in the wavefront organisation: raygen = nlos_begin, one k_wf_nlos_bounce per bounce
+    NlosConst nlos;
 };
 struct WfConfig { int stack; bool scene_lds; size_t lds_bytes; };
 
 size_t wf_planes_bytes(uint32_t n_slots);
 bool wf_plan(const SceneDev &sc, WfConfig &cfg);
 // which: 0 raygen, 1 trace (closest hit + material-sorted queues, or occlusion when a.trace_any), 2 shade,
-// 3 time-bin scatter-add, 4 shadow-ray generation
+// 3 time-bin scatter-add, 4 shadow-ray generation, 5 one whole NLOS bounce (a.nlos_on)
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream);
 
 // scratch (variant 1): device buffer of >= 8 * (width * height + 2) bytes for the run table; NULL forces the atomics

@@ -252,8 +252,9 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
         uint32_t pixel, s, pl;
         slot_to_lane(a, slot, pixel, s, pl);
         Path p;
-        path_begin(p, a.cam, a.film, a.rc, pixel, s);
-        if (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) {              // transientpath.py:133-138
+        if (a.nlos_on) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
+        else path_begin(p, a.cam, a.film, a.rc, pixel, s);
+        if (!a.nlos_on && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {              // transientpath.py:133-138
             Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
             ++n_closest;
             if (h0.prim >= 0) p.dist = -h0.t;
@@ -571,6 +572,108 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     }
 }
 
+// ---- NLOS tier in the wavefront organisation ------------------------------------------------------
+// One launch per bounce runs the WHOLE loop iteration of transient_nlos_path (nlos_bounce: closest hit, laser /
+// emitter sampling with its shadow rays, hidden-geometry or BSDF sampling, Russian roulette) for every slot of the
+// segment's live list; path state lives in the SoA planes between launches, contributions become per-pixel records for
+// k_wf_scatter, survivors are compacted into the next live list.  It is the second, independent organisation of this tier
+// (k_fused<NLOS> being the first): same per-path arithmetic (mtr_nlos.h), different machinery around it — state in HBM
+// instead of registers, records + the stand-alone scatter-add instead of LDS row histograms, host loop over bounces.
+template <int STACK, bool SCENE_LDS>
+__global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_next_p = (uint32_t *)smem;
+    const int tid = threadIdx.x;
+    SceneView sv; WStack<STACK> st; uint32_t off;
+    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
+    uint32_t *s_rec = (uint32_t *)(smem + off);
+    float *s_steady = (float *)(smem + off + al16(a.G * 4u));
+    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const uint32_t par = a.parity;
+    uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
+    wf_ticket_begin(a, tid);
+    for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
+        const uint32_t pl0 = sg * a.G;
+        const uint32_t npx = min(a.G, a.P - pl0);
+        for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
+        for (uint32_t t = tid; t < 4 * npx; t += kBlock) s_steady[t] = 0.0f;
+        if (tid == 0) *s_next_p = 0u;
+        __syncthreads();
+        const uint32_t n_live = a.seg_live[(size_t)par * a.n_seg + sg];
+        const uint32_t *q = a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+        uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
+        const uint32_t n_round = (n_live + 63u) & ~63u;
+        for (uint32_t i = tid; i < n_round; i += kBlock) {
+            bool alive = false;
+            uint32_t slot = 0;
+            if (i < n_live) {
+                slot = q[i];
+                uint32_t pixel, s, pl;
+                slot_to_lane(a, slot, pixel, s, pl);
+                Path p;
+                load_state(P, slot, p);
+                const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                RecordSink sink;
+                sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
+                sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
+                sink.n_freq = 0u; sink.freq = nullptr; sink.start_opl = a.film.start_opl;
+                sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = p.lane;
+                sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
+                BounceStats bs; bs.closest = 0; bs.shadow = 0;
+                alive = nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bs);
+                n_closest += bs.closest; n_shadow += bs.shadow; ++n_bounce;
+                n_splats += sink.n_splats; n_over += sink.n_overflow;
+                store_state(P, slot, p, false);
+                if (alive) ++n_alive;
+                else {
+                    const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
+                    if (fx < a.film.width && fy < a.film.height) {
+                        float *sp = s_steady + 4 * (pl - pl0);
+                        __hip_atomic_fetch_add(sp, p.L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 1, p.L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 2, p.L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(sp + 3, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            if (__ballot(alive) != 0ull) {
+                const uint32_t pos = wave_append(s_next_p, alive);
+                if (alive) q_next[pos] = slot;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
+        for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
+        for (uint32_t t = tid; t < 4 * npx; t += kBlock) {
+            const float v = s_steady[t];
+            if (v != 0.0f) {
+                const uint32_t pixel = a.pix0 + pl0 + (t >> 2);
+                const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;
+                if (cx < a.film.width && cy < a.film.height) a.steady_out[((size_t)cy * a.film.width + cx) * 4u + (t & 3u)] += v;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.counters) {
+        const unsigned vals[5] = { n_closest, n_shadow, n_splats, n_bounce, n_over };
+        unsigned long long *dst[5] = { &a.counters->rays_closest, &a.counters->rays_shadow, &a.counters->splats_issued,
+                                       &a.counters->bounces, &a.counters->splats_overflow };
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            unsigned v = vals[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if ((tid & 63) == 0 && v) atomicAdd(dst[k], (unsigned long long)v);
+        }
+    }
+    if (a.live_total) {
+        unsigned v = n_alive;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((tid & 63) == 0 && v) atomicAdd(a.live_total, v);
+    }
+}
+
 // ---- the time-bin scatter-add: one workgroup per pixel of the tile ------------------------------
 // LDS float atomics (ds_add_f32) retire at a fixed 3 clocks per LANE on gfx950 whatever the address
 // pattern (204 G adds/s for the whole chip, measured), 64-bit integer LDS atomics at 2.7 T/s.  The row
@@ -725,7 +828,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
-                            : which == 4 ? k_wf_shadow_gen<STACK, SL> : k_wf_shade<STACK, SL>;
+                            : which == 4 ? k_wf_shadow_gen<STACK, SL> : which == 5 ? k_wf_nlos_bounce<STACK, SL> : k_wf_shade<STACK, SL>;
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
