@@ -506,10 +506,9 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
         // config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
         uint32_t mode = p->mode;
         if (s->nlos.on && mode == MTR_MODE_AUTO) mode = MTR_MODE_FUSED;      // (wavefront = the second organisation, on request)
-        if (f.n_freq) {                      // phasor film: contributions are kept as (opl, value) records -> wavefront pipeline
+        if (f.n_freq) {                      // phasor film: (opl, value) records -> wavefront pipeline by default; LDS (Re, Im) rows in the fused kernel on request
             if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
-            if (mode == MTR_MODE_FUSED) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film runs in the wavefront pipeline only");
-            mode = MTR_MODE_WAVEFRONT;
+            if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
         }
         if (mode == MTR_MODE_AUTO) {
             FusedArgs probe = a; FusedConfig pc{};

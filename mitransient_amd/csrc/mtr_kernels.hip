@@ -19,10 +19,9 @@
 namespace mtr {
 
 // ------------------------------------------------------------------ helpers
-template <int DEPTH>
 struct LdsStack {
     int32_t *base;     // &stack[tid]; entry k lives at base[k * kBlock]  (one bank column per lane)
-    int sp;            // DEPTH >= BVH depth, and the array has DEPTH + 1 rows: push_if may write row sp == DEPTH
+    int sp;            // the column has FusedArgs::stack_rows rows: one per stacked group + the row push_if writes before it counts
     __device__ __forceinline__ void reset() { sp = 0; }
     // unconditional LDS write, conditional increment: no branch in the node step
     __device__ __forceinline__ void push_if(bool c, int32_t v) { base[sp * kBlock] = v; sp += c ? 1 : 0; }
@@ -91,6 +90,27 @@ struct LdsHistSink {
     }
 };
 
+// phasor_hdr_film in the fused kernel: the workgroup's ring holds (Re, Im) per frequency instead of time bins —
+// [G][2F] — and every contribution adds its F terms (phasor_image_block.py:42-67) with LDS float atomics
+struct LdsPhasorSink {
+    float *row;                        // the pixel's slot: 2F floats
+    const float *freq; uint32_t n_freq; float start_opl;
+    uint32_t film_w, lane, n_splats;
+    SplatLog log;
+    __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
+                                          float opl, uint32_t depth, uint32_t kind)
+    {
+        const float rel = opl - start_opl;                                   // phasor_hdr_film.py:249
+        for (uint32_t f = 0; f < n_freq; ++f) {
+            float c, sn;
+            phasor_term(freq[f], rel, c, sn);
+            lds_add(row + 2u * f, r * c); lds_add(row + 2u * f + 1u, r * sn);
+        }
+        ++n_splats;
+        if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
+    }
+};
+
 // contract form: f32 atomics straight into the (H,W,T,4) tensor in HBM
 struct GlobalAtomicSink {
     float *film; uint32_t film_w, bins;
@@ -120,7 +140,8 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 #endif
 // MINW: waves per SIMD the register allocator must leave room for.  4 when four workgroups fit a CU; long rows (one
 // 48 KB histogram per workgroup: three per CU) get the 168-register budget of 3 waves per SIMD instead of spilling.
-template <int STACK, bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES>
+// PHASOR: phasor_hdr_film (HIST_LDS form only): the ring rows hold (Re, Im) per frequency, the flush adds 2F floats per pixel
+template <bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES, bool PHASOR = false>
 __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -168,15 +189,15 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     uint32_t *s_owner = (uint32_t *)(smem + off); off += align16(K * 4);      // pixel ordinal that may use the slot
     uint32_t *s_done = (uint32_t *)(smem + off); off += align16(K * 4);       // paths of that pixel that have ended
     float *s_hist = (float *)(smem + off);
-    const uint32_t T = a.film.bins;
+    const uint32_t T = PHASOR ? 2u * a.film.n_freq : a.film.bins;       // floats of one plane of a row
     const uint32_t plane = K * T;
 
     if (tid < 6) s_cnt[tid] = 0ull;
     for (uint32_t k = tid; k < K; k += kBlock) s_done[k] = 0u;
     for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady[k] = 0.0f;
-    if (HIST_LDS) for (uint32_t k = tid; k < 3 * plane; k += kBlock) s_hist[k] = 0.0f;
+    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : 3u) * plane; k += kBlock) s_hist[k] = 0.0f;
 
-    LdsStack<STACK> st; st.base = s_stack + tid; st.sp = 0;
+    LdsStack st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
     st.ls[0] = st.ls[1] = st.ws[0] = st.ws[1] = 0; st.wmax = 0; st.wcalls = 0;
 #endif
@@ -267,7 +288,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         uint32_t did_shadow = 0u, did_splats = 0u;                 // this iteration's per-lane counts (0..1, 0..2)
         if (alive) {
             BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
-            if (HIST_LDS) {
+            if (PHASOR) {
+                LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
+                sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                did_splats = sink.n_splats;
+            } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
@@ -310,7 +336,14 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             const uint32_t wl = tid & 63u;
             if (cx < a.film.width && cy < a.film.height) {
                 const size_t fpix = (size_t)cy * a.film.width + cx;
-                if (HIST_LDS) {
+                if (PHASOR) {          // (H, W, 2F + 1): Re, Im per frequency, then the weight channel (stays 0)
+                    float *dst = a.film_out + fpix * (size_t)(T + 1u);
+                    float *h = s_hist + fs * T;
+                    for (uint32_t t = wl; t < T; t += 64u) {
+                        const float v = h[t];
+                        if (v != 0.0f) { dst[t] = (a.rc.flags & MTR_FLAG_FILM_ZERO) ? v : dst[t] + v; h[t] = 0.0f; }
+                    }
+                } else if (HIST_LDS) {
                     float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
                     float *h = s_hist + fs * T;
                     // four bins per lane and pass (16-byte LDS reads, 64 contiguous bytes of film per lane); rows and planes
@@ -432,7 +465,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     uint32_t fixed = rows * kBlock * 4 + 64;
     if (cfg.scene_lds) fixed += scene_b;
     // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
-    const uint32_t row_bytes = film.bins * 12u;
+    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * 12u;     // (Re, Im) per frequency | 3 planes of T bins
     const uint32_t hist_budget = 48u * 1024u;
     uint32_t g_want = (MTR_FUSED_SEG_LANES + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
     if (g_want < 1) g_want = 1;
@@ -477,14 +510,18 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     return true;
 }
 
-template <int STACK, bool NLOS>
+template <bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
-    if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<STACK, true, true, NLOS, 3> : k_fused<STACK, true, true, NLOS>;
-    else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<STACK, true, false, NLOS>;
-    else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<STACK, false, true, NLOS>;
-    else k = k_fused<STACK, false, false, NLOS>;
+    if (!NLOS && args.film.n_freq) {
+        if (!cfg.hist_lds) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
+        k = cfg.scene_lds ? k_fused<true, true, false, MTR_FUSED_MIN_WAVES, true> : k_fused<false, true, false, MTR_FUSED_MIN_WAVES, true>;
+    }
+    else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
+    else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;
+    else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<false, true, NLOS>;
+    else k = k_fused<false, false, NLOS>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(args.ticket, 0, sizeof(uint32_t), stream);
@@ -497,7 +534,7 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
 __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst nc, q4 *targets)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LdsStack<64> st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
+    LdsStack st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
     sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
     sv.wnodes = nullptr; sv.wnodes4 = nullptr;
@@ -527,20 +564,7 @@ hipError_t launch_nlos_prepare(const SceneDev &sc, const NlosConst &nc, q4 *targ
 
 hipError_t launch_fused(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
-    if (args.nlos_on) {
-        switch (cfg.stack) {
-        case 8: return launch_fused_s<8, true>(args, cfg, stream);
-        case 16: return launch_fused_s<16, true>(args, cfg, stream);
-        case 32: return launch_fused_s<32, true>(args, cfg, stream);
-        default: return launch_fused_s<64, true>(args, cfg, stream);
-        }
-    }
-    switch (cfg.stack) {
-    case 8: return launch_fused_s<8, false>(args, cfg, stream);
-    case 16: return launch_fused_s<16, false>(args, cfg, stream);
-    case 32: return launch_fused_s<32, false>(args, cfg, stream);
-    default: return launch_fused_s<64, false>(args, cfg, stream);
-    }
+    return args.nlos_on ? launch_fused_s<true>(args, cfg, stream) : launch_fused_s<false>(args, cfg, stream);
 }
 
 // ------------------------------------------------------------------ stand-alone time-bin scatter-add
