@@ -291,8 +291,12 @@ extern "C" int hh_check_wide(const mtr_scene_desc *d, uint32_t *n_wide8, uint32_
                     const uint32_t code = (~(uint32_t)ref) & ~kLeafQuadBit, first = code >> 2, cnt = (code & 3u) + 1u;
                     for (uint32_t t = 0; t < cnt; ++t) {
                         const float *v = d->tri_verts + 9 * (size_t)hs.slot_orig[first + t];
-                        for (int p = 0; p < 3; ++p) for (int a = 0; a < 3; ++a)
-                            if ((double)v[3 * p + a] < lo[a] || (double)v[3 * p + a] > hi[a]) return -21;      // a triangle pokes out of its quantised leaf box
+                        // a leaf box holds the triangle, or — for a PIECE of a large triangle (early split clipping) — at
+                        // least overlaps its box
+                        double tl[3] = { 1e300, 1e300, 1e300 }, th[3] = { -1e300, -1e300, -1e300 };
+                        for (int p = 0; p < 3; ++p) for (int a = 0; a < 3; ++a) { tl[a] = std::min(tl[a], (double)v[3 * p + a]); th[a] = std::max(th[a], (double)v[3 * p + a]); }
+                        for (int a = 0; a < 3; ++a)
+                            if (th[a] < lo[a] || tl[a] > hi[a]) return -21;      // the leaf box does not even touch its triangle
                     }
                 }
             }
