@@ -2,7 +2,7 @@ import sys; sys.path.insert(0,'/root/repo')
 import bench, torch
 scene = bench.build_scene(512,512,1024)
 integ = scene.integrator(); integ.collect_stats=True
-s,t = integ.render(scene, spp=64)
+s,t = integ.render(scene, spp=int(sys.argv[1]) if len(sys.argv) > 1 else 64)
 c = integ.last_counters
 # u64 sums of packed (lane<<32 | wave) overflow the low half into the high half; spp=64 keeps them small enough
 for name, x in (('node step', c['splats_overflow']), ('tri test', c['reserved'][0])):
