@@ -178,6 +178,10 @@ enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133
        MTR_FLAG_KEEP_COUNTERS = 16u,       /* do not reset the context's device counters at the start of this call: a render
                                               issued as several asynchronous calls (row bands on alternating streams) sums
                                               its counters on the device; read them once with mtr_counters_read()        */
+       MTR_FLAG_DETERMINISTIC = 32u,       /* fused kernel: accumulate the LDS rows (and the steady sums) in signed 2^-42 fixed
+                                              point with 64-bit integer atomics instead of f32 atomics: sums no longer depend
+                                              on the order in which lanes add, so two runs give the same bits (the wavefront
+                                              organisation's scatter kernel always works this way).  Twice the LDS per row.  */
        MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8u /* sampler seeding variant: PCG32 initseq = TEA.v1 + lane instead of TEA.v1.
                                               drjit's PCG32::seed(size, initstate, initseq) adds arange(size) to initseq;
                                               mitsuba's independent sampler passes size = 1 after the TEA scramble in the

@@ -20,6 +20,7 @@ MTR_FLAG_DISCARD_DIRECT_LIGHT = 2
 MTR_FLAG_FILM_ZERO = 4
 MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8
 MTR_FLAG_KEEP_COUNTERS = 16
+MTR_FLAG_DETERMINISTIC = 32
 MTR_MODE_AUTO, MTR_MODE_FUSED, MTR_MODE_WAVEFRONT = 0, 1, 2
 
 _f3 = C.c_float * 3

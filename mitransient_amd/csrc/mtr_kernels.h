@@ -47,7 +47,7 @@ struct FusedArgs {
     NlosConst nlos;
 };
 
-struct FusedConfig { int stack; bool scene_lds; bool hist_lds; size_t lds_bytes; int grid; int per_cu; };
+struct FusedConfig { int stack; bool scene_lds; bool hist_lds; bool fixed; size_t lds_bytes; int grid; int per_cu; };
 
 // chooses G, LDS carve-up and grid for a render; returns false if nothing fits
 bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_t spp_chunk, int n_cu,

@@ -68,6 +68,16 @@ __device__ __forceinline__ void log_splat(const SplatLog &lg, uint32_t lane, uin
     }
 }
 
+// signed 2^-42 fixed point for order-independent LDS sums (ds_add_u64): resolution 2.3e-13, range +-2^21; a non-zero
+// contribution never rounds to zero
+__device__ __forceinline__ unsigned long long splat_to_fixed(float v)
+{
+    long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42
+    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;
+    return (unsigned long long)q;
+}
+__device__ __forceinline__ float splat_from_fixed(unsigned long long q) { return __ll2float_rn((long long)q) * 2.2737367544323206e-13f; }
+
 #ifndef MTR_FUSED_SEG_LANES
 #define MTR_FUSED_SEG_LANES 2048u      // samples in flight per workgroup the ring of row slots is sized for (1024 / 4096 measured worse)
 #endif
@@ -85,6 +95,20 @@ struct LdsHistSink {
     {
         float *p = hist + row + bin;
         lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b);
+        ++n_splats;
+        if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
+    }
+};
+
+// MTR_FLAG_DETERMINISTIC: the same ring in 64-bit fixed point
+struct LdsFixedSink {
+    unsigned long long *hist; uint32_t plane, row, film_w, lane, n_splats;
+    SplatLog log;
+    __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
+                                          float opl, uint32_t depth, uint32_t kind)
+    {
+        unsigned long long *p = hist + row + bin;
+        atomicAdd(p, splat_to_fixed(r)); atomicAdd(p + plane, splat_to_fixed(g)); atomicAdd(p + 2 * plane, splat_to_fixed(b));
         ++n_splats;
         if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
     }
@@ -141,7 +165,8 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 // MINW: waves per SIMD the register allocator must leave room for.  4 when four workgroups fit a CU; long rows (one
 // 48 KB histogram per workgroup: three per CU) get the 168-register budget of 3 waves per SIMD instead of spilling.
 // PHASOR: phasor_hdr_film (HIST_LDS form only): the ring rows hold (Re, Im) per frequency, the flush adds 2F floats per pixel
-template <bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES, bool PHASOR = false>
+// FIXED: MTR_FLAG_DETERMINISTIC (HIST_LDS form only): rows and steady sums in 64-bit fixed point
+template <bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES, bool PHASOR = false, bool FIXED = false>
 __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -185,7 +210,8 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     // until its last path has ended, then the wave that ended it flushes the row and hands the slot to pixel q + K:
     // lanes of pixel q + 1 start while pixel q drains; the only workgroup barrier is the one between chunks.
     const uint32_t K = a.G;
-    float *s_steady = (float *)(smem + off); off += align16(K * 16);
+    float *s_steady = (float *)(smem + off); off += align16(K * 32);          // [K][4] f32, or u64 fixed point (FIXED)
+    unsigned long long *s_steady64 = (unsigned long long *)s_steady;
     uint32_t *s_owner = (uint32_t *)(smem + off); off += align16(K * 4);      // pixel ordinal that may use the slot
     uint32_t *s_done = (uint32_t *)(smem + off); off += align16(K * 4);       // paths of that pixel that have ended
     float *s_hist = (float *)(smem + off);
@@ -194,8 +220,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 
     if (tid < 6) s_cnt[tid] = 0ull;
     for (uint32_t k = tid; k < K; k += kBlock) s_done[k] = 0u;
-    for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady[k] = 0.0f;
-    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : 3u) * plane; k += kBlock) s_hist[k] = 0.0f;
+    for (uint32_t k = tid; k < K * 8; k += kBlock) s_steady[k] = 0.0f;
+    unsigned long long *s_hist64 = (unsigned long long *)s_hist;
+    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : (FIXED ? 6u : 3u)) * plane; k += kBlock) s_hist[k] = 0.0f;
 
     LdsStack st; st.base = s_stack + tid; st.sp = 0;
 #ifdef MTR_PROFILE_SIMT
@@ -293,6 +320,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
                 did_splats = sink.n_splats;
+            } else if (FIXED) {
+                LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
+                sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
+                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                             : path_bounce(p, sv, a.film, a.rc, st, sink, bstat);
+                if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
@@ -311,8 +344,14 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
                 const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
                 if (fx < a.film.width && fy < a.film.height) {
-                    float *sp = s_steady + 4 * slot;
-                    lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                    if (FIXED) {
+                        unsigned long long *sp = s_steady64 + 4 * slot;
+                        atomicAdd(sp, splat_to_fixed(p.L.x)); atomicAdd(sp + 1, splat_to_fixed(p.L.y));
+                        atomicAdd(sp + 2, splat_to_fixed(p.L.z)); atomicAdd(sp + 3, splat_to_fixed(1.0f));
+                    } else {
+                        float *sp = s_steady + 4 * slot;
+                        lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                    }
                 }
                 // acq_rel: this lane's row / steady adds are performed before the count that may release the row.
                 // (One atomic per wave for the next samples and one per (wave, slot) for the count — ballots, readlanes and a
@@ -342,6 +381,19 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     for (uint32_t t = wl; t < T; t += 64u) {
                         const float v = h[t];
                         if (v != 0.0f) { dst[t] = (a.rc.flags & MTR_FLAG_FILM_ZERO) ? v : dst[t] + v; h[t] = 0.0f; }
+                    }
+                } else if (FIXED) {
+                    float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
+                    unsigned long long *h = s_hist64 + fs * T;
+                    for (uint32_t t = wl; t < T; t += 64u) {
+                        const unsigned long long qr = h[t], qg = h[t + plane], qb = h[t + 2 * plane];
+                        if ((qr | qg | qb) != 0ull) {
+                            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];
+                            v.x += splat_from_fixed(qr); v.y += splat_from_fixed(qg); v.z += splat_from_fixed(qb);
+                            row[t] = v;
+                            h[t] = 0ull; h[t + plane] = 0ull; h[t + 2 * plane] = 0ull;
+                        }
                     }
                 } else if (HIST_LDS) {
                     float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
@@ -382,9 +434,10 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     }
                 }
                 if (wl < 4) {
-                    float v = s_steady[4 * fs + wl];
+                    float v;
+                    if (FIXED) { v = splat_from_fixed(s_steady64[4 * fs + wl]); s_steady64[4 * fs + wl] = 0ull; }
+                    else { v = s_steady[4 * fs + wl]; s_steady[4 * fs + wl] = 0.0f; }
                     if (v != 0.0f) a.steady_out[fpix * 4u + wl] += v;
-                    s_steady[4 * fs + wl] = 0.0f;
                 }
             }
             if (wl == 0) {
@@ -462,25 +515,28 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     // branch-free push writes before it knows whether it counts)
     const uint32_t rows = (cfg.scene_lds ? sc.wide_levels : sc.wide4_levels) + 1u;
     args.stack_rows = rows;
-    uint32_t fixed = rows * kBlock * 4 + 64;
-    if (cfg.scene_lds) fixed += scene_b;
+    uint32_t fixed_b = rows * kBlock * 4 + 64;
+    if (cfg.scene_lds) fixed_b += scene_b;
     // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
-    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * 12u;     // (Re, Im) per frequency | 3 planes of T bins
-    const uint32_t hist_budget = 48u * 1024u;
+    const bool det = (args.rc.flags & MTR_FLAG_DETERMINISTIC) && !film.n_freq;
+    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * (det ? 24u : 12u);     // (Re, Im) per frequency | 3 planes of T bins (f32 | 64-bit fixed point)
+    cfg.fixed = false;
+    const uint32_t hist_budget = (det ? 72u : 48u) * 1024u;
     uint32_t g_want = (MTR_FUSED_SEG_LANES + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
     if (g_want < 1) g_want = 1;
     uint32_t g_fit = row_bytes ? hist_budget / row_bytes : 1u;
     cfg.hist_lds = true;
     uint32_t G;
     if (g_fit >= 1) G = g_want < g_fit ? g_want : g_fit;
-    else if (fixed + row_bytes + 64 <= kLdsMax) G = 1;                  // one long row still fits the CU
+    else if (fixed_b + row_bytes + 64 <= kLdsMax) G = 1;                  // one long row still fits the CU
     else { G = g_want; cfg.hist_lds = false; }                          // row > LDS: f32 atomics to HBM
+    cfg.fixed = det && cfg.hist_lds;
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
     args.div_G = fastdiv_make(G); args.div_spp = fastdiv_make(spp_chunk);
     cfg.stack = stack;
-    cfg.lds_bytes = fixed + align16(G * 16) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
+    cfg.lds_bytes = fixed_b + align16(G * 32) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
     if (cfg.lds_bytes > kLdsMax) return false;
     // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), each with at least g_want pixels
     int per_cu = (int)(kLdsMax / cfg.lds_bytes);
@@ -518,6 +574,7 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
         if (!cfg.hist_lds) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
         k = cfg.scene_lds ? k_fused<true, true, false, MTR_FUSED_MIN_WAVES, true> : k_fused<false, true, false, MTR_FUSED_MIN_WAVES, true>;
     }
+    else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
     else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<false, true, NLOS>;
@@ -603,13 +660,6 @@ __global__ void __launch_bounds__(kBlock) k_splat_runs(const uint32_t *pixel, ui
         for (int64_t q = prev + 1; q <= (int64_t)cur; ++q) starts[q] = i;                   // pixels prev+1 .. cur start here
         if (i == n - 1) for (uint32_t q = cur + 1; q <= npix; ++q) starts[q] = n;
     }
-}
-
-__device__ __forceinline__ unsigned long long splat_to_fixed(float v)
-{
-    long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42
-    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;
-    return (unsigned long long)q;
 }
 
 template <bool FIXED>

@@ -39,6 +39,8 @@ class TransientADIntegrator:
         _ = props.get("block_size", 0)
         # sampler seeding variant (extension; see MTR_FLAG_PCG_INITSEQ_PLUS_LANE in the header): False = TEA(seed, lane) only
         self.pcg_initseq_plus_lane = bool(props.get("amd_pcg_initseq_plus_lane", False))
+        # order-independent (fixed-point) accumulation in the fused kernel: bit-reproducible renders (extension)
+        self.deterministic = bool(props.get("amd_deterministic", False))
         self.mode = _cabi.MTR_MODE_AUTO            # kernel organisation (extension; not a reference key)
         m = props.get("amd_mode", None)
         if m is not None:
@@ -114,6 +116,8 @@ class TransientADIntegrator:
             f |= _cabi.MTR_FLAG_DISCARD_DIRECT_LIGHT
         if self.pcg_initseq_plus_lane:
             f |= _cabi.MTR_FLAG_PCG_INITSEQ_PLUS_LANE
+        if self.deterministic:
+            f |= _cabi.MTR_FLAG_DETERMINISTIC
         return f
 
     def render_params(self, film, seed_value, spp_total, spp_begin=0, spp_end=None,

@@ -601,3 +601,30 @@ def test_warn_negative_and_invalid_sample_values(caplog):
     assert len(caplog.records) == 2 and all("Invalid sample value" in r.getMessage() for r in caplog.records)
     t = blk.torch_tensor().cpu().numpy()
     assert t[0, 0, 0, 0] == 3.0 and t[0, 1, 1, 0] == 3.5
+
+
+@pytest.mark.parametrize("bins", [256, 1024, 4096])
+def test_deterministic_fused_rows(oracle, bins):
+    """amd_deterministic (MTR_FLAG_DETERMINISTIC): the fused kernel's LDS rows and steady sums in 64-bit fixed point — sums no
+    longer depend on the order in which lanes add, so two renders are bit for bit equal (f32 LDS atomics: equal only up to
+    summation order); still the oracle's film within 1e-5, identical counters.  Three row lengths = three ring depths."""
+    scene = make_cornell(width=20, height=12, bins=bins, start=3.0, window=9.0, amd_mode="fused", amd_deterministic=True)
+    s0, t0 = gpu_render(scene, 200)
+    c0 = dict(scene.integrator().last_counters)
+    s1, t1 = gpu_render(scene, 200)
+    assert np.array_equal(t0, t1) and np.array_equal(s0, s1)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 200)
+    assert rel_l2(t0, t_ref) <= TOL and rel_l2(s0, s_ref) <= TOL
+    assert np.array_equal(t0 != 0, t_ref != 0)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert c0[k] == cnt[k], k
+    # two passes accumulated onto each other stay reproducible too (the flush reads, adds, writes in pass order)
+    integ, sens = scene.integrator(), scene.sensors()[0]
+    outs = []
+    for _ in range(2):
+        passes = integ.prepare(scene, sens, 0, 200, [])
+        integ.accumulate(scene, sens, passes, 200, spp_range=(0, 77))
+        integ.accumulate(scene, sens, passes, 200, spp_range=(77, 200))
+        s, t = sens.film().develop()
+        outs.append(np.array(t))
+    assert np.array_equal(outs[0], outs[1]) and rel_l2(outs[0], t_ref) <= TOL
