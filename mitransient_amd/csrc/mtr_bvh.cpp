@@ -216,6 +216,40 @@ void set_empty_child(Node &n, int c, int32_t ref)
 
 } // namespace
 
+bool mesh_is_affine_box(const float *verts, uint32_t first, const float *xf, uint32_t face_tris[12])
+{
+    uint32_t cnt[6] = { 0, 0, 0, 0, 0, 0 }, corners[12][3];
+    for (uint32_t t = 0; t < 12; ++t) {
+        for (int v = 0; v < 3; ++v) {
+            const float *p = verts + 9 * (size_t)(first + t) + 3 * v;
+            uint32_t id = 0;
+            for (int r = 0; r < 3; ++r) {
+                const double q = (double)xf[4 * r] * p[0] + (double)xf[4 * r + 1] * p[1] + (double)xf[4 * r + 2] * p[2] + (double)xf[4 * r + 3];
+                if (!(std::fabs(std::fabs(q) - 1.0) <= 1e-3)) return false;          // every vertex is a corner of the cube
+                id |= q > 0.0 ? 1u << r : 0u;
+            }
+            corners[t][v] = id;
+        }
+        const uint32_t a = corners[t][0], b = corners[t][1], c = corners[t][2];
+        if (a == b || b == c || a == c) return false;
+        const uint32_t same = ~((a ^ b) | (a ^ c)) & 7u;                              // axes on which the three corners agree
+        if (same != 1u && same != 2u && same != 4u) return false;                     // exactly one: the triangle lies in a face
+        const uint32_t axis = same == 1u ? 0u : (same == 2u ? 1u : 2u);
+        const uint32_t f = 2u * axis + ((a >> axis) & 1u);
+        if (cnt[f] == 2u) return false;
+        face_tris[2u * f + cnt[f]++] = first + t;
+    }
+    for (uint32_t f = 0; f < 6; ++f) {
+        if (cnt[f] != 2u) return false;
+        const uint32_t *A = corners[face_tris[2 * f] - first], *B = corners[face_tris[2 * f + 1] - first];
+        uint32_t common[3], n = 0;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (A[i] == B[j] && n < 3) common[n++] = A[i];
+        // the two halves of the face: they share exactly its diagonal (two corners that differ on both free axes)
+        if (n != 2u || (common[0] ^ common[1]) != (7u ^ (1u << (f >> 1)))) return false;
+    }
+    return true;
+}
+
 void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &out)
 {
     out.nodes.clear(); out.order.clear(); out.max_depth = 0; out.n_leaves = 0; out.packet_object.clear();
@@ -376,7 +410,9 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
     std::vector<WChild> ch;
     // an OBJECT subtree with few leaves becomes one node whose boxes live in the object's own space (8-wide tree only)
     const float *xf = nullptr;
-    if (W == 8 && prims && prims->object_xf && verts && !getenv("MTR_NO_OBJECT_NODES")) {
+    bool is_box = false;
+    const bool objects_on = W == 8 && prims && prims->object_xf && verts && !getenv("MTR_NO_OBJECT_NODES");
+    if (objects_on) {
         const int32_t obj = bvh.packet_object[packet];
         std::vector<int32_t> leaves;
         if (obj >= 0) subtree_leaves(bvh, packet, leaves);
@@ -390,14 +426,40 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
                 padded(b, w.lo, w.hi, 1e-4f);          // + the rounding of the ray's own transform in the kernel
                 ch.push_back(w);
             }
+            // a BOX: the object is an affine cube and its six leaves are its six faces -> children in face order
+            if (leaves.size() == 6 && !getenv("MTR_NO_BOX_NODES")) {
+                uint32_t first = 0xffffffffu, faces[12];
+                for (int32_t ref : leaves) {
+                    const uint32_t code = ~(uint32_t)ref;
+                    for (uint32_t k = 0; k <= (code & 3u); ++k) first = std::min(first, bvh.order[(code >> 2) + k]);
+                }
+                bool ok = mesh_is_affine_box(verts, first, xf, faces);
+                std::vector<WChild> by_face(6);
+                uint32_t seen = 0u;
+                for (size_t c = 0; ok && c < 6; ++c) {
+                    const uint32_t code = ~(uint32_t)ch[c].ref, slot = code >> 2;
+                    ok = (code & 3u) == 1u;
+                    for (uint32_t f = 0; ok && f < 6; ++f) {
+                        const uint32_t a = bvh.order[slot], b = bvh.order[slot + 1];
+                        if ((a == faces[2 * f] && b == faces[2 * f + 1]) || (b == faces[2 * f] && a == faces[2 * f + 1])) { by_face[f] = ch[c]; seen |= 1u << f; }
+                    }
+                }
+                if (ok && seen == 63u) { ch = by_face; is_box = true; }
+            }
         }
     }
     if (!xf) {
         packet_children(bvh.nodes[packet], ch);
+        // (an object subtree that will become an object node of its own is never dissolved into its parent)
+        auto opaque = [&](int32_t ref) {
+            if (!objects_on || bvh.packet_object[ref] < 0) return false;
+            std::vector<int32_t> lv; subtree_leaves(bvh, ref, lv);
+            return lv.size() <= width;
+        };
         for (;;) {
             int best = -1; float best_a = -1.0f;
             for (size_t i = 0; i < ch.size(); ++i)
-                if (ch[i].ref >= 0 && half_area(ch[i]) > best_a) { best = (int)i; best_a = half_area(ch[i]); }
+                if (ch[i].ref >= 0 && half_area(ch[i]) > best_a && !opaque(ch[i].ref)) { best = (int)i; best_a = half_area(ch[i]); }
             if (best < 0) break;
             std::vector<WChild> sub;
             packet_children(bvh.nodes[ch[best].ref], sub);
@@ -409,13 +471,13 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
     // rectangles first (8-wide tree: the walk always visits them first, wide_advance), the others in walk order: by centroid
     // along the axis on which their centroids spread most
     size_t nq = 0;
-    if (W == 8) nq = (size_t)(std::stable_partition(ch.begin(), ch.end(), [](const WChild &w) { return is_quad_ref(w.ref); }) - ch.begin());
+    if (W == 8 && !is_box) nq = (size_t)(std::stable_partition(ch.begin(), ch.end(), [](const WChild &w) { return is_quad_ref(w.ref); }) - ch.begin());
     float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (size_t i = nq; i < ch.size(); ++i)
         for (int k = 0; k < 3; ++k) { const float c = 0.5f * (ch[i].lo[k] + ch[i].hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
     int axis = 0;
     for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-    std::stable_sort(ch.begin() + nq, ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
+    if (!is_box) std::stable_sort(ch.begin() + nq, ch.end(), [axis](const WChild &a, const WChild &b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
 
     WNodeT<W> nd{};
     float *f = &nd.box[0].x;
@@ -427,7 +489,7 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
         }
         nd.ref[c] = 0;
     }
-    nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.n_quads = (uint32_t)nq; nd.flags = xf ? 1u : 0u;
+    nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.n_quads = (uint32_t)nq; nd.flags = (xf ? 1u : 0u) | (is_box ? 2u : 0u);
     for (int k = 0; k < 12; ++k) nd.xf[k] = xf ? xf[k] : 0.0f;
     for (size_t c = 0; c < ch.size(); ++c)
         nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, prims, verts, ch[c].ref, wide, level + 1, levels, width) : ch[c].ref;

@@ -214,7 +214,9 @@ template <uint32_t W>
 struct alignas(16) WNodeT {
     q4 box[3 * W / 2];
     int32_t ref[W];
-    uint32_t axis, count, n_quads, flags;     // n_quads: children 0 .. n_quads-1 are rectangle leaves; flags bit 0: object node
+    uint32_t axis, count, n_quads, flags;     // n_quads: children 0 .. n_quads-1 are rectangle leaves; flags bit 0: object node,
+                                              // bit 1: BOX node — the object is the cube [-1,1]^3 and child f = 2 * axis +
+                                              // (coordinate = +1) is the leaf with the two triangles of that face (box_select)
     float xf[12];                             // object nodes: (R | T) rows, local = R * p + T
     static constexpr uint32_t kBytes = 28u * W + 64u, kRefOff = 24u * W, kHdrOff = 28u * W, kXfOff = 28u * W + 16u;
     static constexpr uint32_t kMask = (1u << W) - 1u, kRevBit = 1u << W, kQuadShift = W + 1u, kNodeShift = W + 5u;
@@ -539,6 +541,59 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     else tr.cur = st.empty() ? kTravDone : st.pop();
 }
 
+// BOX nodes (an object that is an affine image of the cube [-1,1]^3, every face split into two triangles: mitsuba's `cube`):
+// instead of slab tests against the six faces' boxes, the slab distances of the cube itself give the points pe, px where
+// the ray enters and leaves it, and only the faces that can hold the closest hit are visited — normally ONE leaf instead of
+// the entry face's and the exit face's.  The selection only prunes; hits, t and barycentrics come from the Moller-Trumbore
+// test of the visited leaves, so the result is bit for bit what visiting all six gives as long as the selection is a superset:
+//   the faces whose plane pe touches — the entry face, both neighbours at an edge, an exit-side plane the ray grazes or
+//   clips a corner through;
+//   and, when the entry test may fail although the ray meets the cube — origin inside it; pe on an edge or a corner (two
+//   planes touched), or on a diagonal of its face, where the ray can slip between two triangles and meet the far side
+//   from within — also the faces px touches.
+// "Touches" = within eps of the plane, the point itself within eps of the cube (else the ray misses it).  eps covers the
+// rounding of the point several times over: 2e-5 + 8e-6 m per axis (m = the magnitude of the terms of the object-space
+// coordinate: its rounding is ~1e-7 m) plus the distance the point slides along that axis when the slab distance is off
+// by the rounding of a coordinate divided by a direction component (grazing rays: large, and then simply more faces, up
+// to all six, are visited).  That slide per unit of direction is also the uncertainty of the slab distances themselves:
+// pe (px) counts only when its distance is neither behind the origin nor beyond tb = min(tmax, closest hit so far) by more
+// than it — a ray leaving a face of the cube does not revisit that face.
+// Returns the mask of faces, bit f = face 2 * axis + (coordinate = +1).
+MTR_HD uint32_t box_select(q4 A, q4 B, q4 C, f3 o, f3 ol, f3 dl, f3 id, float tb)
+{
+    const f3 en = mk(dl.x < 0.0f ? 1.0f : -1.0f, dl.y < 0.0f ? 1.0f : -1.0f, dl.z < 0.0f ? 1.0f : -1.0f);   // entry planes; exit = -en
+    const float tn = fmaxf(fmaxf((en.x - ol.x) * id.x, (en.y - ol.y) * id.y), (en.z - ol.z) * id.z);
+    const float tf = fminf(fminf((-en.x - ol.x) * id.x, (-en.y - ol.y) * id.y), (-en.z - ol.z) * id.z);
+    const f3 mag = mk(fmaf(fabsf(A.z), fabsf(o.z), fmaf(fabsf(A.y), fabsf(o.y), fmaf(fabsf(A.x), fabsf(o.x), fabsf(A.w)))),
+                      fmaf(fabsf(B.z), fabsf(o.z), fmaf(fabsf(B.y), fabsf(o.y), fmaf(fabsf(B.x), fabsf(o.x), fabsf(B.w)))),
+                      fmaf(fabsf(C.z), fabsf(o.z), fmaf(fabsf(C.y), fabsf(o.y), fmaf(fabsf(C.x), fabsf(o.x), fabsf(C.w)))));
+    const float slide = 8e-6f * fmaxf(fmaxf(mag.x * fabsf(id.x), mag.y * fabsf(id.y)), mag.z * fabsf(id.z));
+    const f3 eps = mk(fmaf(slide, fabsf(dl.x), fmaf(8e-6f, mag.x, 2e-5f)), fmaf(slide, fabsf(dl.y), fmaf(8e-6f, mag.y, 2e-5f)),
+                      fmaf(slide, fabsf(dl.z), fmaf(8e-6f, mag.z, 2e-5f)));
+    const f3 pe = mk(fmaf(tn, dl.x, ol.x), fmaf(tn, dl.y, ol.y), fmaf(tn, dl.z, ol.z));
+    const f3 px = mk(fmaf(tf, dl.x, ol.x), fmaf(tf, dl.y, ol.y), fmaf(tf, dl.z, ol.z));
+    const f3 ae = mk(fabsf(pe.x), fabsf(pe.y), fabsf(pe.z));
+    // (`slide` is the uncertainty of tn and tf themselves: a point behind the origin, or beyond the closest hit so far, holds no hit)
+    const bool in_e = (ae.x <= 1.0f + eps.x) && (ae.y <= 1.0f + eps.y) && (ae.z <= 1.0f + eps.z) && (tn >= -slide) && (tn <= tb + slide);
+    const bool in_x = (fabsf(px.x) <= 1.0f + eps.x) && (fabsf(px.y) <= 1.0f + eps.y) && (fabsf(px.z) <= 1.0f + eps.z) && (tf >= -slide) && (tf <= tb + slide);
+    const bool inside = (fabsf(ol.x) <= 1.0f + eps.x) && (fabsf(ol.y) <= 1.0f + eps.y) && (fabsf(ol.z) <= 1.0f + eps.z);
+    const uint32_t bx_en = en.x > 0.0f ? 2u : 1u, by_en = en.y > 0.0f ? 8u : 4u, bz_en = en.z > 0.0f ? 32u : 16u;
+    uint32_t mask = 0u, later = 0u;
+    mask |= (in_e && fabsf(pe.x - en.x) <= eps.x) ? bx_en : 0u;
+    mask |= (in_e && fabsf(pe.y - en.y) <= eps.y) ? by_en : 0u;
+    mask |= (in_e && fabsf(pe.z - en.z) <= eps.z) ? bz_en : 0u;
+    mask |= (in_e && fabsf(pe.x + en.x) <= eps.x) ? (bx_en ^ 3u) : 0u;
+    mask |= (in_e && fabsf(pe.y + en.y) <= eps.y) ? (by_en ^ 12u) : 0u;
+    mask |= (in_e && fabsf(pe.z + en.z) <= eps.z) ? (bz_en ^ 48u) : 0u;
+    later |= (in_x && fabsf(px.x + en.x) <= eps.x) ? (bx_en ^ 3u) : 0u;
+    later |= (in_x && fabsf(px.y + en.y) <= eps.y) ? (by_en ^ 12u) : 0u;
+    later |= (in_x && fabsf(px.z + en.z) <= eps.z) ? (bz_en ^ 48u) : 0u;
+    // a diagonal of the entry face: two of |pe|'s coordinates agree (the third is 1, which the edge test above covers)
+    const bool diagonal = (fabsf(ae.x - ae.y) <= eps.x + eps.y) || (fabsf(ae.y - ae.z) <= eps.y + eps.z) || (fabsf(ae.x - ae.z) <= eps.x + eps.z);
+    const bool risky = inside || diagonal || (mask & (mask - 1u)) != 0u;
+    return mask | (risky ? later : 0u);
+}
+
 // ---- wide trees (SceneView::wnodes / wnodes4) ----
 // next child of the current group (or of the group on top of the stack): sets tr.cur
 template <uint32_t W, class Stack>
@@ -568,6 +623,7 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
     const uint32_t axis = *(const uint32_t *)(nb + N::kHdrOff), count = *(const uint32_t *)(nb + N::kHdrOff + 4u);
     const uint32_t n_quads = *(const uint32_t *)(nb + N::kHdrOff + 8u), flags = *(const uint32_t *)(nb + N::kHdrOff + 12u);
     uint32_t sel0 = tr.sel[0], sel1 = tr.sel[1], sel2 = tr.sel[2];
+    uint32_t box_m = 0u;
     if (flags & 1u) {          // object node: the ray in the shape's object space (t is invariant under the affine map)
         const q4 A = *(const q4 *)(nb + N::kXfOff), B = *(const q4 *)(nb + N::kXfOff + 16u), C = *(const q4 *)(nb + N::kXfOff + 32u);
         const f3 o = tr.o, d = tr.d;
@@ -578,14 +634,16 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
         id = mk(safe_rcp(dl.x), safe_rcp(dl.y), safe_rcp(dl.z));
         noid = mk(-(ol.x * id.x), -(ol.y * id.y), -(ol.z * id.z));
         sel0 = id.x < 0.0f ? 8u : 0u; sel1 = 16u + (id.y < 0.0f ? 8u : 0u); sel2 = 32u + (id.z < 0.0f ? 8u : 0u);
+        if (flags & 2u) box_m = box_select(A, B, C, o, ol, dl, id, tb);
     }
     const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
     uint32_t m = 0u;
+    if (flags & 2u) m = box_m;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t j = 0; j < W / 2u; ++j) {
-        if (OFFS ? (2u * j < count) : true) {
+        if (OFFS ? (2u * j < ((flags & 2u) ? 0u : count)) : true) {
             const char *pb = nb + 48u * j;
             f2 nx, fx, ny, fy, nz, fz;
             if (OFFS) {

@@ -82,7 +82,7 @@ static void rect_to_object(const float c[3], const float du[3], const float dv[3
 }
 // world -> object rows (R | T) of a mesh shape's 3 x 4 to_world; false when the map is singular or axis-aligned (every
 // row of the linear part has one entry: object-space boxes would be the world boxes)
-static bool object_space_of(const float tw[12], float inv[12])
+static bool object_space_of(const float tw[12], float inv[12], bool *axis_aligned = nullptr)
 {
     const double m[9] = { tw[0], tw[1], tw[2], tw[4], tw[5], tw[6], tw[8], tw[9], tw[10] }, t[3] = { tw[3], tw[7], tw[11] };
     double big = 0.0;
@@ -94,7 +94,8 @@ static bool object_space_of(const float tw[12], float inv[12])
         aligned = aligned && nz <= 1;
     }
     const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    if (aligned || !(fabs(det) > 1e-30)) return false;
+    if (axis_aligned) *axis_aligned = aligned;
+    if ((aligned && !axis_aligned) || !(fabs(det) > 1e-30)) return false;
     const double c[9] = { m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
                           m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
                           m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3] };
@@ -141,7 +142,12 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
             continue;
         }
         float inv[12];
-        if (S.has_to_world && S.n_tris >= 4 && S.n_tris <= 16 && object_space_of(S.to_world, inv)) {
+        bool aligned = false;
+        uint32_t faces[12];
+        // (an axis-aligned transform gains nothing from object-space boxes — unless the shape is an affine cube, which
+        // becomes a box node whatever its orientation)
+        if (S.has_to_world && S.n_tris >= 4 && S.n_tris <= 16 && object_space_of(S.to_world, inv, &aligned) &&
+            (!aligned || (S.n_tris == 12 && mesh_is_affine_box(d.tri_verts, S.first_tri, inv, faces)))) {
             for (uint32_t t = 0; t < S.n_tris; ++t) object[S.first_tri + t] = (int32_t)(object_xf.size() / 12);
             object_xf.insert(object_xf.end(), inv, inv + 12);
         }

@@ -177,7 +177,7 @@ extern "C" int hh_print_wide(const mtr_scene_desc *d)
     printf("bvh2 packets %zu, wide nodes %zu, slots %zu\n", hs.nodes.size(), hs.wnodes.size(), hs.tshade.size());
     for (size_t i = 0; i < hs.wnodes.size(); ++i) {
         const WNode &w = hs.wnodes[i];
-        printf("  wnode %zu axis %u count %u quads %u%s:", i, w.axis, w.count, w.n_quads, (w.flags & 1u) ? " OBJECT" : "");
+        printf("  wnode %zu axis %u count %u quads %u%s:", i, w.axis, w.count, w.n_quads, (w.flags & 2u) ? " BOX" : ((w.flags & 1u) ? " OBJECT" : ""));
         const float *f = &w.box[0].x;
         for (uint32_t c = 0; c < w.count; ++c) {
             if (w.ref[c] >= 0) printf(" N%d", w.ref[c]);
@@ -189,6 +189,21 @@ extern "C" int hh_print_wide(const mtr_scene_desc *d)
         printf("\n");
     }
     return 0;
+}
+
+// number of BOX nodes of the 8-wide tree (mtr_core.h box_select); -2 when one of them is not six two-triangle leaves
+extern "C" int hh_count_box_nodes(const mtr_scene_desc *d)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    int n = 0;
+    for (const WNode &w : hs.wnodes) {
+        if (!(w.flags & 2u)) continue;
+        if (!(w.flags & 1u) || w.count != 6u || w.n_quads != 0u) return -2;
+        for (uint32_t c = 0; c < 6u; ++c) if (w.ref[c] >= 0 || ((~(uint32_t)w.ref[c]) & 3u) != 1u || ((~(uint32_t)w.ref[c]) & kLeafQuadBit)) return -2;
+        ++n;
+    }
+    return n;
 }
 
 // structural checks of the collapsed trees (tests/test_scene_host.py): every BVH2 leaf is referenced exactly once by the

@@ -158,12 +158,92 @@ def _bvh_equals_brute_force(oracle, host_harness):
     assert (p0 >= 0).mean() > 0.5
 
 
+def test_object_nodes_equal_brute_force(oracle, host_harness, monkeypatch):
+    """MTR_NO_BOX_NODES: the cubes as plain object nodes (slab tests against the six faces' object-space boxes)."""
+    monkeypatch.setenv("MTR_NO_BOX_NODES", "1")
+    assert host_harness.hh_count_box_nodes(C.byref(make_cornell().data().desc())) == 0
+    host_harness.hh_set_node_pairs(1)
+    host_harness.hh_set_wide(1)
+    try:
+        _bvh_equals_brute_force(oracle, host_harness)
+    finally:
+        host_harness.hh_set_node_pairs(0)
+        host_harness.hh_set_wide(0)
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-tree"])
+@pytest.mark.parametrize("to_world", ["rotated", "sheared-far", "aligned"])
+def test_box_node_equals_brute_force(oracle, host_harness, wide, to_world):
+    """A `cube` is a BOX node of the 8-wide tree (mtr_core.h box_select): the slab distances in object space select the
+    faces whose leaves are visited.  Bit for bit the brute-force answer over all twelve triangles — for rays aimed at the
+    edges and corners, grazing the faces, starting inside the box and starting on its surface."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    T = mi.ScalarTransform4f
+    if to_world == "rotated":
+        tw = T().translate([0.3, -0.2, 0.1]).rotate([1, 2, 3], 37.0).scale([0.3, 0.6, 0.2])
+        M = np.asarray(tw.matrix, np.float64)
+    elif to_world == "aligned":
+        tw = T().translate([0.3, -0.2, 0.1]).scale([0.3, 0.6, 0.2])
+        M = np.asarray(tw.matrix, np.float64)
+    else:                                  # not even orthogonal, and far from the origin (cornell-box units)
+        M = np.array([[80.0, 25.0, 0.0, 350.0], [-10.0, 160.0, 30.0, 165.0], [5.0, -20.0, 90.0, 270.0], [0, 0, 0, 1.0]])
+        tw = T(M)
+    d = mitr.cornell_box()
+    for k in list(d):
+        if isinstance(d[k], dict) and d[k].get("type") in ("cube", "rectangle", "obj") and k != "light":
+            del d[k]
+    d["box"] = {"type": "cube", "to_world": tw, "bsdf": {"type": "diffuse"}}
+    scene = mi.load_dict(d)
+    sd = scene.data()
+    assert host_harness.hh_count_box_nodes(C.byref(sd.desc())) == 1
+    rng = np.random.default_rng(11)
+    n = 150000
+    A, b = M[:3, :3], M[:3, 3]
+    def to_w(p): return p @ A.T + b
+    # targets in object space: faces, edges (two coordinates at +-1), corners (three), each with a jitter of a few ulps .. 1e-3
+    tgt = rng.uniform(-1, 1, (n, 3))
+    kind = rng.integers(0, 4, n)
+    for i in range(3):
+        snap = (kind >= 1) & (rng.random(n) < 0.75) | (kind == 3)
+        tgt[snap, i] = np.sign(tgt[snap, i])
+    tgt += rng.choice([0.0, 1e-7, 1e-5, 1e-3], (n, 1)) * rng.normal(size=(n, 3))
+    org = rng.uniform(-3, 3, (n, 3))
+    inside = rng.random(n) < 0.2
+    org[inside] = rng.uniform(-0.999, 0.999, (inside.sum(), 3))
+    on_face = rng.random(n) < 0.1                                   # origins on (just off) a face, as after a bounce
+    ax = rng.integers(0, 3, n)
+    org[on_face, ax[on_face]] = np.sign(org[on_face, ax[on_face]]) * (1.0 + rng.choice([0.0, 1e-6, 1e-4], on_face.sum()))
+    # (not IN the plane of that face: Moller-Trumbore on an in-plane ray divides noise by noise and reports hits outside the
+    # triangle's own bounding box, which brute force keeps and any BVH culls)
+    tgt[on_face, ax[on_face]] = rng.uniform(-0.9, 0.9, on_face.sum())
+    o = to_w(org).astype(np.float32)
+    dirs = to_w(tgt) - to_w(org)
+    dirs[on_face & (rng.random(n) < 0.5)] *= -1.0                   # ... leaving the surface
+    dirs = (dirs / np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    dirs[:50, 0] = 0.0
+    maxt = np.where(rng.random(n) < 0.7, np.inf, rng.uniform(0.1, 4.0, n) * np.abs(A).max()).astype(np.float32)
+    host_harness.hh_set_node_pairs(1 if wide else 0)
+    host_harness.hh_set_wide(wide)
+    try:
+        t0, p0, occ0 = oracle.intersect(sd, o, dirs, maxt, use_bvh=False)
+        t1, p1, occ1 = _hh_intersect(host_harness, sd, o, dirs, maxt)
+    finally:
+        host_harness.hh_set_node_pairs(0)
+        host_harness.hh_set_wide(0)
+    bad = np.flatnonzero((t0.view(np.uint32) != t1.view(np.uint32)) | (p0 != p1) | (occ0 != occ1))
+    assert bad.size == 0, (bad[:5], t0[bad[:5]], t1[bad[:5]], p0[bad[:5]], p1[bad[:5]], org[bad[:5]], tgt[bad[:5]], maxt[bad[:5]])
+    assert 0.2 < (p0 >= 0).mean() < 0.98
+
+
 def test_bvh_structure(host_harness):
     scene = make_cornell()
     desc = scene.data().desc()
     nn, dd, ll = C.c_uint32(), C.c_uint32(), C.c_uint32()
     assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dd), C.byref(ll)) == 0
     assert ll.value == nn.value + 1 and 9 <= ll.value <= 36 and dd.value <= 8     # fits the smallest LDS stack
+    assert host_harness.hh_count_box_nodes(C.byref(desc)) == 2
 
 
 def test_bvh_degenerate_inputs(oracle, host_harness):
