@@ -11,10 +11,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 7
+MTR_ABI_VERSION = 8
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
-MTR_MAT_TWOSIDED = 1
+MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC = 4, 5
+MTR_MAT_TWOSIDED, MTR_MAT_NONLINEAR = 1, 2
+MTR_ROUGH_TRANSMITTANCE_RES = 64
 MTR_FLAG_CAMERA_UNWARP = 1
 MTR_FLAG_DISCARD_DIRECT_LIGHT = 2
 MTR_FLAG_FILM_ZERO = 4
@@ -30,7 +32,9 @@ _f16 = C.c_float * 16
 class mtr_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32),
                 ("a", _f3), ("b", _f3), ("c", _f3),
-                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("c2", _f3)]
+                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("c2", _f3),
+                ("alpha", C.c_float), ("internal_reflectance", C.c_float), ("specular_sampling_weight", C.c_float),
+                ("reserved", C.c_float), ("external_transmittance", C.c_float * MTR_ROUGH_TRANSMITTANCE_RES)]
 
 
 class mtr_emitter(C.Structure):

@@ -195,6 +195,8 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 #undef UP
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
+    s->dev.has_rough = 0u;
+    for (uint32_t i = 0; i < d->n_materials; ++i) if (bsdf_is_rough(d->materials[i].type)) s->dev.has_rough = 1u;
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
@@ -509,6 +511,13 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
         if (f.n_freq) {                      // phasor film: (opl, value) records -> wavefront pipeline by default; LDS (Re, Im) rows in the fused kernel on request
             if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
             if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
+        }
+        if (s->dev.has_rough) {              // GGX lobes: transient_path with f32 rows only (fused), or the wavefront pipeline
+            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs are not available for the NLOS tier");
+            const bool fused_ok = !f.n_freq && !(p->flags & MTR_FLAG_DETERMINISTIC);
+            if (mode == MTR_MODE_FUSED && !fused_ok)
+                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs with a phasor film or deterministic rows need the wavefront mode");
+            if (mode == MTR_MODE_AUTO && !fused_ok) mode = MTR_MODE_WAVEFRONT;
         }
         if (mode == MTR_MODE_AUTO) {
             FusedArgs probe = a; FusedConfig pc{};

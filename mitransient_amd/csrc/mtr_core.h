@@ -131,7 +131,8 @@ MTR_HD void phasor_term(float freq, float opl, float &c, float &s)
     c = (q == 0u) ? cq : (q == 1u) ? -sq : (q == 2u) ? -cq : sq;
 }
 
-MTR_HD f3 cosine_hemisphere(float u1, float u2)
+// [mitsuba3: warp::square_to_uniform_disk_concentric]
+MTR_HD void concentric_disk(float u1, float u2, float &px, float &py)
 {
     float x = fmaf(2.0f, u1, -1.0f), y = fmaf(2.0f, u2, -1.0f);
     bool swap = fabsf(x) < fabsf(y);
@@ -141,7 +142,12 @@ MTR_HD f3 cosine_hemisphere(float u1, float u2)
     float s, c;
     sincos_quarter(phi, s, c);
     float cs = swap ? s : c, sn = swap ? c : s;
-    float px = r * cs, py = r * sn;
+    px = r * cs; py = r * sn;
+}
+MTR_HD f3 cosine_hemisphere(float u1, float u2)
+{
+    float px, py;
+    concentric_disk(u1, u2, px, py);
     float zz = 1.0f - fmaf(px, px, py * py);
     return mk(px, py, sqrtf(zz > 0.0f ? zz : 0.0f));
 }
@@ -930,8 +936,151 @@ MTR_HD void fresnel_dielectric(float ci, float eta, float &r, float &cos_t, floa
     cos_t = sign_neg(ci) ? cta : -cta;
 }
 
-struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
+// ---- GGX microfacet lobes (MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC) ----
+// Restated from mitsuba 3's MicrofacetDistribution (isotropic alpha, sample_visible = true), RoughConductor and
+// RoughPlastic; operation order is the numerics contract shared with the test oracle (fma only where written).
+// [mitsuba3: MicrofacetDistribution::eval] D(m) = 1 / (pi alpha^2 ((m.x/alpha)^2 + (m.y/alpha)^2 + m.z^2)^2), 0 when D cos <= 1e-20
+MTR_HD float ggx_eval(f3 m, float alpha)
+{
+    const float mx = m.x / alpha, my = m.y / alpha;
+    const float t = fmaf(m.z, m.z, fmaf(my, my, mx * mx));
+    const float result = 1.0f / (((kPi * (alpha * alpha)) * t) * t);
+    return (result * m.z > 1e-20f) ? result : 0.0f;
+}
+// [MicrofacetDistribution::smith_g1] 2 / (1 + sqrt(1 + alpha^2 tan^2)); 1 at perpendicular incidence; 0 when v sees the back of m
+MTR_HD float ggx_smith_g1(f3 v, f3 m, float alpha)
+{
+    const float ax = alpha * v.x, ay = alpha * v.y;
+    const float xy_alpha_2 = fmaf(ay, ay, ax * ax);
+    const float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    float result = 2.0f / (1.0f + sqrtf(1.0f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.0f) result = 1.0f;
+    if (dot(v, m) * v.z <= 0.0f) result = 0.0f;
+    return result;
+}
+// [MicrofacetDistribution::sample_visible_11] slope of a visible normal for incidence cos_theta_i, unit roughness
+MTR_HD void ggx_sample_visible_11(float cos_theta_i, float u1, float u2, float &sx, float &sy)
+{
+    float px, py;
+    concentric_disk(u1, u2, px, py);
+    const float s = 0.5f * (1.0f + cos_theta_i);
+    const float a0 = fmaf(-px, px, 1.0f);
+    const float a = sqrtf(a0 > 0.0f ? a0 : 0.0f);
+    py = fmaf(py, s, fmaf(-a, s, a));                        // lerp(a, py, s)
+    const float z0 = 1.0f - fmaf(py, py, px * px);
+    const float z = sqrtf(z0 > 0.0f ? z0 : 0.0f);
+    const float si0 = fmaf(-cos_theta_i, cos_theta_i, 1.0f);
+    const float sin_theta_i = sqrtf(si0 > 0.0f ? si0 : 0.0f);
+    const float norm = 1.0f / fmaf(sin_theta_i, py, cos_theta_i * z);
+    sx = fmaf(cos_theta_i, py, -(sin_theta_i * z)) * norm;
+    sy = px * norm;
+}
+// [MicrofacetDistribution::sample, sample_visible] visible normal for wi (cos_theta(wi) > 0) and its density
+MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf)
+{
+    const f3 wi_p = normalize(mk(alpha * wi.x, alpha * wi.y, wi.z));            // 1: stretch
+    const float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
+    float sin_phi = 0.0f, cos_phi = 1.0f;                                        // Frame3f::sincos_phi
+    if (fabsf(sin_theta_2) > 4.0f * 5.9604644775390625e-8f) {
+        const float inv = 1.0f / sqrtf(sin_theta_2);
+        sin_phi = fminf(fmaxf(wi_p.y * inv, -1.0f), 1.0f); cos_phi = fminf(fmaxf(wi_p.x * inv, -1.0f), 1.0f);
+    }
+    float sx, sy;
+    ggx_sample_visible_11(wi_p.z, u1, u2, sx, sy);                               // 2: P22 of the stretched direction
+    const float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;                 // 3: rotate, unstretch
+    const float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
+    const f3 m = normalize(mk(-rx, -ry, 1.0f));                                  // 4: normal
+    pdf = ((ggx_eval(m, alpha) * ggx_smith_g1(wi, m, alpha)) * fabsf(dot(wi, m))) / wi.z;
+    return m;
+}
+// [RoughPlastic: lerp_gather(m_external_transmittance, cos_theta, MI_ROUGH_TRANSMITTANCE_RES)]
+MTR_HD float rough_transmittance(const mtr_material &m, float cos_theta)
+{
+    const float x = cos_theta * (float)(MTR_ROUGH_TRANSMITTANCE_RES - 1);
+    uint32_t i = (uint32_t)x;
+    if (i > MTR_ROUGH_TRANSMITTANCE_RES - 2u) i = MTR_ROUGH_TRANSMITTANCE_RES - 2u;
+    const float w1 = x - (float)i, w0 = 1.0f - w1;
+    return fmaf(w0, m.external_transmittance[i], w1 * m.external_transmittance[i + 1u]);
+}
+MTR_HD bool bsdf_is_rough(uint32_t type) { return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC; }
+// value (cosine included) and density of a rough lobe for local directions; wi, wo already on the two-sided side
+// [RoughConductor::eval / ::pdf, RoughPlastic::eval / ::pdf]
+MTR_HD void rough_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &val, float &pdf)
+{
+    val = mk(0, 0, 0); pdf = 0.0f;
+    const float ci = wi.z, co = wo.z;
+    if (!(ci > 0.0f && co > 0.0f)) return;
+    const f3 H = normalize(mk(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
+    const float D = ggx_eval(H, m.alpha);
+    const float g1i = ggx_smith_g1(wi, H, m.alpha);
+    if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
+        const float wih = dot(wi, H);
+        if (wih > 0.0f && dot(wo, H) > 0.0f) pdf = (D * g1i) / (4.0f * ci);
+        if (D != 0.0f) {
+            const float G = g1i * ggx_smith_g1(wo, H, m.alpha);
+            const float r = (D * G) / (4.0f * ci);
+            val = mk((r * fresnel_conductor(wih, m.a[0], m.b[0])) * m.c[0], (r * fresnel_conductor(wih, m.a[1], m.b[1])) * m.c[1],
+                     (r * fresnel_conductor(wih, m.a[2], m.b[2])) * m.c[2]);
+        }
+        return;
+    }
+    // roughplastic
+    const float t_i = rough_transmittance(m, ci), t_o = rough_transmittance(m, co);
+    float ps = (1.0f - t_i) * m.specular_sampling_weight, pdif = t_i * (1.0f - m.specular_sampling_weight);
+    ps = ps / (ps + pdif); pdif = 1.0f - ps;
+    pdf = fmaf(pdif, kInvPi * co, ((D * g1i) / (4.0f * ci)) * ps);
+    float F, ct, eit, eti;
+    fresnel_dielectric(dot(wi, H), m.int_ior / m.ext_ior, F, ct, eit, eti);
+    const float G = g1i * ggx_smith_g1(wo, H, m.alpha);
+    const float spec = ((F * D) * G) / (4.0f * ci);
+    const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+    const float dscale = (((kInvPi * inv_eta_2) * co) * t_i) * t_o;
+    const float a[3] = { m.a[0], m.a[1], m.a[2] };
+    float o[3];
+    for (int k = 0; k < 3; ++k) {
+        const float diff = a[k] / (1.0f - ((m.flags & MTR_MAT_NONLINEAR) ? a[k] * m.internal_reflectance : m.internal_reflectance));
+        o[k] = fmaf(diff, dscale, spec * m.c[k]);
+    }
+    val = mk(o[0], o[1], o[2]);
+}
 
+struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
+// [RoughConductor::sample, RoughPlastic::sample]; wi on the two-sided side
+MTR_HD void rough_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
+{
+    const float ci = wi.z;
+    if (!(ci > 0.0f)) return;
+    if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
+        float pdf;
+        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf);
+        const float wim = dot(wi, mm);
+        const f3 wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));     // reflect(wi, m)
+        bs.wo = wo;
+        const bool ok = (pdf != 0.0f) && (wo.z > 0.0f);
+        const float weight = ggx_smith_g1(wo, mm, m.alpha);
+        bs.pdf = pdf / (4.0f * dot(wo, mm));
+        if (ok) bs.w = mk((fresnel_conductor(wim, m.a[0], m.b[0]) * weight) * m.c[0], (fresnel_conductor(wim, m.a[1], m.b[1]) * weight) * m.c[1],
+                          (fresnel_conductor(wim, m.a[2], m.b[2]) * weight) * m.c[2]);
+        return;
+    }
+    const float t_i = rough_transmittance(m, ci);
+    float ps = (1.0f - t_i) * m.specular_sampling_weight, pdif = t_i * (1.0f - m.specular_sampling_weight);
+    ps = ps / (ps + pdif);
+    f3 wo;
+    if (u1 < ps) {
+        float pdf_m;
+        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf_m);
+        const float wim = dot(wi, mm);
+        wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
+    } else wo = cosine_hemisphere(ua, ub);
+    bs.wo = wo;
+    f3 val; float pdf;
+    rough_eval_pdf(m, wi, wo, val, pdf);
+    bs.pdf = pdf;
+    if (pdf > 0.0f) { const float ip = 1.0f / pdf; bs.w = mk(val.x * ip, val.y * ip, val.z * ip); }
+}
+
+template <bool ROUGH = true>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub)
 {
     BsdfSample bs;
@@ -961,7 +1110,7 @@ MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, 
             float f2 = eti * eti;
             bs.w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
         }
-    }
+    } else if (ROUGH && bsdf_is_rough(m.type)) rough_sample(m, wi, u1, ua, ub, bs);
     if (flip) bs.wo.z = -bs.wo.z;
     return bs;
 }
@@ -1044,7 +1193,7 @@ struct Pending {
 
 // Part A of one loop iteration (transientpath.py:148-218): consumes the closest hit, splats the
 // emission term, samples the emitter and emits the shadow ray.  RNG: next_2d (:193).
-template <class Sink>
+template <bool ROUGH = true, class Sink>
 MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &film, const RenderConst &rc,
                       Sink &sink, Pending &pd, Ray &shadow)
 {
@@ -1086,8 +1235,8 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
         }
     }
 
-    // emitter sampling (:188-213); only smooth BSDFs (diffuse) take part
-    if (pd.active_next && mat.type == MTR_BSDF_DIFFUSE && sc.n_emitters > 0 ) {
+    // emitter sampling (:188-213); only smooth BSDFs (diffuse, the rough lobes) take part
+    if (pd.active_next && (mat.type == MTR_BSDF_DIFFUSE || (ROUGH && bsdf_is_rough(mat.type))) && sc.n_emitters > 0 ) {
         uint32_t ei = 0;
         if (sc.n_emitters > 1) {
             float su = u1 * rc.n_emitters_f;
@@ -1127,6 +1276,14 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                 float sdist = sqrtf(dot(sd, sd));
                 shadow.o = so; shadow.d = sd / sdist; shadow.tmax = sdist * (1.0f - kShadowEps);
                 pd.has_shadow = 1u;
+                if (ROUGH && bsdf_is_rough(mat.type)) {
+                    f3 bval; float bpdf;
+                    rough_eval_pdf(mat, wi_e, wo, bval, bpdf);
+                    float mis_em = mis_weight(pdf, bpdf);
+                    pd.Lr = mk(((p.beta.x * mis_em) * bval.x) * emw.x, ((p.beta.y * mis_em) * bval.y) * emw.y,
+                               ((p.beta.z * mis_em) * bval.z) * emw.z);
+                    pd.opl = p.dist + dist * p.eta;
+                } else
                 if (wi_e.z > 0.0f && wo.z > 0.0f) {
                     float bpdf = kInvPi * wo.z;
                     float mis_em = mis_weight(pdf, bpdf);
@@ -1143,7 +1300,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
 // Part B (transientpath.py:216-257, :318): commits the emitter-sampling term given the shadow-ray
 // answer, samples the BSDF, updates the loop state and applies Russian roulette.
 // RNG: next_1d, next_2d (:223-224), next_1d (:256).  Returns active_next.
-template <class Sink>
+template <bool ROUGH = true, class Sink>
 MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd, const SceneView &sc,
                          const Film &film, const RenderConst &rc, Sink &sink)
 {
@@ -1170,7 +1327,7 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
         const HitCtx c = hit_ctx(sc, p.ray.d, h);
         sp = c.sp;
         if (active_next) {
-            bs = bsdf_sample(sc.mats[c.mat], c.wi, s1, s2a, s2b);                                // :222-227
+            bs = bsdf_sample<ROUGH>(sc.mats[c.mat], c.wi, s1, s2a, s2b);                         // :222-227
             f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                          fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                          fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
@@ -1200,7 +1357,7 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
 
 // One whole iteration of the loop of transientpath.py:140-319, run to completion
 // (closest hit -> shade_hit -> shadow ray -> shade_finish).  Returns active_next.
-template <class Stack, class Sink>
+template <bool ROUGH = true, class Stack, class Sink>
 MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
                         Stack &st, Sink &sink, BounceStats &stats)
 {
@@ -1210,7 +1367,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     stats.closest++;
     Pending pd; Ray shadow;
     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
-    shade_hit(p, h, sc, film, rc, sink, pd, shadow);
+    shade_hit<ROUGH>(p, h, sc, film, rc, sink, pd, shadow);
     st.prof_mark(1);
     bool occluded = false;
     if (pd.has_shadow) {
@@ -1219,7 +1376,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
         occluded = sh.prim >= 0;
     }
     st.prof_mark(0);
-    const bool an = shade_finish(p, h, occluded, pd, sc, film, rc, sink);
+    const bool an = shade_finish<ROUGH>(p, h, occluded, pd, sc, film, rc, sink);
     st.prof_mark(1);
     return an;
 }

@@ -23,6 +23,7 @@ struct SceneDev {
     uint32_t bvh_depth;
     uint32_t wide_levels, wide4_levels;   // levels of wnodes / wnodes4: a wide walk stacks at most one group per level
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS
+    uint32_t has_rough;              // a material is a GGX lobe (MTR_BSDF_ROUGH*): kernels with the rough shading code
 };
 
 struct SplatLog { uint32_t *rec; unsigned long long cap; unsigned long long *count; };
@@ -47,7 +48,7 @@ struct FusedArgs {
     NlosConst nlos;
 };
 
-struct FusedConfig { int stack; bool scene_lds; bool hist_lds; bool fixed; size_t lds_bytes; int grid; int per_cu; };
+struct FusedConfig { int stack; bool scene_lds; bool hist_lds; bool fixed; bool rough; size_t lds_bytes; int grid; int per_cu; };
 
 // chooses G, LDS carve-up and grid for a render; returns false if nothing fits
 bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_t spp_chunk, int n_cu,

@@ -333,7 +333,10 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
                     else {
                         P.q(Q_HIT, slot) = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
                         uint32_t key = 4u;                      // miss
-                        if (tr.h.prim >= 0) key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
+                        if (tr.h.prim >= 0) {
+                            key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
+                            if (bsdf_is_rough(key)) key = 0u;       // the GGX lobes share the list of the smooth BSDFs (emitter sampling)
+                        }
                         s_key[pos] = (uint8_t)key;
                     }
                     pending = false;

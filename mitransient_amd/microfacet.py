@@ -1,0 +1,132 @@
+"""Host-side tables of the rough dielectric coat of ``roughplastic``.
+
+mitsuba computes them when the plugin is built (``RoughPlastic::parameters_changed``): the transmittance of the rough
+interface for 64 incidence cosines, ``eval_transmittance(distr, wi, eta)``, and the mean reflectance seen from inside,
+``mean(eval_reflectance(distr, wi, 1 / eta) * wi.z) * 2`` — both Gauss-Legendre quadratures (32 x 32 nodes when
+eta > 1, 128 x 128 otherwise) of the visible-normal sampling estimator over the unit square.  This module restates
+that quadrature in float64 numpy (GGX, isotropic alpha); the library only interpolates the table
+(``mtr_material.external_transmittance``).  [upstream: mitsuba3 src/bsdfs/roughplastic.cpp, include/mitsuba/render/microfacet.h;
+not present under the reference tree — restated from the published source.]
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RES = 64     # MI_ROUGH_TRANSMITTANCE_RES
+
+
+def _disk(u1, u2):
+    """warp::square_to_uniform_disk_concentric"""
+    x, y = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
+    swap = np.abs(x) < np.abs(y)
+    r = np.where(swap, y, x)
+    rp = np.where(swap, x, y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        phi = 0.25 * np.pi * rp / r
+    phi = np.where((x == 0) & (y == 0), 0.0, phi)
+    s, c = np.sin(phi), np.cos(phi)
+    return r * np.where(swap, s, c), r * np.where(swap, c, s)
+
+
+def _ggx_sample(wi, alpha, u1, u2):
+    """MicrofacetDistribution::sample (visible normals); wi (..., 3) with wi.z > 0"""
+    wp = np.stack([alpha * wi[..., 0], alpha * wi[..., 1], wi[..., 2]], -1)
+    wp = wp / np.linalg.norm(wp, axis=-1, keepdims=True)
+    s2 = 1.0 - wp[..., 2] ** 2
+    flat = np.abs(s2) <= 4.0 * 2.0 ** -24
+    inv = 1.0 / np.sqrt(np.where(flat, 1.0, s2))
+    sin_phi = np.where(flat, 0.0, np.clip(wp[..., 1] * inv, -1, 1))
+    cos_phi = np.where(flat, 1.0, np.clip(wp[..., 0] * inv, -1, 1))
+    ct = wp[..., 2]
+    px, py = _disk(u1, u2)
+    s = 0.5 * (1.0 + ct)
+    a = np.sqrt(np.maximum(1.0 - px * px, 0.0))
+    py = a + (py - a) * s
+    z = np.sqrt(np.maximum(1.0 - px * px - py * py, 0.0))
+    st = np.sqrt(np.maximum(1.0 - ct * ct, 0.0))
+    norm = 1.0 / (st * py + ct * z)
+    sx, sy = (ct * py - st * z) * norm, px * norm
+    rx = (cos_phi * sx - sin_phi * sy) * alpha
+    ry = (sin_phi * sx + cos_phi * sy) * alpha
+    m = np.stack([-rx, -ry, np.ones_like(rx)], -1)
+    return m / np.linalg.norm(m, axis=-1, keepdims=True)
+
+
+def _g1(v, m, alpha):
+    """MicrofacetDistribution::smith_g1"""
+    xy = (alpha * v[..., 0]) ** 2 + (alpha * v[..., 1]) ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = xy / v[..., 2] ** 2
+        r = 2.0 / (1.0 + np.sqrt(1.0 + t))
+    r = np.where(xy == 0, 1.0, r)
+    return np.where(np.sum(v * m, -1) * v[..., 2] <= 0, 0.0, r)
+
+
+def _fresnel(cos_i, eta):
+    """fresnel(cos_theta_i, eta) -> (r, cos_theta_t, eta_it, eta_ti)"""
+    outside = cos_i >= 0
+    eta_it = np.where(outside, eta, 1.0 / eta)
+    eta_ti = np.where(outside, 1.0 / eta, eta)
+    ct2 = 1.0 - (1.0 - cos_i * cos_i) * eta_ti * eta_ti
+    ci = np.abs(cos_i)
+    ct = np.sqrt(np.maximum(ct2, 0.0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a_s = (ci - eta_it * ct) / (ci + eta_it * ct)
+        a_p = (ct - eta_it * ci) / (ct + eta_it * ci)
+    r = 0.5 * (a_s * a_s + a_p * a_p)
+    if eta == 1.0:
+        r = np.zeros_like(r)
+    r = np.where(ci == 0, 1.0, r)
+    return r, np.where(cos_i >= 0, -ct, ct), eta_it, eta_ti
+
+
+def _quadrature(eta):
+    res = 32 if eta > 1 else 128
+    nodes, weights = np.polynomial.legendre.leggauss(res)
+    u = 0.5 * nodes + 0.5
+    u1, u2 = np.meshgrid(u, u, indexing="ij")
+    w = np.outer(weights, weights)
+    return u1, u2, w
+
+
+def eval_reflectance(alpha, mu, eta):
+    """eval_reflectance(distr, wi = (sqrt(1 - mu^2), 0, mu), eta), one value per mu"""
+    u1, u2, w = _quadrature(eta)
+    mu = np.asarray(mu, np.float64)
+    wi = np.stack([np.sqrt(1.0 - mu * mu), np.zeros_like(mu), mu], -1)[:, None, None, :]
+    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None])
+    d = np.sum(wi * m, -1)
+    wo = 2.0 * d[..., None] * m - wi
+    f = _fresnel(d, eta)[0]
+    smith = _g1(wo, m, alpha) * f
+    smith = np.where((wo[..., 2] <= 0) | (f <= 0), 0.0, smith)
+    return np.sum(smith * w[None], axis=(1, 2)) * 0.25
+
+
+def eval_transmittance(alpha, mu, eta):
+    """eval_transmittance(distr, wi, eta)"""
+    u1, u2, w = _quadrature(eta)
+    mu = np.asarray(mu, np.float64)
+    wi = np.stack([np.sqrt(1.0 - mu * mu), np.zeros_like(mu), mu], -1)[:, None, None, :]
+    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None])
+    d = np.sum(wi * m, -1)
+    f, cos_t, eta_it, eta_ti = _fresnel(d, eta)
+    wo = m * (d * eta_ti + cos_t)[..., None] - wi * eta_ti[..., None]          # refract(wi, m, cos_theta_t, eta_ti)
+    smith = _g1(wo, m, alpha) * (1.0 - f)
+    smith = np.where((wo[..., 2] >= 0) | (f >= 1), 0.0, smith)
+    return np.sum(smith * w[None], axis=(1, 2)) * 0.25
+
+
+_cache = {}
+
+
+def rough_plastic_tables(alpha: float, eta: float):
+    """(external_transmittance float32[64], internal_reflectance float32) of RoughPlastic::parameters_changed"""
+    key = (float(np.float32(alpha)), float(np.float32(eta)))
+    if key not in _cache:
+        a, e = key
+        mu = np.maximum(1e-6, np.linspace(0.0, 1.0, RES))
+        ext = eval_transmittance(a, mu, e)
+        internal = float(np.mean(eval_reflectance(a, mu, 1.0 / e) * mu) * 2.0)
+        _cache[key] = (ext.astype(np.float32), np.float32(internal))
+    return _cache[key]

@@ -163,17 +163,18 @@ class _SceneBuilder:
         t = bd.get("type")
         ab = self.base_dir if self.approx else None          # bitmap -> mean colour only when approximating
         if self.approx:
-            # nearest material of the hot path's model (opt-in, documented in DESIGN.md): rough microfacet lobes
-            # collapse to their smooth limit, the plastic coat is dropped, bump/normal maps are ignored
+            # nearest material of the hot path's model (opt-in, documented in DESIGN.md): bitmap textures become their mean
+            # colour, bump/normal maps are ignored, the smooth plastic coat is dropped; with approximate_materials="smooth"
+            # (the config-5 bench fixture) the GGX lobes of roughconductor / roughplastic also collapse to their smooth limit
             if t in ("bumpmap", "normalmap"):
                 inner = [v for k, v in bd.items() if isinstance(v, dict) and v.get("type") not in ("bitmap", None)
                          and k != "type" and "filename" not in v]
                 if len(inner) != 1:
                     raise ValueError(f"{t}: exactly one nested BSDF is expected")
                 return self._make_material(self._resolve(inner[0])[0])
-            if t == "roughconductor":
+            if t == "roughconductor" and self.approx == "smooth":
                 bd = dict(bd, type="conductor"); t = "conductor"
-            elif t in ("roughplastic", "plastic"):
+            elif t == "plastic" or (t == "roughplastic" and self.approx == "smooth"):
                 bd = {"type": "diffuse", "reflectance": bd.get("diffuse_reflectance", 0.5)}; t = "diffuse"
             elif t in ("roughdielectric", "thindielectric"):
                 bd = dict(bd, type="dielectric"); t = "dielectric"
@@ -209,8 +210,46 @@ class _SceneBuilder:
             st = _color3(bd.get("specular_transmittance", 1.0), "dielectric.specular_transmittance")
             for k in range(3):
                 m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
+        elif t in ("roughconductor", "roughplastic"):
+            # GGX lobes [mitsuba3: src/bsdfs/roughconductor.cpp, roughplastic.cpp]: isotropic alpha, visible-normal sampling
+            if str(bd.get("distribution", "beckmann")) != "ggx":
+                raise ValueError(f"{t}: only distribution = \"ggx\" is available (mitsuba's default is beckmann: say so explicitly)")
+            if "alpha_u" in bd or "alpha_v" in bd:
+                raise ValueError(f"{t}: anisotropic roughness (alpha_u / alpha_v) is not available")
+            if not bd.get("sample_visible", True):
+                raise ValueError(f"{t}: sample_visible = false is not available")
+            alpha = bd.get("alpha", 0.1)
+            if isinstance(alpha, dict):
+                raise ValueError(f"{t}: textured alpha is not available")
+            m.alpha = np.float32(alpha)
+            sr = _color3(bd.get("specular_reflectance", 1.0), f"{t}.specular_reflectance", ab)
+            if t == "roughconductor":
+                m.type = _cabi.MTR_BSDF_ROUGHCONDUCTOR
+                if "material" in bd and bd["material"] != "none":
+                    raise ValueError("roughconductor: material presets other than 'none' are not available; pass eta/k")
+                eta = _color3(bd.get("eta", 0.0), "roughconductor.eta")
+                kk = _color3(bd.get("k", 1.0), "roughconductor.k")
+                for k in range(3):
+                    m.a[k], m.b[k], m.c[k] = np.float32(eta[k]), np.float32(kk[k]), np.float32(sr[k])
+            else:
+                from .microfacet import rough_plastic_tables
+                m.type = _cabi.MTR_BSDF_ROUGHPLASTIC
+                m.int_ior = np.float32(_ior(bd.get("int_ior"), "polypropylene"))
+                m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
+                diff = _color3(bd.get("diffuse_reflectance", 0.5), "roughplastic.diffuse_reflectance", ab)
+                for k in range(3):
+                    m.a[k], m.c[k] = np.float32(diff[k]), np.float32(sr[k])
+                if bd.get("nonlinear", False):
+                    m.flags |= _cabi.MTR_MAT_NONLINEAR
+                eta = float(np.float32(m.int_ior) / np.float32(m.ext_ior))
+                ext, internal = rough_plastic_tables(float(m.alpha), eta)
+                for k in range(_cabi.MTR_ROUGH_TRANSMITTANCE_RES):
+                    m.external_transmittance[k] = ext[k]
+                m.internal_reflectance = internal
+                d_mean = float(np.mean([np.float32(x) for x in diff])); s_mean = float(np.mean([np.float32(x) for x in sr]))
+                m.specular_sampling_weight = np.float32(s_mean / (d_mean + s_mean))
         else:
-            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, twosided)")
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, roughconductor, roughplastic, twosided)")
         return m
 
     # -- shapes ------------------------------------------------------------
@@ -579,9 +618,16 @@ def save_geometry(sd: "SceneData", path: str, **meta):
 def load_geometry(path: str) -> Dict[str, Any]:
     import json
     z = np.load(path)
-    if list(z["layout"]) != [C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]:
+    msize = C.sizeof(_cabi.mtr_material)
+    mat_bytes = z["materials"]
+    layout = list(z["layout"])
+    if layout[0] == 64 and msize > 64:           # written with ABI <= 7: mtr_material grew by appended fields (rough lobes) only
+        mat_bytes = np.pad(mat_bytes.reshape(-1, 64), ((0, 0), (0, msize - 64))).reshape(-1)
+        layout[0] = msize
+    if layout != [msize, C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]:
         raise ValueError(f"{path}: material / emitter record sizes {list(z['layout'])} do not match this C-ABI; "
                          "regenerate with tests/golden/make_golden.py")
+    z = dict(z.items()); z["materials"] = mat_bytes
     nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
     ne = z["emitters"].size // C.sizeof(_cabi.mtr_emitter)
     mats = (_cabi.mtr_material * max(1, nm)).from_buffer_copy(z["materials"].tobytes().ljust(C.sizeof(_cabi.mtr_material), b"\0"))

@@ -592,14 +592,117 @@ static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, f
     *r = rr;
     *cos_t = (cos_i < 0.0f || (cos_i == 0.0f && signbit(cos_i))) ? ct : -ct;   /* mulsign_neg */
 }
-static int bsdf_is_smooth(const mtr_material *m) { return m->type == MTR_BSDF_DIFFUSE; }
+/* ---- GGX microfacet lobes: mitsuba 3's MicrofacetDistribution (isotropic alpha, sample_visible = true), RoughConductor and
+ * RoughPlastic, restated from the published source (upstream not present under /root/reference: unverified here).
+ * [MicrofacetDistribution::eval]: 1 / (pi alpha_u alpha_v (sqr(m.x/alpha_u) + sqr(m.y/alpha_v) + sqr(m.z))^2), 0 when D cos <= 1e-20 */
+static float ggx_eval(v3 m, float alpha)
+{
+    float mx = m.x / alpha, my = m.y / alpha;
+    float t = fmaf(m.z, m.z, fmaf(my, my, mx * mx));
+    float result = 1.0f / (((ORC_PI * (alpha * alpha)) * t) * t);
+    return (result * m.z > 1e-20f) ? result : 0.0f;
+}
+/* [MicrofacetDistribution::smith_g1] */
+static float ggx_smith_g1(v3 v, v3 m, float alpha)
+{
+    float ax = alpha * v.x, ay = alpha * v.y;
+    float xy_alpha_2 = fmaf(ay, ay, ax * ax);
+    float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    float result = 2.0f / (1.0f + sqrtf(1.0f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.0f) result = 1.0f;                 /* perpendicular incidence: no shadowing / masking */
+    if (vdot(v, m) * v.z <= 0.0f) result = 0.0f;           /* the back of the microfacet is not seen from the front */
+    return result;
+}
+/* [MicrofacetDistribution::sample_visible_11] (GGX) */
+static void ggx_sample_visible_11(float cos_theta_i, float u1, float u2, float *sx, float *sy)
+{
+    float px, py;
+    square_to_disk(u1, u2, &px, &py);
+    float s = 0.5f * (1.0f + cos_theta_i);
+    float a0 = fmaf(-px, px, 1.0f);
+    float a = sqrtf(a0 > 0.0f ? a0 : 0.0f);
+    py = fmaf(py, s, fmaf(-a, s, a));                      /* lerp(safe_sqrt(1 - p.x^2), p.y, s) */
+    float z0 = 1.0f - fmaf(py, py, px * px);
+    float z = sqrtf(z0 > 0.0f ? z0 : 0.0f);
+    float si0 = fmaf(-cos_theta_i, cos_theta_i, 1.0f);
+    float sin_theta_i = sqrtf(si0 > 0.0f ? si0 : 0.0f);
+    float norm = 1.0f / fmaf(sin_theta_i, py, cos_theta_i * z);
+    *sx = fmaf(cos_theta_i, py, -(sin_theta_i * z)) * norm;
+    *sy = px * norm;
+}
+/* [MicrofacetDistribution::sample], visible normals: stretch, sample the slope, rotate + unstretch, normal and density */
+static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf)
+{
+    v3 wi_p = vnormalize(V(alpha * wi.x, alpha * wi.y, wi.z));
+    float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
+    float sin_phi = 0.0f, cos_phi = 1.0f;                  /* [Frame3f::sincos_phi] */
+    if (fabsf(sin_theta_2) > 4.0f * 5.9604644775390625e-8f) {
+        float inv = 1.0f / sqrtf(sin_theta_2);
+        sin_phi = fminf(fmaxf(wi_p.y * inv, -1.0f), 1.0f); cos_phi = fminf(fmaxf(wi_p.x * inv, -1.0f), 1.0f);
+    }
+    float sx, sy;
+    ggx_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
+    float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;
+    float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
+    v3 m = vnormalize(V(-rx, -ry, 1.0f));
+    *pdf = ((ggx_eval(m, alpha) * ggx_smith_g1(wi, m, alpha)) * fabsf(vdot(wi, m))) / wi.z;
+    return m;
+}
+/* [RoughPlastic: dr::lerp_gather over m_external_transmittance, MI_ROUGH_TRANSMITTANCE_RES = 64] */
+static float rough_transmittance(const mtr_material *m, float cos_theta)
+{
+    float x = cos_theta * (float)(MTR_ROUGH_TRANSMITTANCE_RES - 1);
+    uint32_t i = (uint32_t)x;
+    if (i > MTR_ROUGH_TRANSMITTANCE_RES - 2u) i = MTR_ROUGH_TRANSMITTANCE_RES - 2u;
+    float w1 = x - (float)i, w0 = 1.0f - w1;
+    return fmaf(w0, m->external_transmittance[i], w1 * m->external_transmittance[i + 1u]);
+}
+static int bsdf_is_rough(const mtr_material *m) { return m->type == MTR_BSDF_ROUGHCONDUCTOR || m->type == MTR_BSDF_ROUGHPLASTIC; }
+static float fresnel_conductor(float cos_i, float eta_r, float eta_i);
+static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, float *eta_it, float *eta_ti);
+/* [RoughConductor::eval / ::pdf], [RoughPlastic::eval / ::pdf]; wi, wo local, already on the two-sided side */
+static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
+{
+    val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
+    float ci = wi.z, co = wo.z;
+    if (!(ci > 0.0f && co > 0.0f)) return;
+    v3 H = vnormalize(V(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
+    float D = ggx_eval(H, m->alpha);
+    float g1i = ggx_smith_g1(wi, H, m->alpha);
+    if (m->type == MTR_BSDF_ROUGHCONDUCTOR) {
+        float wih = vdot(wi, H);
+        if (wih > 0.0f && vdot(wo, H) > 0.0f) *pdf = (D * g1i) / (4.0f * ci);
+        if (D != 0.0f) {
+            float G = g1i * ggx_smith_g1(wo, H, m->alpha);
+            float r = (D * G) / (4.0f * ci);
+            for (int k = 0; k < 3; ++k) val[k] = (r * fresnel_conductor(wih, m->a[k], m->b[k])) * m->c[k];
+        }
+        return;
+    }
+    float t_i = rough_transmittance(m, ci), t_o = rough_transmittance(m, co);
+    float ps = (1.0f - t_i) * m->specular_sampling_weight, pdif = t_i * (1.0f - m->specular_sampling_weight);
+    ps = ps / (ps + pdif); pdif = 1.0f - ps;
+    *pdf = fmaf(pdif, ORC_INV_PI * co, ((D * g1i) / (4.0f * ci)) * ps);
+    float F, ct, eit, eti;
+    fresnel_dielectric(vdot(wi, H), m->int_ior / m->ext_ior, &F, &ct, &eit, &eti);
+    float G = g1i * ggx_smith_g1(wo, H, m->alpha);
+    float spec = ((F * D) * G) / (4.0f * ci);
+    float eta = m->int_ior / m->ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+    float dscale = (((ORC_INV_PI * inv_eta_2) * co) * t_i) * t_o;
+    for (int k = 0; k < 3; ++k) {
+        float diff = m->a[k] / (1.0f - ((m->flags & MTR_MAT_NONLINEAR) ? m->a[k] * m->internal_reflectance : m->internal_reflectance));
+        val[k] = fmaf(diff, dscale, spec * m->c[k]);
+    }
+}
+static int bsdf_is_smooth(const mtr_material *m) { return m->type == MTR_BSDF_DIFFUSE || bsdf_is_rough(m); }
 
 /* eval_pdf: returns value (incl. cos) and pdf for a world-frame-local wo */
 static void bsdf_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
 {
     val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
-    if (m->type != MTR_BSDF_DIFFUSE) return;
+    if (!bsdf_is_smooth(m)) return;
     if ((m->flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (bsdf_is_rough(m)) { rough_eval_pdf(m, wi, wo, val, pdf); return; }
     float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
     for (int k = 0; k < 3; ++k) val[k] = (m->a[k] * ORC_INV_PI) * co;
@@ -631,9 +734,56 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
         else { bs->wo = V(-eti * wi.x, -eti * wi.y, ct); bs->eta = eit;
                for (int k = 0; k < 3; ++k) bs->w[k] = m->c2[k] * (eti * eti); }
         break; }
+    case MTR_BSDF_ROUGHCONDUCTOR: {          /* [RoughConductor::sample] */
+        if (!(ci > 0.0f)) break;
+        float pdf;
+        v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf);
+        float wim = vdot(wi, mm);
+        v3 wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));   /* reflect(wi, m) */
+        bs->wo = wo;
+        int ok = (pdf != 0.0f) && (wo.z > 0.0f);
+        float weight = ggx_smith_g1(wo, mm, m->alpha);        /* sample_visible: weight = G1(wo) */
+        bs->pdf = pdf / (4.0f * vdot(wo, mm));                /* Jacobian of the half-direction mapping */
+        if (ok) for (int k = 0; k < 3; ++k) bs->w[k] = (fresnel_conductor(wim, m->a[k], m->b[k]) * weight) * m->c[k];
+        break; }
+    case MTR_BSDF_ROUGHPLASTIC: {            /* [RoughPlastic::sample]: lobe by sample1, then pdf() and eval() / pdf */
+        if (!(ci > 0.0f)) break;
+        float t_i = rough_transmittance(m, ci);
+        float ps = (1.0f - t_i) * m->specular_sampling_weight, pdif = t_i * (1.0f - m->specular_sampling_weight);
+        ps = ps / (ps + pdif);
+        v3 wo;
+        if (u1 < ps) {
+            float pdf_m;
+            v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf_m);
+            float wim = vdot(wi, mm);
+            wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
+        } else wo = square_to_cos_hemi(ua, ub);
+        bs->wo = wo;
+        float val[3], pdf;
+        rough_eval_pdf(m, wi, wo, val, &pdf);
+        bs->pdf = pdf;
+        if (pdf > 0.0f) { float ip = 1.0f / pdf; for (int k = 0; k < 3; ++k) bs->w[k] = val[k] * ip; }
+        break; }
     default: break;
     }
     if (flip) bs->wo.z = -bs->wo.z;
+}
+
+/* test hooks: the BSDF functions on arrays of local directions */
+void orc_bsdf_eval_pdf(const mtr_material *m, uint32_t n, const float *wi3, const float *wo3, float *val3, float *pdf)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        bsdf_eval_pdf(m, V(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), val3 + 3 * i, pdf + i);
+}
+void orc_bsdf_sample(const mtr_material *m, uint32_t n, const float *wi3, const float *u1, const float *ua, const float *ub,
+                     float *wo3, float *pdf, float *w3)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        bsample bs;
+        bsdf_sample(m, V(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), u1[i], ua[i], ub[i], &bs);
+        wo3[3 * i] = bs.wo.x; wo3[3 * i + 1] = bs.wo.y; wo3[3 * i + 2] = bs.wo.z; pdf[i] = bs.pdf;
+        for (int k = 0; k < 3; ++k) w3[3 * i + k] = bs.w[k];
+    }
 }
 
 /* ------------------------------------------------------------------ */

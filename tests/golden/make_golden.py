@@ -85,9 +85,9 @@ def example_scenes():
     for name in ("cbox_diffuse", "cbox_mirror"):
         sc = mi.load_file(f"{ref}/transient/cornell-box/{name}.xml")
         save_fixture(sc, os.path.join(HERE, f"{name}_scene.npz"), source=f"examples/transient/cornell-box/{name}.xml")
-    sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials=True)
+    sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials="smooth")
     save_fixture(sc, os.path.join(ROOT, "mitransient_amd", "data", "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
-                 approximate_materials=True)
+                 approximate_materials="smooth")
     np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
 
 

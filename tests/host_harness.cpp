@@ -169,6 +169,30 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     return 0;
 }
 
+// the product's BSDF arithmetic on arrays of local directions (tests/test_rough_bsdf.py)
+extern "C" void hh_bsdf_eval_pdf(const mtr_material *m, uint32_t n, const float *wi3, const float *wo3, float *val3, float *pdf)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        f3 wi = mk(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = mk(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+        f3 v = mk(0, 0, 0); float p = 0.0f;
+        if ((m->flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+        if (bsdf_is_rough(m->type)) rough_eval_pdf(*m, wi, wo, v, p);
+        else if (m->type == MTR_BSDF_DIFFUSE && wi.z > 0.0f && wo.z > 0.0f) {
+            p = kInvPi * wo.z; v = mk((m->a[0] * kInvPi) * wo.z, (m->a[1] * kInvPi) * wo.z, (m->a[2] * kInvPi) * wo.z);
+        }
+        val3[3 * i] = v.x; val3[3 * i + 1] = v.y; val3[3 * i + 2] = v.z; pdf[i] = p;
+    }
+}
+extern "C" void hh_bsdf_sample(const mtr_material *m, uint32_t n, const float *wi3, const float *u1, const float *ua, const float *ub,
+                               float *wo3, float *pdf, float *w3)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const BsdfSample bs = bsdf_sample<true>(*m, mk(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), u1[i], ua[i], ub[i]);
+        wo3[3 * i] = bs.wo.x; wo3[3 * i + 1] = bs.wo.y; wo3[3 * i + 2] = bs.wo.z; pdf[i] = bs.pdf;
+        w3[3 * i] = bs.w.x; w3[3 * i + 1] = bs.w.y; w3[3 * i + 2] = bs.w.z;
+    }
+}
+
 // debugging aid: prints the 8-wide tree of a scene (child counts, leaf / inner refs, walk axis)
 extern "C" int hh_print_wide(const mtr_scene_desc *d)
 {

@@ -1,0 +1,234 @@
+"""GGX lobes (MTR_BSDF_ROUGHCONDUCTOR / MTR_BSDF_ROUGHPLASTIC: mitsuba's `roughconductor`, `roughplastic` with
+distribution = ggx, sample_visible = true): the oracle's restatement checked against what a BSDF must satisfy (densities
+integrate to one, samples follow the density, weight * pdf = value, reciprocity, energy), the product's arithmetic bit for
+bit against the oracle, and renders with these materials through both."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import hh_render
+
+FP = C.POINTER(C.c_float)
+
+
+def _mat(kind, alpha=0.1, twosided=False, nonlinear=True, diffuse=(0.5, 0.3, 0.2)):
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import _SceneBuilder
+    mi.set_variant("llvm_ad_rgb")
+    if kind == "roughconductor":
+        bd = {"type": "roughconductor", "distribution": "ggx", "alpha": alpha, "eta": [1.657, 0.880, 0.521],
+              "k": [9.224, 6.270, 4.837], "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.7]}}
+    else:
+        bd = {"type": "roughplastic", "distribution": "ggx", "alpha": alpha, "int_ior": 1.5, "ext_ior": 1.0,
+              "nonlinear": nonlinear, "diffuse_reflectance": {"type": "rgb", "value": list(diffuse)}}
+    if twosided:
+        bd = {"type": "twosided", "bsdf": bd}
+    return _SceneBuilder({}, ".")._make_material(bd)
+
+
+def _dirs(n, rng, upper=True):
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if upper:
+        v[:, 2] = np.abs(v[:, 2])
+    return np.ascontiguousarray(v, np.float32)
+
+
+def _eval(lib, prefix, m, wi, wo):
+    n = len(wi)
+    val = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+    getattr(lib, prefix + "bsdf_eval_pdf")(C.byref(m), n, wi.ctypes.data_as(FP), wo.ctypes.data_as(FP), val.ctypes.data_as(FP), pdf.ctypes.data_as(FP))
+    return val, pdf
+
+
+def _sample(lib, prefix, m, wi, u1, ua, ub):
+    n = len(wi)
+    wo = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32); w = np.zeros((n, 3), np.float32)
+    getattr(lib, prefix + "bsdf_sample")(C.byref(m), n, wi.ctypes.data_as(FP), u1.ctypes.data_as(FP), ua.ctypes.data_as(FP),
+                                         ub.ctypes.data_as(FP), wo.ctypes.data_as(FP), pdf.ctypes.data_as(FP), w.ctypes.data_as(FP))
+    return wo, pdf, w
+
+
+KINDS = ["roughconductor", "roughplastic"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("alpha", [0.05, 0.1, 0.4])
+def test_product_arithmetic_equals_oracle(oracle, host_harness, kind, alpha):
+    """every bit of eval / pdf / sample, 2 x 10^5 random direction pairs incl. grazing ones and the two-sided flip"""
+    rng = np.random.default_rng(3)
+    for twosided in (False, True):
+        m = _mat(kind, alpha, twosided)
+        n = 200000
+        wi, wo = _dirs(n, rng, upper=not twosided), _dirs(n, rng, upper=False)
+        wi[:1000, 2] *= 1e-3; wo[1000:2000, 2] *= 1e-3
+        wi[2000:2100] = [0, 0, 1]                                          # perpendicular incidence
+        v0, p0 = _eval(oracle.lib(), "orc_", m, wi, wo)
+        v1, p1 = _eval(host_harness, "hh_", m, wi, wo)
+        assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+        assert (p0 > 0).mean() > 0.3
+        u = rng.random((3, n)).astype(np.float32)
+        a = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+        b = _sample(host_harness, "hh_", m, wi, u[0], u[1], u[2])
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def _hemisphere_grid(n_t=512, n_p=1024):
+    """midpoint rule in (cos theta, phi): directions and solid-angle weights"""
+    ct = (np.arange(n_t) + 0.5) / n_t
+    ph = (np.arange(n_p) + 0.5) / n_p * 2 * np.pi
+    CT, PH = np.meshgrid(ct, ph, indexing="ij")
+    st = np.sqrt(1 - CT * CT)
+    d = np.stack([st * np.cos(PH), st * np.sin(PH), CT], -1).reshape(-1, 3).astype(np.float32)
+    return np.ascontiguousarray(d), 2 * np.pi / (n_t * n_p)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("alpha", [0.1, 0.4])
+def test_density_integrates_to_one_and_energy_is_bounded(oracle, kind, alpha):
+    m = _mat(kind, alpha)
+    wo, dw = _hemisphere_grid()
+    for mu in (0.95, 0.6, 0.25):
+        wi = np.tile(np.array([[np.sqrt(1 - mu * mu), 0, mu]], np.float32), (len(wo), 1))
+        val, pdf = _eval(oracle.lib(), "orc_", m, wi, wo)
+        total = pdf.astype(np.float64).sum() * dw
+        # the density integrates to the probability that a sample is usable at all: a visible normal can reflect wi below
+        # the horizon (more often at grazing incidence and large alpha), and that part of the lobe is lost
+        rng = np.random.default_rng(1)
+        ns = 200000
+        u = rng.random((3, ns)).astype(np.float32)
+        swo, spdf, sw = _sample(oracle.lib(), "orc_", m, np.ascontiguousarray(wi[:ns]), u[0], u[1], u[2])
+        usable = ((swo[:, 2] > 0) & (spdf > 0)).mean()
+        assert abs(total - usable) < 0.01 and 0.5 < total <= 1.001, (kind, alpha, mu, total, usable)
+        if mu > 0.9 and alpha <= 0.1:
+            assert total > 0.98
+        albedo = val.astype(np.float64).sum(0) * dw
+        assert np.all(albedo <= 1.0 + 1e-3) and np.all(albedo > 0.05)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_samples_follow_the_density_and_weights_are_value_over_pdf(oracle, kind):
+    m = _mat(kind, 0.25)
+    rng = np.random.default_rng(5)
+    n = 400000
+    mu = 0.7
+    wi = np.tile(np.array([[np.sqrt(1 - mu * mu), 0, mu]], np.float32), (n, 1))
+    u = rng.random((3, n)).astype(np.float32)
+    wo, pdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+    ok = (pdf > 0) & (w.max(1) > 0)
+    assert ok.mean() > 0.9
+    val, pdf2 = _eval(oracle.lib(), "orc_", m, wi[ok], wo[ok])
+    # the density reported with the sample is the density of that direction, and weight * pdf is the value
+    assert np.allclose(pdf[ok], pdf2, rtol=2e-4, atol=1e-6)
+    assert np.allclose(w[ok] * pdf[ok, None], val, rtol=2e-3, atol=1e-6)
+    # histogram of the sampled directions against the integrated density
+    n_t, n_p = 16, 16
+    it = np.minimum((wo[ok, 2] * n_t).astype(int), n_t - 1)
+    ip = np.minimum(((np.arctan2(wo[ok, 1], wo[ok, 0]) / (2 * np.pi)) % 1.0 * n_p).astype(int), n_p - 1)
+    hist = np.bincount(it * n_p + ip, minlength=n_t * n_p).astype(np.float64) / n
+    g, dw = _hemisphere_grid(256, 512)
+    _, pg = _eval(oracle.lib(), "orc_", m, np.tile(wi[:1], (len(g), 1)), g)
+    gt = np.minimum((g[:, 2] * n_t).astype(int), n_t - 1)
+    gp = np.minimum(((np.arctan2(g[:, 1], g[:, 0]) / (2 * np.pi)) % 1.0 * n_p).astype(int), n_p - 1)
+    expect = np.bincount(gt * n_p + gp, weights=pg.astype(np.float64) * dw, minlength=n_t * n_p)
+    big = expect > 2e-3
+    assert big.sum() > 20
+    sigma = np.sqrt(expect[big] / n)
+    assert np.all(np.abs(hist[big] - expect[big]) < 6 * sigma + 0.02 * expect[big])     # 2 %: the midpoint rule across cell borders
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_reciprocity(oracle, kind):
+    """f(wi, wo) = value / cos(theta_o) is symmetric"""
+    m = _mat(kind, 0.3)
+    rng = np.random.default_rng(9)
+    a, b = _dirs(20000, rng), _dirs(20000, rng)
+    keep = (a[:, 2] > 0.05) & (b[:, 2] > 0.05)
+    a, b = np.ascontiguousarray(a[keep]), np.ascontiguousarray(b[keep])
+    v_ab, _ = _eval(oracle.lib(), "orc_", m, a, b)
+    v_ba, _ = _eval(oracle.lib(), "orc_", m, b, a)
+    assert np.allclose(v_ab / b[:, 2:3], v_ba / a[:, 2:3], rtol=2e-3, atol=1e-6)
+
+
+def test_rough_plastic_tables():
+    from mitransient_amd.microfacet import rough_plastic_tables
+    ext, internal = rough_plastic_tables(0.001, 1.5)
+    assert abs(ext[-1] - 0.96) < 1e-3                      # smooth limit at normal incidence: 1 - ((n - 1) / (n + 1))^2
+    assert 0.55 < internal < 0.62                          # ~ the diffuse Fresnel reflectance from inside (0.596 for n = 1.5)
+    ext, internal = rough_plastic_tables(0.1, 1.5)
+    assert np.all(np.diff(ext[8:]) > -1e-3) and 0.9 < ext[-1] < 0.97 and 0.3 < ext[0] < 0.8
+
+
+def _rough_cornell(**film):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
+    d["sensor"]["film"].update(film)
+    d["floor"]["bsdf"] = {"type": "roughplastic", "distribution": "ggx", "alpha": 0.1, "int_ior": 1.5, "nonlinear": True,
+                          "diffuse_reflectance": {"type": "rgb", "value": [0.58, 0.42, 0.3]}}
+    d["large-box"]["bsdf"] = {"type": "roughconductor", "distribution": "ggx", "alpha": 0.15, "eta": [1.657, 0.880, 0.521],
+                              "k": [9.224, 6.270, 4.837]}
+    d["back"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "roughplastic", "distribution": "ggx", "alpha": 0.3,
+                                                      "diffuse_reflectance": {"type": "rgb", "value": [0.2, 0.5, 0.7]}}}
+    d["small-box"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "roughconductor", "distribution": "ggx", "alpha": 0.05,
+                                                           "eta": 0.2, "k": 3.9}}
+    return d
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-8"])
+def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide):
+    import mitransient_amd.mi as mi
+    d = _rough_cornell()
+    d["integrator"].update(max_depth=-1, rr_depth=4)
+    scene = mi.load_dict(d)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 3, 24)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    host_harness.hh_set_node_pairs(wide); host_harness.hh_set_wide(wide)
+    try:
+        ht, hs, hc = hh_render(host_harness, sd, p)
+    finally:
+        host_harness.hh_set_node_pairs(0); host_harness.hh_set_wide(0)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert hc[k] == cnt[k]
+    assert np.count_nonzero(t4) > 3000 and np.isfinite(t4).all()
+
+
+def test_energy_identity_with_rough_materials(oracle):
+    """transient.sum(time) == steady when the window holds every path (1-simple-nlos-scenes.ipynb md cell 8)"""
+    import mitransient_amd.mi as mi
+    d = _rough_cornell(start_opl=0.0, bin_width_opl=1.0, temporal_bins=128)
+    scene = mi.load_dict(d)
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 32)
+    t4, s4, cnt = oracle.render(scene.data(), p)
+    steady = s4[..., :3] / np.maximum(s4[..., 3:4], 1)
+    assert np.allclose(t4[..., :3].sum(2), steady, rtol=2e-4, atol=1e-6)
+    assert steady.mean() > 0.05
+
+
+def test_rough_lobes_tend_to_their_smooth_limits(oracle):
+    """alpha -> 0: the steady image of a roughconductor wall tends to the conductor's (same eta / k); compared in the mean
+    over the image at a few hundred samples per pixel (k sigma)"""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    means = {}
+    for name, bsdf in (("rough", {"type": "roughconductor", "distribution": "ggx", "alpha": 0.002, "eta": 0.2, "k": 3.9}),
+                       ("smooth", {"type": "conductor", "eta": 0.2, "k": 3.9})):
+        d = mitr.cornell_box()
+        d["sensor"]["film"].update(width=16, height=16, temporal_bins=8, start_opl=0.0, bin_width_opl=4.0)
+        d["back"]["bsdf"] = bsdf
+        scene = mi.load_dict(d)
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 256)
+        t4, s4, _ = oracle.render(scene.data(), p)
+        img = s4[..., :3] / s4[..., 3:4]
+        means[name] = (img.mean(), img.std() / np.sqrt(img.size))
+    (a, sa), (b, sb) = means["rough"], means["smooth"]
+    assert abs(a - b) < 0.03 * b + 6 * (sa + sb)

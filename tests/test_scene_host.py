@@ -73,8 +73,11 @@ def test_plugin_defaults_and_errors():
     with pytest.raises(ValueError, match="unknown plugin"):
         mi.load_dict(d)
     d = mitr.cornell_box()
-    d["floor"]["bsdf"] = {"type": "roughplastic"}
+    d["floor"]["bsdf"] = {"type": "roughdielectric"}
     with pytest.raises(ValueError, match="unknown plugin"):
+        mi.load_dict(d).data()
+    d["floor"]["bsdf"] = {"type": "roughplastic"}              # mitsuba's default distribution (beckmann) is not built
+    with pytest.raises(ValueError, match="ggx"):
         mi.load_dict(d).data()
     d = mitr.cornell_box()
     d["sensor"]["film"]["crop_width"] = 9999

@@ -168,12 +168,23 @@ def test_unsupported_materials_raise_unless_approximated(tmp_path):
                           "diffuse_reflectance": {"type": "bitmap", "filename": str(tmp_path / "grey.png")}}}
     d["back"]["bsdf"] = {"type": "bumpmap", "map": {"type": "bitmap", "filename": str(tmp_path / "grey.png")},
                          "bsdf": {"type": "roughconductor", "alpha": 0.1, "eta": [1.6, 0.9, 0.5], "k": [9.2, 6.3, 4.8]}}
-    with pytest.raises(ValueError, match="unknown plugin"):
+    with pytest.raises(ValueError, match="ggx"):                      # mitsuba's default (beckmann) is not built: say ggx
         mi.load_dict(d).data()
+    d["floor"]["bsdf"]["bsdf"]["distribution"] = "ggx"
+    d["back"]["bsdf"]["bsdf"]["distribution"] = "ggx"
+    with pytest.raises(ValueError, match="unknown plugin|bitmap"):    # bitmap textures, bump maps: only approximated
+        mi.load_dict(d).data()
+    lin = ((188 / 255 + 0.055) / 1.055) ** 2.4                       # sRGB -> linear mean colour of the bitmap
+    # approximate_materials=True: textures -> mean colour, bump map ignored; the GGX lobes stay what they are
     sd = mi.load_dict(d, approximate_materials=True).data()
     mats = [sd.materials[i] for i in range(sd.n_materials)]
+    fl = [m for m in mats if m.type == 5 and m.flags & 1]
+    assert any(abs(m.a[0] - lin) < 1e-6 and abs(m.alpha - 0.1) < 1e-7 and 0.5 < m.external_transmittance[63] < 1 for m in fl)
+    assert any(m.type == 4 and abs(m.a[0] - 1.6) < 1e-6 for m in mats)
+    # approximate_materials="smooth" (the config-5 bench fixture): the lobes collapse to diffuse / conductor as well
+    sd = mi.load_dict(d, approximate_materials="smooth").data()
+    mats = [sd.materials[i] for i in range(sd.n_materials)]
     fl = [m for m in mats if m.type == 0 and m.flags == 1]
-    lin = ((188 / 255 + 0.055) / 1.055) ** 2.4                       # sRGB -> linear mean colour of the bitmap
     assert any(abs(m.a[0] - lin) < 1e-6 for m in fl)
     assert any(m.type == 1 and abs(m.a[0] - 1.6) < 1e-6 for m in mats)
 
