@@ -28,6 +28,7 @@ SPLAT_BYTES = 24.0         # algorithmic bytes per issued time-bin contribution 
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
+MATERIALS = "smooth"       # --materials (staircase only): "smooth" = the SURVEY section-8d mapping (default) | "rough" = GGX lobes kept
 SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry)
 
 
@@ -38,7 +39,7 @@ def build_scene(width, height, bins, max_depth=8, mode=None):
     if SCENE == "staircase":
         from mitransient_amd.scenes import staircase
         kw = {"amd_mode": mode} if mode else {}
-        sc = staircase(width=width, height=height, temporal_bins=bins, max_depth=65, **kw)
+        sc = staircase(width=width, height=height, temporal_bins=bins, max_depth=65, materials=MATERIALS, **kw)
         film = sc.sensors()[0].film()
         film.start_opl, film.bin_width_opl = 0.0, 40.0 / bins     # the reference's 0..40 window (400 x 0.1), SURVEY §8d
         return sc
@@ -134,6 +135,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--materials", default="smooth", choices=["smooth", "rough"],
+                    help="staircase only: 'smooth' = roughplastic -> diffuse, roughconductor -> conductor (the SURVEY section-8d "
+                         "workload); 'rough' = the scene file's GGX lobes (roughplastic, roughconductor) kept")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase"],
                     help="staircase: BASELINE configs[4] (512x512, 2048 bins over OPL 0..40, 2048 spp, max_depth 65; "
                          "the reference's scene.xml geometry with approximate materials)")
@@ -146,8 +150,9 @@ def main():
     ap.add_argument("--no-scatter-leg", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
-    global SCENE
+    global SCENE, MATERIALS
     SCENE = args.scene
+    MATERIALS = args.materials
     dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (512, 512, 2048, 2048)}[SCENE]
     args.width, args.height, args.bins, args.spp = [d if a is None else a
                                                     for a, d in zip((args.width, args.height, args.bins, args.spp), dflt)]
@@ -280,7 +285,7 @@ def main():
             "config": {"workload": (f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
                                     f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0") if SCENE == "cornell" else
-                                   (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, approximate materials), "
+                                   (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes kept, textures -> mean colour") + f"), "
                                     f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
                        "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",

@@ -130,10 +130,26 @@ def from_fixture(path, film=None, integrator=None, spp=None):
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")       # scene data shipped with the package
 
 
-def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, **integrator):
+def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, materials="smooth", **integrator):
     """BASELINE config 5: the reference's examples/diff-transient/staircase/scene.xml ('The Wooden Staircase' by
-    Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles, flattened with approximate_materials=True
-    (roughplastic -> diffuse, roughconductor -> conductor, bitmap -> mean colour, bump map ignored)."""
-    return from_fixture(os.path.join(DATA_DIR, "staircase_geometry.npz"),
-                        film={"width": width, "height": height, "temporal_bins": temporal_bins},
-                        integrator=dict(max_depth=max_depth, **integrator), spp=spp)
+    Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles.  ``materials="smooth"`` (the bench workload,
+    SURVEY section 8d): flattened with approximate_materials="smooth" (roughplastic -> diffuse, roughconductor -> conductor,
+    bitmap -> mean colour, bump map ignored); ``materials="rough"``: the GGX lobes of the scene file kept
+    (approximate_materials=True: only textures and the bump map are approximated)."""
+    scene = from_fixture(os.path.join(DATA_DIR, "staircase_geometry.npz"),
+                         film={"width": width, "height": height, "temporal_bins": temporal_bins},
+                         integrator=dict(max_depth=max_depth, **integrator), spp=spp)
+    if materials == "rough":
+        import ctypes as C
+        from . import _cabi
+        z = np.load(os.path.join(DATA_DIR, "staircase_materials_rough.npz"))
+        if int(z["layout"][0]) != C.sizeof(_cabi.mtr_material):
+            raise ValueError("staircase_materials_rough.npz was written for another C-ABI; regenerate with tests/golden/make_golden.py")
+        g = scene.geometry_
+        nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
+        if nm != g["n_materials"]:
+            raise ValueError("staircase_materials_rough.npz does not belong to staircase_geometry.npz")
+        g["materials"] = (_cabi.mtr_material * nm).from_buffer_copy(z["materials"].tobytes())
+    elif materials != "smooth":
+        raise ValueError("materials: 'smooth' or 'rough'")
+    return scene

@@ -88,6 +88,15 @@ def example_scenes():
     sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials="smooth")
     save_fixture(sc, os.path.join(ROOT, "mitransient_amd", "data", "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
                  approximate_materials="smooth")
+    # the same scene with its GGX lobes kept (roughplastic / roughconductor; textures -> mean colour, bump map ignored): only
+    # the material table differs, so it travels as a small side file next to the geometry
+    import ctypes as C
+    from mitransient_amd import _cabi
+    sr = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials=True).data()
+    assert sr.n_materials == sc.data().n_materials and np.array_equal(sr.tri_material, sc.data().tri_material)
+    np.savez_compressed(os.path.join(ROOT, "mitransient_amd", "data", "staircase_materials_rough.npz"),
+                        materials=np.frombuffer(bytes(sr.materials), dtype=np.uint8)[:sr.n_materials * C.sizeof(_cabi.mtr_material)],
+                        layout=np.asarray([C.sizeof(_cabi.mtr_material)]))
     np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
 
 

@@ -64,3 +64,19 @@ def test_rough_materials_unsupported_combinations_fail_loudly():
     a = gpu_render(scene, 4)
     b = gpu_render(mi.load_dict(d), 4)
     assert np.array_equal(a[1], b[1]) and np.count_nonzero(a[1]) > 100
+
+
+def test_staircase_config5_geometry_with_its_rough_materials(oracle):
+    """BASELINE config 5 geometry with the scene file's own GGX lobes (6 roughplastic woods, 2 roughconductor metals;
+    textures -> mean colour, bump map ignored), reduced film: wavefront pipeline in HBM against the oracle"""
+    from mitransient_amd.scenes import staircase
+    scene = staircase(width=45, height=80, spp=4, materials="rough")
+    sd = scene.data()
+    kinds = sorted(sd.materials[i].type for i in range(sd.n_materials))
+    assert kinds.count(5) == 6 and kinds.count(4) == 2
+    s_gpu, t_gpu = gpu_render(scene, 4)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 4)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
