@@ -182,6 +182,12 @@ typedef struct mtr_scene_desc {
      * not degenerate, coordinate_system(n) otherwise (and for every triangle when this is NULL); then
      * SurfaceInteraction::initialize_sh_frame: s = normalize(dp_du - n * dot(n, dp_du)), t = n x s. */
     const float    *tri_uv;
+    /* Per-corner SHADING normals (host, n_tris*9 floats: n0 n1 n2, unit length, world space; optional; ABI 8).  A triangle
+     * whose nine floats are all zero — and every triangle when this is NULL — is flat-shaded (face_normals = true, cube,
+     * rectangle).  Otherwise, as in mitsuba's Mesh::compute_surface_interaction: sh_frame.n = normalize(b0 n0 + b1 n1 +
+     * b2 n2), the tangent from dp_du by initialize_sh_frame; the geometric normal keeps the ray offsets and the emitter
+     * densities. */
+    const float    *tri_normals;
 } mtr_scene_desc;
 
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */

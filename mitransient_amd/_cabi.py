@@ -91,7 +91,8 @@ class mtr_scene_desc(C.Structure):
                 ("nlos", C.POINTER(mtr_nlos_desc)),
                 ("n_shapes", C.c_uint32),
                 ("shapes", C.POINTER(mtr_shape)),
-                ("tri_uv", C.POINTER(C.c_float))]
+                ("tri_uv", C.POINTER(C.c_float)),
+                ("tri_normals", C.POINTER(C.c_float))]
 
 
 class mtr_render_params(C.Structure):

@@ -186,17 +186,19 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
     UP(hs.nodes, nodes); UP(hs.tpairs, tpairs); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
-    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr;
+    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr; s->dev.vnormals = nullptr;
     s->dev.wnodes = nullptr; s->dev.n_wnodes = (uint32_t)hs.wnodes.size();
     if (hs.has_wide) UP(hs.wnodes, wnodes);
     s->dev.wnodes4 = nullptr; s->dev.n_wnodes4 = (uint32_t)hs.wnodes4.size();
     UP(hs.wnodes4, wnodes4);
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
+    if (!hs.vnormals.empty()) UP(hs.vnormals, vnormals);
 #undef UP
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.has_rough = 0u;
     for (uint32_t i = 0; i < d->n_materials; ++i) if (bsdf_is_rough(d->materials[i].type)) s->dev.has_rough = 1u;
+    if (!hs.vnormals.empty()) s->dev.has_rough = 1u;            // smooth-shaded triangles: the extended shading code as well
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
@@ -513,10 +515,10 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
         }
         if (s->dev.has_rough) {              // GGX lobes: transient_path with f32 rows only (fused), or the wavefront pipeline
-            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs are not available for the NLOS tier");
+            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles are not available for the NLOS tier");
             const bool fused_ok = !f.n_freq && !(p->flags & MTR_FLAG_DETERMINISTIC);
             if (mode == MTR_MODE_FUSED && !fused_ok)
-                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs with a phasor film or deterministic rows need the wavefront mode");
+                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles with a phasor film or deterministic rows need the wavefront mode");
             if (mode == MTR_MODE_AUTO && !fused_ok) mode = MTR_MODE_WAVEFRONT;
         }
         if (mode == MTR_MODE_AUTO) {

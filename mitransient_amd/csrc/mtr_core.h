@@ -256,8 +256,12 @@ constexpr uint32_t kLeafQuadBit = 0x40000000u;      // in the leaf code ~ref = (
 //   h[0] = (n.x, n.y, n.z, s.x)  h[1] = (s.y, s.z, t.x, t.y)  h[2] = (t.z, p1.x, p1.y, p1.z)  h[3] = (p2.x, p2.y, p2.z, p0.x)
 //   h[4] = (p0.y, p0.z, mat_em, orig)      mat_em: material index | (emitter index + 1) << 16
 // rectangle slots: p0 := to_world * (0,0,0), p1 := du, p2 := dv (hit point = c + du * u + dv * v), orig |= kShadeQuadBit
+// smooth-shaded triangles (interpolated vertex normals, mtr_scene_desc.tri_normals): h[0] = (ng.x, ng.y, ng.z, dp_du.x),
+// h[1] = (dp_du.y, dp_du.z, -, -) — the geometric normal and the tangent direction from which the frame is built at the hit
+// (hit_ctx) — orig |= kShadeSmoothBit; the three vertex normals live in SceneView::vnormals[3 * slot ..]
 struct alignas(16) TriShade { q4 h[5]; };
 constexpr uint32_t kShadeQuadBit = 0x80000000u;
+constexpr uint32_t kShadeSmoothBit = 0x40000000u;
 struct alignas(16) Emitter {                       // 80 B
     float center[3], du[3], dv[3], n[3], radiance[3], inv_area;       // rectangle: analytic sampling
     uint32_t is_mesh, first_tri, n_tris, pad;                          // mesh: triangle range (ORIGINAL indices)
@@ -294,6 +298,7 @@ struct SceneView {
     // 3 quads (p0, e1.x) (e1.yz, e2.xy) (e2.z, n) and the face distribution normalised within the mesh
     const q4 *samp_tris;
     const float *face_pmf, *face_cdf;
+    const q4 *vnormals;       // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
 };
 
 // [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
@@ -1152,8 +1157,19 @@ MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderCo
 
 // Surface interaction rebuilt from (ray direction, primitive, barycentrics): cheap enough to
 // recompute on both sides of the shadow ray instead of keeping 15 registers alive across it.
-struct HitCtx { f3 sp, sn, ss, stt, wi; uint32_t mat, em_plus1; };
+// sn / ss / stt: the SHADING frame (si.sh_frame); gn: the geometric normal (si.n), which keeps the ray offsets and the
+// emitter densities.  They differ only on smooth-shaded triangles.
+struct HitCtx { f3 sp, sn, ss, stt, wi, gn; uint32_t mat, em_plus1; };
 
+// [mitsuba3: SurfaceInteraction::initialize_sh_frame] s = normalize(dp_du - n * dot(n, dp_du)), t = n x s
+MTR_HD void sh_frame_of(f3 n, f3 dp_du, f3 &s, f3 &t)
+{
+    const float dn = dot(n, dp_du);
+    s = normalize(mk(fmaf(-n.x, dn, dp_du.x), fmaf(-n.y, dn, dp_du.y), fmaf(-n.z, dn, dp_du.z)));
+    t = cross(n, s);
+}
+
+template <bool SMOOTH = true>
 MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
 {
     HitCtx c;
@@ -1166,6 +1182,16 @@ MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
     if (fbits(he.w) & kShadeQuadBit)          // rectangle: to_world.transform_affine((u, v, 0)) = fmadd(dv, v, fmadd(du, u, c))
         c.sp = mk(fmaf(hd.x, b2, fmaf(hc.y, b1, hd.w)), fmaf(hd.y, b2, fmaf(hc.z, b1, he.x)), fmaf(hd.z, b2, fmaf(hc.w, b1, he.y)));
     c.sn = mk(ha.x, ha.y, ha.z); c.ss = mk(ha.w, hb.x, hb.y); c.stt = mk(hb.z, hb.w, hc.x);
+    c.gn = c.sn;
+    if (SMOOTH && (fbits(he.w) & kShadeSmoothBit)) {
+        // [mitsuba3: Mesh::compute_surface_interaction] n = fmadd(n2, b2, fmadd(n1, b1, n0 * b0)), normalised
+        const q4 *vn = sc.vnormals + 3u * (uint32_t)h.prim;
+        const q4 n0 = vn[0], n1 = vn[1], n2 = vn[2];
+        const f3 ns = normalize(mk(fmaf(n2.x, b2, fmaf(n1.x, b1, n0.x * b0)), fmaf(n2.y, b2, fmaf(n1.y, b1, n0.y * b0)),
+                                   fmaf(n2.z, b2, fmaf(n1.z, b1, n0.z * b0))));
+        c.sn = ns;
+        sh_frame_of(ns, mk(ha.w, hb.x, hb.y), c.ss, c.stt);
+    }
     const f3 md = -ray_d;
     c.wi = mk(dot(md, c.ss), dot(md, c.stt), dot(md, c.sn));
     const uint32_t mat_em = fbits(he.z);
@@ -1205,7 +1231,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
     const bool in_film = (fx < film.width) & (fy < film.height);
     float u1 = rng_f32(p.rng), u2 = rng_f32(p.rng);                  // :193, unconditional for a live lane
     if (!valid) return;
-    const HitCtx c = hit_ctx(sc, p.ray.d, h);
+    const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
     const mtr_material &mat = sc.mats[c.mat];
 
     // direct emission (:166-176)
@@ -1216,7 +1242,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
         f3 dd = rel / dist;
         float em_pdf = 0.0f;
         if (!p.prev_delta) {
-            float dp = dot(dd, c.sn);
+            float dp = dot(dd, c.gn);
             if (dp < 0.0f) {
                 float adp = fabsf(dp);
                 em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
@@ -1271,7 +1297,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                 f3 wi_e = c.wi;
                 if ((mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
                 // shadow ray: spawn_ray_to(ds.p) + ray_test
-                f3 so = offset_point(c.sp, c.sn, ep - c.sp);
+                f3 so = offset_point(c.sp, c.gn, ep - c.sp);
                 f3 sd = ep - so;
                 float sdist = sqrtf(dot(sd, sd));
                 shadow.o = so; shadow.d = sd / sdist; shadow.tmax = sdist * (1.0f - kShadowEps);
@@ -1324,14 +1350,14 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
     f3 sp = mk(0, 0, 0);
     p.L = mk((p.L.x + pd.Le.x) + Lr.x, (p.L.y + pd.Le.y) + Lr.y, (p.L.z + pd.Le.z) + Lr.z);    // :230
     if (valid) {
-        const HitCtx c = hit_ctx(sc, p.ray.d, h);
+        const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
         sp = c.sp;
         if (active_next) {
             bs = bsdf_sample<ROUGH>(sc.mats[c.mat], c.wi, s1, s2a, s2b);                         // :222-227
             f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                          fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                          fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
-            p.ray.o = offset_point(c.sp, c.sn, wo_w);                                            // si.spawn_ray :231
+            p.ray.o = offset_point(c.sp, c.gn, wo_w);                                            // si.spawn_ray :231
             p.ray.d = wo_w;
             p.ray.tmax = kInf;
         }

@@ -20,10 +20,12 @@ struct SceneDev {
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;
     const q4 *samp_tris; const float *face_pmf, *face_cdf;   // mesh-emitter sampling tables (HBM; null without mesh emitters)
+    const q4 *vnormals;              // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
     uint32_t bvh_depth;
     uint32_t wide_levels, wide4_levels;   // levels of wnodes / wnodes4: a wide walk stacks at most one group per level
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS
-    uint32_t has_rough;              // a material is a GGX lobe (MTR_BSDF_ROUGH*): kernels with the rough shading code
+    uint32_t has_rough;              // the scene needs the EXTENDED shading code (kernels instantiated with ROUGH = true): a material
+                                     // is a GGX lobe (MTR_BSDF_ROUGH*), or a triangle is smooth-shaded (vnormals)
 };
 
 struct SplatLog { uint32_t *rec; unsigned long long cap; unsigned long long *count; };

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
     sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
-    sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf;
+    sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf; sv.vnormals = a.sc.vnormals;
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (fused_plan); the BVH2 packets stay in HBM, unused
         const uint32_t tree_bytes = a.sc.n_wnodes * (uint32_t)sizeof(WNode);
@@ -603,13 +603,13 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     sv.wnodes = nullptr; sv.wnodes4 = nullptr;
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
-    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf;
+    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
     const uint32_t total = nlos_target_count(nc);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         const Ray r = nlos_prepare_ray(nc, i);
         const Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
         f3 p = mk(0, 0, 0);
-        if (h.prim >= 0) p = hit_ctx(sv, r.d, h).sp;
+        if (h.prim >= 0) p = hit_ctx<false>(sv, r.d, h).sp;
         targets[i] = q4{ p.x, p.y, p.z, h.prim >= 0 ? 1.0f : 0.0f };
     }
 }

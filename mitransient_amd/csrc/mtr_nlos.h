@@ -212,7 +212,7 @@ MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, 
     stats.closest++;
     if (h2.prim < 0) return mk(0, 0, 0);
     if (!(bs.x > kDrEps || bs.y > kDrEps || bs.z > kDrEps)) return mk(0, 0, 0);               // :539-540
-    const HitCtx c2 = hit_ctx(sc, rb.d, h2);
+    const HitCtx c2 = hit_ctx<false>(sc, rb.d, h2);
     const f3 md = -dd;
     const float wlz = dot(md, c2.sn);                                                          // cos_theta(si_bsdf.to_local(-d))
     if (!(wlz > 0.0f)) return mk(0, 0, 0);                                                     // :543
@@ -271,8 +271,8 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     bool active_next = ((p.depth + 1u) < rc.max_depth) & valid;                                   // :782
     f3 Lr = mk(0, 0, 0);
     HitCtx c;
-    c.sp = mk(0, 0, 0); c.sn = mk(0, 0, 1); c.ss = mk(1, 0, 0); c.stt = mk(0, 1, 0); c.wi = mk(0, 0, 0); c.mat = 0; c.em_plus1 = 0;
-    if (valid) c = hit_ctx(sc, p.ray.d, h);
+    c.sp = mk(0, 0, 0); c.sn = mk(0, 0, 1); c.gn = mk(0, 0, 1); c.ss = mk(1, 0, 0); c.stt = mk(0, 1, 0); c.wi = mk(0, 0, 0); c.mat = 0; c.em_plus1 = 0;
+    if (valid) c = hit_ctx<false>(sc, p.ray.d, h);
     // the only emitter is the projector (not a surface): Le = 0 (:757-777)
     if (active_next && sc.mats[c.mat].type == MTR_BSDF_DIFFUSE) {                                 // active_em :785-786
         if ((nc.flags & MTR_NLOS_LASER_SAMPLING) && nc.capture_type == MTR_CAPTURE_EXHAUSTIVE) {

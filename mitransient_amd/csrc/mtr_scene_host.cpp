@@ -57,12 +57,7 @@ static f3 coordinate_system_s(f3 n)
     return mk((neg ? -x : x) + 1.0f, neg ? -b : b, neg ? -nx : nx);
 }
 // [mitsuba3: SurfaceInteraction::initialize_sh_frame]
-static void sh_frame_from(f3 n, f3 dp_du, f3 &s, f3 &t)
-{
-    const float dn = dot(n, dp_du);
-    s = normalize(mk(fmaf(-n.x, dn, dp_du.x), fmaf(-n.y, dn, dp_du.y), fmaf(-n.z, dn, dp_du.z)));
-    t = cross(n, s);
-}
+static void sh_frame_from(f3 n, f3 dp_du, f3 &s, f3 &t) { sh_frame_of(n, dp_du, s, t); }
 // rows of a rectangle's to_object from (c, du, dv): the inverse of [du dv n^ | c], n^ = normalize(du x dv); f64 -> f32
 // (numerics contract: the same operations, in the same order, as the test oracle's restatement)
 static void rect_to_object(const float c[3], const float du[3], const float dv[3], float rx[4], float ry[4], float rz[4])
@@ -169,6 +164,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     s.wide4_levels = build_wide4(bvh, s.wnodes4);
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
+    s.vnormals.clear();
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
         const uint32_t o = bvh.order[slot] != kPadSlot ? bvh.order[slot] : bvh.order[slot - 1];   // pad: repeat the leaf's last triangle
         s.slot_orig[slot] = o;
@@ -213,6 +209,17 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         }
         f3 sdir, t;
         sh_frame_from(n, dp_du, sdir, t);
+        // smooth-shaded: the frame is built at the hit from the interpolated normal (hit_ctx); the record keeps dp_du
+        bool smooth = false;
+        if (d.tri_normals) {
+            const float *vn = d.tri_normals + 9 * (size_t)o;
+            for (int k = 0; k < 9; ++k) smooth = smooth || vn[k] != 0.0f;
+            if (smooth) {
+                if (s.vnormals.empty()) s.vnormals.assign(3 * (size_t)n_slots, q4{ 0, 0, 0, 0 });
+                for (int k = 0; k < 3; ++k) s.vnormals[3 * (size_t)slot + k] = q4{ vn[3 * k], vn[3 * k + 1], vn[3 * k + 2], 0.0f };
+                sdir = dp_du; t = mk(0, 0, 0);
+            }
+        }
         float *g = &s.tpairs[slot >> 1].g[0].x;            // interleaved pair record: dword 2*k + half
         const float comp[9] = { p0.x, p0.y, p0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };
         const uint32_t half = slot & 1u;
@@ -222,7 +229,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
         h.h[2] = q4{ t.z, v[3], v[4], v[5] };
         h.h[3] = q4{ v[6], v[7], v[8], p0.x };
-        h.h[4] = q4{ p0.y, p0.z, bitsf(mat_em), bitsf(o) };
+        h.h[4] = q4{ p0.y, p0.z, bitsf(mat_em), bitsf(o | (smooth ? kShadeSmoothBit : 0u)) };
     }
     s.ems.resize(d.n_emitters);
     for (uint32_t i = 0; i < d.n_emitters; ++i) {

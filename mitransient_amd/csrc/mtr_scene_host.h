@@ -21,6 +21,7 @@ struct HostScene {
     std::vector<mtr_material> mats;
     std::vector<Emitter> ems;
     std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView
+    std::vector<q4> vnormals;                  // [3 * n_slots] vertex normals, when a triangle is smooth-shaded (empty otherwise)
     std::vector<float> face_pmf, face_cdf;
     uint32_t bvh_depth = 0, n_leaves = 0;
     uint32_t wide_levels = 0, wide4_levels = 0;        // levels of the collapsed trees (= their traversal stack bound)

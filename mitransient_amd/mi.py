@@ -204,6 +204,7 @@ class Scene:
                 raise AssertionError(f"You have defined multiple ({len(self.emitters_)}) emitters in the scene with a "
                                      "NLOS capture meter. You should have only 1.")
             sd.nlos = nlos_desc_from(self.integrator_, sensor, self.emitters_[0], sd.relay_shape)
+            sd.tri_normals = None          # the NLOS tier shades flat (documented: DESIGN.md section 10); vertex normals are not passed on
         return sd
 
     def gpu_handle(self, ctx, sensor=0):

@@ -129,6 +129,7 @@ class _SceneBuilder:
         self.tri_mat: List[np.ndarray] = []
         self.tri_em: List[np.ndarray] = []
         self.tri_uv: List[Optional[np.ndarray]] = []          # per shape: (n, 6) corner texture coordinates, or None
+        self.tri_normals: List[Optional[np.ndarray]] = []     # per shape: (n, 9) world-space corner normals (smooth shading), or None = flat
         self.materials: List[_cabi.mtr_material] = []
         self.mat_cache: Dict[int, int] = {}
         self.emitters: List[_cabi.mtr_emitter] = []
@@ -257,6 +258,7 @@ class _SceneBuilder:
         t = sd.get("type")
         tw = to_transform(sd.get("to_world"))
         uv = None
+        normals = None
         if t == "rectangle":
             # an analytic primitive (mtr_shape.is_rectangle); the two triangles carry its material / emitter / index
             corners = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float64)
@@ -270,15 +272,23 @@ class _SceneBuilder:
             if not os.path.isabs(fn):
                 fn = os.path.join(self.base_dir, fn)
             if fn not in self.mesh_cache:
-                self.mesh_cache[fn] = load_obj(fn, with_uv=True) if t == "obj" else (load_ply(fn), None)
-            v, uv = self.mesh_cache[fn]
+                self.mesh_cache[fn] = load_obj(fn, with_uv=True, with_normals=True) if t == "obj" else (load_ply(fn), None, None)
+            v, uv, vn = self.mesh_cache[fn]
             tris = tw.transform_affine(v.reshape(-1, 3)).reshape(-1, 3, 3)
+            # shading normals [mitsuba3: Mesh::compute_surface_interaction]: interpolated vertex normals unless face_normals;
+            # normals go to world space by the inverse transpose and are renormalised (obj.cpp)
+            if vn is not None and not sd.get("face_normals", False):
+                nt = vn.reshape(-1, 3) @ np.linalg.inv(tw.matrix[:3, :3])
+                ln = np.linalg.norm(nt, axis=1, keepdims=True)
+                normals = np.where(ln > 0, nt / np.where(ln > 0, ln, 1.0), 0.0).reshape(-1, 9)
         else:
             raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported shapes: rectangle, cube, obj, ply)")
         if sd.get("flip_normals", False):
             tris = tris[:, [0, 2, 1], :]
             if uv is not None:
                 uv = uv.reshape(-1, 3, 2)[:, [0, 2, 1], :].reshape(-1, 6)
+            if normals is not None:
+                normals = -normals.reshape(-1, 3, 3)[:, [0, 2, 1], :].reshape(-1, 9)
         bsdf, em = None, None
         for k, v in sd.items():
             # nested plugins are recognised by type, not by key (keys are arbitrary, as in mitsuba): emitter, sensor,
@@ -321,6 +331,7 @@ class _SceneBuilder:
         self.tri_mat.append(np.full(n, mi_, dtype=np.uint32))
         self.tri_em.append(np.full(n, em_index, dtype=np.int32))
         self.tri_uv.append(None if uv is None else np.asarray(uv, dtype=np.float32).reshape(n, 6))
+        self.tri_normals.append(None if normals is None else np.asarray(normals, dtype=np.float32).reshape(n, 9))
         self.shape_names.append(name)
         self.shape_ranges.append((first, first + n))
         sh = _cabi.mtr_shape()
@@ -354,11 +365,15 @@ def _cube_tris():
     return verts[idx], uvs[idx].reshape(-1, 6)
 
 
-def load_obj(path: str, with_uv: bool = False):
-    """Wavefront OBJ -> (n,3,3) float64 triangle soup (positions; fan-triangulated; ``l``/``vn`` and groups are ignored:
-    faces are flat-shaded).  ``with_uv``: also the corner texture coordinates (n,6) float32 — or None when the file has no
-    ``vt`` or some face corner lacks one — which only orient the shading frame (mtr_scene_desc.tri_uv)."""
+def load_obj(path: str, with_uv: bool = False, with_normals: bool = False):
+    """Wavefront OBJ -> (n,3,3) float64 triangle soup (positions; fan-triangulated; ``l`` and groups are ignored).
+    ``with_uv``: also the corner texture coordinates (n,6) float32 — or None when the file has no ``vt`` or some face
+    corner lacks one — which only orient the shading frame (mtr_scene_desc.tri_uv).  ``with_normals``: also the corner
+    normals (n,3,3) float64 from ``vn`` — or, when the file has none (or a corner lacks one), the angle-weighted vertex
+    normals mitsuba computes in that case (Mesh::recompute_vertex_normals over vertices that share position and texture
+    index); returns (tris, uv, normals)."""
     verts, uvs, tris, tuv = [], [], [], []
+    vns, tvn = [], []
     with open(path, "r") as fh:
         for line in fh:
             if line.startswith("v "):
@@ -367,8 +382,11 @@ def load_obj(path: str, with_uv: bool = False):
             elif line.startswith("vt "):
                 p = line.split()
                 uvs.append((float(p[1]), float(p[2]) if len(p) > 2 else 0.0))
+            elif line.startswith("vn "):
+                p = line.split()
+                vns.append((float(p[1]), float(p[2]), float(p[3])))
             elif line.startswith("f "):
-                idx, tix = [], []
+                idx, tix, nix = [], [], []
                 for tok in line.split()[1:]:
                     parts = tok.split("/")
                     i = int(parts[0])
@@ -378,18 +396,52 @@ def load_obj(path: str, with_uv: bool = False):
                         tix.append(j - 1 if j > 0 else len(uvs) + j)
                     else:
                         tix.append(-1)
+                    if len(parts) > 2 and parts[2]:
+                        j = int(parts[2])
+                        nix.append(j - 1 if j > 0 else len(vns) + j)
+                    else:
+                        nix.append(-1)
                 for k in range(1, len(idx) - 1):
                     tris.append((idx[0], idx[k], idx[k + 1]))
                     tuv.append((tix[0], tix[k], tix[k + 1]))
+                    tvn.append((nix[0], nix[k], nix[k + 1]))
     v = np.asarray(verts, dtype=np.float64)
     t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
-    if not with_uv:
+    if not with_uv and not with_normals:
         return v[t]
     tu = np.asarray(tuv, dtype=np.int64).reshape(-1, 3)
     uv = None
     if uvs and tu.size and tu.min() >= 0:
         uv = np.asarray(uvs, dtype=np.float32)[tu].reshape(-1, 6)
-    return v[t], uv
+    if not with_normals:
+        return v[t], uv
+    tn = np.asarray(tvn, dtype=np.int64).reshape(-1, 3)
+    if vns and tn.size and tn.min() >= 0:
+        normals = np.asarray(vns, dtype=np.float64)[tn]
+    else:
+        normals = vertex_normals(v, t, tu)
+    return v[t], uv, normals
+
+
+def vertex_normals(v: np.ndarray, t: np.ndarray, key2: Optional[np.ndarray] = None) -> np.ndarray:
+    """[mitsuba3: Mesh::recompute_vertex_normals] corner normals (n,3,3) of an indexed mesh without normals: every face adds
+    its unit normal, weighted by its angle at the corner, to the vertices it touches; a "vertex" is what the loader keeps
+    apart: position index (and texture index ``key2`` when given)."""
+    P = v[t]                                                   # (n,3,3)
+    fn = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1.0), 0.0)
+    key = t if key2 is None else t * (int(key2.max()) + 2) + (key2 + 1)
+    uniq, inv = np.unique(key.reshape(-1), return_inverse=True)
+    acc = np.zeros((len(uniq), 3))
+    for i in range(3):
+        d0 = P[:, (i + 1) % 3] - P[:, i]; d1 = P[:, (i + 2) % 3] - P[:, i]
+        d0 /= np.maximum(np.linalg.norm(d0, axis=1, keepdims=True), 1e-300); d1 /= np.maximum(np.linalg.norm(d1, axis=1, keepdims=True), 1e-300)
+        ang = np.arccos(np.clip(np.sum(d0 * d1, axis=1), -1.0, 1.0))
+        np.add.at(acc, inv.reshape(-1, 3)[:, i], fn * ang[:, None])
+    la = np.linalg.norm(acc, axis=1, keepdims=True)
+    acc = np.where(la > 0, acc / np.where(la > 0, la, 1.0), 0.0)
+    return acc[inv.reshape(-1, 3)]
 
 
 _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
@@ -533,6 +585,7 @@ class SceneData:
         self.shapes = (_cabi.mtr_shape * 1)()
         self.n_shapes = 0
         self.tri_uv = None               # (n_tris, 6) f32 corner texture coordinates, or None
+        self.tri_normals = None          # (n_tris, 9) f32 corner shading normals (all-zero rows: flat triangle), or None
         self.nlos = None                 # mtr_nlos_desc for the NLOS tier
 
     def desc(self) -> _cabi.mtr_scene_desc:
@@ -550,6 +603,7 @@ class SceneData:
         d.n_shapes = self.n_shapes
         d.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape)) if self.n_shapes else None
         d.tri_uv = self.tri_uv.ctypes.data_as(C.POINTER(C.c_float)) if self.tri_uv is not None else None
+        d.tri_normals = self.tri_normals.ctypes.data_as(C.POINTER(C.c_float)) if self.tri_normals is not None else None
         if self.nlos is not None:
             self.nlos.n_shapes = self.n_shapes
             self.nlos.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape))
@@ -611,6 +665,7 @@ def save_geometry(sd: "SceneData", path: str, **meta):
         emitters=np.frombuffer(bytes(sd.emitters), dtype=np.uint8)[:sd.n_emitters * C.sizeof(_cabi.mtr_emitter)],
         shapes=np.frombuffer(bytes(sd.shapes), dtype=np.uint8)[:sd.n_shapes * C.sizeof(_cabi.mtr_shape)],
         tri_uv=sd.tri_uv if sd.tri_uv is not None else np.zeros((0, 6), np.float32),
+        tri_normals=sd.tri_normals if sd.tri_normals is not None else np.zeros((0, 9), np.float32),
         layout=np.asarray([C.sizeof(_cabi.mtr_material), C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]),
         meta=np.asarray(json.dumps(meta)))
 
@@ -636,6 +691,8 @@ def load_geometry(path: str) -> Dict[str, Any]:
     shapes = (_cabi.mtr_shape * max(1, ns)).from_buffer_copy(z["shapes"].tobytes().ljust(C.sizeof(_cabi.mtr_shape), b"\0"))
     return {"shapes": shapes, "n_shapes": ns,
             "tri_uv": np.ascontiguousarray(z["tri_uv"], dtype=np.float32) if z["tri_uv"].shape[0] else None,
+            "tri_normals": (np.ascontiguousarray(z["tri_normals"], dtype=np.float32)
+                            if "tri_normals" in z and z["tri_normals"].shape[0] else None),
             "tri_verts": np.ascontiguousarray(z["tri_verts"], dtype=np.float32),
             "tri_material": np.ascontiguousarray(z["tri_material"].astype(np.uint32)),
             "tri_emitter": np.ascontiguousarray(z["tri_emitter"].astype(np.int32)),
@@ -661,10 +718,14 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
         b.materials, b.emitters = list(geometry["materials"])[:geometry["n_materials"]], list(geometry["emitters"])[:geometry["n_emitters"]]
         b.shapes = list(geometry["shapes"])[:geometry["n_shapes"]]
         sd.tri_uv = geometry["tri_uv"]
+        sd.tri_normals = geometry.get("tri_normals")
     if b.tri_verts:
         sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
         sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))
         sd.tri_emitter = np.ascontiguousarray(np.concatenate(b.tri_em))
+        if any(u is not None for u in b.tri_normals):   # flat shapes: all-zero normals
+            sd.tri_normals = np.ascontiguousarray(np.concatenate(
+                [u if u is not None else np.zeros((v.shape[0], 9), np.float32) for u, v in zip(b.tri_normals, b.tri_verts)]))
         if any(u is not None for u in b.tri_uv):        # shapes without texture coordinates: a degenerate (all-zero) parameterisation
             sd.tri_uv = np.ascontiguousarray(np.concatenate(
                 [u if u is not None else np.zeros((v.shape[0], 6), np.float32) for u, v in zip(b.tri_uv, b.tri_verts)]))

@@ -130,12 +130,15 @@ def from_fixture(path, film=None, integrator=None, spp=None):
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")       # scene data shipped with the package
 
 
-def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, materials="smooth", **integrator):
+def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, materials="smooth", vertex_normals=False,
+              **integrator):
     """BASELINE config 5: the reference's examples/diff-transient/staircase/scene.xml ('The Wooden Staircase' by
     Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles.  ``materials="smooth"`` (the bench workload,
     SURVEY section 8d): flattened with approximate_materials="smooth" (roughplastic -> diffuse, roughconductor -> conductor,
     bitmap -> mean colour, bump map ignored); ``materials="rough"``: the GGX lobes of the scene file kept
-    (approximate_materials=True: only textures and the bump map are approximated)."""
+    (approximate_materials=True: only textures and the bump map are approximated).  ``vertex_normals=True``: the meshes'
+    own shading normals (the scene file sets face_normals on 157 of its 774 shapes only; 91.5 % of the triangles are
+    smooth-shaded) instead of flat shading everywhere."""
     scene = from_fixture(os.path.join(DATA_DIR, "staircase_geometry.npz"),
                          film={"width": width, "height": height, "temporal_bins": temporal_bins},
                          integrator=dict(max_depth=max_depth, **integrator), spp=spp)
@@ -152,4 +155,9 @@ def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, m
         g["materials"] = (_cabi.mtr_material * nm).from_buffer_copy(z["materials"].tobytes())
     elif materials != "smooth":
         raise ValueError("materials: 'smooth' or 'rough'")
+    if vertex_normals:
+        tn = np.load(os.path.join(DATA_DIR, "staircase_normals.npz"))["tri_normals"]
+        if tn.shape != (scene.geometry_["tri_verts"].shape[0], 9):
+            raise ValueError("staircase_normals.npz does not belong to staircase_geometry.npz")
+        scene.geometry_["tri_normals"] = np.ascontiguousarray(tn, dtype=np.float32)
     return scene

@@ -199,7 +199,9 @@ void orc_square_to_cos_hemi(float u1, float u2, float *out3)
 /* ------------------------------------------------------------------ */
 typedef struct {
     v3 p0, e1, e2;     /* [mitsuba3: Mesh::ray_intersect_triangle] */
-    v3 n, s, t;        /* geometric normal == shading normal (flat); frame s,t [mitsuba3: SurfaceInteraction::initialize_sh_frame] */
+    v3 n, s, t;        /* geometric normal; frame s,t of a flat-shaded triangle [mitsuba3: SurfaceInteraction::initialize_sh_frame] */
+    v3 dp_du;          /* the tangent direction the frame is built from (smooth-shaded triangles rebuild it at the hit) */
+    int smooth;        /* mtr_scene_desc.tri_normals holds vertex normals for this triangle */
     /* analytic `rectangle` [mitsuba3: src/shapes/rectangle.cpp]: kind 1 = the primitive (first of its two carrier
      * triangles), kind 2 = the second carrier (never intersected), kind 0 = a mesh triangle */
     int kind;
@@ -289,6 +291,8 @@ static void build_tris(orc_scene *sc)
             }
         }
         sh_frame_from(T->n, dp_du, &T->s, &T->t);
+        T->dp_du = dp_du; T->smooth = 0;
+        if (d->tri_normals) for (int k = 0; k < 9; ++k) if (d->tri_normals[9 * (size_t)i + k] != 0.0f) T->smooth = 1;
     }
     /* analytic rectangles [mitsuba3: Rectangle::update / compute_surface_interaction]: one primitive, one frame */
     for (uint32_t k = 0; k < d->n_shapes && d->shapes; ++k) {
@@ -516,7 +520,8 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
 /* Surface interaction  [mitsuba3: Mesh::compute_surface_interaction]  */
 /* ------------------------------------------------------------------ */
 typedef struct {
-    int valid; float t; v3 p, n, s, tt, wi; int prim;
+    int valid; float t; v3 p, n, s, tt, wi; int prim;       /* n, s, tt: the shading frame (si.sh_frame) */
+    v3 ng;                                                     /* si.n: the geometric normal (ray offsets, emitter densities) */
 } sinter;
 
 static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
@@ -535,7 +540,13 @@ static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
         si.p = V(fmaf(T->qdv.x, h.v, fmaf(T->qdu.x, h.u, T->qc.x)),
                  fmaf(T->qdv.y, h.v, fmaf(T->qdu.y, h.u, T->qc.y)),
                  fmaf(T->qdv.z, h.v, fmaf(T->qdu.z, h.u, T->qc.z)));
-    si.n = T->n; si.s = T->s; si.tt = T->t;
+    si.n = T->n; si.s = T->s; si.tt = T->t; si.ng = T->n;
+    if (T->smooth) {        /* sh_frame.n = normalize(fmadd(n2, b2, fmadd(n1, b1, n0 * b0))), then initialize_sh_frame */
+        const float *vn = sc->d->tri_normals + 9 * (size_t)h.prim;
+        si.n = vnormalize(V(fmaf(vn[6], b2, fmaf(vn[3], b1, vn[0] * b0)), fmaf(vn[7], b2, fmaf(vn[4], b1, vn[1] * b0)),
+                            fmaf(vn[8], b2, fmaf(vn[5], b1, vn[2] * b0))));
+        sh_frame_from(si.n, T->dp_du, &si.s, &si.tt);
+    }
     v3 md = vneg(r->d);
     si.wi = V(vdot(md, si.s), vdot(md, si.tt), vdot(md, si.n));   /* to_local(-ray.d) */
     return si;
@@ -553,8 +564,8 @@ static v3 offset_p(const sinter *si, v3 d)
 {
     float m = fmaxf(fabsf(si->p.x), fmaxf(fabsf(si->p.y), fabsf(si->p.z)));
     float mag = (1.0f + m) * ORC_RAY_EPS;
-    mag = mulsign(mag, vdot(si->n, d));
-    return vfma(si->n, mag, si->p);
+    mag = mulsign(mag, vdot(si->ng, d));
+    return vfma(si->ng, mag, si->p);
 }
 
 /* ------------------------------------------------------------------ */
@@ -968,7 +979,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
             /* pdf_emitter_direction(prev_si, ds, ~prev_bsdf_delta) [AreaLight::pdf_direction, Shape::pdf_direction] */
             float em_pdf = 0.0f;
             if (!prev_delta) {
-                float dp = vdot(dd, si.n);
+                float dp = vdot(dd, si.ng);
                 if (dp < 0.0f) {
                     float adp = fabsf(dp);
                     em_pdf = sc->em_inv_area[em] * (adp != 0.0f ? (dist * dist) / adp : 0.0f);

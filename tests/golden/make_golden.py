@@ -97,6 +97,9 @@ def example_scenes():
     np.savez_compressed(os.path.join(ROOT, "mitransient_amd", "data", "staircase_materials_rough.npz"),
                         materials=np.frombuffer(bytes(sr.materials), dtype=np.uint8)[:sr.n_materials * C.sizeof(_cabi.mtr_material)],
                         layout=np.asarray([C.sizeof(_cabi.mtr_material)]))
+    # ... and the meshes' vertex normals (face_normals is set on 157 of the 774 shapes only), same triangle order
+    assert np.array_equal(sr.tri_verts, sc.data().tri_verts)
+    np.savez_compressed(os.path.join(ROOT, "mitransient_amd", "data", "staircase_normals.npz"), tri_normals=sr.tri_normals)
     np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
 
 

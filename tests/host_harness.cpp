@@ -66,6 +66,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
+    sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
     RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
     HostSink sink{ t4, hs.film.width, hs.film.bins, 0, hs.film };
     ArrStack st; st.sp = 0;
@@ -84,7 +85,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
             const Ray r = nlos_prepare_ray(k, i);
             Hit h = traverse<false>(sv, r.o, r.d, r.tmax, st);
             f3 pp = mk(0, 0, 0);
-            if (h.prim >= 0) pp = hit_ctx(sv, r.d, h).sp;
+            if (h.prim >= 0) pp = hit_ctx<false>(sv, r.d, h).sp;
             targets[i] = q4{ pp.x, pp.y, pp.z, 0.0f };
         }
         k.targets = targets.data();
@@ -157,6 +158,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
+    sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
     ArrStack st; st.sp = 0;
     for (uint32_t i = 0; i < n; ++i) {
         f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);

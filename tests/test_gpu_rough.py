@@ -80,3 +80,34 @@ def test_staircase_config5_geometry_with_its_rough_materials(oracle):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_smooth_shaded_sphere_matches_oracle(oracle, tmp_path, mode):
+    """interpolated vertex normals (mtr_scene_desc.tri_normals) on a mesh with a non-uniform to_world: the shading frame is
+    rebuilt at the hit, the geometric normal keeps the ray offsets; diffuse, a GGX lobe and glass"""
+    from test_smooth_normals import sphere_scene
+    for bsdf in (None, {"type": "roughconductor", "distribution": "ggx", "alpha": 0.2, "eta": 0.2, "k": 3.9},
+                 {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}):
+        scene = sphere_scene(tmp_path, bsdf=bsdf, width=40, height=32)
+        scene.integrator().mode = {"fused": 1, "wavefront": 2}[mode]
+        s_gpu, t_gpu = gpu_render(scene, 16, seed=2)
+        s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16, seed=2)
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+        got = scene.integrator().last_counters
+        for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+            assert got[k] == cnt[k], k
+
+
+def test_staircase_config5_faithful_shading(oracle):
+    """config 5 geometry with the scene file's GGX lobes AND its vertex normals (91.5 % of the triangles smooth-shaded)"""
+    from mitransient_amd.scenes import staircase
+    scene = staircase(width=45, height=80, spp=4, materials="rough", vertex_normals=True)
+    sd = scene.data()
+    assert sd.tri_normals is not None and 0.9 < np.any(sd.tri_normals != 0, axis=1).mean() < 0.93
+    s_gpu, t_gpu = gpu_render(scene, 4)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 4)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

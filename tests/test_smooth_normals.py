@@ -1,0 +1,149 @@
+"""Interpolated shading normals (mtr_scene_desc.tri_normals; mitsuba's Mesh::compute_surface_interaction with vertex
+normals): loader, product arithmetic against the oracle, and what smooth shading must do to an image."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import hh_render
+
+
+def write_sphere_obj(path, n_lat=6, n_lon=10, r=0.3, c=(0.0, -0.3, 0.0), with_vn=True):
+    """a UV sphere; vn = the analytic normal of the vertex"""
+    v, f = [], []
+    for i in range(n_lat + 1):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            v.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    idx = lambda i, j: i * n_lon + (j % n_lon) + 1
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b, c_, d = idx(i, j), idx(i, j + 1), idx(i + 1, j + 1), idx(i + 1, j)
+            if i > 0:
+                f.append((a, b, c_))
+            if i < n_lat - 1:
+                f.append((a, c_, d))
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % (c[0] + r * p[0], c[1] + r * p[1], c[2] + r * p[2]))
+        if with_vn:
+            for p in v:
+                fh.write("vn %.9g %.9g %.9g\n" % p)
+        for t in f:
+            fh.write("f " + " ".join(("%d//%d" % (k, k)) if with_vn else str(k) for k in t) + "\n")
+    return len(f)
+
+
+def sphere_scene(tmp_path, face_normals=False, bsdf=None, with_vn=True, n_lat=6, n_lon=10, **film):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    path = str(tmp_path / f"sphere_{n_lat}_{n_lon}_{int(with_vn)}.obj")
+    write_sphere_obj(path, n_lat, n_lon, with_vn=with_vn)
+    d = mitr.cornell_box()
+    del d["small-box"], d["large-box"]
+    d["sensor"]["film"].update(width=24, height=24, temporal_bins=32, start_opl=3.5, bin_width_opl=6.0 / 32)
+    d["sensor"]["film"].update(film)
+    d["ball"] = {"type": "obj", "filename": path, "face_normals": face_normals,
+                 "to_world": mi.ScalarTransform4f().rotate([0, 0, 1], 20.0).scale([1.0, 1.3, 1.0]),
+                 "bsdf": bsdf or {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.7, 0.7, 0.7]}}}
+    return mi.load_dict(d)
+
+
+def test_obj_normals_and_recomputed_vertex_normals(tmp_path):
+    from mitransient_amd.scene import load_obj
+    p = str(tmp_path / "s.obj")
+    n = write_sphere_obj(p, 8, 12)
+    tris, uv, normals = load_obj(p, with_uv=True, with_normals=True)
+    assert tris.shape == (n, 3, 3) and normals.shape == (n, 3, 3) and uv is None
+    c = np.array([0.0, -0.3, 0.0])
+    assert np.allclose(normals, (tris - c) / 0.3, atol=1e-6)                     # vn = the analytic normal
+    # without vn: angle-weighted vertex normals [Mesh::recompute_vertex_normals] — on a sphere, close to the analytic ones
+    write_sphere_obj(p, 8, 12, with_vn=False)
+    tris2, _, normals2 = load_obj(p, with_uv=True, with_normals=True)
+    assert np.allclose(np.linalg.norm(normals2, axis=2), 1.0, atol=1e-12)
+    ring = np.abs(tris2[..., 1] - c[1]) < 0.29          # (the poles are n_lon separate vertices in this mesh: each sees two faces only)
+    assert np.abs(normals2 - (tris2 - c) / 0.3)[ring].max() < 0.12
+    shared = {}
+    for t, nn, r in zip(tris2.reshape(-1, 3), normals2.reshape(-1, 3), ring.reshape(-1)):
+        if r:
+            shared.setdefault(tuple(np.round(t, 9)), []).append(nn)
+    assert all(np.allclose(v, v[0]) for v in shared.values())                    # one normal per vertex: smooth across faces
+    # plain call keeps its old return type
+    assert load_obj(p).shape == (n, 3, 3)
+
+
+def test_scene_data_flags(tmp_path):
+    sd = sphere_scene(tmp_path).data()
+    assert sd.tri_normals is not None and sd.tri_normals.shape == (sd.tri_verts.shape[0], 9)
+    smooth = np.any(sd.tri_normals != 0, axis=1)
+    assert smooth.sum() == 100 and (~smooth).sum() == sd.tri_verts.shape[0] - 100       # rectangles stay flat
+    nn = sd.tri_normals[smooth].reshape(-1, 3)
+    assert np.allclose(np.linalg.norm(nn, axis=1), 1.0, atol=1e-6)               # inverse-transpose transform + renormalisation
+    # non-uniform scale: the normal is NOT the scaled position direction, it stays perpendicular to the surface
+    v = sd.tri_verts[smooth].reshape(-1, 3, 3)
+    fn = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    assert (np.sum(sd.tri_normals[smooth].reshape(-1, 3, 3).mean(1) * fn, axis=1) > 0.9).all()
+    assert sphere_scene(tmp_path, face_normals=True).data().tri_normals is None
+
+
+@pytest.mark.parametrize("bsdf", ["diffuse", "roughconductor", "dielectric"])
+@pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-8"])
+def test_host_harness_smooth_sphere_bit_for_bit(oracle, host_harness, tmp_path, bsdf, wide):
+    b = {"diffuse": None,
+         "roughconductor": {"type": "roughconductor", "distribution": "ggx", "alpha": 0.2, "eta": 0.2, "k": 3.9},
+         "dielectric": {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}}[bsdf]
+    scene = sphere_scene(tmp_path, bsdf=b)
+    sd = scene.data()
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 1, 24)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    host_harness.hh_set_node_pairs(wide); host_harness.hh_set_wide(wide)
+    try:
+        ht, hs, hc = hh_render(host_harness, sd, p)
+    finally:
+        host_harness.hh_set_node_pairs(0); host_harness.hh_set_wide(0)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert hc[k] == cnt[k]
+    assert np.count_nonzero(t4) > 2000 and np.isfinite(t4).all()
+
+
+def test_smooth_shading_approaches_the_finely_tessellated_surface(oracle, tmp_path):
+    """direct light on a coarse sphere: with interpolated normals the image is closer to that of a finely tessellated
+    (flat-shaded) sphere than the coarse flat-shaded one is — inside the silhouette, which interpolation cannot change"""
+    imgs = {}
+    for name, kw in (("coarse-flat", dict(face_normals=True)), ("coarse-smooth", dict()),
+                     ("fine-flat", dict(face_normals=True, n_lat=48, n_lon=96))):
+        scene = sphere_scene(tmp_path, width=40, height=40, temporal_bins=4, start_opl=0.0, bin_width_opl=8.0, **kw)
+        scene.integrator().max_depth = 2
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 96)
+        t4, s4, _ = oracle.render(scene.data(), p)
+        imgs[name] = s4[..., :3].mean(-1) / s4[..., 3]
+    # pixels whose whole footprint lies on the ball (camera rays through the four corners and the centre hit it) — on the
+    # coarse AND on the fine mesh: interpolation cannot change the silhouette
+    core = np.ones((40, 40), bool)
+    for kw in (dict(), dict(n_lat=48, n_lon=96)):
+        sd = sphere_scene(tmp_path, width=40, height=40, **kw).data()
+        first_ball = int(np.flatnonzero(np.any(sd.tri_normals != 0, axis=1))[0]) if sd.tri_normals is not None else 12
+        for j1, j2 in ((0.02, 0.02), (0.98, 0.02), (0.02, 0.98), (0.98, 0.98), (0.5, 0.5)):
+            o = np.zeros((1600, 3), np.float32); dd = np.zeros((1600, 3), np.float32)
+            for py in range(40):
+                for px in range(40):
+                    o[py * 40 + px], dd[py * 40 + px], _ = oracle.camera_ray(sd, px, py, j1, j2)
+            t, prim, _ = oracle.intersect(sd, o, dd)
+            core &= (prim >= first_ball).reshape(40, 40)
+    assert core.sum() > 30
+    e_flat = np.abs(imgs["coarse-flat"] - imgs["fine-flat"])[core].mean()
+    e_smooth = np.abs(imgs["coarse-smooth"] - imgs["fine-flat"])[core].mean()
+    assert imgs["fine-flat"][core].mean() > 0.02
+    assert e_smooth < 0.7 * e_flat, (e_smooth, e_flat)
+
+
+def test_energy_identity_with_smooth_normals(oracle, tmp_path):
+    scene = sphere_scene(tmp_path, temporal_bins=128, start_opl=0.0, bin_width_opl=1.0)
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 16)
+    t4, s4, cnt = oracle.render(scene.data(), p)
+    steady = s4[..., :3] / np.maximum(s4[..., 3:4], 1)
+    assert np.allclose(t4[..., :3].sum(2), steady, rtol=2e-4, atol=1e-6)
