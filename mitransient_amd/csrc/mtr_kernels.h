@@ -28,6 +28,23 @@ struct SceneDev {
                                      // is a GGX lobe (MTR_BSDF_ROUGH*), or a triangle is smooth-shaded (vnormals)
 };
 
+// streaming accesses (data touched once): non-temporal 16-byte load / store
+__device__ __forceinline__ uint4 nt_load(const uint4 *p)
+{
+    const uint32_t *w = (const uint32_t *)p;
+    return make_uint4(__builtin_nontemporal_load(w), __builtin_nontemporal_load(w + 1), __builtin_nontemporal_load(w + 2), __builtin_nontemporal_load(w + 3));
+}
+__device__ __forceinline__ float4 nt_load(const float4 *p)
+{
+    const float *w = (const float *)p;
+    return make_float4(__builtin_nontemporal_load(w), __builtin_nontemporal_load(w + 1), __builtin_nontemporal_load(w + 2), __builtin_nontemporal_load(w + 3));
+}
+__device__ __forceinline__ void nt_store(float4 *p, float4 v)
+{
+    float *w = (float *)p;
+    __builtin_nontemporal_store(v.x, w); __builtin_nontemporal_store(v.y, w + 1); __builtin_nontemporal_store(v.z, w + 2); __builtin_nontemporal_store(v.w, w + 3);
+}
+
 struct SplatLog { uint32_t *rec; unsigned long long cap; unsigned long long *count; };
 
 struct FusedArgs {

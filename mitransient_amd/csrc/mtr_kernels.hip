@@ -685,13 +685,15 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
         const uint64_t lo = starts[px], hi = starts[px + 1];
         if (lo == hi) continue;                                      // (uniform across the workgroup)
         for (uint64_t i = lo + tid; i < hi; i += kBlock) {
-            const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
+            // (contributions and film rows are touched once: non-temporal accesses, as in k_wf_scatter)
+            const int32_t bin = film_row_bin(film, __builtin_nontemporal_load(s.opl + i), s.laser ? s.laser[i] : 0u);
             if (bin < 0) continue;
+            const float vr = __builtin_nontemporal_load(s.r + i), vg = __builtin_nontemporal_load(s.g + i), vb = __builtin_nontemporal_load(s.b + i);
             if (FIXED) {
                 unsigned long long *p = row64 + bin;
-                atomicAdd(p, splat_to_fixed(s.r[i])); atomicAdd(p + T, splat_to_fixed(s.g[i])); atomicAdd(p + 2 * T, splat_to_fixed(s.b[i]));
+                atomicAdd(p, splat_to_fixed(vr)); atomicAdd(p + T, splat_to_fixed(vg)); atomicAdd(p + 2 * T, splat_to_fixed(vb));
             } else {
-                lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
+                lds_add(row + bin, vr); lds_add(row + T + bin, vg); lds_add(row + 2 * T + bin, vb);
             }
             ++mine;
         }
@@ -710,7 +712,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
                 nz = r != 0.0f || g != 0.0f || b != 0.0f;
                 if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
             }
-            if (nz) { float4 v = dst[t]; v.x += r; v.y += g; v.z += b; dst[t] = v; }
+            if (nz) { float4 v = nt_load(dst + t); v.x += r; v.y += g; v.z += b; nt_store(dst + t, v); }
         }
         __syncthreads();
     }

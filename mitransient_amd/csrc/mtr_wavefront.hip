@@ -709,24 +709,34 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
         else for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
     }
     __syncthreads();
+    // The record stream of the NEXT pixel is requested before the current row is flushed.  Records and film rows are
+    // touched exactly once: NON-TEMPORAL loads and stores keep them from displacing each other in L2 (config 2, 1.33 GB per
+    // launch: 0.336 -> 0.281 ms = 50 -> 59 % of the HBM roof; the prefetch and a grid of one resident round of workgroups
+    // alone changed nothing; without the LDS adds 0.314, without the film flush 0.239 ms)
+    constexpr int kBatch = 8;                 // independent 16-byte loads in flight per lane (coalesced)
+    uint4 r[kBatch];
+    uint32_t n_next_all = blockIdx.x < a.P ? a.rec_count[blockIdx.x] : 0u;
+    auto fetch = [&](uint32_t pl_, uint32_t n_, uint32_t base) {
+        const uint4 *rec_ = a.rec + (size_t)pl_ * a.rec_cap;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * kBlock + tid;
+            r[k] = (i < n_) ? nt_load(rec_ + i) : make_uint4(0xffffffffu, 0u, 0u, 0u);
+        }
+    };
+    if (blockIdx.x < a.P) fetch(blockIdx.x, rows ? min(n_next_all, a.rec_cap) : 0u, 0u);
     for (uint32_t pl = blockIdx.x; pl < a.P; pl += gridDim.x) {
         const uint32_t pixel = a.pix0 + pl;
         const uint32_t cy = pixel / a.film.crop_w, cx = pixel - cy * a.film.crop_w;    // film coords (crop offset removed)
         const bool in_film = (cx < a.film.width) & (cy < a.film.height);
         const size_t fpix = (size_t)cy * a.film.width + cx;
-        const uint32_t n_all = a.rec_count[pl];
+        const uint32_t n_all = n_next_all;
         const uint32_t n = rows ? min(n_all, a.rec_cap) : 0u;
         const bool store_only = a.film_zero && n_all <= a.rec_cap;      // no overflow atomics landed on this row
-        const uint4 *rec = a.rec + (size_t)pl * a.rec_cap;
-        // stream the records: 8 independent 16-byte loads in flight per lane (coalesced), then the LDS adds
-        constexpr int kBatch = 8;
-        for (uint32_t base = 0; base < n; base += kBatch * kBlock) {
-            uint4 r[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const uint32_t i = base + k * kBlock + tid;
-                r[k] = (i < n) ? rec[i] : make_uint4(0xffffffffu, 0u, 0u, 0u);
-            }
+        const uint32_t pl_next = pl + gridDim.x;
+        if (pl_next < a.P) n_next_all = a.rec_count[pl_next];
+        for (uint32_t base = 0; base < n || base == 0u; base += kBatch * kBlock) {
+            if (base != 0u) fetch(pl, n, base);
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 if (r[k].x != 0xffffffffu) {
@@ -744,27 +754,28 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
                 }
             }
         }
+        if (pl_next < a.P) fetch(pl_next, rows ? min(n_next_all, a.rec_cap) : 0u, 0u);      // in flight across the flush below
         __syncthreads();
         if (rows) {
             float4 *dst = (float4 *)(a.film_out + fpix * T * 4u);
             for (uint32_t t = tid; t < T; t += kBlock) {
-                float r, g, b;
+                float r_, g, b;
                 bool nz;
                 if (FIXED) {
                     const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
                     nz = (qr | qg | qb) != 0ull;
-                    r = from_fixed(qr); g = from_fixed(qg); b = from_fixed(qb);
+                    r_ = from_fixed(qr); g = from_fixed(qg); b = from_fixed(qb);
                     if (nz) { row64[t] = 0ull; row64[T + t] = 0ull; row64[2 * T + t] = 0ull; }
                 } else {
-                    r = row[t]; g = row[T + t]; b = row[2 * T + t];
-                    nz = r != 0.0f || g != 0.0f || b != 0.0f;
+                    r_ = row[t]; g = row[T + t]; b = row[2 * T + t];
+                    nz = r_ != 0.0f || g != 0.0f || b != 0.0f;
                     if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
                 }
                 if ((nz || store_only) && in_film) {          // store_only: whole lines, zeros included (the row is contiguous)
                     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (!store_only) v = dst[t];                  // accumulate onto earlier passes / overflow atomics
-                    v.x += r; v.y += g; v.z += b;
-                    dst[t] = v;
+                    v.x += r_; v.y += g; v.z += b;
+                    nt_store(dst + t, v);
                 }
             }
         }
@@ -869,6 +880,15 @@ hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, 
         void (*k)(const WfArgs) = fixed ? k_wf_scatter<true> : k_wf_scatter<false>;
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        // one RESIDENT round of workgroups: with 24 KB rows six fit a CU; eight per CU would leave a second, third-full round
+        // of workgroups behind the first
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0) {
+            int per_cu = (int)((160u * 1024u) / lds);
+            if (per_cu > 8) per_cu = 8;
+            if (per_cu < 1) per_cu = 1;
+            if (grid > n_cu * per_cu) grid = n_cu * per_cu;
+        }
         hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
         return hipGetLastError();
     }
