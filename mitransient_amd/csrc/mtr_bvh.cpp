@@ -516,6 +516,19 @@ uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
     uint32_t levels = 0;
     std::vector<WNodeT<4>> full;
     wide_rec<4>(bvh, nullptr, nullptr, 0, full, 1, levels, 4);
+    {   // breadth-first order: the top of the tree — the nodes every ray visits — sits at the lowest indices
+        std::vector<uint32_t> order{ 0u }, pos(full.size(), 0u);
+        for (size_t i = 0; i < order.size(); ++i)
+            for (uint32_t c = 0; c < full[order[i]].count; ++c)
+                if (full[order[i]].ref[c] >= 0) order.push_back((uint32_t)full[order[i]].ref[c]);
+        for (size_t i = 0; i < order.size(); ++i) pos[order[i]] = (uint32_t)i;
+        std::vector<WNodeT<4>> bfs(full.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            bfs[i] = full[order[i]];
+            for (uint32_t c = 0; c < bfs[i].count; ++c) if (bfs[i].ref[c] >= 0) bfs[i].ref[c] = (int32_t)pos[bfs[i].ref[c]];
+        }
+        full.swap(bfs);
+    }
     wide.resize(full.size());
     for (size_t i = 0; i < full.size(); ++i) {
         const WNodeT<4> &w = full[i];
