@@ -543,6 +543,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     int per_cu = (int)(kLdsMax / cfg.lds_bytes);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
+    if (cfg.rough && per_cu > 3) per_cu = 3;          // the extended-shading kernels hold 168 registers: three workgroups per CU are resident
     if (const char *e = getenv("MTR_FUSED_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }     // experiments
     cfg.per_cu = per_cu;
     long grid = (long)n_cu * per_cu;
