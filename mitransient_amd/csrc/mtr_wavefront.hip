@@ -115,23 +115,30 @@ __device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned ch
 //   Q_PREV (prev_p.xyz, depth | prev_delta << 31)   Q_RNG (state lo, hi, inc lo, hi)   Q_HIT (t, u, v, prim)
 enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_RNG, Q_HIT, PL_COUNT };
 
-struct Planes {
+// NT: scenes walked in HBM.  Their path state, rays and hits stream through every kernel of a bounce exactly once —
+// NON-TEMPORAL accesses keep them from pushing the scene (BVH nodes, triangles) out of L2: staircase, 720 x 1280 x 64 spp,
+// 244 ms per render on every run; with ordinary accesses 249 ms on some boxes / runs and 285 - 290 ms on others (same
+// binary).  (The same hint on the ray and shadow-ray lists changes nothing.)  With the scene in LDS the state is what L2
+// should hold between the kernels of a bounce: ordinary accesses (config 2, wavefront organisation: 155 ms per render,
+// 180 - 185 ms with the hint).
+template <bool NT>
+struct PlanesT {
     float4 *base; uint32_t n;
-    __device__ __forceinline__ float4 &q(int pl, uint32_t slot) const { return base[(size_t)pl * n + slot]; }
-    // Path state, rays and hits stream through every kernel of a bounce exactly once: NON-TEMPORAL accesses, so that they
-    // do not push the scene (BVH nodes, triangles) out of L2.  Staircase, 720 x 1280 x 64 spp: 244 ms per render on every
-    // run; with ordinary accesses 249 ms on some boxes / runs and 285 - 290 ms on others (same binary).  The same hint on the
-    // ray and shadow-ray lists changes nothing.
-    __device__ __forceinline__ float4 ld(int pl, uint32_t slot) const { return nt_load(base + (size_t)pl * n + slot); }
-    __device__ __forceinline__ void st(int pl, uint32_t slot, float4 v) const { nt_store(base + (size_t)pl * n + slot, v); }
+    __device__ __forceinline__ float4 ld(int pl, uint32_t slot) const { return NT ? nt_load(base + (size_t)pl * n + slot) : base[(size_t)pl * n + slot]; }
+    __device__ __forceinline__ void st(int pl, uint32_t slot, float4 v) const
+    {
+        if (NT) nt_store(base + (size_t)pl * n + slot, v); else base[(size_t)pl * n + slot] = v;
+    }
 };
 
+template <class Planes>
 __device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s, float &eta)
 {
     const float4 a = P.ld(Q_RAY0, s), b = P.ld(Q_RAY1, s);
     Ray r; r.o = mk(a.x, a.y, a.z); r.tmax = a.w; r.d = mk(b.x, b.y, b.z); eta = b.w;
     return r;
 }
+template <class Planes>
 __device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_inc)
 {
     P.st(Q_RAY0, s, make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax));
@@ -143,6 +150,7 @@ __device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const P
     P.st(Q_RNG, s, make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)),
                                 __uint_as_float((uint32_t)p.rng.inc), __uint_as_float((uint32_t)(p.rng.inc >> 32))));
 }
+template <class Planes>
 __device__ __forceinline__ void load_state(const Planes &P, uint32_t s, Path &p)
 {
     p.ray = load_ray(P, s, p.eta);
@@ -252,7 +260,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
     const int tid = threadIdx.x;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
-    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     uint32_t n_closest = 0;
     for (uint32_t slot = blockIdx.x * kBlock + tid; slot < a.n_slots; slot += gridDim.x * kBlock) {
         uint32_t pixel, s, pl;
@@ -307,7 +315,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint8_t *s_key = (uint8_t *)(smem + off);                   // [seg] hit material type per list position
-    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
 #ifdef MTR_PROFILE_SIMT
     unsigned long long prof[4] = { 0, 0, 0, 0 };      // node iterations, lanes in them, leaf iterations, lanes in them
@@ -406,7 +414,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
 // shadow list for k_wf_trace (occlusion), and k_wf_shade re-runs shade_hit for real with the answer in `occ`.
 // (Shadow rays traced inside k_wf_shade, one traverse<true>() per lane, were 83 % of that kernel on the staircase —
 // 169 of 204 ms — for the same reason as closest hits: lanes waiting for the slowest ray of their wave.)
-template <int STACK, bool SCENE_LDS>
+template <int STACK, bool SCENE_LDS, bool EXT>
 __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -414,7 +422,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
     const int tid = threadIdx.x;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
-    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     wf_ticket_begin(a, tid);
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         if (tid == 0) *s_tail = 0u;
@@ -441,7 +449,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
                 { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                 NullSink sink;
                 Pending pd;
-                shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                shade_hit<EXT>(p, h, sv, a.film, a.rc, sink, pd, shadow);
                 want = pd.has_shadow != 0u;
             }
             if (__ballot(want) != 0ull) {
@@ -463,7 +471,9 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
 // waves per SIMD the register allocator leaves room for: a scene in HBM/L2 needs the occupancy to hide its latency
 // (4: 425 ms vs 3: 452 ms on the staircase); with the scene in LDS the 168 registers of 3 waves avoid 29 spilled
 // dwords (187 ms vs 215 ms per config-2 render)
-template <int STACK, bool SCENE_LDS>
+// EXT: the extended shading code (GGX lobes, interpolated normals) — only scenes that need it pay for it
+// (config 2, wavefront organisation: k_wf_shade 1.44 ms per launch without, 1.82 ms with)
+template <int STACK, bool SCENE_LDS, bool EXT>
 __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -473,7 +483,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
     float *s_steady = (float *)(smem + off + al16(a.G * 4u));   // [G][4] radiance sums of the paths that end here
-    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
     wf_ticket_begin(a, tid);
@@ -514,7 +524,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                     sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
                     Pending pd; Ray shadow;
                     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
-                    shade_hit(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                    shade_hit<EXT>(p, h, sv, a.film, a.rc, sink, pd, shadow);
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
@@ -523,7 +533,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
                             occluded = sh.prim >= 0;
                         } else occluded = a.occ[slot] != 0;   // traced by k_wf_trace from the list k_wf_shadow_gen wrote (staircase: 360 vs 300 ms)
                     }
-                    alive = shade_finish(p, h, occluded, pd, sv, a.film, a.rc, sink);
+                    alive = shade_finish<EXT>(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     store_state(P, slot, p, false);
@@ -598,7 +608,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);
     float *s_steady = (float *)(smem + off + al16(a.G * 4u));
-    const Planes P{ (float4 *)a.planes, a.n_slots };
+    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
     wf_ticket_begin(a, tid);
@@ -847,8 +857,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_phasor_scatter(const WfArgs a)
 template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
+    const bool ext = a.sc.has_rough != 0u;
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
-                            : which == 4 ? k_wf_shadow_gen<STACK, SL> : which == 5 ? k_wf_nlos_bounce<STACK, SL> : k_wf_shade<STACK, SL>;
+                            : which == 4 ? (ext ? k_wf_shadow_gen<STACK, SL, true> : k_wf_shadow_gen<STACK, SL, false>)
+                            : which == 5 ? k_wf_nlos_bounce<STACK, SL>
+                            : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
