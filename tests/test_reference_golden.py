@@ -21,6 +21,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 GOLD = os.path.join(ROOT, "tests", "golden", "mitsuba_c1.npz")
 needs_gold = pytest.mark.skipif(not os.path.exists(GOLD), reason="no reference render available (parity unpinned)")
+GOLD_ROUGH = os.path.join(ROOT, "tests", "golden", "mitsuba_rough.npz")      # the GGX lobes (restated from memory of mitsuba 3)
+needs_gold_rough = pytest.mark.skipif(not os.path.exists(GOLD_ROUGH), reason="no reference render of the rough scene available")
+
+
+def make_rough_cornell():
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from gen_golden_with_mitsuba import rough_cornell
+    mi.set_variant("llvm_ad_rgb")
+    return mi.load_dict(rough_cornell(mitr.cornell_box()))
 
 K_SIGMA = 5.0
 SEEDINGS = {"tea": False, "tea+lane": True}
@@ -106,6 +116,32 @@ def test_oracle_against_reference_render(oracle):
     g = np.load(GOLD)
     v = classify(g, _oracle_render(oracle, make_cornell()))
     print("oracle vs", list(g["versions"]), "->", v)
+    assert v["exact_seeding"] is not None or v["statistical"], v
+
+
+def test_rough_pin_scene_loads_and_self_classifies(oracle):
+    """the second pinned scene (tools/gen_golden_with_mitsuba.py: rough_cornell) is a dictionary both sides accept, and
+    the procedure recognises its own render"""
+    from gen_golden_with_mitsuba import pack_render
+    scene = make_rough_cornell()
+    sd = scene.data()
+    kinds = sorted(sd.materials[i].type for i in range(sd.n_materials))
+    assert kinds.count(4) == 2 and kinds.count(5) == 2
+    render = _oracle_render(oracle, scene)
+    g = {}
+    for prefix, spp, seed in (("lo", 16, 0), ("hi", 128, 1)):
+        s3, t3 = render(spp, seed, False, None)
+        g.update(pack_render(prefix, s3, t3))
+        g[f"{prefix}_spp_seed"] = np.asarray([spp, seed])
+    v = classify(g, render)
+    assert v["exact_seeding"] == "tea" and v["statistical"], v
+
+
+@needs_gold_rough
+def test_oracle_rough_lobes_against_reference_render(oracle):
+    g = np.load(GOLD_ROUGH)
+    v = classify(g, _oracle_render(oracle, make_rough_cornell()))
+    print("oracle (GGX lobes) vs", list(g["versions"]), "->", v)
     assert v["exact_seeding"] is not None or v["statistical"], v
 
 
