@@ -40,7 +40,7 @@ def build_scene(width, height, bins, max_depth=8, mode=None):
         from mitransient_amd.scenes import staircase
         kw = {"amd_mode": mode} if mode else {}
         sc = staircase(width=width, height=height, temporal_bins=bins, max_depth=65, materials=MATERIALS,
-                       vertex_normals=(MATERIALS == "rough"), **kw)
+                       vertex_normals=(MATERIALS == "rough"), textures=(MATERIALS == "rough"), **kw)
         film = sc.sensors()[0].film()
         film.start_opl, film.bin_width_opl = 0.0, 40.0 / bins     # the reference's 0..40 window (400 x 0.1), SURVEY §8d
         return sc
@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--materials", default="smooth", choices=["smooth", "rough"],
                     help="staircase only: 'smooth' = roughplastic -> diffuse, roughconductor -> conductor (the SURVEY section-8d "
-                         "workload); 'rough' = the scene file's GGX lobes (roughplastic, roughconductor) and its vertex normals kept")
+                         "workload); 'rough' = the scene as its file describes it: GGX lobes (roughplastic, roughconductor), vertex normals, bitmap textures")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase"],
                     help="staircase: BASELINE configs[4] (512x512, 2048 bins over OPL 0..40, 2048 spp, max_depth 65; "
                          "the reference's scene.xml geometry with approximate materials)")
@@ -286,7 +286,7 @@ def main():
             "config": {"workload": (f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
                                     f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0") if SCENE == "cornell" else
-                                   (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes and vertex normals kept, textures -> mean colour") + f"), "
+                                   (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes, vertex normals and (256-px) bitmap textures as in the scene file") + f"), "
                                     f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
                        "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",

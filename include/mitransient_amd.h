@@ -66,13 +66,20 @@ typedef struct mtr_material {
     float    alpha;       /* GGX roughness (alpha_u = alpha_v)                   */
     float    internal_reflectance;   /* roughplastic: mean rough reflectance of the coat seen from inside          */
     float    specular_sampling_weight; /* roughplastic: s_mean / (d_mean + s_mean)                                 */
-    float    reserved;
+    uint32_t albedo_texture;  /* 1 + index into mtr_scene_desc.textures of a bitmap that replaces `a` (diffuse reflectance,
+                                 roughplastic diffuse_reflectance) at the hit's texture coordinate; 0 = the constant `a` */
     /* roughplastic: transmittance of the rough coat for cos(theta) = max(1e-6, k / 63), k = 0 .. 63 — mitsuba computes
      * this table when the plugin is built (RoughPlastic::parameters_changed: eval_transmittance by Gauss-Legendre
      * quadrature over visible normals); the caller does the same (mitransient_amd/scene.py: rough_plastic_tables) and the
      * library only interpolates it */
     float    external_transmittance[MTR_ROUGH_TRANSMITTANCE_RES];
 } mtr_material;
+
+/* `bitmap` texture (mitsuba: filter_type = bilinear, wrap_mode = repeat, to_uv = identity): linear RGB */
+typedef struct mtr_texture {
+    uint32_t width, height;
+    const float *rgb;      /* host, height * width * 3 floats, row 0 first (v = 0), already linear (sRGB decoded by the caller) */
+} mtr_texture;
 
 /* ---- emitters: `area` emitter attached to a `rectangle` (analytic sampling) or to a triangle mesh ---- */
 typedef struct mtr_emitter {
@@ -188,6 +195,11 @@ typedef struct mtr_scene_desc {
      * b2 n2), the tangent from dp_du by initialize_sh_frame; the geometric normal keeps the ray offsets and the emitter
      * densities. */
     const float    *tri_normals;
+    /* Bitmap textures referenced by mtr_material.albedo_texture (host; optional).  The lookup uses tri_uv exactly as given:
+     * uv = fmadd(uv2, b2, fmadd(uv1, b1, uv0 b0)) (a rectangle: (prim_uv + 1) / 2); mitsuba's OBJ loader flips v
+     * (flip_tex_coords), the caller passes the flipped coordinates. */
+    uint32_t        n_textures;
+    const mtr_texture *textures;
 } mtr_scene_desc;
 
 /* ---- integrator: `transient_path` properties (common.py:22-30) ---------- */

@@ -34,7 +34,11 @@ class mtr_material(C.Structure):
                 ("a", _f3), ("b", _f3), ("c", _f3),
                 ("int_ior", C.c_float), ("ext_ior", C.c_float), ("c2", _f3),
                 ("alpha", C.c_float), ("internal_reflectance", C.c_float), ("specular_sampling_weight", C.c_float),
-                ("reserved", C.c_float), ("external_transmittance", C.c_float * MTR_ROUGH_TRANSMITTANCE_RES)]
+                ("albedo_texture", C.c_uint32), ("external_transmittance", C.c_float * MTR_ROUGH_TRANSMITTANCE_RES)]
+
+
+class mtr_texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float))]
 
 
 class mtr_emitter(C.Structure):
@@ -92,7 +96,9 @@ class mtr_scene_desc(C.Structure):
                 ("n_shapes", C.c_uint32),
                 ("shapes", C.POINTER(mtr_shape)),
                 ("tri_uv", C.POINTER(C.c_float)),
-                ("tri_normals", C.POINTER(C.c_float))]
+                ("tri_normals", C.POINTER(C.c_float)),
+                ("n_textures", C.c_uint32),
+                ("textures", C.POINTER(mtr_texture))]
 
 
 class mtr_render_params(C.Structure):

@@ -186,19 +186,20 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
     UP(hs.nodes, nodes); UP(hs.tpairs, tpairs); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
-    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr; s->dev.vnormals = nullptr;
+    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr; s->dev.vnormals = nullptr; s->dev.texels = s->dev.tex_info = s->dev.uvs = nullptr;
     s->dev.wnodes = nullptr; s->dev.n_wnodes = (uint32_t)hs.wnodes.size();
     if (hs.has_wide) UP(hs.wnodes, wnodes);
     s->dev.wnodes4 = nullptr; s->dev.n_wnodes4 = (uint32_t)hs.wnodes4.size();
     UP(hs.wnodes4, wnodes4);
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
     if (!hs.vnormals.empty()) UP(hs.vnormals, vnormals);
+    if (!hs.texels.empty()) { UP(hs.texels, texels); UP(hs.tex_info, tex_info); UP(hs.uvs, uvs); }
 #undef UP
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.has_rough = 0u;
     for (uint32_t i = 0; i < d->n_materials; ++i) if (bsdf_is_rough(d->materials[i].type)) s->dev.has_rough = 1u;
-    if (!hs.vnormals.empty()) s->dev.has_rough = 1u;            // smooth-shaded triangles: the extended shading code as well
+    if (!hs.vnormals.empty() || !hs.texels.empty()) s->dev.has_rough = 1u;      // smooth-shaded triangles, bitmap textures: the extended shading code as well
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);

@@ -299,6 +299,9 @@ struct SceneView {
     const q4 *samp_tris;
     const float *face_pmf, *face_cdf;
     const q4 *vnormals;       // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
+    // bitmap textures (HBM; null without textures): all texels as RGBA f32, per texture (first texel, width, height, -),
+    // and the corner texture coordinates by slot: (u0, v0, u1, v1) (u2, v2, -, -)
+    const q4 *texels; const q4 *tex_info; const q4 *uvs;
 };
 
 // [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
@@ -1010,7 +1013,7 @@ MTR_HD float rough_transmittance(const mtr_material &m, float cos_theta)
 MTR_HD bool bsdf_is_rough(uint32_t type) { return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC; }
 // value (cosine included) and density of a rough lobe for local directions; wi, wo already on the two-sided side
 // [RoughConductor::eval / ::pdf, RoughPlastic::eval / ::pdf]
-MTR_HD void rough_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &val, float &pdf)
+MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &val, float &pdf)
 {
     val = mk(0, 0, 0); pdf = 0.0f;
     const float ci = wi.z, co = wo.z;
@@ -1040,7 +1043,7 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &val, float &
     const float spec = ((F * D) * G) / (4.0f * ci);
     const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
     const float dscale = (((kInvPi * inv_eta_2) * co) * t_i) * t_o;
-    const float a[3] = { m.a[0], m.a[1], m.a[2] };
+    const float a[3] = { albedo.x, albedo.y, albedo.z };
     float o[3];
     for (int k = 0; k < 3; ++k) {
         const float diff = a[k] / (1.0f - ((m.flags & MTR_MAT_NONLINEAR) ? a[k] * m.internal_reflectance : m.internal_reflectance));
@@ -1051,7 +1054,7 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &val, float &
 
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
 // [RoughConductor::sample, RoughPlastic::sample]; wi on the two-sided side
-MTR_HD void rough_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
+MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
 {
     const float ci = wi.z;
     if (!(ci > 0.0f)) return;
@@ -1080,13 +1083,13 @@ MTR_HD void rough_sample(const mtr_material &m, f3 wi, float u1, float ua, float
     } else wo = cosine_hemisphere(ua, ub);
     bs.wo = wo;
     f3 val; float pdf;
-    rough_eval_pdf(m, wi, wo, val, pdf);
+    rough_eval_pdf(m, albedo, wi, wo, val, pdf);
     bs.pdf = pdf;
     if (pdf > 0.0f) { const float ip = 1.0f / pdf; bs.w = mk(val.x * ip, val.y * ip, val.z * ip); }
 }
 
 template <bool ROUGH = true>
-MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub)
+MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)
 {
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
@@ -1096,7 +1099,7 @@ MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, 
     if (m.type == MTR_BSDF_DIFFUSE) {
         bs.wo = cosine_hemisphere(ua, ub);
         bs.pdf = kInvPi * bs.wo.z;
-        if (ci > 0.0f && bs.pdf > 0.0f) bs.w = mk(m.a[0], m.a[1], m.a[2]);
+        if (ci > 0.0f && bs.pdf > 0.0f) bs.w = ROUGH ? albedo : mk(m.a[0], m.a[1], m.a[2]);
     } else if (m.type == MTR_BSDF_CONDUCTOR) {
         bs.wo = mk(-wi.x, -wi.y, wi.z); bs.pdf = 1.0f; bs.delta = true;
         if (ci > 0.0f)
@@ -1115,7 +1118,7 @@ MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, 
             float f2 = eti * eti;
             bs.w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
         }
-    } else if (ROUGH && bsdf_is_rough(m.type)) rough_sample(m, wi, u1, ua, ub, bs);
+    } else if (ROUGH && bsdf_is_rough(m.type)) rough_sample(m, albedo, wi, u1, ua, ub, bs);
     if (flip) bs.wo.z = -bs.wo.z;
     return bs;
 }
@@ -1197,6 +1200,40 @@ MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
     const uint32_t mat_em = fbits(he.z);
     c.mat = mat_em & 0xffffu; c.em_plus1 = mat_em >> 16;
     return c;
+}
+
+// [mitsuba3: BitmapTexture::eval, filter_type = bilinear, wrap_mode = repeat] uv -> texel space (u w - 1/2, v h - 1/2),
+// the four neighbours wrapped by the positive modulo, fmadd(w0.y, fmadd(w0.x, v00, w1.x v10), w1.y fmadd(w0.x, v01, w1.x v11))
+MTR_HD f3 texture_eval(const q4 *texels, q4 info, float u, float v)
+{
+    const int32_t W = (int32_t)fbits(info.y), H = (int32_t)fbits(info.z);
+    const float fu = fmaf(u, (float)W, -0.5f), fv = fmaf(v, (float)H, -0.5f);
+    const float flu = floorf(fu), flv = floorf(fv);
+    const float w1x = fu - flu, w1y = fv - flv, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const int32_t ix = (int32_t)flu, iy = (int32_t)flv;
+    int32_t x0 = ix % W, x1 = (ix + 1) % W, y0 = iy % H, y1 = (iy + 1) % H;
+    x0 += x0 < 0 ? W : 0; x1 += x1 < 0 ? W : 0; y0 += y0 < 0 ? H : 0; y1 += y1 < 0 ? H : 0;
+    const q4 *t = texels + fbits(info.x);
+    const q4 v00 = t[(size_t)y0 * W + x0], v10 = t[(size_t)y0 * W + x1], v01 = t[(size_t)y1 * W + x0], v11 = t[(size_t)y1 * W + x1];
+    const float r0 = fmaf(w0x, v00.x, w1x * v10.x), r1 = fmaf(w0x, v01.x, w1x * v11.x);
+    const float g0 = fmaf(w0x, v00.y, w1x * v10.y), g1 = fmaf(w0x, v01.y, w1x * v11.y);
+    const float b0 = fmaf(w0x, v00.z, w1x * v10.z), b1 = fmaf(w0x, v01.z, w1x * v11.z);
+    return mk(fmaf(w0y, r0, w1y * r1), fmaf(w0y, g0, w1y * g1), fmaf(w0y, b0, w1y * b1));
+}
+// the colour `a` of a material at a hit: the constant, or its bitmap at the interpolated texture coordinate
+// [Mesh::compute_surface_interaction: si.uv = fmadd(uv2, b2, fmadd(uv1, b1, uv0 * b0)); Rectangle: (prim_uv + 1) / 2]
+template <bool EXT>
+MTR_HD f3 material_albedo(const SceneView &sc, const mtr_material &m, const Hit &h)
+{
+    if (!EXT || m.albedo_texture == 0u || !sc.texels) return mk(m.a[0], m.a[1], m.a[2]);
+    float u, v;
+    if (fbits(sc.tshade[h.prim].h[4].w) & kShadeQuadBit) { u = fmaf(h.u, 0.5f, 0.5f); v = fmaf(h.v, 0.5f, 0.5f); }
+    else {
+        const q4 a = sc.uvs[2u * (uint32_t)h.prim], b = sc.uvs[2u * (uint32_t)h.prim + 1u];
+        const float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
+        u = fmaf(b.x, b2, fmaf(a.z, b1, a.x * b0)); v = fmaf(b.y, b2, fmaf(a.w, b1, a.y * b0));
+    }
+    return texture_eval(sc.texels, sc.tex_info[m.albedo_texture - 1u], u, v);
 }
 
 // [mitsuba3: Interaction::offset_p]
@@ -1304,7 +1341,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                 pd.has_shadow = 1u;
                 if (ROUGH && bsdf_is_rough(mat.type)) {
                     f3 bval; float bpdf;
-                    rough_eval_pdf(mat, wi_e, wo, bval, bpdf);
+                    rough_eval_pdf(mat, material_albedo<ROUGH>(sc, mat, h), wi_e, wo, bval, bpdf);
                     float mis_em = mis_weight(pdf, bpdf);
                     pd.Lr = mk(((p.beta.x * mis_em) * bval.x) * emw.x, ((p.beta.y * mis_em) * bval.y) * emw.y,
                                ((p.beta.z * mis_em) * bval.z) * emw.z);
@@ -1313,9 +1350,10 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                 if (wi_e.z > 0.0f && wo.z > 0.0f) {
                     float bpdf = kInvPi * wo.z;
                     float mis_em = mis_weight(pdf, bpdf);
-                    pd.Lr = mk(((p.beta.x * mis_em) * ((mat.a[0] * kInvPi) * wo.z)) * emw.x,
-                               ((p.beta.y * mis_em) * ((mat.a[1] * kInvPi) * wo.z)) * emw.y,
-                               ((p.beta.z * mis_em) * ((mat.a[2] * kInvPi) * wo.z)) * emw.z);
+                    const f3 alb = material_albedo<ROUGH>(sc, mat, h);
+                    pd.Lr = mk(((p.beta.x * mis_em) * ((alb.x * kInvPi) * wo.z)) * emw.x,
+                               ((p.beta.y * mis_em) * ((alb.y * kInvPi) * wo.z)) * emw.y,
+                               ((p.beta.z * mis_em) * ((alb.z * kInvPi) * wo.z)) * emw.z);
                     pd.opl = p.dist + dist * p.eta;                  // :217
                 }
             }
@@ -1353,7 +1391,7 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
         const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
         sp = c.sp;
         if (active_next) {
-            bs = bsdf_sample<ROUGH>(sc.mats[c.mat], c.wi, s1, s2a, s2b);                         // :222-227
+            bs = bsdf_sample<ROUGH>(sc.mats[c.mat], c.wi, s1, s2a, s2b, material_albedo<ROUGH>(sc, sc.mats[c.mat], h));     // :222-227
             f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                          fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                          fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));

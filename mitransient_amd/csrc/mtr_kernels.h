@@ -21,6 +21,7 @@ struct SceneDev {
     const Emitter *ems; uint32_t n_ems;
     const q4 *samp_tris; const float *face_pmf, *face_cdf;   // mesh-emitter sampling tables (HBM; null without mesh emitters)
     const q4 *vnormals;              // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
+    const q4 *texels, *tex_info, *uvs;   // bitmap textures (HBM; null without): see SceneView
     uint32_t bvh_depth;
     uint32_t wide_levels, wide4_levels;   // levels of wnodes / wnodes4: a wide walk stacks at most one group per level
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS

@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     SceneView sv;
     sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
     sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf; sv.vnormals = a.sc.vnormals;
+    sv.texels = a.sc.texels; sv.tex_info = a.sc.tex_info; sv.uvs = a.sc.uvs;
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (fused_plan); the BVH2 packets stay in HBM, unused
         const uint32_t tree_bytes = a.sc.n_wnodes * (uint32_t)sizeof(WNode);
@@ -605,6 +606,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
+    sv.texels = sc.texels; sv.tex_info = sc.tex_info; sv.uvs = sc.uvs;
     const uint32_t total = nlos_target_count(nc);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         const Ray r = nlos_prepare_ray(nc, i);

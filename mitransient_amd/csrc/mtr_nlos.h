@@ -304,7 +304,7 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
     if (active_next) {
         if (do_hg) bs = nlos_hidden_geometry(c, sc.mats[c.mat], a2a, a2b, nc);
-        else bs = bsdf_sample(sc.mats[c.mat], c.wi, b1, b2a, b2b);
+        else bs = bsdf_sample<false>(sc.mats[c.mat], c.wi, b1, b2a, b2b, mk(0, 0, 0));
         const f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                            fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                            fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));

@@ -165,6 +165,23 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
     s.vnormals.clear();
+    // bitmap textures: texels to RGBA f32, texture coordinates by slot (filled in the slot loop below)
+    s.texels.clear(); s.tex_info.clear(); s.uvs.clear();
+    bool textured = false;
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+        if (d.materials[i].albedo_texture > d.n_textures) return "material references an unknown texture";
+        textured = textured || d.materials[i].albedo_texture != 0u;
+    }
+    if (textured) {
+        if (!d.textures) return "textures missing";
+        for (uint32_t t = 0; t < d.n_textures; ++t) {
+            const mtr_texture &T = d.textures[t];
+            if (!T.rgb || T.width == 0 || T.height == 0 || T.width > 16384u || T.height > 16384u) return "bad texture";
+            s.tex_info.push_back(q4{ bitsf((uint32_t)s.texels.size()), bitsf(T.width), bitsf(T.height), 0.0f });
+            for (size_t k = 0; k < (size_t)T.width * T.height; ++k) s.texels.push_back(q4{ T.rgb[3 * k], T.rgb[3 * k + 1], T.rgb[3 * k + 2], 0.0f });
+        }
+        s.uvs.assign(2 * (size_t)n_slots, q4{ 0, 0, 0, 0 });
+    }
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
         const uint32_t o = bvh.order[slot] != kPadSlot ? bvh.order[slot] : bvh.order[slot - 1];   // pad: repeat the leaf's last triangle
         s.slot_orig[slot] = o;
@@ -219,6 +236,10 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
                 for (int k = 0; k < 3; ++k) s.vnormals[3 * (size_t)slot + k] = q4{ vn[3 * k], vn[3 * k + 1], vn[3 * k + 2], 0.0f };
                 sdir = dp_du; t = mk(0, 0, 0);
             }
+        }
+        if (textured && d.tri_uv) {
+            const float *uv = d.tri_uv + 6 * (size_t)o;
+            s.uvs[2 * (size_t)slot] = q4{ uv[0], uv[1], uv[2], uv[3] }; s.uvs[2 * (size_t)slot + 1] = q4{ uv[4], uv[5], 0.0f, 0.0f };
         }
         float *g = &s.tpairs[slot >> 1].g[0].x;            // interleaved pair record: dword 2*k + half
         const float comp[9] = { p0.x, p0.y, p0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };

@@ -22,6 +22,9 @@ struct HostScene {
     std::vector<Emitter> ems;
     std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView
     std::vector<q4> vnormals;                  // [3 * n_slots] vertex normals, when a triangle is smooth-shaded (empty otherwise)
+    // bitmap textures (empty without): texels as RGBA f32 of all textures, (first texel, width, height, 0) per texture, and
+    // the corner texture coordinates by slot, two quads each
+    std::vector<q4> texels; std::vector<q4> tex_info; std::vector<q4> uvs;
     std::vector<float> face_pmf, face_cdf;
     uint32_t bvh_depth = 0, n_leaves = 0;
     uint32_t wide_levels = 0, wide4_levels = 0;        // levels of the collapsed trees (= their traversal stack bound)

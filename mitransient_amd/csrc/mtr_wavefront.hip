@@ -67,6 +67,7 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     int32_t *s_stack = (int32_t *)(smem + off); off += wf_stack_rows(sc, SCENE_LDS) * kBlock * 4u;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
+    sv.texels = sc.texels; sv.tex_info = sc.tex_info; sv.uvs = sc.uvs;
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (wf_plan), as in k_fused
         WNode *n = (WNode *)(smem + off); off += al16(sc.n_wnodes * sizeof(WNode));

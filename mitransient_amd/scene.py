@@ -74,6 +74,26 @@ def bitmap_mean_colour(path: str, raw: bool = False) -> np.ndarray:
     return a.reshape(-1, 3).mean(axis=0)
 
 
+def load_bitmap_texture(path: str, raw: bool = False, max_size: Optional[int] = None) -> np.ndarray:
+    """8-bit image -> (H, W, 3) float32 linear RGB, row 0 first [mitsuba3: BitmapTexture with raw = false decodes sRGB];
+    ``max_size``: box-downsample so that neither side exceeds it (data fixtures of large textures)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert("RGB")
+        if max_size and max(im.size) > max_size:
+            k = max_size / float(max(im.size))
+            im = im.resize((max(1, round(im.size[0] * k)), max(1, round(im.size[1] * k))), Image.BOX)
+        a = np.asarray(im, dtype=np.float64) / 255.0
+    return decode_texture_u8(np.round(a * 255.0).astype(np.uint8), raw)
+
+
+def decode_texture_u8(u8: np.ndarray, raw: bool = False) -> np.ndarray:
+    a = np.asarray(u8, dtype=np.float64) / 255.0
+    if not raw:
+        a = _srgb_to_linear(a)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 def _color3(v, what="color", approx_base=None):
     if isinstance(v, dict):
         t = v.get("type")
@@ -130,6 +150,8 @@ class _SceneBuilder:
         self.tri_em: List[np.ndarray] = []
         self.tri_uv: List[Optional[np.ndarray]] = []          # per shape: (n, 6) corner texture coordinates, or None
         self.tri_normals: List[Optional[np.ndarray]] = []     # per shape: (n, 9) world-space corner normals (smooth shading), or None = flat
+        self.textures: List[np.ndarray] = []                  # (H, W, 3) float32 linear RGB bitmaps referenced by materials
+        self.texture_cache: Dict[Any, int] = {}
         self.materials: List[_cabi.mtr_material] = []
         self.mat_cache: Dict[int, int] = {}
         self.emitters: List[_cabi.mtr_emitter] = []
@@ -155,6 +177,23 @@ class _SceneBuilder:
         self.mat_cache[key] = len(self.materials) - 1
         return self.mat_cache[key]
 
+    def _albedo(self, m, v, what, ab):
+        """the colour `a` of a material: a constant, or (approximate_materials unset or 'textures') a bitmap texture whose
+        mean stands in wherever a single colour is needed"""
+        if isinstance(v, dict) and v.get("type") == "bitmap" and self.approx in (False, None, "textures"):
+            if v.get("filter_type", "bilinear") != "bilinear" or v.get("wrap_mode", "repeat") != "repeat" or "to_uv" in v:
+                raise ValueError(f"{what}: bitmap textures are available with filter_type = bilinear, wrap_mode = repeat and no to_uv")
+            fn = v.get("filename")
+            if not os.path.isabs(fn):
+                fn = os.path.join(self.base_dir, fn)
+            key = (fn, bool(v.get("raw", False)))
+            if key not in self.texture_cache:
+                self.textures.append(load_bitmap_texture(fn, key[1]))
+                self.texture_cache[key] = len(self.textures) - 1
+            m.albedo_texture = self.texture_cache[key] + 1
+            return self.textures[m.albedo_texture - 1].reshape(-1, 3).mean(axis=0).astype(np.float64)
+        return _color3(v, what, ab)
+
     def _make_material(self, bd) -> _cabi.mtr_material:
         m = _cabi.mtr_material()
         m.int_ior, m.ext_ior = 1.0, 1.0
@@ -162,8 +201,9 @@ class _SceneBuilder:
             m.c[k] = 1.0
             m.c2[k] = 1.0
         t = bd.get("type")
-        ab = self.base_dir if self.approx else None          # bitmap -> mean colour only when approximating
+        ab = self.base_dir if self.approx and self.approx != "textures" else None      # bitmap -> mean colour only when approximating
         if self.approx:
+            # (approximate_materials="textures": bump maps ignored like True, but bitmaps on reflectances stay textures)
             # nearest material of the hot path's model (opt-in, documented in DESIGN.md): bitmap textures become their mean
             # colour, bump/normal maps are ignored, the smooth plastic coat is dropped; with approximate_materials="smooth"
             # (the config-5 bench fixture) the GGX lobes of roughconductor / roughplastic also collapse to their smooth limit
@@ -191,7 +231,7 @@ class _SceneBuilder:
             return m
         if t == "diffuse":
             m.type = _cabi.MTR_BSDF_DIFFUSE
-            refl = _color3(bd.get("reflectance", 0.5), "diffuse.reflectance", ab)
+            refl = self._albedo(m, bd.get("reflectance", 0.5), "diffuse.reflectance", ab)
             for k in range(3):
                 m.a[k] = np.float32(refl[k])
         elif t == "conductor":
@@ -237,7 +277,7 @@ class _SceneBuilder:
                 m.type = _cabi.MTR_BSDF_ROUGHPLASTIC
                 m.int_ior = np.float32(_ior(bd.get("int_ior"), "polypropylene"))
                 m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
-                diff = _color3(bd.get("diffuse_reflectance", 0.5), "roughplastic.diffuse_reflectance", ab)
+                diff = self._albedo(m, bd.get("diffuse_reflectance", 0.5), "roughplastic.diffuse_reflectance", ab)
                 for k in range(3):
                     m.a[k], m.c[k] = np.float32(diff[k]), np.float32(sr[k])
                 if bd.get("nonlinear", False):
@@ -412,7 +452,8 @@ def load_obj(path: str, with_uv: bool = False, with_normals: bool = False):
     tu = np.asarray(tuv, dtype=np.int64).reshape(-1, 3)
     uv = None
     if uvs and tu.size and tu.min() >= 0:
-        uv = np.asarray(uvs, dtype=np.float32)[tu].reshape(-1, 6)
+        uv = np.asarray(uvs, dtype=np.float32)[tu].reshape(-1, 6).copy()
+        uv[:, 1::2] = np.float32(1.0) - uv[:, 1::2]          # [mitsuba3: obj.cpp flip_tex_coords = true] (the frame is unaffected)
     if not with_normals:
         return v[t], uv
     tn = np.asarray(tvn, dtype=np.int64).reshape(-1, 3)
@@ -586,6 +627,7 @@ class SceneData:
         self.n_shapes = 0
         self.tri_uv = None               # (n_tris, 6) f32 corner texture coordinates, or None
         self.tri_normals = None          # (n_tris, 9) f32 corner shading normals (all-zero rows: flat triangle), or None
+        self.textures = []               # [(H, W, 3) f32 linear RGB] bitmaps referenced by mtr_material.albedo_texture
         self.nlos = None                 # mtr_nlos_desc for the NLOS tier
 
     def desc(self) -> _cabi.mtr_scene_desc:
@@ -604,6 +646,12 @@ class SceneData:
         d.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape)) if self.n_shapes else None
         d.tri_uv = self.tri_uv.ctypes.data_as(C.POINTER(C.c_float)) if self.tri_uv is not None else None
         d.tri_normals = self.tri_normals.ctypes.data_as(C.POINTER(C.c_float)) if self.tri_normals is not None else None
+        if self.textures:
+            self._tex_desc = (_cabi.mtr_texture * len(self.textures))()
+            for i, t in enumerate(self.textures):
+                self._tex_desc[i].height, self._tex_desc[i].width = int(t.shape[0]), int(t.shape[1])
+                self._tex_desc[i].rgb = t.ctypes.data_as(C.POINTER(C.c_float))
+            d.n_textures, d.textures = len(self.textures), C.cast(self._tex_desc, C.POINTER(_cabi.mtr_texture))
         if self.nlos is not None:
             self.nlos.n_shapes = self.n_shapes
             self.nlos.shapes = C.cast(self.shapes, C.POINTER(_cabi.mtr_shape))
@@ -719,10 +767,12 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
         b.shapes = list(geometry["shapes"])[:geometry["n_shapes"]]
         sd.tri_uv = geometry["tri_uv"]
         sd.tri_normals = geometry.get("tri_normals")
+        sd.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in geometry.get("textures", [])]
     if b.tri_verts:
         sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
         sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))
         sd.tri_emitter = np.ascontiguousarray(np.concatenate(b.tri_em))
+        sd.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in b.textures]
         if any(u is not None for u in b.tri_normals):   # flat shapes: all-zero normals
             sd.tri_normals = np.ascontiguousarray(np.concatenate(
                 [u if u is not None else np.zeros((v.shape[0], 9), np.float32) for u, v in zip(b.tri_normals, b.tri_verts)]))

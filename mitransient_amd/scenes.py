@@ -131,14 +131,17 @@ DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")     
 
 
 def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, materials="smooth", vertex_normals=False,
-              **integrator):
+              textures=False, **integrator):
     """BASELINE config 5: the reference's examples/diff-transient/staircase/scene.xml ('The Wooden Staircase' by
     Wig42, CC-BY 3.0, Mitsuba version by B. Bitterli), 262,663 triangles.  ``materials="smooth"`` (the bench workload,
     SURVEY section 8d): flattened with approximate_materials="smooth" (roughplastic -> diffuse, roughconductor -> conductor,
     bitmap -> mean colour, bump map ignored); ``materials="rough"``: the GGX lobes of the scene file kept
     (approximate_materials=True: only textures and the bump map are approximated).  ``vertex_normals=True``: the meshes'
     own shading normals (the scene file sets face_normals on 157 of its 774 shapes only; 91.5 % of the triangles are
-    smooth-shaded) instead of flat shading everywhere."""
+    smooth-shaded) instead of flat shading everywhere.  ``textures=True``: the nine bitmap textures of the scene's
+    reflectances (fixture: box-downsampled to at most 256 pixels a side, 8-bit sRGB) instead of their mean colours —
+    with materials="rough" and vertex_normals=True that is the scene as its file describes it (its one bumpmap wraps a BSDF
+    that the shapes reference directly by id: it is never instantiated, in mitsuba neither)."""
     scene = from_fixture(os.path.join(DATA_DIR, "staircase_geometry.npz"),
                          film={"width": width, "height": height, "temporal_bins": temporal_bins},
                          integrator=dict(max_depth=max_depth, **integrator), spp=spp)
@@ -155,6 +158,18 @@ def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, m
         g["materials"] = (_cabi.mtr_material * nm).from_buffer_copy(z["materials"].tobytes())
     elif materials != "smooth":
         raise ValueError("materials: 'smooth' or 'rough'")
+    if textures:
+        from .scene import decode_texture_u8
+        z = np.load(os.path.join(DATA_DIR, "staircase_textures.npz"))
+        g = scene.geometry_
+        if len(z["tex_of_mat"]) != g["n_materials"]:
+            raise ValueError("staircase_textures.npz does not belong to staircase_geometry.npz")
+        g["textures"] = [decode_texture_u8(z[f"tex{i}"]) for i in range(int(z["n"][0]))]
+        for i, t in enumerate(z["tex_of_mat"]):
+            g["materials"][i].albedo_texture = int(t)
+        uv = np.array(g["tri_uv"], dtype=np.float32, copy=True)            # the fixture keeps the OBJ files' v: flip it as mitsuba does
+        uv[:, 1::2] = np.float32(1.0) - uv[:, 1::2]
+        g["tri_uv"] = uv
     if vertex_normals:
         tn = np.load(os.path.join(DATA_DIR, "staircase_normals.npz"))["tri_normals"]
         if tn.shape != (scene.geometry_["tri_verts"].shape[0], 9):

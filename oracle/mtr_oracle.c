@@ -521,6 +521,7 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
 /* ------------------------------------------------------------------ */
 typedef struct {
     int valid; float t; v3 p, n, s, tt, wi; int prim;       /* n, s, tt: the shading frame (si.sh_frame) */
+    float uv[2];                                               /* si.uv */
     v3 ng;                                                     /* si.n: the geometric normal (ray offsets, emitter densities) */
 } sinter;
 
@@ -541,6 +542,12 @@ static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
                  fmaf(T->qdv.y, h.v, fmaf(T->qdu.y, h.u, T->qc.y)),
                  fmaf(T->qdv.z, h.v, fmaf(T->qdu.z, h.u, T->qc.z)));
     si.n = T->n; si.s = T->s; si.tt = T->t; si.ng = T->n;
+    /* [Mesh::compute_surface_interaction] si.uv = fmadd(uv2, b2, fmadd(uv1, b1, uv0 * b0)); [Rectangle] (prim_uv + 1) / 2 */
+    if (T->kind == 1) { si.uv[0] = fmaf(h.u, 0.5f, 0.5f); si.uv[1] = fmaf(h.v, 0.5f, 0.5f); }
+    else if (sc->d->tri_uv) {
+        const float *uv = sc->d->tri_uv + 6 * (size_t)h.prim;
+        si.uv[0] = fmaf(uv[4], b2, fmaf(uv[2], b1, uv[0] * b0)); si.uv[1] = fmaf(uv[5], b2, fmaf(uv[3], b1, uv[1] * b0));
+    }
     if (T->smooth) {        /* sh_frame.n = normalize(fmadd(n2, b2, fmadd(n1, b1, n0 * b0))), then initialize_sh_frame */
         const float *vn = sc->d->tri_normals + 9 * (size_t)h.prim;
         si.n = vnormalize(V(fmaf(vn[6], b2, fmaf(vn[3], b1, vn[0] * b0)), fmaf(vn[7], b2, fmaf(vn[4], b1, vn[1] * b0)),
@@ -550,6 +557,36 @@ static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
     v3 md = vneg(r->d);
     si.wi = V(vdot(md, si.s), vdot(md, si.tt), vdot(md, si.n));   /* to_local(-ray.d) */
     return si;
+}
+/* [mitsuba3: BitmapTexture::eval, filter_type = bilinear, wrap_mode = repeat] (restated; upstream not under /root/reference):
+ * uv -> texel space (u w - 1/2, v h - 1/2), four neighbours wrapped by the positive modulo,
+ * fmadd(w0.y, fmadd(w0.x, v00, w1.x v10), w1.y fmadd(w0.x, v01, w1.x v11)) */
+static void texture_eval(const mtr_texture *T, float u, float v, float out[3])
+{
+    float fu = fmaf(u, (float)T->width, -0.5f), fv = fmaf(v, (float)T->height, -0.5f);
+    float flu = floorf(fu), flv = floorf(fv);
+    float w1x = fu - flu, w1y = fv - flv, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    int32_t ix = (int32_t)flu, iy = (int32_t)flv, W = (int32_t)T->width, H = (int32_t)T->height;
+    int32_t x0 = ix % W, x1 = (ix + 1) % W, y0 = iy % H, y1 = (iy + 1) % H;
+    x0 += x0 < 0 ? W : 0; x1 += x1 < 0 ? W : 0; y0 += y0 < 0 ? H : 0; y1 += y1 < 0 ? H : 0;
+    const float *v00 = T->rgb + 3 * ((size_t)y0 * W + x0), *v10 = T->rgb + 3 * ((size_t)y0 * W + x1);
+    const float *v01 = T->rgb + 3 * ((size_t)y1 * W + x0), *v11 = T->rgb + 3 * ((size_t)y1 * W + x1);
+    for (int k = 0; k < 3; ++k) {
+        float f0 = fmaf(w0x, v00[k], w1x * v10[k]), f1 = fmaf(w0x, v01[k], w1x * v11[k]);
+        out[k] = fmaf(w0y, f0, w1y * f1);
+    }
+}
+void orc_texture_eval(const mtr_texture *T, uint32_t n, const float *u, const float *v, float *out3)
+{
+    for (uint32_t i = 0; i < n; ++i) texture_eval(T, u[i], v[i], out3 + 3 * i);
+}
+/* a material with its colour `a` taken from its bitmap at the hit (a copy), or the material itself */
+static const mtr_material *material_at(const mtr_scene_desc *d, const mtr_material *m, const sinter *si, mtr_material *copy)
+{
+    if (!m || m->albedo_texture == 0u || !d->textures || m->albedo_texture > d->n_textures) return m;
+    *copy = *m;
+    texture_eval(&d->textures[m->albedo_texture - 1u], si->uv[0], si->uv[1], copy->a);
+    return copy;
 }
 /* [mitsuba3: Frame3f::to_world] fmadd(n, v.z, fmadd(t, v.y, s * v.x)) */
 static v3 to_world(const sinter *si, v3 v)
@@ -966,7 +1003,8 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
         hit_t h = intersect(sc, &ray, use_bvh); C->closest++;            /* :148-151 */
         sinter si = make_si(sc, &ray, h);
         distance += si.t * eta;                                          /* :154 (inf on a miss) */
-        const mtr_material *mat = si.valid ? &d->materials[d->tri_material[si.prim]] : NULL;
+        mtr_material mat_copy;
+        const mtr_material *mat = si.valid ? material_at(d, &d->materials[d->tri_material[si.prim]], &si, &mat_copy) : NULL;
         int em = si.valid ? d->tri_emitter[si.prim] : -1;
 
         /* ---- direct emission :166-176 ---- */

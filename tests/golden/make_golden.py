@@ -100,6 +100,24 @@ def example_scenes():
     # ... and the meshes' vertex normals (face_normals is set on 157 of the 774 shapes only), same triangle order
     assert np.array_equal(sr.tri_verts, sc.data().tri_verts)
     np.savez_compressed(os.path.join(ROOT, "mitransient_amd", "data", "staircase_normals.npz"), tri_normals=sr.tri_normals)
+    # ... and its nine bitmap textures, box-downsampled to at most 256 pixels a side (8-bit sRGB), with the material -> texture table
+    from PIL import Image
+    from mitransient_amd import scene as S
+    names, orig = [], S.load_bitmap_texture
+    S.load_bitmap_texture = lambda path, raw=False, max_size=None: (names.append(path), orig(path, raw, max_size))[1]
+    sf = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml").data()
+    S.load_bitmap_texture = orig
+    arrs = {}
+    for i, path in enumerate(names):
+        with Image.open(path) as im:
+            im = im.convert("RGB")
+            k = 256 / float(max(im.size))
+            if k < 1:
+                im = im.resize((max(1, round(im.size[0] * k)), max(1, round(im.size[1] * k))), Image.BOX)
+            arrs[f"tex{i}"] = np.asarray(im, dtype=np.uint8)
+    np.savez_compressed(os.path.join(ROOT, "mitransient_amd", "data", "staircase_textures.npz"), n=np.asarray([len(names)]),
+                        names=np.asarray([os.path.basename(n) for n in names]),
+                        tex_of_mat=np.array([sf.materials[i].albedo_texture for i in range(sf.n_materials)], np.uint32), **arrs)
     np.savez_compressed(os.path.join(HERE, "nlos_Z_geometry.npz"), tris=load_obj(f"{ref}/transient-nlos/Z.obj").astype(np.float32))
 
 

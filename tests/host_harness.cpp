@@ -67,6 +67,8 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
+    sv.texels = hs.texels.empty() ? nullptr : hs.texels.data(); sv.tex_info = hs.tex_info.empty() ? nullptr : hs.tex_info.data();
+    sv.uvs = hs.uvs.empty() ? nullptr : hs.uvs.data();
     RenderConst rc = make_render_const(*p, hs.film, sv.n_emitters);
     HostSink sink{ t4, hs.film.width, hs.film.bins, 0, hs.film };
     ArrStack st; st.sp = 0;
@@ -159,6 +161,8 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
+    sv.texels = hs.texels.empty() ? nullptr : hs.texels.data(); sv.tex_info = hs.tex_info.empty() ? nullptr : hs.tex_info.data();
+    sv.uvs = hs.uvs.empty() ? nullptr : hs.uvs.data();
     ArrStack st; st.sp = 0;
     for (uint32_t i = 0; i < n; ++i) {
         f3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), dd = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
@@ -178,7 +182,7 @@ extern "C" void hh_bsdf_eval_pdf(const mtr_material *m, uint32_t n, const float 
         f3 wi = mk(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = mk(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
         f3 v = mk(0, 0, 0); float p = 0.0f;
         if ((m->flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
-        if (bsdf_is_rough(m->type)) rough_eval_pdf(*m, wi, wo, v, p);
+        if (bsdf_is_rough(m->type)) rough_eval_pdf(*m, mk(m->a[0], m->a[1], m->a[2]), wi, wo, v, p);
         else if (m->type == MTR_BSDF_DIFFUSE && wi.z > 0.0f && wo.z > 0.0f) {
             p = kInvPi * wo.z; v = mk((m->a[0] * kInvPi) * wo.z, (m->a[1] * kInvPi) * wo.z, (m->a[2] * kInvPi) * wo.z);
         }
@@ -189,7 +193,7 @@ extern "C" void hh_bsdf_sample(const mtr_material *m, uint32_t n, const float *w
                                float *wo3, float *pdf, float *w3)
 {
     for (uint32_t i = 0; i < n; ++i) {
-        const BsdfSample bs = bsdf_sample<true>(*m, mk(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), u1[i], ua[i], ub[i]);
+        const BsdfSample bs = bsdf_sample<true>(*m, mk(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), u1[i], ua[i], ub[i], mk(m->a[0], m->a[1], m->a[2]));
         wo3[3 * i] = bs.wo.x; wo3[3 * i + 1] = bs.wo.y; wo3[3 * i + 2] = bs.wo.z; pdf[i] = bs.pdf;
         w3[3 * i] = bs.w.x; w3[3 * i + 1] = bs.w.y; w3[3 * i + 2] = bs.w.z;
     }

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     from mitransient_amd import _cabi
-    names = ["mtr_material", "mtr_emitter", "mtr_camera", "mtr_film_desc", "mtr_scene_desc", "mtr_shape", "mtr_nlos_desc",
+    names = ["mtr_material", "mtr_emitter", "mtr_camera", "mtr_film_desc", "mtr_scene_desc", "mtr_shape", "mtr_nlos_desc", "mtr_texture",
              "mtr_render_params", "mtr_counters", "mtr_splat_soa", "mtr_kernel_times"]
     prog = '#include <stdio.h>\n#include "mitransient_amd.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}"

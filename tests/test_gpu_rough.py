@@ -111,3 +111,32 @@ def test_staircase_config5_faithful_shading(oracle):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("bsdf_type", ["diffuse", "roughplastic"])
+def test_textured_scene_matches_oracle(oracle, tmp_path, mode, bsdf_type):
+    """bitmap textures on a (diffuse) reflectance: bilinear, repeat; an OBJ panel (flipped v) and a cube (its own coordinates)"""
+    from test_textures import textured_scene
+    scene = textured_scene(tmp_path, bsdf_type, width=40, height=40)
+    scene.integrator().mode = {"fused": 1, "wavefront": 2}[mode]
+    s_gpu, t_gpu = gpu_render(scene, 16, seed=4)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16, seed=4)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
+def test_staircase_config5_as_its_file_describes_it(oracle):
+    """config 5 geometry with GGX lobes, vertex normals AND the nine bitmap textures (256-px fixtures)"""
+    from mitransient_amd.scenes import staircase
+    scene = staircase(width=45, height=80, spp=4, materials="rough", vertex_normals=True, textures=True)
+    sd = scene.data()
+    assert len(sd.textures) == 9 and sum(1 for i in range(sd.n_materials) if sd.materials[i].albedo_texture) == 9
+    s_gpu, t_gpu = gpu_render(scene, 4)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 4)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
