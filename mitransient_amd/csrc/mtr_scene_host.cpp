@@ -237,8 +237,14 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
                 sdir = dp_du; t = mk(0, 0, 0);
             }
         }
-        if (textured && d.tri_uv) {
-            const float *uv = d.tri_uv + 6 * (size_t)o;
+        if (textured) {
+            // a mesh without texture coordinates (none given, or this shape's are all zero): si.uv = (b1, b2)
+            // [Mesh::compute_surface_interaction], i.e. the corners (0,0) (1,0) (0,1)
+            const float bary[6] = { 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 1.0f };
+            const float *uv = d.tri_uv ? d.tri_uv + 6 * (size_t)o : bary;
+            bool any_uv = false;
+            for (int k = 0; k < 6; ++k) any_uv = any_uv || uv[k] != 0.0f;
+            if (!any_uv) uv = bary;
             s.uvs[2 * (size_t)slot] = q4{ uv[0], uv[1], uv[2], uv[3] }; s.uvs[2 * (size_t)slot + 1] = q4{ uv[4], uv[5], 0.0f, 0.0f };
         }
         float *g = &s.tpairs[slot >> 1].g[0].x;            // interleaved pair record: dword 2*k + half

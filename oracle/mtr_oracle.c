@@ -544,8 +544,13 @@ static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
     si.n = T->n; si.s = T->s; si.tt = T->t; si.ng = T->n;
     /* [Mesh::compute_surface_interaction] si.uv = fmadd(uv2, b2, fmadd(uv1, b1, uv0 * b0)); [Rectangle] (prim_uv + 1) / 2 */
     if (T->kind == 1) { si.uv[0] = fmaf(h.u, 0.5f, 0.5f); si.uv[1] = fmaf(h.v, 0.5f, 0.5f); }
-    else if (sc->d->tri_uv) {
-        const float *uv = sc->d->tri_uv + 6 * (size_t)h.prim;
+    else {
+        /* without vertex texture coordinates (none, or all zero for this shape's triangles): si.uv = (b1, b2) */
+        static const float bary[6] = { 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 1.0f };
+        const float *uv = sc->d->tri_uv ? sc->d->tri_uv + 6 * (size_t)h.prim : bary;
+        int any_uv = 0;
+        for (int k = 0; k < 6; ++k) any_uv |= uv[k] != 0.0f;
+        if (!any_uv) uv = bary;
         si.uv[0] = fmaf(uv[4], b2, fmaf(uv[2], b1, uv[0] * b0)); si.uv[1] = fmaf(uv[5], b2, fmaf(uv[3], b1, uv[1] * b0));
     }
     if (T->smooth) {        /* sh_frame.n = normalize(fmadd(n2, b2, fmadd(n1, b1, n0 * b0))), then initialize_sh_frame */

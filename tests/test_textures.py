@@ -109,6 +109,28 @@ def test_host_harness_textured_scene_bit_for_bit(oracle, host_harness, tmp_path,
     assert np.count_nonzero(t4) > 2000
 
 
+def test_mesh_without_texture_coordinates_uses_barycentrics(oracle, host_harness, tmp_path):
+    """si.uv = (b1, b2) when the mesh carries no texture coordinates (Mesh::compute_surface_interaction)"""
+    import mitransient_amd.mi as mi
+    import mitransient_amd as mitr
+    mi.set_variant("llvm_ad_rgb")
+    make_texture(str(tmp_path / "tex.png"))
+    (tmp_path / "quad.obj").write_text("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nf 1 2 3\nf 1 3 4\n")
+    d = mitr.cornell_box()
+    del d["small-box"], d["large-box"]
+    d["sensor"]["film"].update(width=24, height=24, temporal_bins=8, start_opl=3.5, bin_width_opl=0.75)
+    d["panel"] = {"type": "obj", "filename": str(tmp_path / "quad.obj"), "face_normals": True,
+                  "to_world": mi.ScalarTransform4f().translate([0.0, 0.0, -0.6]).scale([0.7, 0.5, 1.0]),
+                  "bsdf": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "bitmap", "filename": str(tmp_path / "tex.png")}}}}
+    scene = mi.load_dict(d)
+    sd = scene.data()
+    assert sd.tri_uv is None or not np.any(sd.tri_uv[sd.tri_material == max(sd.tri_material)])
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 16)
+    t4, s4, cnt = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and np.count_nonzero(t4) > 500
+
+
 def test_texture_lands_where_its_coordinates_say(oracle, tmp_path):
     """direct light only: the left half of the panel reflects red, the right half green, and the blue stripe (row 0 of the
     file = v 1 of the OBJ = the panel's TOP edge) shows at the top"""
