@@ -15,7 +15,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmp, partition, height=18):
+def _scene(kind, height):
+    from conftest import make_cornell
+    if kind == "cornell":
+        return make_cornell(width=24, height=height, bins=48)
+    import mitransient_amd.mi as mi
+    from test_rough_bsdf import _rough_cornell
+    return mi.load_dict(_rough_cornell(width=24, height=height, temporal_bins=48, bin_width_opl=6.0 / 48))
+
+
+def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -23,9 +32,8 @@ def _worker(rank, world, port, tmp, partition, height=18):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from conftest import make_cornell
         from mitransient_amd import distributed as md
-        scene = make_cornell(width=24, height=height, bins=48)
+        scene = _scene(kind, height)
         steady, transient = md.DistributedRenderer(scene, partition=partition, gather=True).render(spp=10, seed=3)
         torch.cuda.synchronize()
         np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
@@ -68,6 +76,25 @@ def test_two_rank_pipelined_band_reduction(tmp_path):
         s = np.load(tmp_path / f"s{r}.npy")
         assert t.shape == t_ref.shape == (32, 24, 48, 3)
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+
+
+def test_two_rank_pipelined_with_rough_materials(tmp_path):
+    """the band-pipelined path with a scene that runs the extended-shading kernels (GGX lobes on four shapes)"""
+    from conftest import rel_l2
+    scene = _scene("rough", 32)
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=10)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "spp", 32, "rough"), nprocs=2, join=True)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        assert t.shape == t_ref.shape == (32, 24, 48, 3)
+        assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+    assert np.count_nonzero(t_ref) > 2000
 
 
 def test_rccl_api_path_with_one_rank():
