@@ -167,9 +167,6 @@ def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, m
         g["textures"] = [decode_texture_u8(z[f"tex{i}"]) for i in range(int(z["n"][0]))]
         for i, t in enumerate(z["tex_of_mat"]):
             g["materials"][i].albedo_texture = int(t)
-        uv = np.array(g["tri_uv"], dtype=np.float32, copy=True)            # the fixture keeps the OBJ files' v: flip it as mitsuba does
-        uv[:, 1::2] = np.float32(1.0) - uv[:, 1::2]
-        g["tri_uv"] = uv
     if vertex_normals:
         tn = np.load(os.path.join(DATA_DIR, "staircase_normals.npz"))["tri_normals"]
         if tn.shape != (scene.geometry_["tri_verts"].shape[0], 9):

@@ -86,6 +86,8 @@ def example_scenes():
         sc = mi.load_file(f"{ref}/transient/cornell-box/{name}.xml")
         save_fixture(sc, os.path.join(HERE, f"{name}_scene.npz"), source=f"examples/transient/cornell-box/{name}.xml")
     sc = mi.load_file(f"{ref}/diff-transient/staircase/scene.xml", approximate_materials="smooth")
+    # the geometry fixture is the SURVEY section-8d workload: flat shading (the vertex normals travel in staircase_normals.npz)
+    sc.data().tri_normals = None
     save_fixture(sc, os.path.join(ROOT, "mitransient_amd", "data", "staircase_geometry.npz"), source="examples/diff-transient/staircase/scene.xml",
                  approximate_materials="smooth")
     # the same scene with its GGX lobes kept (roughplastic / roughconductor; textures -> mean colour, bump map ignored): only
