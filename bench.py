@@ -127,6 +127,8 @@ def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1
             "valu_issue_frac": insts * 2.0 / (1024 * avg_launch_ms * 1e-3 * 2.4e9),
             "lanes_per_valu_inst": c["valu_lanes_per_inst"], "valu_insts_per_launch": insts,
             "traffic": c.get("hbm_bytes_per_launch"), "avg_launch_ms": avg_launch_ms,
+            "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE; algorithmic 24 B x contributions = 10.7 GB per config-2 launch — the excess is "
+                            "WRITE_SIZE: register-spill scratch evicted from L2 (DESIGN.md section 6)",
             "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
                       + str(c.get("profile", "")) + ") over the launch time measured live (HIP events)"}
 
