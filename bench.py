@@ -28,6 +28,42 @@ SPLAT_BYTES = 24.0         # algorithmic bytes per issued time-bin contribution 
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources the HIP library is built from.  tools/profile.sh stores it in
+    profiles/traffic.json next to the counters it collects; a roofline that divides committed counters by a live time is
+    only printed when the two agree (otherwise the kernel was edited after it was last profiled)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "mitransient_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "mitransient_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "mitransient_amd", "csrc", "*.cpp")) +
+                   [os.path.join(ROOT, "mitransient_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "mitransient_amd.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (the form the driver uses for N = 1): start the N ranks here, exactly
+    as the driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), and
+    pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 MATERIALS = "smooth"       # --materials (staircase only): "smooth" = the SURVEY section-8d mapping (default) | "rough" = GGX lobes kept
 SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry)
 
@@ -95,28 +131,52 @@ def cpu_baseline(width, height, bins, spp_total, target_s=15.0):
                     "Dr.Jit-LLVM path, which is not installable here; the GPU/CPU ratio says little about kernel quality"}
 
 
-def pmc_from_profiles(kernel):
+_TRAFFIC = None
+
+
+def traffic_file():
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                _TRAFFIC = json.load(fh)
+        except Exception:
+            _TRAFFIC = {}
+    return _TRAFFIC
+
+
+def profile_is_current(section=None):
+    """the committed counters were collected from THIS source tree (tools/profile.sh records bench.py's source_hash())"""
+    t = traffic_file()
+    t = t.get(section, {}) if section else t
+    return bool(t) and t.get("source_hash") == source_hash()
+
+
+def pmc_from_profiles(kernel, section=None):
     """Counters per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools/profile.sh: separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    ``section``: None = the config-2 passes (top level), "staircase" = the config-5 passes.
     {} when no profile of this kernel is committed: bench.py itself cannot collect PMC counters."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get(kernel, {}) or {}
-    except Exception:
-        return {}
+    t = traffic_file()
+    if section:
+        t = t.get(section, {})
+    v = t.get(kernel, {})
+    return v if isinstance(v, dict) else {}
 
 
-def traffic_from_profiles(kernel):
-    return pmc_from_profiles(kernel).get("hbm_bytes_per_launch")
+def traffic_from_profiles(kernel, section=None):
+    """HBM bytes per launch from the PMC passes — None when they were not collected from this source tree"""
+    if not profile_is_current(section):
+        return None
+    return pmc_from_profiles(kernel, section).get("hbm_bytes_per_launch")
 
 
-def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1.0):
+def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1.0, section=None):
     """The path kernel is bound by VALU issue + SIMT divergence, not by HBM: achieved = VALU lane-operations
     per launch (SQ_INSTS_VALU x active lanes per instruction, from the committed PMC pass of the SAME workload) / the
     launch time measured live with HIP events; peak = the f32 vector roof."""
-    c = pmc_from_profiles(kernel)
-    if not workload_matches or "valu_insts_per_launch" not in c or avg_launch_ms <= 0:
+    c = pmc_from_profiles(kernel, section)
+    if not workload_matches or "valu_insts_per_launch" not in c or avg_launch_ms <= 0 or not profile_is_current(section):
         return None
     # the profile is of ONE launch per render; a multi-GPU step issues the same per-rank work as `launches_per_render` band launches
     insts = c["valu_insts_per_launch"] / launches_per_render
@@ -127,10 +187,50 @@ def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1
             "valu_issue_frac": insts * 2.0 / (1024 * avg_launch_ms * 1e-3 * 2.4e9),
             "lanes_per_valu_inst": c["valu_lanes_per_inst"], "valu_insts_per_launch": insts,
             "traffic": c.get("hbm_bytes_per_launch"), "avg_launch_ms": avg_launch_ms,
-            "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE; algorithmic 24 B x contributions = 10.7 GB per config-2 launch — the excess is "
-                            "WRITE_SIZE: register-spill scratch evicted from L2 (DESIGN.md section 6)",
+            "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the PMC passes",
+            "profile_source_hash": source_hash(),
+            "note": "frac = executed VALU instructions x active lanes / time: a utilisation figure — it also rises when a kernel "
+                    "executes MORE instructions, so read it beside avg_launch_ms and valu_insts_per_launch",
             "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
-                      + str(c.get("profile", "")) + ") over the launch time measured live (HIP events)"}
+                      + str(c.get("profile", "")) + "; same source hash as the library that ran) over the launch time measured live (HIP events)"}
+
+
+def extra_config_legs(spp4, spp5):
+    """Untimed side legs (rank 0, N = 1): BASELINE configs[3] (NLOS confocal Z scene, one GPU's share of the 4096 spp) and
+    configs[4] (the staircase) at reduced sample counts, each with its own HIP-event time and counters, so that the
+    driver-run line carries them next to the headline."""
+    import torch
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scenes import nlos_z, staircase
+    out = {}
+
+    def run(scene, spp, reps=2):
+        integ = scene.integrator()
+        integ.collect_stats = True
+        for _ in range(reps):                                  # the first render pays the workspace allocation
+            integ.render(scene, spp=spp, seed=0)
+        torch.cuda.synchronize()
+        c, tm = integ.total_counters, integ.total_times
+        rays = c["rays_closest"] + c["rays_shadow"]
+        r = {"ms": tm["total_ms"], "Mray_per_s": rays / tm["total_ms"] / 1e3, "time_bins_per_s": c["splats_issued"] / tm["total_ms"] * 1e3,
+             "counters": {k: c[k] for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")},
+             "mode": "wavefront" if tm["scatter_launches"] else "fused"}
+        if tm.get("wf_trace_kernel_launches"):
+            r["k_wf_trace_ms"] = tm["wf_trace_ms"]
+        return r
+    mi.set_variant("llvm_ad_rgb")
+    t0 = time.perf_counter()
+    sc4 = nlos_z(width=256, height=256, temporal_bins=4096, spp=spp4)
+    out["config4_share"] = dict(run(sc4, spp4), workload=f"NLOS confocal Z scene (reference Z.obj), 256x256 px, 4096 time bins (start_opl 1.85, "
+                                f"width 2^-11), {spp4} of 4096 spp (one GPU's share of 8), max_depth -1, rr_depth 5")
+    del sc4
+    sc5 = staircase(width=512, height=512, temporal_bins=2048, max_depth=65, materials="smooth")
+    film = sc5.sensors()[0].film()
+    film.start_opl, film.bin_width_opl = 0.0, 40.0 / 2048
+    out["config5_reduced"] = dict(run(sc5, spp5), workload=f"staircase scene.xml geometry (262,663 triangles, approximate materials), 512x512 px, "
+                                  f"2048 time bins (start_opl 0, width 40/2048), {spp5} of 2048 spp, max_depth 65, camera_unwarp")
+    out["wall_s"] = time.perf_counter() - t0
+    return out
 
 
 def main():
@@ -151,8 +251,11 @@ def main():
     ap.add_argument("--mode", default=None, choices=[None, "auto", "fused", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scatter-leg", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the untimed config-4 / config-5 side legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     global SCENE, MATERIALS
     SCENE = args.scene
     MATERIALS = args.materials
@@ -168,7 +271,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node N for --gpus N "
+                         "(or with no launcher at all: bench.py then starts its ranks itself)")
     # dry-run hooks (single-GPU box): MTR_BENCH_DEVICE pins every rank to one device, MTR_BENCH_BACKEND=gloo
     # replaces RCCL (which needs one device per rank) so that the N>1 code path can be exercised end to end
     device_index = int(os.environ.get("MTR_BENCH_DEVICE", local_rank))
@@ -199,48 +303,57 @@ def main():
     integ = scene.integrator()
     integ.collect_stats = True
     spp_total = args.spp * world
-    renderer = mdist.DistributedRenderer(scene, partition="spp", gather=True)
-
-    totals = {"paths": 0, "rays_closest": 0, "rays_shadow": 0, "splats_issued": 0, "bounces": 0}
-    kernel_ms = []
-    trace_launches = 0
-    wf_seen = False                      # MTR_MODE_AUTO resolves inside the library: wavefront runs scatter launches
-
-    def step(timed):
-        nonlocal trace_launches, wf_seen
-        steady, transient = renderer.render(spp=spp_total, seed=0)
-        if timed:
-            for k in totals:
-                totals[k] += integ.total_counters[k]
-            kernel_ms.append(integ.total_times["trace_ms"])          # sum over the launches of this step
-            trace_launches += integ.total_times["trace_launches"]
-            wf_seen = wf_seen or integ.total_times["scatter_launches"] > 0
-        return steady, transient
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    del out
+    def timed_run(renderer):
+        """W untimed + K timed steps of `renderer`, fenced on both sides; returns (elapsed s = max over ranks, counters summed
+        over ranks, per-step kernel ms of this rank, launches, wavefront seen, k_wf_trace ms / launches of this rank)"""
+        totals = {"paths": 0, "rays_closest": 0, "rays_shadow": 0, "splats_issued": 0, "bounces": 0}
+        kernel_ms, launches, wf_seen, wft_ms, wft_n = [], 0, False, 0.0, 0
+        for _ in range(args.warmup):
+            renderer.render(spp=spp_total, seed=0)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = renderer.render(spp=spp_total, seed=0)
+            # (counters and HIP-event times were read back inside render(): collect_stats)
+            for k in totals:
+                totals[k] += integ.total_counters[k]
+            kernel_ms.append(integ.total_times["trace_ms"])          # sum over the launches of this step
+            launches += integ.total_times["trace_launches"]
+            wf_seen = wf_seen or integ.total_times["scatter_launches"] > 0
+            wft_ms += integ.total_times.get("wf_trace_ms", 0.0)
+            wft_n += integ.total_times.get("wf_trace_kernel_launches", 0)
+        fence()
+        elapsed = time.perf_counter() - t0
+        del out
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            c = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            for k, v in zip(sorted(totals), c.tolist()):
+                totals[k] = int(v)
+        return elapsed, totals, kernel_ms, launches, wf_seen, wft_ms, wft_n
 
-    # max over ranks of the elapsed time; sums of the counters
+    renderer = mdist.DistributedRenderer(scene, partition="spp", gather=True)
+    elapsed, totals, kernel_ms, trace_launches, wf_seen, wft_ms, wft_n = timed_run(renderer)
+    path_taken = renderer.last_path
+    # N > 1: the same steps with the film reduction ALONE (reduce-scatter, every rank keeps the developed rows it owns —
+    # north_star's "single RCCL reduce"); the headline keeps the all-gather that hands every rank the whole tensor
+    rs_only = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([totals[k] for k in sorted(totals)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        for k, v in zip(sorted(totals), c.tolist()):
-            totals[k] = int(v)
+        r2 = mdist.DistributedRenderer(scene, partition="spp", gather=False)
+        e2, t2, *_ = timed_run(r2)
+        rs_only = {"ms_per_step": e2 / args.steps * 1e3, "value": (t2["rays_closest"] + t2["rays_shadow"]) / e2 / 1e6,
+                   "unit": "Mray/s", "what": "reduce_scatter(film) only: every rank develops and keeps its rows of each band "
+                                             "(3 GiB all-gather of the developed tensor left out)", "path": r2.last_path}
+        del r2
 
     # ---- untimed extra leg (rank 0, N=1): the same render in wavefront mode, to time the stand-alone
     # time-bin scatter-add kernel (k_wf_scatter) with HIP events on its stream
@@ -255,12 +368,20 @@ def main():
         n_l = max(1, tm["scatter_launches"])
         b_l = SPLAT_BYTES * cn["splats_issued"] / n_l
         avg = tm["scatter_ms"] / n_l
+        default_wl_sc = (SCENE == "cornell" and (args.width, args.height, args.bins, args.spp) == dflt)
         scatter = {"kernel": "k_wf_scatter (MTR_MODE_WAVEFRONT, untimed extra leg)", "bound": "hbm",
                    "achieved": b_l / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": b_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_wf_scatter"),
+                   "frac": b_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "traffic": traffic_from_profiles("k_wf_scatter") if default_wl_sc else None,
                    "avg_launch_ms": avg, "launches_per_render": n_l, "algorithmic_bytes_per_launch": b_l,
                    "render_ms_wavefront": tm["total_ms"]}
         del sc2, i2
+
+    extra = None
+    if rank == 0 and world == 1 and SCENE == "cornell" and not args.no_extra_configs:
+        del renderer, scene
+        torch.cuda.empty_cache()
+        extra = extra_config_legs(512, 128)
 
     if rank == 0:
         rays = totals["rays_closest"] + totals["rays_shadow"]
@@ -291,32 +412,64 @@ def main():
                                    (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes, vertex normals and (256-px) bitmap textures as in the scene file") + f"), "
                                     f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
-                       "parallelism": f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather" if world > 1 else "1 GPU",
+                       "parallelism": (f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather, 8 row bands pipelined against the path kernel"
+                                       if world > 1 else "1 GPU"),
                        "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE == "cornell"
                                              else "auto (wavefront: scene in HBM)")},
             # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
             # `scatter_add` below is the stand-alone scatter-add kernel of the wavefront organisation
             "counters_per_step": {k: v / args.steps for k, v in totals.items()},
+            "source_hash": source_hash(),
         }
+        default_wl = (args.width, args.height, args.bins, args.spp) == dflt and args.mode in (None, "auto")
         hbm_line = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles("k_fused") if kname == "k_fused" else None,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic_from_profiles("k_fused") if (kname == "k_fused" and SCENE == "cornell" and default_wl) else None,
                     "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         # the dominant kernel's bound: k_fused keeps the scatter-add in LDS, so the HBM line only says how little it moves;
-        # what bounds it is VALU issue at ~27 of 64 active lanes (PMC passes of the same workload, profiles/)
-        default_wl = (SCENE == "cornell" and (args.width, args.height, args.bins, args.spp) == dflt and world >= 1)
-        vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps) if fused else None
+        # what bounds it is VALU issue at ~30 of 64 active lanes (PMC passes of the same workload and the same sources, profiles/)
+        vline = None
+        if fused and SCENE == "cornell":
+            vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps)
+        elif not fused and SCENE == "staircase" and MATERIALS == "smooth" and wft_n:
+            # config 5: the dominant kernel is k_wf_trace (closest-hit and any-hit runs); its launches are timed alone with HIP
+            # events; the PMC passes (tools/profile.sh ... --scene staircase) ran the SAME command, so instructions per RENDER
+            # divide by the k_wf_trace time per render
+            c5 = pmc_from_profiles("k_wf_trace", "staircase")
+            per_render_ms = wft_ms / args.steps
+            if default_wl and profile_is_current("staircase") and c5.get("valu_insts_per_render"):
+                lane_ops = c5["valu_insts_per_render"] * c5["valu_lanes_per_inst"]
+                ach = lane_ops / (per_render_ms * 1e-3) / 1e12
+                vline = {"kernel": "k_wf_trace", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                         "frac": ach / VALU_PEAK_TLANEOPS, "valu_issue_frac": c5["valu_insts_per_render"] * 2.0 / (1024 * per_render_ms * 1e-3 * 2.4e9),
+                         "lanes_per_valu_inst": c5["valu_lanes_per_inst"], "valu_insts_per_render": c5["valu_insts_per_render"],
+                         "kernel_ms_per_render": per_render_ms, "launches_per_render": wft_n / args.steps,
+                         "share_of_step": per_render_ms / ms_per_step, "traffic": c5.get("hbm_bytes_per_render"),
+                         "wait_any_frac": c5.get("wait_any_frac"), "profile_source_hash": source_hash(),
+                         "note": "k_wf_trace waits on divergent 16-byte loads from L1/L2 (wait_any_frac), so its issue fraction is the "
+                                 "honest utilisation figure; HBM traffic is a small fraction of the roof (scene resident in L2)",
+                         "source": "profiles/traffic.json[staircase] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"}
         if vline is not None:
             vline["launches_per_step"] = n_launch / args.steps
             res["roofline"] = vline
             res["roofline_hbm"] = hbm_line
         else:
             res["roofline"] = hbm_line
+            if (SCENE == "cornell" and fused and default_wl and not profile_is_current()) or \
+               (SCENE == "staircase" and default_wl and not profile_is_current("staircase")):
+                res["roofline_stale"] = True      # profiles/traffic.json was collected from other sources: counter-based lines omitted
+        if not fused and wft_n:
+            res["k_wf_trace_ms_per_step"] = wft_ms / args.steps
         if world > 1:
             res["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
             res["comm_backend"] = backend
+            res["render_path"] = path_taken
+            res["reduce_scatter_only"] = rs_only
         if scatter:
             res["scatter_add"] = scatter
+        if extra:
+            res["extra_configs"] = extra
         if cpu_res is not None:
             res["cpu_baseline"] = cpu_res
             res["gpu_over_cpu"] = res["value"] / cpu_res["value"]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 8
+#define MTR_ABI_VERSION 9
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -89,6 +89,9 @@ typedef struct mtr_emitter {
     float radiance[3];
     uint32_t is_mesh;     /* 1: the emitter is the triangle range below (obj / cube shapes) */
     uint32_t first_tri, n_tris;
+    uint32_t flip_normals; /* rectangle (ABI 9): the shape's `flip_normals` — the emitting side is -normalize(du x dv);
+                              sample positions are unchanged (mitsuba negates the normal, not the parameterisation).
+                              A mesh emitter's flip is the winding of its triangles. */
 } mtr_emitter;
 
 /* ---- sensor: `perspective` (utils.py:92-105 of the reference) ----------- */
@@ -132,12 +135,16 @@ enum { MTR_NLOS_LASER_SAMPLING = 1u,          /* nlos_laser_sampling            
        MTR_NLOS_DISCARD_DIRECT = 32u,         /* discard_direct_paths                             */
        MTR_NLOS_FORCE_EQUAL_GRIDS = 64u       /* force_equal_illumination_scanning (Exhaustive)   */ };
 
+enum { MTR_RECT_ANALYTIC = 1u, MTR_RECT_FLIP_NORMALS = 2u };     /* mtr_shape.is_rectangle */
 typedef struct mtr_shape {          /* one scene shape = a contiguous triangle range */
     uint32_t first_tri, n_tris;
     uint32_t is_rectangle;          /* analytic `rectangle`: the shape is ONE primitive — mitsuba's Rectangle::ray_intersect
                                        (ray to object space, t = -o.z/d.z, |x|,|y| <= 1), one shading frame, sample_position by
                                        to_world.  Its two triangles (0,1,2) (0,2,3) of the corners (-1,-1) (1,-1) (1,1) (-1,1)
-                                       only CARRY the material / emitter / index of the primitive (hits report the first one). */
+                                       only CARRY the material / emitter / index of the primitive (hits report the first one).
+                                       Bit MTR_RECT_FLIP_NORMALS (ABI 9): the shape's `flip_normals` — geometric and shading
+                                       normal are -normalize(du x dv) (and t = n x s follows); the local parameterisation,
+                                       hence prim_uv and sample_position, is unchanged. */
     float    center[3], du[3], dv[3];   /* rectangle only: to_world*(0,0,0), half edges to_world*(1,0,0) - center, to_world*(0,1,0) - center */
     uint32_t has_to_world;          /* meshes: to_world below is the shape's object -> world transform (cube: of [-1,1]^3; obj / ply:
                                        of the file's coordinates).  Only an acceleration hint (oriented bounds); 0 = unknown */
@@ -274,7 +281,9 @@ typedef struct mtr_kernel_times {
     float    scatter_ms;      /* wavefront: sum of time-bin scatter-add launches (0 if fused)   */
     uint32_t trace_launches;
     uint32_t scatter_launches;
-    uint32_t reserved[3];
+    float    wf_trace_ms;     /* wavefront (ABI 9): sum of the k_wf_trace launches alone (closest-hit and any-hit runs) */
+    uint32_t wf_trace_kernel_launches; /* ... and their number                                   */
+    uint32_t reserved[1];
 } mtr_kernel_times;
 
 typedef struct mtr_ctx   mtr_ctx;
@@ -321,6 +330,16 @@ int  mtr_film_clear(mtr_ctx *, const mtr_film_desc *, float *transient_hwt4 /*de
 int  mtr_render(mtr_scene *, const mtr_render_params *,
                 float *transient_hwt4, float *steady_hw4,
                 mtr_counters *counters_out /*host*/, mtr_kernel_times *times_out /*host*/);
+
+/* Which kernel organisation mtr_render would run for these parameters on this scene (MTR_MODE_AUTO resolved exactly as
+ * mtr_render resolves it; MTR_MODE_FUSED or MTR_MODE_WAVEFRONT in *mode_out).  A caller that overlaps several mtr_render
+ * calls of ONE scene on different streams needs this: only the fused organisation keeps its per-launch state apart
+ * (rotating work tickets); the wavefront organisation has one workspace per scene and must stay on one stream. */
+int  mtr_render_plan(mtr_scene *, const mtr_render_params *, uint32_t *mode_out);
+
+/* Zero the context's device counters on the context stream (then issue every mtr_render of the render with
+ * MTR_FLAG_KEEP_COUNTERS and read the sums once with mtr_counters_read). */
+int  mtr_counters_reset(mtr_ctx *);
 
 /* The context's device counters as they stand (summed over every mtr_render since the last one without
  * MTR_FLAG_KEEP_COUNTERS).  The caller has synchronised the streams those renders ran on. */

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 8
+MTR_ABI_VERSION = 9
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC = 4, 5
@@ -24,6 +24,7 @@ MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8
 MTR_FLAG_KEEP_COUNTERS = 16
 MTR_FLAG_DETERMINISTIC = 32
 MTR_MODE_AUTO, MTR_MODE_FUSED, MTR_MODE_WAVEFRONT = 0, 1, 2
+MTR_RECT_ANALYTIC, MTR_RECT_FLIP_NORMALS = 1, 2
 
 _f3 = C.c_float * 3
 _f16 = C.c_float * 16
@@ -43,7 +44,8 @@ class mtr_texture(C.Structure):
 
 class mtr_emitter(C.Structure):
     _fields_ = [("center", _f3), ("du", _f3), ("dv", _f3), ("radiance", _f3),
-                ("is_mesh", C.c_uint32), ("first_tri", C.c_uint32), ("n_tris", C.c_uint32)]
+                ("is_mesh", C.c_uint32), ("first_tri", C.c_uint32), ("n_tris", C.c_uint32),
+                ("flip_normals", C.c_uint32)]
 
 
 class mtr_camera(C.Structure):
@@ -129,19 +131,21 @@ class mtr_splat_soa(C.Structure):
 class mtr_kernel_times(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("trace_ms", C.c_float), ("scatter_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("scatter_launches", C.c_uint32),
-                ("reserved", C.c_uint32 * 3)]
+                ("wf_trace_ms", C.c_float), ("wf_trace_kernel_launches", C.c_uint32),
+                ("reserved", C.c_uint32 * 1)]
 
     def as_dict(self):
         return {"total_ms": float(self.total_ms), "trace_ms": float(self.trace_ms),
                 "scatter_ms": float(self.scatter_ms), "trace_launches": int(self.trace_launches),
-                "scatter_launches": int(self.scatter_launches)}
+                "scatter_launches": int(self.scatter_launches), "wf_trace_ms": float(self.wf_trace_ms),
+                "wf_trace_kernel_launches": int(self.wf_trace_kernel_launches)}
 
 
 # Every symbol include/mitransient_amd.h declares (checked by tests/test_abi.py).
 EXPORTS = [
     "mtr_abi_version", "mtr_ctx_create", "mtr_ctx_destroy", "mtr_ctx_set_stream", "mtr_last_error",
     "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_set_nlos", "mtr_scene_bvh_info",
-    "mtr_film_clear", "mtr_render", "mtr_counters_read", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
+    "mtr_film_clear", "mtr_render", "mtr_render_plan", "mtr_counters_reset", "mtr_counters_read", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
 ]
 
 _lib = None
@@ -180,6 +184,8 @@ def load_library() -> C.CDLL:
     lib.mtr_scene_set_nlos.argtypes = [vp, C.POINTER(mtr_nlos_desc)]
     lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mtr_counters_read.argtypes = [vp, C.POINTER(mtr_counters)]
+    lib.mtr_counters_reset.argtypes = [vp]
+    lib.mtr_render_plan.argtypes = [vp, C.POINTER(mtr_render_params), C.POINTER(C.c_uint32)]
     lib.mtr_film_clear.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp]
     lib.mtr_render.argtypes = [vp, C.POINTER(mtr_render_params), vp, vp,
                                C.POINTER(mtr_counters), C.POINTER(mtr_kernel_times)]

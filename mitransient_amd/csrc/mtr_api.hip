@@ -331,7 +331,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
 }
 
 static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4, const RenderConst &rc,
-                     float *trace_ms, float *scatter_ms, uint32_t *n_trace, uint32_t *n_scatter, bool timed)
+                     float *trace_ms, float *scatter_ms, uint32_t *n_trace, uint32_t *n_scatter, bool timed, uint32_t *n_trace_kernel)
 {
     mtr_ctx *c = s->ctx;
     const Film &f = s->film;
@@ -373,7 +373,20 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     const bool unbounded = p->max_depth < 0 || p->max_depth > 256 || s->nlos.on;
     // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
     const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth + (s->nlos.on ? 2u : 0u));
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev, trace_ev;
+    // (timed renders only) events around every k_wf_trace launch: the dominant kernel of scenes in HBM is timed alone
+    auto trace_timed = [&](int which, int grid_) -> hipError_t {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
+            e = hipEventCreate(&e1); if (e != hipSuccess) return e;
+            e = hipEventRecord(e0, c->stream); if (e != hipSuccess) return e;
+        }
+        hipError_t e = launch_wf(a, cfg, which, grid_, c->stream);
+        if (e != hipSuccess) return e;
+        if (timed) { e = hipEventRecord(e1, c->stream); if (e != hipSuccess) return e; trace_ev.push_back({ e0, e1 }); }
+        return hipSuccess;
+    };
 
     for (uint32_t s0 = 0; s0 < spp_chunk; s0 += S) {
         const uint32_t Scur = std::min(S, spp_chunk - s0);
@@ -412,11 +425,11 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                     continue;
                 }
                 a.trace_any = 0u;
-                HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream)); a.ticket_cur ^= 1u;  // closest hit + material lists
+                HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                // closest hit + material lists
                 if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
                     HIP_TRY(c, launch_wf(a, cfg, 4, grid, c->stream)); a.ticket_cur ^= 1u;   // shadow rays of the emitter samples
                     a.trace_any = 1u;
-                    HIP_TRY(c, launch_wf(a, cfg, 1, grid, c->stream)); a.ticket_cur ^= 1u;   // their occlusion
+                    HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                   // their occlusion
                     *n_trace += 2;
                 }
                 HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream)); a.ticket_cur ^= 1u;  // shade (+ inline shadow rays when the scene is in LDS) + compaction
@@ -449,7 +462,43 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
         }
     }
-    *scatter_ms = acc_scatter; (void)trace_ms;
+    float acc_trace = 0.0f;
+    for (auto &pr : trace_ev) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+        acc_trace += ms;
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    *scatter_ms = acc_scatter; *trace_ms = acc_trace; *n_trace_kernel = (uint32_t)trace_ev.size();
+    return MTR_OK;
+}
+
+// MTR_MODE_AUTO -> the organisation that runs: the fused kernel when the whole scene can be staged in LDS (measured 143 vs
+// 168 ms on config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
+static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pixels, uint32_t spp_chunk, uint32_t *mode_io)
+{
+    mtr_ctx *c = s->ctx;
+    const Film &f = s->film;
+    uint32_t mode = *mode_io;
+    if (s->nlos.on && mode == MTR_MODE_AUTO) mode = MTR_MODE_FUSED;      // (wavefront = the second organisation, on request)
+    if (f.n_freq) {                      // phasor film: (opl, value) records -> wavefront pipeline by default; LDS (Re, Im) rows in the fused kernel on request
+        if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
+        if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
+    }
+    if (s->dev.has_rough) {              // GGX lobes: transient_path with f32 rows only (fused), or the wavefront pipeline
+        if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles / bitmap textures are not available for the NLOS tier");
+        const bool fused_ok = !f.n_freq && !(p->flags & MTR_FLAG_DETERMINISTIC);
+        if (mode == MTR_MODE_FUSED && !fused_ok)
+            return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles with a phasor film or deterministic rows need the wavefront mode");
+        if (mode == MTR_MODE_AUTO && !fused_ok) mode = MTR_MODE_WAVEFRONT;
+    }
+    if (mode == MTR_MODE_AUTO) {
+        FusedArgs probe{}; FusedConfig pc{};
+        probe.sc = s->dev; probe.cam = s->cam; probe.film = f; probe.rc = make_render_const(*p, f, s->dev.n_ems); probe.nlos_on = s->nlos.on ? 1u : 0u;
+        const bool fits = fused_plan(s->dev, f, n_pixels, spp_chunk, c->n_cu, probe, pc) && pc.scene_lds;
+        mode = fits ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
+    }
+    *mode_io = mode;
     return MTR_OK;
 }
 
@@ -504,32 +553,13 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     if (!(p->flags & MTR_FLAG_KEEP_COUNTERS)) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     if (s->log.count) HIP_TRY(c, hipMemsetAsync(s->log.count, 0, sizeof(unsigned long long), c->stream));
     if (times_out) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    uint32_t launches = 0, scatter_launches = 0;
-    float scatter_ms = 0.0f;
+    uint32_t launches = 0, scatter_launches = 0, wf_trace_n = 0;
+    float scatter_ms = 0.0f, wf_trace_ms = 0.0f;
     if (n_pixels && a.spp_chunk) {
-        // MTR_MODE_AUTO: the fused kernel when the whole scene can be staged in LDS (measured 143 vs 168 ms on
-        // config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
         uint32_t mode = p->mode;
-        if (s->nlos.on && mode == MTR_MODE_AUTO) mode = MTR_MODE_FUSED;      // (wavefront = the second organisation, on request)
-        if (f.n_freq) {                      // phasor film: (opl, value) records -> wavefront pipeline by default; LDS (Re, Im) rows in the fused kernel on request
-            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
-            if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
-        }
-        if (s->dev.has_rough) {              // GGX lobes: transient_path with f32 rows only (fused), or the wavefront pipeline
-            if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles are not available for the NLOS tier");
-            const bool fused_ok = !f.n_freq && !(p->flags & MTR_FLAG_DETERMINISTIC);
-            if (mode == MTR_MODE_FUSED && !fused_ok)
-                return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles with a phasor film or deterministic rows need the wavefront mode");
-            if (mode == MTR_MODE_AUTO && !fused_ok) mode = MTR_MODE_WAVEFRONT;
-        }
-        if (mode == MTR_MODE_AUTO) {
-            FusedArgs probe = a; FusedConfig pc{};
-            const bool fits = fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, probe, pc) && pc.scene_lds;
-            mode = fits ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
-        }
+        if (int r = resolve_mode(s, p, n_pixels, a.spp_chunk, &mode)) return r;
         if (mode == MTR_MODE_WAVEFRONT) {
-            float tr_ms = 0.0f;
-            int r = wf_render(s, p, t4, s4, a.rc, &tr_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr);
+            int r = wf_render(s, p, t4, s4, a.rc, &wf_trace_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr, &wf_trace_n);
             if (r) return r;
         } else {
             FusedConfig cfg{};
@@ -558,8 +588,28 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
             times_out->total_ms = ms; times_out->trace_ms = ms - scatter_ms; times_out->scatter_ms = scatter_ms;
             times_out->trace_launches = launches; times_out->scatter_launches = scatter_launches;
+            times_out->wf_trace_ms = wf_trace_ms; times_out->wf_trace_kernel_launches = wf_trace_n;
         }
     }
+    return MTR_OK;
+}
+
+int mtr_render_plan(mtr_scene *s, const mtr_render_params *p, uint32_t *mode_out)
+{
+    if (!s || !p || !mode_out) return fail(s ? s->ctx : nullptr, MTR_ERR_INVALID, "mtr_render_plan: NULL argument");
+    if (p->mode > MTR_MODE_WAVEFRONT) return fail(s->ctx, MTR_ERR_INVALID, "mtr_render_plan: unknown mode");
+    if (p->pixel_begin > p->pixel_end || p->spp_begin > p->spp_end) return fail(s->ctx, MTR_ERR_INVALID, "mtr_render_plan: bad range");
+    uint32_t mode = p->mode;
+    if (int r = resolve_mode(s, p, p->pixel_end - p->pixel_begin, p->spp_end - p->spp_begin, &mode)) return r;
+    *mode_out = mode;
+    return MTR_OK;
+}
+
+int mtr_counters_reset(mtr_ctx *c)
+{
+    if (!c) return fail(c, MTR_ERR_INVALID, "mtr_counters_reset: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     return MTR_OK;
 }
 

@@ -193,7 +193,8 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
             // (index = its first carrier triangle)
             const uint32_t prim = R->first_tri;
             const f3 c = ld3(R->center), du = ld3(R->du), dv = ld3(R->dv);
-            const f3 n = normalize(cross(du, dv));                              // normalize(to_world * Normal3f(0, 0, 1))
+            f3 n = normalize(cross(du, dv));                                    // normalize(to_world * Normal3f(0, 0, 1))
+            if (R->is_rectangle & MTR_RECT_FLIP_NORMALS) n = mk(-n.x, -n.y, -n.z);   // [Rectangle: flip_normals negates the frame normal, not the parameterisation]
             f3 sdir, t;
             sh_frame_from(n, du, sdir, t);                                      // dp_du = to_world * (2, 0, 0): same direction
             float rx[4], ry[4], rz[4];
@@ -278,6 +279,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         f3 cr = cross(ld3(e.du), ld3(e.dv));
         float len = sqrtf(dot(cr, cr));
         f3 n = cr / len;
+        if (e.flip_normals) n = mk(-n.x, -n.y, -n.z);
         E.n[0] = n.x; E.n[1] = n.y; E.n[2] = n.z;
         E.inv_area = 1.0f / (4.0f * len);      // rectangle area = |(2 du) x (2 dv)|
     }
@@ -357,7 +359,8 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
             const f3 cr = cross(ld3(S.du), ld3(S.dv));
             const double len = sqrt((double)cr.x * cr.x + (double)cr.y * cr.y + (double)cr.z * cr.z);
             a = 4.0 * len;
-            const f3 nn = cr / sqrtf(dot(cr, cr));
+            f3 nn = cr / sqrtf(dot(cr, cr));
+            if (S.is_rectangle & MTR_RECT_FLIP_NORMALS) nn = mk(-nn.x, -nn.y, -nn.z);
             D.n[0] = nn.x; D.n[1] = nn.y; D.n[2] = nn.z;
         }
         D.inv_area = (float)(1.0 / a);

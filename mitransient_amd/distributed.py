@@ -120,7 +120,7 @@ class DistributedRenderer:
         if self.partition == "spp":
             my_spp = shard_range(total_spp, world, rank)
             nb = self.bands
-            if self.gather and nb > 1 and ch == H and cw == W and H % (nb * world) == 0:
+            if nb > 1 and ch == H and cw == W and H % (nb * world) == 0:
                 self.last_path = "pipelined"
                 return self._render_pipelined(integ, sens, film, passes, total_spp, my_spp, nb, world)
             integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp)
@@ -174,9 +174,16 @@ class DistributedRenderer:
         raw_t = film.transient_storage.torch_tensor()
         raw_s = film.steady_accum()
         dev = raw_t.device
-        out_t = torch.empty(tuple(film.raw_shape()[:-1]) + (3,), dtype=torch.float32, device=dev)
-        out_s = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         rows_b = H // nb
+        gather = self.gather
+        rank = dist.get_rank(self.group)
+        per = rows_b // world                       # rows of a band this rank owns after the reduce-scatter
+        # gather=False: "the single RCCL reduce" only — every rank keeps the developed rows it owns (band b: rows
+        # b*rows_b + rank*per ... + per), stacked in band order; ``owned_rows`` lists them
+        n_out = H if gather else nb * per
+        out_t = torch.empty((n_out,) + tuple(film.raw_shape()[1:-1]) + (3,), dtype=torch.float32, device=dev)
+        out_s = torch.empty((n_out, W, 3), dtype=torch.float32, device=dev)
+        self.owned_rows = None if gather else [b * rows_b + rank * per + i for b in range(nb) for i in range(per)]
         main = torch.cuda.current_stream(dev)
         side = getattr(self, "_side_stream", None)
         if side is None:
@@ -190,10 +197,19 @@ class DistributedRenderer:
         lanes = getattr(self, "_render_streams", None)
         if lanes is None:
             lanes = self._render_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        # ... but ONLY launches of the fused kernel may overlap (each takes its own work-ticket slot): the wavefront
+        # organisation keeps one workspace per scene — path state, queues, records, segment tickets — so its bands stay
+        # on ONE stream, in order
+        if integ.resolved_mode(scene, sens, total_spp, my_spp, (0, rows_b * W)) != "fused":
+            lanes = (lanes[0], lanes[0])
+        self.last_band_streams = 1 if lanes[0] is lanes[1] else 2
+        # the device counters are zeroed ONCE, before any band starts (a reset issued by band 0 on its own stream could
+        # land after band 1, on the other stream, had begun to count)
+        integ.reset_counters(film)
         start = torch.cuda.Event()
         start.record(main)
-        for st in lanes:
-            st.wait_event(start)                    # the clear of prepare() ran on the main stream
+        for st in set(lanes):
+            st.wait_event(start)                    # the clear of prepare() and the counter reset ran on the main stream
         band_ev = []
         for b in range(nb):
             r0, r1 = b * rows_b, (b + 1) * rows_b
@@ -204,7 +220,7 @@ class DistributedRenderer:
                 # every band owns its rows: they are still zero from prepare()'s clear when the band's only pass flushes them;
                 # no read-back per band (the launches stay asynchronous): counters sum on the device
                 integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W),
-                                 rows_are_zero=True, defer_stats="first" if b == 0 else "more")
+                                 rows_are_zero=True, defer_stats="more")
                 ready.record(lanes[b & 1])
             band_ev.append((begin, ready))
             with torch.cuda.stream(side):
@@ -213,11 +229,12 @@ class DistributedRenderer:
                     side.synchronize()              # gloo collectives are host-driven (CPU test path)
                 slab_t = reduce_scatter_rows(raw_t[r0:r1], self.group)          # THE film reduction, band b
                 slab_s = reduce_scatter_rows(raw_s[r0:r1], self.group)
-                d_t, d_s = film.develop_slab(slab_t, slab_s)
-                got_t = all_gather_rows(d_t, rows_b, self.group)
-                got_s = all_gather_rows(d_s, rows_b, self.group)
-                out_t[r0:r1].copy_(got_t)
-                out_s[r0:r1].copy_(got_s)
+                if gather:
+                    d_t, d_s = film.develop_slab(slab_t, slab_s)
+                    out_t[r0:r1].copy_(all_gather_rows(d_t, rows_b, self.group))
+                    out_s[r0:r1].copy_(all_gather_rows(d_s, rows_b, self.group))
+                else:
+                    film.develop_slab(slab_t, slab_s, out=(out_t[b * per:(b + 1) * per], out_s[b * per:(b + 1) * per]))
         main.wait_stream(side)
         for st in lanes:
             main.wait_stream(st)

@@ -210,14 +210,19 @@ class TransientHDRFilm:
             out = out[..., :1].contiguous()
         return TensorXf(out)
 
-    def develop_slab(self, raw_t, raw_s):
+    def develop_slab(self, raw_t, raw_s, out=None):
         """develop() of a row slab (rows, W, T, 4) / (rows, W, 4): used by the multi-GPU path after the
-        reduce-scatter, so that every GPU develops 1/N of the film."""
+        reduce-scatter, so that every GPU develops 1/N of the film.  ``out``: (transient, steady) contiguous
+        destination tensors of the slab's developed shape (written in place), or None to allocate."""
         torch = require_gpu()
         rows = int(raw_t.shape[0])
         W = self.size_[0]
-        out_t = torch.empty((rows,) + self.raw_shape()[1:-1] + (3,), dtype=torch.float32, device=raw_t.device)
-        out_s = torch.empty((rows, W, 3), dtype=torch.float32, device=raw_t.device)
+        if out is not None:
+            out_t, out_s = out
+            assert out_t.is_contiguous() and out_s.is_contiguous() and out_t.shape[0] == rows and out_s.shape[0] == rows
+        else:
+            out_t = torch.empty((rows,) + self.raw_shape()[1:-1] + (3,), dtype=torch.float32, device=raw_t.device)
+            out_s = torch.empty((rows, W, 3), dtype=torch.float32, device=raw_t.device)
         if rows == 0:
             return out_t, out_s
         ctx = get_context(raw_t.device.index)

@@ -53,6 +53,15 @@ class TransientADIntegrator:
         self.total_times = None
         self.collect_stats = False
 
+    @property
+    def amd_mode(self):
+        """kernel organisation (extension): "auto" | "fused" | "wavefront" """
+        return {0: "auto", 1: "fused", 2: "wavefront"}[int(self.mode)]
+
+    @amd_mode.setter
+    def amd_mode(self, m):
+        self.mode = {"auto": 0, "fused": 1, "wavefront": 2}[m]
+
     def aov_names(self):
         return []
 
@@ -195,6 +204,26 @@ class TransientADIntegrator:
                     self.total_times[k] += self.last_times[k]
             if progress_callback:
                 progress_callback((i + 1) / len(samplers_spps))
+
+    def resolved_mode(self, scene, sensor, total_spp, spp_range=None, pixel_range=None):
+        """the kernel organisation mtr_render would run (MTR_MODE_AUTO resolved by the library): "fused" | "wavefront".
+        Callers that overlap several calls of one render on different streams need it: only the fused organisation
+        keeps its per-launch state apart."""
+        film = sensor.film()
+        ctx = get_context(film._device.index)
+        handle = scene.gpu_handle(ctx, sensor)
+        s0, s1 = (0, total_spp) if spp_range is None else spp_range
+        p0, p1 = (0, None) if pixel_range is None else pixel_range
+        params = self.render_params(film, 0, total_spp, s0, s1, p0, p1)
+        mode = C.c_uint32(0)
+        ctx.check(ctx.lib.mtr_render_plan(handle, C.byref(params), C.byref(mode)), "mtr_render_plan")
+        return {_cabi.MTR_MODE_FUSED: "fused", _cabi.MTR_MODE_WAVEFRONT: "wavefront"}[int(mode.value)]
+
+    def reset_counters(self, film):
+        """zero the device counters on the CURRENT stream (then every call of the render passes defer_stats="more")"""
+        ctx = get_context(film._device.index)
+        ctx.bind_current_stream()
+        ctx.check(ctx.lib.mtr_counters_reset(ctx.handle), "mtr_counters_reset")
 
     def fetch_counters(self, film):
         """counters summed on the device over the deferred calls of one render (the caller synchronised their streams)"""

@@ -357,6 +357,7 @@ class _SceneBuilder:
                 dv = tw.transform_affine(np.array([0, 1.0, 0])) - c
                 for k in range(3):
                     e.center[k], e.du[k], e.dv[k] = np.float32(c[k]), np.float32(du[k]), np.float32(dv[k])
+                e.flip_normals = 1 if sd.get("flip_normals", False) else 0      # [Rectangle::sample_position: ps.n = -frame.n]
             else:                                   # triangle-mesh emitter: sampled by face area [Mesh::sample_position]
                 e.is_mesh = 1
                 e.first_tri = sum(a.shape[0] for a in self.tri_verts)
@@ -376,6 +377,10 @@ class _SceneBuilder:
         self.shape_ranges.append((first, first + n))
         sh = _cabi.mtr_shape()
         sh.first_tri, sh.n_tris, sh.is_rectangle = first, n, 1 if t == "rectangle" else 0
+        if t == "rectangle" and sd.get("flip_normals", False):
+            # the analytic primitive takes its normal from du x dv, not from the carrier triangles' winding (swapped above):
+            # mitsuba's Rectangle negates the frame normal and keeps the parameterisation (MTR_RECT_FLIP_NORMALS)
+            sh.is_rectangle |= _cabi.MTR_RECT_FLIP_NORMALS
         sh.has_to_world = 1                       # object -> world of the mesh (an acceleration hint: oriented bounds)
         for i, x in enumerate(np.asarray(tw.matrix, dtype=np.float64)[:3, :].reshape(-1)):
             sh.to_world[i] = np.float32(x)
@@ -727,10 +732,15 @@ def load_geometry(path: str) -> Dict[str, Any]:
     if layout[0] == 64 and msize > 64:           # written with ABI <= 7: mtr_material grew by appended fields (rough lobes) only
         mat_bytes = np.pad(mat_bytes.reshape(-1, 64), ((0, 0), (0, msize - 64))).reshape(-1)
         layout[0] = msize
+    em_bytes = z["emitters"]
+    esize = C.sizeof(_cabi.mtr_emitter)
+    if layout[1] == 60 and esize > 60:           # written with ABI <= 8: mtr_emitter grew by an appended field (flip_normals) only
+        em_bytes = np.pad(em_bytes.reshape(-1, 60), ((0, 0), (0, esize - 60))).reshape(-1)
+        layout[1] = esize
     if layout != [msize, C.sizeof(_cabi.mtr_emitter), C.sizeof(_cabi.mtr_shape)]:
         raise ValueError(f"{path}: material / emitter record sizes {list(z['layout'])} do not match this C-ABI; "
                          "regenerate with tests/golden/make_golden.py")
-    z = dict(z.items()); z["materials"] = mat_bytes
+    z = dict(z.items()); z["materials"] = mat_bytes; z["emitters"] = em_bytes
     nm = z["materials"].size // C.sizeof(_cabi.mtr_material)
     ne = z["emitters"].size // C.sizeof(_cabi.mtr_emitter)
     mats = (_cabi.mtr_material * max(1, nm)).from_buffer_copy(z["materials"].tobytes().ljust(C.sizeof(_cabi.mtr_material), b"\0"))

@@ -173,3 +173,39 @@ def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, m
             raise ValueError("staircase_normals.npz does not belong to staircase_geometry.npz")
         scene.geometry_["tri_normals"] = np.ascontiguousarray(tn, dtype=np.float32)
     return scene
+
+def nlos_z(width=256, height=256, temporal_bins=4096, bin_width_opl=2.0 ** -11, start_opl=1.85, capture="confocal", spp=512,
+           irradiance=1.0, **integrator):
+    """BASELINE config 4's scene (examples/transient-nlos/nlos_Z.xml, tests/integration/test_nlos.py:1-78 of the reference):
+    the reference's Z.obj (6 triangles; data fixture ``data/nlos_Z_geometry.npz``, written back to an .obj so that it goes
+    through the ``obj`` shape plugin) at z = 1, a 2 x 2 relay ``rectangle`` at the origin carrying a nlos_capture_meter,
+    projector + sensor origin at (-0.5, 0, 0.25), fov 0.2, laser + hidden-geometry sampling on,
+    account_first_and_last_bounces off, max_depth -1 / rr_depth 5."""
+    import tempfile
+    import mitransient_amd as mitr
+    from . import mi
+    tris = np.load(os.path.join(DATA_DIR, "nlos_Z_geometry.npz"))["tris"]
+    lines = [f"v {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}" for v in tris.reshape(-1, 3)]
+    lines += [f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}" for i in range(len(tris))]
+    with tempfile.TemporaryDirectory() as tmp:
+        obj = os.path.join(tmp, "Z.obj")
+        with open(obj, "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
+        relay = mi.load_dict({
+            "type": "rectangle", "bsdf": white,
+            "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
+                            "sensor_origin": [-0.5, 0.0, 0.25],
+                            "film": {"type": "transient_hdr_film", "width": width, "height": height, "temporal_bins": temporal_bins,
+                                     "bin_width_opl": bin_width_opl, "start_opl": start_opl, "rfilter": {"type": "box"}}}})
+        laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
+                              "irradiance": {"type": "rgb", "value": [irradiance] * 3}, "fov": 0.2})
+        idict = {"type": "transient_nlos_path", "max_depth": -1, "rr_depth": 5, "nlos_laser_sampling": True,
+                 "nlos_hidden_geometry_sampling": True, "account_first_and_last_bounces": False,
+                 "capture_type": capture, "temporal_filter": "box"}
+        idict.update(integrator)
+        scene = mi.load_dict({"type": "scene", "integrator": idict, "laser": laser, "relay_wall": relay,
+                              "Z": {"type": "obj", "filename": obj, "to_world": T().translate([0.0, 0.0, 1.0]), "bsdf": white}})
+        scene.data()                      # flatten now: the mesh file goes away with the temporary directory
+    mitr.nlos.focus_emitter_at_relay_wall_pixel((width / 2, height / 2), relay, laser)
+    return scene

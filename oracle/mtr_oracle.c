@@ -303,6 +303,7 @@ static void build_tris(orc_scene *sc)
         Q->qc = V(S->center[0], S->center[1], S->center[2]);
         Q->qdu = V(S->du[0], S->du[1], S->du[2]); Q->qdv = V(S->dv[0], S->dv[1], S->dv[2]);
         Q->n = vnormalize(vcross(Q->qdu, Q->qdv));                          /* normalize(to_world * Normal3f(0, 0, 1)) */
+        if (S->is_rectangle & MTR_RECT_FLIP_NORMALS) Q->n = V(-Q->n.x, -Q->n.y, -Q->n.z);   /* [Rectangle: flip_normals] */
         sh_frame_from(Q->n, Q->qdu, &Q->s, &Q->t);                          /* dp_du = to_world * (2, 0, 0): same direction */
         rect_to_object(S->center, S->du, S->dv, Q->rx, Q->ry, Q->rz);
         sc->tris[S->first_tri + 1].n = Q->n; sc->tris[S->first_tri + 1].s = Q->s; sc->tris[S->first_tri + 1].t = Q->t;
@@ -329,6 +330,7 @@ static void build_tris(orc_scene *sc)
         v3 c = vcross(du, dv);
         float len = sqrtf(vdot(c, c));
         sc->em_n[i] = vdivs(c, len);
+        if (e->flip_normals) sc->em_n[i] = V(-sc->em_n[i].x, -sc->em_n[i].y, -sc->em_n[i].z);
         /* [mitsuba3: Rectangle: surface_area = |cross(dp_du, dp_dv)|, dp_du = to_world*(2,0,0)] */
         sc->em_inv_area[i] = 1.0f / (4.0f * len);
     }
@@ -1268,6 +1270,7 @@ static void nlos_build(nlos_scene *N, const orc_scene *sc, int use_bvh)
             double len = sqrt((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z);
             a = 4.0 * len;
             N->rect_n[s] = vdivs(c, sqrtf(vdot(c, c)));
+            if (S->is_rectangle & MTR_RECT_FLIP_NORMALS) N->rect_n[s] = V(-N->rect_n[s].x, -N->rect_n[s].y, -N->rect_n[s].z);
         }
         N->shape_inv_area[s] = (float)(1.0 / a);
         /* transientnlospath.py:277-292: the relay wall has weight 0 unless ..._includes_relay_wall */

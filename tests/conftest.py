@@ -70,7 +70,7 @@ def hh_render(lib, sd, params):
 
 
 def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, film=None,
-              laser_fov=0.2, sensor_extra=None, focus=None, **integ):
+              laser_fov=0.2, sensor_extra=None, focus=None, hidden_bsdf=None, **integ):
     """NLOS scene in the style of tests/integration/test_nlos.py:1-78 and examples/transient-nlos/nlos_Z.xml:
     2x2 relay wall at the origin with a nlos_capture_meter, projector laser and sensor at (-0.5, 0, 0.25),
     hidden geometry at z = 1 (a 0.8 x 0.8 quad, or a procedural 'Z' of 6 triangles / 3 quads)."""
@@ -93,7 +93,7 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
              "nlos_hidden_geometry_sampling": True, "capture_type": capture, "temporal_filter": "box"}
     idict.update(integ)
     d = {"type": "scene", "integrator": idict, "laser": laser, "relay_wall": relay}
-    white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
+    white = hidden_bsdf or {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
     if hidden == "quad":
         d["hidden"] = {"type": "rectangle", "to_world": T().translate([0, 0, 1]).rotate([0, 1, 0], 180).scale(0.4), "bsdf": white}
     else:   # three bars of a 'Z' facing the wall (-z normals), as cubes squashed flat: 36 triangles

@@ -19,6 +19,8 @@ def _scene(kind, height):
     from conftest import make_cornell
     if kind == "cornell":
         return make_cornell(width=24, height=height, bins=48)
+    if kind == "cornell_wf":
+        return make_cornell(width=24, height=height, bins=48, amd_mode="wavefront")
     import mitransient_amd.mi as mi
     from test_rough_bsdf import _rough_cornell
     return mi.load_dict(_rough_cornell(width=24, height=height, temporal_bins=48, bin_width_opl=6.0 / 48))
@@ -33,11 +35,15 @@ def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mitransient_amd import distributed as md
-        scene = _scene(kind, height)
-        steady, transient = md.DistributedRenderer(scene, partition=partition, gather=True).render(spp=10, seed=3)
+        gather = kind != "cornell_nogather"
+        scene = _scene(kind if gather else "cornell", height)
+        r = md.DistributedRenderer(scene, partition=partition, gather=gather)
+        steady, transient = r.render(spp=10, seed=3)
         torch.cuda.synchronize()
         np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
         np.save(os.path.join(tmp, f"s{rank}.npy"), np.array(steady))
+        with open(os.path.join(tmp, f"info{rank}.txt"), "w") as fh:
+            fh.write(f"{r.last_path} {getattr(r, 'last_band_streams', 0)} {' '.join(map(str, getattr(r, 'owned_rows', None) or []))}")
     finally:
         dist.destroy_process_group()
 
@@ -114,3 +120,93 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def test_two_rank_pipelined_wavefront_bands_stay_on_one_stream(tmp_path):
+    """the wavefront organisation has ONE workspace per scene, so its row bands must not overlap on two
+    streams.  2 ranks x 8 bands with amd_mode='wavefront' against the single-process film."""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=24, height=32, bins=48, amd_mode="wavefront")
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=10)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "spp", 32, "cornell_wf"), nprocs=2, join=True)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+        path, streams = (tmp_path / f"info{r}.txt").read_text().split()[:2]
+        assert path == "pipelined" and streams == "1"
+    # ... and the fused organisation does use both
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "spp", 32, "cornell"), nprocs=2, join=True)
+    assert (tmp_path / "info0.txt").read_text().split()[:2] == ["pipelined", "2"]
+
+
+def test_two_rank_reduce_scatter_only(tmp_path):
+    """gather=False: the film reduction alone — every rank keeps the developed rows it owns (owned_rows), which together
+    are the single-process render"""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=24, height=32, bins=48)
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=10)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "spp", 32, "cornell_nogather"), nprocs=2, join=True)
+    seen = np.zeros(32, bool)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        info = (tmp_path / f"info{r}.txt").read_text().split()
+        rows = np.array([int(x) for x in info[2:]])
+        assert info[0] == "pipelined" and t.shape[0] == len(rows) == 16 and not seen[rows].any()
+        seen[rows] = True
+        assert rel_l2(t, t_ref[rows]) <= 1e-6 and rel_l2(s, s_ref[rows]) <= 1e-6
+    assert seen.all()
+
+
+def _bench_line(env_extra, args, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--spp", "8", "--width", "128", "--height", "128", "--bins", "256", "--no-cpu-baseline"]
+
+
+def test_bench_self_launches_its_ranks():
+    """the driver's command form for N > 1 WITHOUT a launcher — `python bench.py --gpus 2 ...` — starts its two ranks
+    itself and prints one JSON line (both ranks on this box's GPU, gloo instead of RCCL: MTR_BENCH_* dry-run hooks)"""
+    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0"}, ["--gpus", "2"] + BENCH_SMALL)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["comm_backend"] == "gloo" and res["rccl_ranks"] == 0
+    assert res["render_path"] == "pipelined" and res["scaling"] == "weak"
+    assert res["counters_per_step"]["paths"] == 128 * 128 * 8 * 2            # weak scaling: 8 spp per rank
+    assert res["reduce_scatter_only"]["path"] == "pipelined" and res["reduce_scatter_only"]["ms_per_step"] > 0
+    assert res["value"] > 0 and res["roofline"]["bound"] in ("hbm", "valu")
+
+
+def test_bench_under_torchrun_matches_the_contract():
+    """the same branch launched as the driver launches it: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MTR_BENCH_BACKEND="gloo", MTR_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + BENCH_SMALL, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["counters_per_step"]["paths"] == 128 * 128 * 8 * 2
+
+
+def test_bench_two_ranks_over_rccl():
+    """... and over RCCL proper wherever two GPUs are visible (skips on the one-GPU box)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    res = _bench_line({}, ["--gpus", "2"] + BENCH_SMALL)
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["comm_backend"] == "nccl" and res["render_path"] == "pipelined"

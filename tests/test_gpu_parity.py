@@ -628,3 +628,18 @@ def test_deterministic_fused_rows(oracle, bins):
         s, t = sens.film().develop()
         outs.append(np.array(t))
     assert np.array_equal(outs[0], outs[1]) and rel_l2(outs[0], t_ref) <= TOL
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("which", ["flip+turn", "floor"])
+def test_flip_normals_on_rectangles(oracle, mode, which):
+    """`flip_normals` on analytic rectangles (an emitter turned away and flipped back; a flipped one-sided floor)"""
+    from test_oracle import _flipped_cornell
+    scene = _flipped_cornell("flip+turn" if which == "flip+turn" else None, floor_flipped=(which == "floor"))
+    scene.integrator().amd_mode = mode
+    s_gpu, t_gpu = gpu_render(scene, 16, seed=2)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16, seed=2)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k

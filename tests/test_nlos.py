@@ -314,3 +314,25 @@ def test_is_confocal_capture_meter(oracle, host_harness):
     assert b > 0 and abs(a - b) <= 0.1 * b
     with pytest.raises(RuntimeError, match=r"film with size \[1,1\]"):
         make_nlos(sx=4, sy=4, capture="single", sensor_extra={"original_film_width": 8, "original_film_height": 8})
+
+
+def test_textured_hidden_geometry_uses_the_mean_colour(oracle, host_harness, tmp_path):
+    """the NLOS tier shades with constant reflectances — a bitmap on the hidden object is replaced by its mean
+    colour (Texture::mean(), which the loader stores in mtr_material.a) instead of refusing the scene"""
+    from test_textures import make_texture
+    import mitransient_amd.mi as mi
+    a = make_texture(str(tmp_path / "tex.png"))
+    tex = {"type": "diffuse", "reflectance": {"type": "bitmap", "filename": str(tmp_path / "tex.png")}}
+    scene = make_nlos(capture="confocal", hidden="quad", hidden_bsdf=tex)
+    sd = scene.data()
+    assert sd.nlos is not None and not sd.textures and all(sd.materials[i].albedo_texture == 0 for i in range(sd.n_materials))
+    from mitransient_amd.scene import _srgb_to_linear as srgb_to_linear
+    mean = srgb_to_linear(a.astype(np.float64) / 255.0).reshape(-1, 3).mean(axis=0)
+    flat = scene_with_mean = make_nlos(capture="confocal", hidden="quad",
+                                       hidden_bsdf={"type": "diffuse", "reflectance": {"type": "rgb", "value": [float(x) for x in mean]}})
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 24)
+    t4, s4, c = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    t4m, s4m, cm = oracle.render(flat.data(), p, n_threads=1)
+    assert np.count_nonzero(t4) > 50 and rel_l2(t4, t4m) <= 1e-5

@@ -372,3 +372,48 @@ def test_mesh_emitter_equals_rectangle_emitter_in_expectation(oracle, tmp_path):
     (ta, sa), (tb, sb) = imgs
     assert np.allclose(sa, sb, rtol=0.02)
     assert rel_l2(ta, tb) < 0.03
+
+
+def _flipped_cornell(light=None, floor_flipped=False, **film):
+    """cornell_box() with `flip_normals` on rectangles.  light="flip+turn": the light turned to face the ceiling AND
+    flipped (emits downwards again, with a mirrored parameterisation); "turn": turned only (emits into the ceiling)."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
+    d["sensor"]["film"].update(film)
+    if light in ("flip+turn", "turn"):
+        d["light"]["to_world"] = T().translate([0, 0.99, 0.01]).rotate([1, 0, 0], -90).scale([0.23, 0.19, 0.19])
+        if light == "flip+turn":
+            d["light"]["flip_normals"] = True
+    if floor_flipped:
+        d["floor"]["flip_normals"] = True
+    return mi.load_dict(d)
+
+
+def test_flip_normals_on_rectangles(oracle, host_harness):
+    """`flip_normals` on an analytic rectangle negates the frame normal [mitsuba3: Rectangle] — emitter side,
+    one-sided BSDF side — and leaves the parameterisation alone.  Product arithmetic == oracle bit for bit; a light turned
+    away and flipped back lights the box like the original; turned away only, it lights (almost) nothing; a flipped
+    (one-sided, diffuse) floor reflects nothing."""
+    def run(scene, spp=32):
+        sd = scene.data()
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, spp)
+        t4, s4, cnt = oracle.render(sd, p, n_threads=0)
+        ht, hs, hc = hh_render(host_harness, sd, p)
+        assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc == {**hc, **{k: cnt[k] for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")}}
+        return s4[..., :3] / np.maximum(s4[..., 3:], 1)
+    base = run(_flipped_cornell())
+    back = run(_flipped_cornell("flip+turn"))
+    away = run(_flipped_cornell("turn"))
+    e0, e1, e2 = float(base.sum()), float(back.sum()), float(away.sum())
+    assert abs(e1 - e0) <= 0.05 * e0, (e0, e1)
+    assert e2 <= 0.3 * e0, (e0, e2)      # (light leaks out of the 1 cm gap below the ceiling by inter-reflection)
+    sd = _flipped_cornell("flip+turn").data()
+    assert sd.emitters[0].flip_normals == 1 and sd.shapes[0].is_rectangle == 3
+    # flipped floor: the floor's rows of the image (below the boxes) go black — it only blocks
+    dark = run(_flipped_cornell(floor_flipped=True))
+    assert float(base[21:24, 8:16].sum()) > 1.0 and float(dark[21:24, 8:16].sum()) <= 0.01 * float(base[21:24, 8:16].sum())
+    assert float(dark.sum()) < 0.9 * e0

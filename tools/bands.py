@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'/root/repo')
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # config 2 rendered as ONE launch vs as 8 row-band launches (what the multi-GPU pipeline does per rank): cost of the per-launch tails
 import bench, torch
 scene = bench.build_scene(512,512,1024)

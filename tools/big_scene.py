@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'/root/repo')
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import mitransient_amd.mi as mi
 from mitransient_amd.scenes import staircase_like

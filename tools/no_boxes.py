@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0, '/root/repo')
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # config 2 with and without the two boxes: how much of the render is the object-node part of the traversal?
 import torch, mitransient_amd as mitr, mitransient_amd.mi as mi
 mi.set_variant("llvm_ad_rgb")

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # -DMTR_PROFILE_OCC build: how full are k_fused's persistent waves?  (wave iterations with a live lane, live lanes, lanes
 # holding a sample whose row slot is not free yet)
 import bench, torch

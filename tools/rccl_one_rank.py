@@ -3,7 +3,8 @@
 band-pipelined DistributedRenderer forced through its multi-rank branch.  RCCL moves nothing with one rank, but every API
 call, option and tensor layout of the N > 1 path executes."""
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import numpy as np, torch, torch.distributed as dist
 torch.cuda.set_device(0)

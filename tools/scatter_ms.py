@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, torch
 scene = bench.build_scene(512,512,1024, mode='wavefront')
 integ = scene.integrator(); integ.collect_stats=True

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, torch
 bench.SCENE = "staircase"
 scene = bench.build_scene(360, 640, 400, mode="fused")

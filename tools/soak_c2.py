@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # config 2 rendered repeatedly: counters must repeat exactly, films up to the summation order; fused vs wavefront likewise
 import bench, torch, numpy as np
 def run(mode):

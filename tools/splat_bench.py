@@ -3,7 +3,7 @@ Python): S synthetic contributions into a 512 x 512 x 1024 film, pixel uniform o
 bin ~ clipped Normal(400, 120), rgb ~ U(0, 1).  Reports contributions/s and algorithmic GB/s (24 B per contribution)
 against the 8 TB/s HBM peak.   usage: python tools/splat_bench.py [log2 S = 28]"""
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import mitransient_amd as mitr

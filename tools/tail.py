@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # -DMTR_PROFILE_TAIL build: first workgroup start, first and last workgroup end of k_fused (100 MHz wall clock)
 import bench, torch
 scene = bench.build_scene(512,512,1024)
