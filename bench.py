@@ -84,6 +84,8 @@ def build_scene(width, height, bins, max_depth=8, mode=None):
     d["sensor"]["film"].update(width=width, height=height, temporal_bins=bins, start_opl=3.5,
                                bin_width_opl=6.0 / bins)
     d["integrator"]["max_depth"] = max_depth
+    if os.environ.get("MTR_BENCH_CLASSIC_FILM"):             # experiments: clear + accumulate + develop instead of developed rows
+        d["integrator"]["amd_direct_develop"] = False
     if os.environ.get("MTR_BENCH_DETERMINISTIC"):            # experiments: fixed-point (order-independent) LDS rows in k_fused
         d["integrator"]["amd_deterministic"] = True
     if mode:

@@ -222,6 +222,14 @@ enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133
                                               point with 64-bit integer atomics instead of f32 atomics: sums no longer depend
                                               on the order in which lanes add, so two runs give the same bits (the wavefront
                                               organisation's scatter kernel always works this way).  Twice the LDS per row.  */
+       MTR_FLAG_DEVELOPED_ROWS = 64u,      /* single-pass film lifecycle (ABI 9): `transient_hwt4` of mtr_render is the DEVELOPED tensor
+                                              (H, W, T, 3) — for every pixel of [pixel_begin, pixel_end) the whole row is STORED,
+                                              zeros included — so the call replaces mtr_film_clear + mtr_render +
+                                              mtr_film_develop of the transient tensor (the weight channel of the reference's
+                                              raw block stays 0: develop divides by 1, the developed values ARE the raw sums).
+                                              The row holds the samples of THIS call only: use it when one call renders all
+                                              samples of its pixels.  Honoured by the fused organisation with LDS rows
+                                              (mtr_render_plan reports it); MTR_ERR_UNSUPPORTED otherwise.               */
        MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8u /* sampler seeding variant: PCG32 initseq = TEA.v1 + lane instead of TEA.v1.
                                               drjit's PCG32::seed(size, initstate, initseq) adds arange(size) to initseq;
                                               mitsuba's independent sampler passes size = 1 after the TEA scramble in the
@@ -335,7 +343,8 @@ int  mtr_render(mtr_scene *, const mtr_render_params *,
  * mtr_render resolves it; MTR_MODE_FUSED or MTR_MODE_WAVEFRONT in *mode_out).  A caller that overlaps several mtr_render
  * calls of ONE scene on different streams needs this: only the fused organisation keeps its per-launch state apart
  * (rotating work tickets); the wavefront organisation has one workspace per scene and must stay on one stream. */
-int  mtr_render_plan(mtr_scene *, const mtr_render_params *, uint32_t *mode_out);
+int  mtr_render_plan(mtr_scene *, const mtr_render_params *, uint32_t *mode_out,
+                     uint32_t *developed_rows_ok /* may be NULL: 1 when MTR_FLAG_DEVELOPED_ROWS would be honoured */);
 
 /* Zero the context's device counters on the context stream (then issue every mtr_render of the render with
  * MTR_FLAG_KEEP_COUNTERS and read the sums once with mtr_counters_read). */

@@ -23,6 +23,7 @@ MTR_FLAG_FILM_ZERO = 4
 MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8
 MTR_FLAG_KEEP_COUNTERS = 16
 MTR_FLAG_DETERMINISTIC = 32
+MTR_FLAG_DEVELOPED_ROWS = 64
 MTR_MODE_AUTO, MTR_MODE_FUSED, MTR_MODE_WAVEFRONT = 0, 1, 2
 MTR_RECT_ANALYTIC, MTR_RECT_FLIP_NORMALS = 1, 2
 
@@ -185,7 +186,7 @@ def load_library() -> C.CDLL:
     lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mtr_counters_read.argtypes = [vp, C.POINTER(mtr_counters)]
     lib.mtr_counters_reset.argtypes = [vp]
-    lib.mtr_render_plan.argtypes = [vp, C.POINTER(mtr_render_params), C.POINTER(C.c_uint32)]
+    lib.mtr_render_plan.argtypes = [vp, C.POINTER(mtr_render_params), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mtr_film_clear.argtypes = [vp, C.POINTER(mtr_film_desc), vp, vp]
     lib.mtr_render.argtypes = [vp, C.POINTER(mtr_render_params), vp, vp,
                                C.POINTER(mtr_counters), C.POINTER(mtr_kernel_times)]

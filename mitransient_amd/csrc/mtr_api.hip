@@ -475,7 +475,8 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
 
 // MTR_MODE_AUTO -> the organisation that runs: the fused kernel when the whole scene can be staged in LDS (measured 143 vs
 // 168 ms on config 2), the wavefront pipeline otherwise (BVH in HBM/L2: 21 vs 66 ms on an 81k-triangle scene)
-static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pixels, uint32_t spp_chunk, uint32_t *mode_io)
+static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pixels, uint32_t spp_chunk, uint32_t *mode_io,
+                        uint32_t *developed_ok = nullptr)
 {
     mtr_ctx *c = s->ctx;
     const Film &f = s->film;
@@ -499,6 +500,14 @@ static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pix
         mode = fits ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
     }
     *mode_io = mode;
+    if (developed_ok) {          // MTR_FLAG_DEVELOPED_ROWS: the fused kernel's row flush, rows in LDS, time bins (not a phasor film)
+        *developed_ok = 0u;
+        if (mode == MTR_MODE_FUSED && !f.n_freq) {
+            FusedArgs probe{}; FusedConfig pc{};
+            probe.sc = s->dev; probe.cam = s->cam; probe.film = f; probe.rc = make_render_const(*p, f, s->dev.n_ems); probe.nlos_on = s->nlos.on ? 1u : 0u;
+            if (fused_plan(s->dev, f, n_pixels, spp_chunk, c->n_cu, probe, pc) && pc.hist_lds) *developed_ok = 1u;
+        }
+    }
     return MTR_OK;
 }
 
@@ -556,8 +565,10 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     uint32_t launches = 0, scatter_launches = 0, wf_trace_n = 0;
     float scatter_ms = 0.0f, wf_trace_ms = 0.0f;
     if (n_pixels && a.spp_chunk) {
-        uint32_t mode = p->mode;
-        if (int r = resolve_mode(s, p, n_pixels, a.spp_chunk, &mode)) return r;
+        uint32_t mode = p->mode, dev_ok = 0u;
+        if (int r = resolve_mode(s, p, n_pixels, a.spp_chunk, &mode, &dev_ok)) return r;
+        if ((p->flags & MTR_FLAG_DEVELOPED_ROWS) && !dev_ok)
+            return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: MTR_FLAG_DEVELOPED_ROWS needs the fused organisation with time-bin rows in LDS (see mtr_render_plan)");
         if (mode == MTR_MODE_WAVEFRONT) {
             int r = wf_render(s, p, t4, s4, a.rc, &wf_trace_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr, &wf_trace_n);
             if (r) return r;
@@ -594,13 +605,13 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     return MTR_OK;
 }
 
-int mtr_render_plan(mtr_scene *s, const mtr_render_params *p, uint32_t *mode_out)
+int mtr_render_plan(mtr_scene *s, const mtr_render_params *p, uint32_t *mode_out, uint32_t *developed_rows_ok)
 {
     if (!s || !p || !mode_out) return fail(s ? s->ctx : nullptr, MTR_ERR_INVALID, "mtr_render_plan: NULL argument");
     if (p->mode > MTR_MODE_WAVEFRONT) return fail(s->ctx, MTR_ERR_INVALID, "mtr_render_plan: unknown mode");
     if (p->pixel_begin > p->pixel_end || p->spp_begin > p->spp_end) return fail(s->ctx, MTR_ERR_INVALID, "mtr_render_plan: bad range");
     uint32_t mode = p->mode;
-    if (int r = resolve_mode(s, p, p->pixel_end - p->pixel_begin, p->spp_end - p->spp_begin, &mode)) return r;
+    if (int r = resolve_mode(s, p, p->pixel_end - p->pixel_begin, p->spp_end - p->spp_begin, &mode, developed_rows_ok)) return r;
     *mode_out = mode;
     return MTR_OK;
 }

@@ -383,6 +383,26 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                         const float v = h[t];
                         if (v != 0.0f) { dst[t] = (a.rc.flags & MTR_FLAG_FILM_ZERO) ? v : dst[t] + v; h[t] = 0.0f; }
                     }
+                } else if (HIST_LDS && (a.rc.flags & MTR_FLAG_DEVELOPED_ROWS)) {
+                    // the caller's tensor is the DEVELOPED one, (H, W, T, 3): this launch holds every sample of the pixel, the
+                    // weight channel is identically 0 (develop divides by 1), so the row goes out whole — zeros included,
+                    // contiguous 12 bytes per lane — and neither a cleared film nor a develop pass is needed.  Written once,
+                    // never read here: non-temporal, so the stream does not displace the waves' scratch lines from L2.
+                    float *row3 = a.film_out + fpix * (size_t)T * 3u;
+                    for (uint32_t t = wl; t < T; t += 64u) {
+                        float r, gc, b;
+                        if (FIXED) {
+                            unsigned long long *h = s_hist64 + fs * T;
+                            r = splat_from_fixed(h[t]); gc = splat_from_fixed(h[t + plane]); b = splat_from_fixed(h[t + 2 * plane]);
+                            h[t] = 0ull; h[t + plane] = 0ull; h[t + 2 * plane] = 0ull;
+                        } else {
+                            float *h = s_hist + fs * T;
+                            r = h[t]; gc = h[t + plane]; b = h[t + 2 * plane];
+                            h[t] = 0.0f; h[t + plane] = 0.0f; h[t + 2 * plane] = 0.0f;
+                        }
+                        float *o = row3 + 3u * t;
+                        __builtin_nontemporal_store(r, o); __builtin_nontemporal_store(gc, o + 1); __builtin_nontemporal_store(b, o + 2);
+                    }
                 } else if (FIXED) {
                     float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
                     unsigned long long *h = s_hist64 + fs * T;

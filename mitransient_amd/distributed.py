@@ -104,14 +104,13 @@ class DistributedRenderer:
         sens = scene.sensors()[sensor]
         film = sens.film()
         integ.check_transient_(scene, sens)
+        if world == 1:
+            self.last_path = "single"
+            return integ.render(scene, sens, seed=seed, spp=spp)      # (incl. the single-pass film lifecycle when it applies)
         passes = integ.prepare(scene, sens, seed, spp, integ.aov_names())
         total_spp = sum(s for _, s in passes)
         W, H = film.size()
         cw, ch = film.crop_size()
-        if world == 1:
-            self.last_path = "single"
-            integ.accumulate(scene, sens, passes, total_spp)
-            return film.develop()
         self.last_path = self.partition
         # reject what the slab develop cannot do BEFORE any rendering (a phasor film has no time rows to scatter;
         # an exhaustive film's "steady" image is a mean over channels of the gathered tensor)

@@ -47,6 +47,12 @@ class TransientHDRFilm:
         self._steady_accum = None     # (H, W, 4): sum of L, sample count
         self.film_is_zero = False     # True between clear()/prepare() and the first accumulated pass
         self._device = None
+        # single-pass film lifecycle (extension): the integrator sets ``direct_develop`` before prepare() when ONE pass of
+        # the fused kernel renders every sample of every pixel — its row flush then stores the DEVELOPED (H,W,T,3) tensor
+        # whole (MTR_FLAG_DEVELOPED_ROWS), so the 4-channel block is neither allocated and cleared nor developed; the raw
+        # block is rebuilt from it on request (its weight channel is identically 0)
+        self.direct_develop = False
+        self._developed = None
 
     # -- mi.Film accessors -------------------------------------------------
     def size(self):
@@ -94,9 +100,33 @@ class TransientHDRFilm:
         self.channels = list("LW" if variant.is_monochromatic() else "RGBW") + list(aovs)
         self.crop_offset_xyt = (self.crop_offset_[0], self.crop_offset_[1], 0)
         self.crop_size_xyt = (self.size_[0], self.size_[1], self.temporal_bins)
+        if self.direct_develop:
+            torch = require_gpu()
+            shape = self.raw_shape()[:-1] + (3,)
+            if self._developed is None or tuple(self._developed.shape) != shape or self._developed.device != self._device:
+                self._developed = None            # (free before allocating: two 3 GiB tensors need not coexist)
+                self._developed = torch.empty(shape, dtype=torch.float32, device=self._device)
+            self.transient_storage = None         # the raw block is not needed (and its 4 GiB are not held)
+            self.film_is_zero = False
+            return len(self.channels)
+        self._developed = None
         self.transient_storage = self.create_block()
         self.film_is_zero = True
         return len(self.channels)
+
+    def developed_storage(self):
+        """the (H, W, T, 3) tensor a direct-develop render writes (None in the ordinary lifecycle)"""
+        return self._developed if self.direct_develop else None
+
+    def _ensure_raw(self):
+        """the 4-channel accumulator, rebuilt from a direct-develop render when something needs it (raw output, more
+        contributions from Python, a second pass): raw = (developed rgb, weight 0)"""
+        if self.transient_storage is None and self._developed is not None:
+            self.transient_storage = self.create_block()
+            self.transient_storage.torch_tensor()[..., :3].copy_(self._developed)
+            self._developed = None
+            self.direct_develop = False
+        return self.transient_storage
 
     def create_block(self):
         n_ch = 4                                            # storage channels (see prepare_transient_)
@@ -119,7 +149,12 @@ class TransientHDRFilm:
     def clear(self):
         if self._steady_accum is not None:
             self._steady_accum.zero_()
-        if self.transient_storage:
+        if self.transient_storage is None and self._developed is not None:
+            self._developed = None
+            self.direct_develop = False
+            self.transient_storage = self.create_block()
+            self.film_is_zero = True
+        elif self.transient_storage:
             self.transient_storage.clear()
             self.film_is_zero = True
 
@@ -145,6 +180,7 @@ class TransientHDRFilm:
         if active is not None:
             ok &= torch.as_tensor(active, dtype=torch.bool, device=dev)
         pixel = torch.where(ok, py * W + px, torch.full_like(px, W * H))   # out-of-range id -> dropped by the kernel
+        self._ensure_raw()
         self.film_is_zero = False
         laser = None
         if self.exhaustive_scan:            # row position laser_x * Lh + laser_y (transient_image_block.py:136-138)
@@ -190,9 +226,15 @@ class TransientHDRFilm:
         return TensorXf(steady), transient_image
 
     def develop_transient_(self, raw: bool = False):
+        torch = require_gpu()
+        if self._developed is not None and self.transient_storage is None:
+            if raw:
+                self._ensure_raw()
+            else:
+                out = self._developed             # written whole by the render: already developed
+                return TensorXf(out[..., :1].contiguous() if variant.is_monochromatic() else out)
         if not self.transient_storage:
             raise RuntimeError("No transient storage allocated, was prepare_transient_() called first?")
-        torch = require_gpu()
         if raw and variant.is_monochromatic():
             t = self.transient_storage.torch_tensor()
             return TensorXf(torch.stack((t[..., 0], t[..., 3]), dim=-1))          # "LW"

@@ -41,6 +41,10 @@ class TransientADIntegrator:
         self.pcg_initseq_plus_lane = bool(props.get("amd_pcg_initseq_plus_lane", False))
         # order-independent (fixed-point) accumulation in the fused kernel: bit-reproducible renders (extension)
         self.deterministic = bool(props.get("amd_deterministic", False))
+        # single-pass film lifecycle (extension): when one pass of the fused kernel renders all samples of all pixels, let its
+        # row flush store the developed (H,W,T,3) tensor directly — no cleared 4-channel block, no develop pass.  Same values
+        # (the weight channel is 0: develop divides by 1).  False keeps the reference's clear / accumulate / develop steps.
+        self.direct_develop = bool(props.get("amd_direct_develop", True))
         self.mode = _cabi.MTR_MODE_AUTO            # kernel organisation (extension; not a reference key)
         m = props.get("amd_mode", None)
         if m is not None:
@@ -66,8 +70,10 @@ class TransientADIntegrator:
         return []
 
     # -- common.py:32-85 ---------------------------------------------------
-    def prepare(self, scene, sensor, seed, spp, aovs):
+    def prepare(self, scene, sensor, seed, spp, aovs, _direct_develop=False):
         film = sensor.film()
+        if hasattr(film, "direct_develop"):
+            film.direct_develop = bool(_direct_develop)      # only render() asks for the single-pass lifecycle
         sampler = sensor.sampler().clone()
         if spp != 0:
             sampler.set_sample_count(spp)
@@ -155,10 +161,30 @@ class TransientADIntegrator:
             sensor = scene.sensors()[sensor]
         film = sensor.film()
         self.check_transient_(scene, sensor)
-        samplers_spps = self.prepare(scene=scene, sensor=sensor, seed=seed, spp=spp, aovs=self.aov_names())
+        direct = spp_range is None and pixel_range is None and self._direct_develop_ok(scene, sensor, spp)
+        samplers_spps = self.prepare(scene=scene, sensor=sensor, seed=seed, spp=spp, aovs=self.aov_names(), _direct_develop=direct)
         total_spp = sum(s for _, s in samplers_spps)
         self.accumulate(scene, sensor, samplers_spps, total_spp, spp_range, pixel_range, progress_callback)
         return film.develop()
+
+    def _direct_develop_ok(self, scene, sensor, spp):
+        """one pass, every sample of every film pixel in one launch of the fused kernel with LDS rows: its row flush can
+        store the developed tensor (MTR_FLAG_DEVELOPED_ROWS)"""
+        film = sensor.film()
+        if not self.direct_develop or type(film) is not TransientHDRFilm:
+            return False
+        if tuple(film.crop_size()) != tuple(film.size()) or tuple(film.crop_offset()) != (0, 0):
+            return False                                    # rows outside the crop window would never be written
+        spp = spp if spp != 0 else sensor.sampler().sample_count()
+        W, H = film.size()
+        if W * H * spp > self.max_wavefront_size:
+            return False                                    # split render: several passes add into the block
+        ctx = get_context()
+        handle = scene.gpu_handle(ctx, sensor)
+        params = self.render_params(film, 0, spp)
+        mode, ok = C.c_uint32(0), C.c_uint32(0)
+        ctx.check(ctx.lib.mtr_render_plan(handle, C.byref(params), C.byref(mode), C.byref(ok)), "mtr_render_plan")
+        return bool(ok.value)
 
     def accumulate(self, scene, sensor, samplers_spps, total_spp, spp_range=None, pixel_range=None,
                    progress_callback=None, rows_are_zero=None, defer_stats=None):
@@ -171,7 +197,11 @@ class TransientADIntegrator:
         ctx = get_context(film._device.index)
         ctx.bind_current_stream()
         handle = scene.gpu_handle(ctx, sensor)
-        tptr = C.c_void_p(film.transient_storage.torch_tensor().data_ptr())
+        direct = film.developed_storage() if hasattr(film, "developed_storage") else None
+        if direct is not None and (len(samplers_spps) > 1 or spp_range is not None or pixel_range is not None):
+            direct = None
+            film._ensure_raw()                    # (a direct-develop film asked to accumulate in parts: back to the block)
+        tptr = C.c_void_p((direct if direct is not None else film.transient_storage.torch_tensor()).data_ptr())
         sptr = C.c_void_p(film.steady_accum().data_ptr())
         multi = len(samplers_spps) > 1
         if multi and spp_range is not None:
@@ -182,7 +212,9 @@ class TransientADIntegrator:
             # a pass of a split render indexes its lanes with ITS sample count (its own sampler) and scales by the total
             params = self.render_params(film, sampler_i.seed_value(), spp_i if multi else total_spp, s0, s1, p0, p1,
                                         spp_scale=total_spp if multi else 0)
-            if film.film_is_zero or (rows_are_zero and i == 0):
+            if direct is not None:
+                params.flags |= _cabi.MTR_FLAG_DEVELOPED_ROWS  # the row flush stores the developed (H,W,T,3) rows whole
+            elif film.film_is_zero or (rows_are_zero and i == 0):
                 params.flags |= _cabi.MTR_FLAG_FILM_ZERO      # first pass after clear(): row flushes may store
             film.film_is_zero = False
             stats_now = self.collect_stats and defer_stats is None
@@ -216,7 +248,7 @@ class TransientADIntegrator:
         p0, p1 = (0, None) if pixel_range is None else pixel_range
         params = self.render_params(film, 0, total_spp, s0, s1, p0, p1)
         mode = C.c_uint32(0)
-        ctx.check(ctx.lib.mtr_render_plan(handle, C.byref(params), C.byref(mode)), "mtr_render_plan")
+        ctx.check(ctx.lib.mtr_render_plan(handle, C.byref(params), C.byref(mode), None), "mtr_render_plan")
         return {_cabi.MTR_MODE_FUSED: "fused", _cabi.MTR_MODE_WAVEFRONT: "wavefront"}[int(mode.value)]
 
     def reset_counters(self, film):

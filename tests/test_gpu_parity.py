@@ -643,3 +643,42 @@ def test_flip_normals_on_rectangles(oracle, mode, which):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("det", [False, True], ids=["f32-rows", "fixed-point-rows"])
+def test_single_pass_film_lifecycle(oracle, det):
+    """MTR_FLAG_DEVELOPED_ROWS: one pass of the fused kernel stores the developed (H,W,T,3) rows whole — no cleared block,
+    no develop pass — and gives what clear + accumulate + develop gives (bit for bit with order-independent rows)."""
+    import torch
+    a = make_cornell(width=40, height=24, bins=100, amd_mode="fused", amd_deterministic=det)
+    b = make_cornell(width=40, height=24, bins=100, amd_mode="fused", amd_deterministic=det, amd_direct_develop=False)
+    fa, fb = a.sensors()[0].film(), b.sensors()[0].film()
+    # the output tensor starts as garbage: every row must be written, zeros included
+    sa, ta = gpu_render(a, 16, seed=4)
+    assert fa.direct_develop and fa.transient_storage is None and fa.developed_storage() is not None
+    fa.developed_storage().fill_(float("nan"))
+    sa, ta = gpu_render(a, 16, seed=4)
+    sb, tb = gpu_render(b, 16, seed=4)
+    assert not fb.direct_develop and fb.transient_storage is not None
+    assert ta.shape == tb.shape == (24, 40, 100, 3) and np.isfinite(ta).all()
+    if det:
+        assert np.array_equal(ta, tb)
+    assert rel_l2(ta, tb) <= 1e-6 and rel_l2(sa, sb) <= 1e-6
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, a, 16, seed=4)
+    assert rel_l2(ta, t_ref) <= TOL and a.integrator().last_counters["splats_issued"] == cnt["splats_issued"]
+    # the raw block on request: (developed rgb, weight 0)
+    s_raw, t_raw = fa.develop(raw=True)
+    t_raw = np.array(t_raw)
+    assert t_raw.shape == (24, 40, 100, 4) and np.array_equal(t_raw[..., :3], ta) and np.all(t_raw[..., 3] == 0)
+    # a render in parts (sample shards) on the same film falls back to the accumulating block
+    integ = a.integrator()
+    passes = integ.prepare(a, a.sensors()[0], 4, 16, [])
+    assert not fa.direct_develop
+    integ.accumulate(a, a.sensors()[0], passes, 16, spp_range=(0, 7))
+    integ.accumulate(a, a.sensors()[0], passes, 16, spp_range=(7, 16))
+    torch.cuda.synchronize()
+    assert rel_l2(np.array(fa.develop()[1]), tb) <= 1e-6
+    # a crop window, or the wavefront organisation, keep the classic lifecycle
+    c = make_cornell(width=40, height=24, bins=100, amd_mode="wavefront")
+    gpu_render(c, 4)
+    assert not c.sensors()[0].film().direct_develop
