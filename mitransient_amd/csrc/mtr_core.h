@@ -1431,6 +1431,9 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     stats.closest++;
     Pending pd; Ray shadow;
     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
+    // (stacks that park path state in LDS: the values come back where they are used, so that they hold no register across
+    // the traversals)
+    if (Stack::kPark) { p.prev_p = st.unpark_prev_p(); p.prev_pdf = st.unpark_prev_pdf(); p.rng.inc = st.unpark_inc(); }
     shade_hit<ROUGH>(p, h, sc, film, rc, sink, pd, shadow);
     st.prof_mark(1);
     bool occluded = false;
@@ -1440,7 +1443,9 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
         occluded = sh.prim >= 0;
     }
     st.prof_mark(0);
+    if (Stack::kPark) p.rng.inc = st.unpark_inc();
     const bool an = shade_finish<ROUGH>(p, h, occluded, pd, sc, film, rc, sink);
+    if (Stack::kPark) { st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); }
     st.prof_mark(1);
     return an;
 }

@@ -33,6 +33,13 @@ namespace {
 
 template <int DEPTH>
 struct WStack {
+    static constexpr bool kPark = false;      // (k_fused's stack can park path state in LDS: mtr_kernels.hip)
+    __device__ __forceinline__ void park_prev_p(mtr::f3) {}
+    __device__ __forceinline__ mtr::f3 unpark_prev_p() const { return mtr::mk(0, 0, 0); }
+    __device__ __forceinline__ void park_inc(uint64_t) {}
+    __device__ __forceinline__ uint64_t unpark_inc() const { return 0; }
+    __device__ __forceinline__ void park_prev_pdf(float) {}
+    __device__ __forceinline__ float unpark_prev_pdf() const { return 0.0f; }
     int32_t *base; int sp;
     __device__ __forceinline__ void reset() { sp = 0; }
     __device__ __forceinline__ void push_if(bool c, int32_t v) { base[sp * kBlock] = v; sp += c ? 1 : 0; }

@@ -778,6 +778,28 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
         sd.tri_uv = geometry["tri_uv"]
         sd.tri_normals = geometry.get("tri_normals")
         sd.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in geometry.get("textures", [])]
+        if _variant.is_monochromatic():
+            # the records were flattened from RGB values: the monochromatic variants replace every colour by its luminance at
+            # load time (_color3), so the same happens to the stored tables (copies: the fixture stays as it is)
+            def lum3(v):
+                c = [np.float32(v[0]), np.float32(v[1]), np.float32(v[2])]
+                return (c[0] * np.float32(0.212671) + c[1] * np.float32(0.715160)) + c[2] * np.float32(0.072169)
+            mats, ems = [], []
+            for m in b.materials:
+                m = type(m).from_buffer_copy(m)
+                for fld in ("a", "b", "c", "c2"):
+                    arr = getattr(m, fld)
+                    arr[0] = arr[1] = arr[2] = lum3(arr)
+                if m.type == _cabi.MTR_BSDF_ROUGHPLASTIC and (m.a[0] + m.c[0]) > 0:
+                    m.specular_sampling_weight = np.float32(m.c[0] / (m.a[0] + m.c[0]))
+                mats.append(m)
+            for e in b.emitters:
+                e = type(e).from_buffer_copy(e)
+                e.radiance[0] = e.radiance[1] = e.radiance[2] = lum3(e.radiance)
+                ems.append(e)
+            b.materials, b.emitters = mats, ems
+            sd.textures = [np.repeat(((t[..., 0] * np.float32(0.212671) + t[..., 1] * np.float32(0.715160)) + t[..., 2] * np.float32(0.072169))[..., None], 3, axis=-1)
+                           for t in sd.textures]
     if b.tri_verts:
         sd.tri_verts = np.ascontiguousarray(np.concatenate(b.tri_verts).reshape(-1, 9))
         sd.tri_material = np.ascontiguousarray(np.concatenate(b.tri_mat))

@@ -175,7 +175,7 @@ def staircase(width=720, height=1280, temporal_bins=400, spp=64, max_depth=65, m
     return scene
 
 def nlos_z(width=256, height=256, temporal_bins=4096, bin_width_opl=2.0 ** -11, start_opl=1.85, capture="confocal", spp=512,
-           irradiance=1.0, **integrator):
+           irradiance=1.0, film_extra=None, **integrator):
     """BASELINE config 4's scene (examples/transient-nlos/nlos_Z.xml, tests/integration/test_nlos.py:1-78 of the reference):
     the reference's Z.obj (6 triangles; data fixture ``data/nlos_Z_geometry.npz``, written back to an .obj so that it goes
     through the ``obj`` shape plugin) at z = 1, a 2 x 2 relay ``rectangle`` at the origin carrying a nlos_capture_meter,
@@ -196,8 +196,9 @@ def nlos_z(width=256, height=256, temporal_bins=4096, bin_width_opl=2.0 ** -11, 
             "type": "rectangle", "bsdf": white,
             "nlos_sensor": {"type": "nlos_capture_meter", "sampler": {"type": "independent", "sample_count": spp, "seed": 0},
                             "sensor_origin": [-0.5, 0.0, 0.25],
-                            "film": {"type": "transient_hdr_film", "width": width, "height": height, "temporal_bins": temporal_bins,
-                                     "bin_width_opl": bin_width_opl, "start_opl": start_opl, "rfilter": {"type": "box"}}}})
+                            "film": dict({"type": "transient_hdr_film", "width": width, "height": height, "temporal_bins": temporal_bins,
+                                          "bin_width_opl": bin_width_opl, "start_opl": start_opl, "rfilter": {"type": "box"}},
+                                         **(film_extra or {}))}})
         laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
                               "irradiance": {"type": "rgb", "value": [irradiance] * 3}, "fov": 0.2})
         idict = {"type": "transient_nlos_path", "max_depth": -1, "rr_depth": 5, "nlos_laser_sampling": True,

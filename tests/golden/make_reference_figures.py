@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Decodes the figures the reference's OWN notebooks hold — outputs of real mitransient 1.2.0 on Mitsuba 3.6.4 / 3.7.0,
+embedded as PNGs in the .ipynb files under /root/reference/examples — into the data fixture
+``tests/golden/reference_figures.npz`` (pixel arrays, 8-bit RGB) plus what a reader sees on each figure: the notebook
+cell that drew it, the parameters in its title and the tick spacing of its colour bar / axes (read off the figure).
+
+These are the only reference-PRODUCED data in the tree (the reference's tests assert shapes only): they pin orientation,
+time axis, units and normalisation of the NLOS tier, the transient Cornell box and the phasor film at figure precision
+(tests/test_reference_figures.py).  Run in the authoring container (needs /root/reference); the GPU box only sees the .npz.
+"""
+import base64
+import io
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/examples"
+
+# (notebook, code cell index, image ordinal within the cell) -> (name, what the figure shows)
+FIGURES = [
+    # examples/transient-nlos/1-simple-nlos-scenes.ipynb (llvm_ad_mono, Mitsuba 3.7.0): Z.obj at z = 1, 64 x 64 scan, 300 bins of
+    # 0.006 from 1.85, projector irradiance 100, 25 000 spp
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 12, 0, "nlos_single_pixel_11_11",
+     dict(kind="line", capture="single", pixel=[11, 11], x_tick_step=50.0, y_tick_step=0.01, x_first_tick=0.0, y_first_tick=0.0)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 14, 0, "nlos_single_t30", dict(kind="hot", capture="single", t=30, tick_step=0.02)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 14, 1, "nlos_single_t60", dict(kind="hot", capture="single", t=60, tick_step=0.01)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 14, 2, "nlos_single_t90", dict(kind="hot", capture="single", t=90, tick_step=0.005)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 19, 0, "nlos_confocal_t23", dict(kind="hot", capture="confocal", t=23, tick_step=0.025)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 19, 1, "nlos_confocal_t30", dict(kind="hot", capture="confocal", t=30, tick_step=0.05)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 19, 2, "nlos_confocal_t35", dict(kind="hot", capture="confocal", t=35, tick_step=0.05)),
+    # exhaustive capture: 32 x 32 scan x 32 x 32 illuminated points, 5 000 spp; np.array(data)[:, :, laser_x, laser_y, t, 0]
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 25, 0, "nlos_exhaustive_t60_l5_15",
+     dict(kind="hot", capture="exhaustive", t=60, laser=[5, 15], tick_step=0.005)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 25, 1, "nlos_exhaustive_t60_l15_15",
+     dict(kind="hot", capture="exhaustive", t=60, laser=[15, 15], tick_step=0.02)),
+    ("transient-nlos/1-simple-nlos-scenes.ipynb", 25, 2, "nlos_exhaustive_t60_l25_15",
+     dict(kind="hot", capture="exhaustive", t=60, laser=[25, 15], tick_step=0.005)),
+    # examples/transient/4-rainbow_visualization.ipynb (llvm_ad_rgb, Mitsuba 3.6.4): cornell-box/cbox_diffuse.xml, 4096 spp
+    ("transient/4-rainbow_visualization.ipynb", 10, 0, "cbox_rainbow_fusion",
+     dict(kind="rgb", mode="rainbow_fusion", modulo=20, min_modulo=0, max_modulo=5, max_time_bins=200)),
+    ("transient/4-rainbow_visualization.ipynb", 11, 0, "cbox_sparse_fusion",
+     dict(kind="rgb", mode="sparse_fusion", modulo=10, min_modulo=0, max_modulo=3, max_time_bins=200, scale_fusion=0.8)),
+    ("transient/4-rainbow_visualization.ipynb", 12, 0, "cbox_peak_time_fusion",
+     dict(kind="rgb", mode="peak_time_fusion", modulo=7, min_modulo=0, max_modulo=1, max_time_bins=200, scale_fusion=2)),
+    # examples/transient/3-frequency_space_rendering.ipynb (llvm_ad_mono, Mitsuba 3.6.4): cornell-box/cbox_diffuse_freq.xml, 128 spp;
+    # real part of frequency i = 0, 10, 20, 30, 40 of the 41, 'seismic' between -max|data| and +max|data|
+    ("transient/3-frequency_space_rendering.ipynb", 14, 0, "cbox_freq_00", dict(kind="seismic", freq_index=0, tick_step=0.1)),
+    ("transient/3-frequency_space_rendering.ipynb", 14, 1, "cbox_freq_10", dict(kind="seismic", freq_index=10, tick_step=0.1)),
+    ("transient/3-frequency_space_rendering.ipynb", 14, 2, "cbox_freq_20", dict(kind="seismic", freq_index=20, tick_step=0.1)),
+    ("transient/3-frequency_space_rendering.ipynb", 14, 3, "cbox_freq_30", dict(kind="seismic", freq_index=30, tick_step=0.1)),
+    ("transient/3-frequency_space_rendering.ipynb", 14, 4, "cbox_freq_40", dict(kind="seismic", freq_index=40, tick_step=0.1)),
+]
+
+
+def main():
+    books = {}
+    arrays, meta = {}, {}
+    for nb, cell, ordinal, name, info in FIGURES:
+        if nb not in books:
+            books[nb] = json.load(open(os.path.join(REF, nb)))
+        outs = [o["data"]["image/png"] for o in books[nb]["cells"][cell].get("outputs", []) if "image/png" in o.get("data", {})]
+        png = outs[ordinal]
+        im = Image.open(io.BytesIO(base64.b64decode(png if isinstance(png, str) else "".join(png))))
+        a = np.asarray(im.convert("RGBA"))
+        # figures are drawn on an opaque white canvas with transparent margins: composite over white
+        alpha = a[..., 3:4].astype(np.float32) / 255.0
+        rgb = np.rint(a[..., :3].astype(np.float32) * alpha + 255.0 * (1.0 - alpha)).astype(np.uint8)
+        arrays[name] = rgb
+        meta[name] = dict(info, notebook="examples/" + nb, cell=cell, ordinal=ordinal)
+        print(name, rgb.shape)
+    np.savez_compressed(os.path.join(HERE, "reference_figures.npz"), meta=np.asarray(json.dumps(meta)), **arrays)
+    print("wrote reference_figures.npz", os.path.getsize(os.path.join(HERE, "reference_figures.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,13 @@ using namespace mtr;
 
 namespace {
 struct ArrStack {
+    static constexpr bool kPark = false;      // (k_fused's stack can park path state in LDS: mtr_kernels.hip)
+    void park_prev_p(mtr::f3) {}
+    mtr::f3 unpark_prev_p() const { return mtr::mk(0, 0, 0); }
+    void park_inc(uint64_t) {}
+    uint64_t unpark_inc() const { return 0; }
+    void park_prev_pdf(float) {}
+    float unpark_prev_pdf() const { return 0.0f; }
     int32_t v[130]; int sp;
     void reset() { sp = 0; }
     void push_if(bool c, int32_t x) { v[sp] = x; sp += c ? 1 : 0; }
