@@ -191,6 +191,8 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     if (hs.has_wide) UP(hs.wnodes, wnodes);
     s->dev.wnodes4 = nullptr; s->dev.n_wnodes4 = (uint32_t)hs.wnodes4.size();
     UP(hs.wnodes4, wnodes4);
+    s->dev.wnodes8q = nullptr; s->dev.n_wnodes8q = (uint32_t)hs.wnodes8q.size();
+    if (!hs.wnodes8q.empty()) UP(hs.wnodes8q, wnodes8q);
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
     if (!hs.vnormals.empty()) UP(hs.vnormals, vnormals);
     if (!hs.texels.empty()) { UP(hs.texels, texels); UP(hs.tex_info, tex_info); UP(hs.uvs, uvs); }
@@ -201,7 +203,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     for (uint32_t i = 0; i < d->n_materials; ++i) if (bsdf_is_rough(d->materials[i].type)) s->dev.has_rough = 1u;
     if (!hs.vnormals.empty() || !hs.texels.empty()) s->dev.has_rough = 1u;      // smooth-shaded triangles, bitmap textures: the extended shading code as well
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
-    s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels;
+    s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
     s->n_emitters_area = d->n_emitters;
     if (d->nlos) {

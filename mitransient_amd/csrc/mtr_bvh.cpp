@@ -509,66 +509,108 @@ uint32_t build_wide(const BvhBuild &bvh, const BvhPrims *prims, const float *ver
     wide_rec<kWide>(bvh, prims, verts, 0, wide, 1, levels, width);
     return levels;
 }
-uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
+namespace {
+
+// collapse to width W, breadth-first order (the top of the tree — the nodes every ray visits — sits at the lowest indices),
+// then the children's planes quantised to 8 bits on the node's own grid: origin = the node's lower corner, one power-of-two
+// step per axis, the smallest whose 255 multiples cover the extent; every plane rounds outwards (checked in f64).
+// emit(i, node, meta, plo[3], phi[3]): plo[k] / phi[k] hold byte c = child c of axis k (64-bit: up to 8 children)
+template <uint32_t W, class Emit>
+uint32_t build_quantised(const BvhBuild &bvh, size_t &n_out, Emit emit)
 {
-    wide.clear();
-    if (bvh.nodes.empty()) return 0;
     uint32_t levels = 0;
-    std::vector<WNodeT<4>> full;
-    wide_rec<4>(bvh, nullptr, nullptr, 0, full, 1, levels, 4);
-    {   // breadth-first order: the top of the tree — the nodes every ray visits — sits at the lowest indices
+    std::vector<WNodeT<W>> full;
+    wide_rec<W>(bvh, nullptr, nullptr, 0, full, 1, levels, W);
+    {
         std::vector<uint32_t> order{ 0u }, pos(full.size(), 0u);
         for (size_t i = 0; i < order.size(); ++i)
             for (uint32_t c = 0; c < full[order[i]].count; ++c)
                 if (full[order[i]].ref[c] >= 0) order.push_back((uint32_t)full[order[i]].ref[c]);
         for (size_t i = 0; i < order.size(); ++i) pos[order[i]] = (uint32_t)i;
-        std::vector<WNodeT<4>> bfs(full.size());
+        std::vector<WNodeT<W>> bfs(full.size());
         for (size_t i = 0; i < order.size(); ++i) {
             bfs[i] = full[order[i]];
             for (uint32_t c = 0; c < bfs[i].count; ++c) if (bfs[i].ref[c] >= 0) bfs[i].ref[c] = (int32_t)pos[bfs[i].ref[c]];
         }
         full.swap(bfs);
     }
-    wide.resize(full.size());
+    n_out = full.size();
     for (size_t i = 0; i < full.size(); ++i) {
-        const WNodeT<4> &w = full[i];
+        const WNodeT<W> &w = full[i];
         const float *f = &w.box[0].x;
         auto lo = [&](uint32_t c, int k) { return f[4 * (3 * (c >> 1) + k) + (c & 1)]; };
         auto hi = [&](uint32_t c, int k) { return f[4 * (3 * (c >> 1) + k) + 2 + (c & 1)]; };
-        QNode4 q{};
-        float *org = &q.q[0].x;
+        float org[3];
         uint32_t meta = (w.axis << 24) | (w.count << 26);
-        uint32_t plo[3] = { 0, 0, 0 }, phi[3] = { 0, 0, 0 };
+        uint64_t plo[3] = { 0, 0, 0 }, phi[3] = { 0, 0, 0 };
         for (int k = 0; k < 3; ++k) {
             float o = INFINITY, top = -INFINITY;
             for (uint32_t c = 0; c < w.count; ++c) { o = std::min(o, lo(c, k)); top = std::max(top, hi(c, k)); }
             org[k] = o;
-            // smallest power-of-two step whose 255 multiples cover the extent; every plane rounds outwards (checked in f64)
             int e = -100;
             const double ext = (double)top - (double)o;
             if (ext > 0.0) e = std::max(-100, (int)std::ceil(std::log2(ext / 255.0)));
             for (;; ++e) {
                 const double step = std::ldexp(1.0, e);
                 bool ok = true;
-                uint32_t wl = 0, wh = 0;
+                uint64_t wl = 0, wh = 0;
                 for (uint32_t c = 0; c < w.count && ok; ++c) {
                     long ql = (long)std::floor(((double)lo(c, k) - (double)o) / step), qh = (long)std::ceil(((double)hi(c, k) - (double)o) / step);
                     while (ql > 0 && (double)o + (double)ql * step > (double)lo(c, k)) --ql;
                     while ((double)o + (double)qh * step < (double)hi(c, k)) ++qh;
                     if (ql < 0) ql = 0;
                     if (qh > 255) { ok = false; break; }
-                    wl |= (uint32_t)ql << (8 * c); wh |= (uint32_t)qh << (8 * c);
+                    wl |= (uint64_t)ql << (8 * c); wh |= (uint64_t)qh << (8 * c);
                 }
                 if (ok) { plo[k] = wl; phi[k] = wh; break; }
             }
             meta |= (uint32_t)(e + 127) << (8 * k);
         }
-        q.q[0].w = bitsf(meta);
-        for (int c = 0; c < 4; ++c) (&q.q[1].x)[c] = bitsf((uint32_t)w.ref[c]);
-        q.q[2] = q4{ bitsf(plo[0]), bitsf(plo[1]), bitsf(plo[2]), bitsf(phi[0]) };
-        q.q[3] = q4{ bitsf(phi[1]), bitsf(phi[2]), 0.0f, 0.0f };
-        wide[i] = q;
+        emit(i, w, org, meta, plo, phi);
     }
+    return levels;
+}
+
+} // namespace
+
+uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide)
+{
+    wide.clear();
+    if (bvh.nodes.empty()) return 0;
+    size_t n = 0;
+    std::vector<QNode4> out;
+    const uint32_t levels = build_quantised<4>(bvh, n, [&](size_t i, const WNodeT<4> &w, const float *org, uint32_t meta, const uint64_t *plo, const uint64_t *phi) {
+        if (out.size() <= i) out.resize(i + 1);
+        QNode4 q{};
+        q.q[0] = q4{ org[0], org[1], org[2], bitsf(meta) };
+        for (int c = 0; c < 4; ++c) (&q.q[1].x)[c] = bitsf((uint32_t)w.ref[c]);
+        q.q[2] = q4{ bitsf((uint32_t)plo[0]), bitsf((uint32_t)plo[1]), bitsf((uint32_t)plo[2]), bitsf((uint32_t)phi[0]) };
+        q.q[3] = q4{ bitsf((uint32_t)phi[1]), bitsf((uint32_t)phi[2]), 0.0f, 0.0f };
+        out[i] = q;
+    });
+    wide.swap(out);
+    return levels;
+}
+
+uint32_t build_wide8q(const BvhBuild &bvh, std::vector<QNode8> &wide)
+{
+    wide.clear();
+    if (bvh.nodes.empty()) return 0;
+    size_t n = 0;
+    std::vector<QNode8> out;
+    const uint32_t levels = build_quantised<8>(bvh, n, [&](size_t i, const WNodeT<8> &w, const float *org, uint32_t meta, const uint64_t *plo, const uint64_t *phi) {
+        if (out.size() <= i) out.resize(i + 1);
+        QNode8 q{};
+        auto lo32 = [](uint64_t v) { return bitsf((uint32_t)v); };
+        auto hi32 = [](uint64_t v) { return bitsf((uint32_t)(v >> 32)); };
+        q.q[0] = q4{ org[0], org[1], org[2], bitsf(meta) };
+        q.q[1] = q4{ lo32(plo[0]), hi32(plo[0]), lo32(plo[1]), hi32(plo[1]) };
+        q.q[2] = q4{ lo32(plo[2]), hi32(plo[2]), lo32(phi[0]), hi32(phi[0]) };
+        q.q[3] = q4{ lo32(phi[1]), hi32(phi[1]), lo32(phi[2]), hi32(phi[2]) };
+        for (int c = 0; c < 8; ++c) (&q.q[4].x)[c] = bitsf((uint32_t)w.ref[c]);
+        out[i] = q;
+    });
+    wide.swap(out);
     return levels;
 }
 

@@ -42,5 +42,7 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
 uint32_t build_wide(const BvhBuild &bvh, const BvhPrims *prims, const float *verts, std::vector<WNode> &wide);
 // the same, 4 wide (one node per 128-byte line): scenes walked in HBM
 uint32_t build_wide4(const BvhBuild &bvh, std::vector<QNode4> &wide);
+// ... and 8 wide with the same quantisation (QNode8, 96 bytes)
+uint32_t build_wide8q(const BvhBuild &bvh, std::vector<QNode8> &wide);
 
 } // namespace mtr

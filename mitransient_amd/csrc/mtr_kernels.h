@@ -16,6 +16,7 @@ struct SceneDev {
     const Node *nodes; uint32_t n_nodes;
     const WNode *wnodes; uint32_t n_wnodes;                            // 8-wide tree over the same leaves (null for large scenes)
     const QNode4 *wnodes4; uint32_t n_wnodes4;                         // quantised 4-wide tree (always present)
+    const QNode8 *wnodes8q; uint32_t n_wnodes8q;                       // quantised 8-wide tree (scenes walked in HBM; null: walk wnodes4)
     const TriPair *tpairs; const TriShade *tshade; uint32_t n_slots;   // triangle slots (even), see mtr_core.h
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;
@@ -23,7 +24,7 @@ struct SceneDev {
     const q4 *vnormals;              // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
     const q4 *texels, *tex_info, *uvs;   // bitmap textures (HBM; null without): see SceneView
     uint32_t bvh_depth;
-    uint32_t wide_levels, wide4_levels;   // levels of wnodes / wnodes4: a wide walk stacks at most one group per level
+    uint32_t wide_levels, wide4_levels, wide8q_levels;   // levels of wnodes / wnodes4 / wnodes8q: a wide walk stacks at most one group per level
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS
     uint32_t has_rough;              // the scene needs the EXTENDED shading code (kernels instantiated with ROUGH = true): a material
                                      // is a GGX lobe (MTR_BSDF_ROUGH*), or a triangle is smooth-shaded (vnormals)

@@ -221,11 +221,11 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         copy16(ts, a.sc.tshade, align16(a.sc.n_slots * sizeof(TriShade)), tid);
         copy16(mm, a.sc.mats, align16(a.sc.n_mats * sizeof(mtr_material)), tid);
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.wnodes8q = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
     } else {
         sv.nodes = a.sc.nodes; sv.tpairs = a.sc.tpairs; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
-        sv.wnodes = nullptr; sv.wnodes4 = a.sc.wnodes4;
+        sv.wnodes = nullptr; sv.wnodes4 = a.sc.wnodes4; sv.wnodes8q = a.sc.wnodes8q;
         sv.node_pairs = false;
     }
     // ---- work distribution: workgroups draw CHUNKS of a.chunk consecutive pixels from a global ticket counter (pixels
@@ -561,7 +561,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
     // the kernel walks a WIDE tree (8-wide in LDS, quantised 4-wide in HBM): one stacked group per level (+ the row the
     // branch-free push writes before it knows whether it counts)
-    const uint32_t rows = (cfg.scene_lds ? sc.wide_levels : sc.wide4_levels) + 1u;
+    const uint32_t rows = (cfg.scene_lds ? sc.wide_levels : (sc.wnodes8q ? sc.wide8q_levels : sc.wide4_levels)) + 1u;
     args.stack_rows = rows;
     uint32_t fixed_b = (rows + (args.nlos_on ? 0u : LdsStack::kParkRows)) * kBlock * 4 + 64;
     if (cfg.scene_lds) fixed_b += scene_b;
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     LdsStack st; st.base = (int32_t *)smem + threadIdx.x; st.sp = 0;
     SceneView sv;
     sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
-    sv.wnodes = nullptr; sv.wnodes4 = nullptr;
+    sv.wnodes = nullptr; sv.wnodes4 = nullptr; sv.wnodes8q = nullptr;
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;

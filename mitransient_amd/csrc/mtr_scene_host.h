@@ -13,6 +13,7 @@ namespace mtr {
 struct HostScene {
     std::vector<Node> nodes;
     std::vector<WNode> wnodes;                 // 8-wide collapse of `nodes` (small scenes only: walked in LDS)
+    std::vector<QNode8> wnodes8q;              // quantised 8-wide collapse (large scenes only)
     std::vector<QNode4> wnodes4;               // quantised 4-wide collapse of `nodes` (walked in HBM by the wavefront kernels)
     bool has_wide = false;                     // wnodes is valid (possibly empty: a scene without triangles)
     std::vector<TriPair> tpairs;               // [n_slots / 2]
@@ -27,7 +28,7 @@ struct HostScene {
     std::vector<q4> texels; std::vector<q4> tex_info; std::vector<q4> uvs;
     std::vector<float> face_pmf, face_cdf;
     uint32_t bvh_depth = 0, n_leaves = 0;
-    uint32_t wide_levels = 0, wide4_levels = 0;        // levels of the collapsed trees (= their traversal stack bound)
+    uint32_t wide_levels = 0, wide4_levels = 0, wide8q_levels = 0;        // levels of the collapsed trees (= their traversal stack bound)
     Camera cam{};
     Film film{};
 };

@@ -59,7 +59,7 @@ __device__ __forceinline__ void cp16(void *dst, const void *src, uint32_t bytes,
 }
 
 // stage the scene in LDS (or point at HBM) and carve the traversal stack
-__host__ __device__ inline uint32_t wf_stack_rows(const SceneDev &sc, bool scene_lds) { return (scene_lds ? sc.wide_levels : sc.wide4_levels) + 1u; }
+__host__ __device__ inline uint32_t wf_stack_rows(const SceneDev &sc, bool scene_lds) { return (scene_lds ? sc.wide_levels : (sc.wnodes8q ? sc.wide8q_levels : sc.wide4_levels)) + 1u; }
 
 template <int STACK, bool SCENE_LDS>
 __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem, int tid, SceneView &sv, WStack<STACK> &st,
@@ -87,12 +87,12 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
         cp16(ts, sc.tshade, al16(sc.n_slots * sizeof(TriShade)), tid);
         cp16(mm, sc.mats, al16(sc.n_mats * sizeof(mtr_material)), tid);
         cp16(ee, sc.ems, al16(sc.n_ems * sizeof(Emitter)), tid);
-        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
+        sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.wnodes8q = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
         __syncthreads();
     } else {
         sv.nodes = sc.nodes; sv.tpairs = sc.tpairs; sv.tshade = sc.tshade; sv.mats = sc.mats; sv.ems = sc.ems;
-        sv.wnodes = nullptr; sv.wnodes4 = sc.wnodes4;
+        sv.wnodes = nullptr; sv.wnodes4 = sc.wnodes4; sv.wnodes8q = sc.wnodes8q;
         sv.node_pairs = false;
     }
     st.base = s_stack + tid; st.sp = 0;
@@ -385,8 +385,13 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
                 if (n_node >= n_leaf) { if (at_node) wide_node_step<kWide, true>(tr, sv.wnodes, st); }
                 else { if (at_leaf) wide_leaf_step<kWide>(tr, sv, sv.wnodes, st, any_hit); }
             } else {
-                if (n_node >= n_leaf) { if (at_node) qwide_node_step(tr, sv.wnodes4, st); }
-                else { if (at_leaf) qwide_leaf_step(tr, sv, st, any_hit); }
+                if (sv.wnodes8q) {
+                    if (n_node >= n_leaf) { if (at_node) q8_node_step(tr, sv.wnodes8q, st); }
+                    else { if (at_leaf) q8_leaf_step(tr, sv, st, any_hit); }
+                } else {
+                    if (n_node >= n_leaf) { if (at_node) qwide_node_step(tr, sv.wnodes4, st); }
+                    else { if (at_leaf) qwide_leaf_step(tr, sv, st, any_hit); }
+                }
             }
         }
         __syncthreads();

@@ -58,7 +58,7 @@ struct HostSink {
 static bool g_node_pairs = false;
 extern "C" void hh_set_node_pairs(int on) { g_node_pairs = on != 0; }
 // ... and so is the 8-wide tree the fused kernel walks in LDS
-static int g_wide = 0;       // 1: 8-wide (LDS form), 2: 4-wide (HBM form; scenes with more than 256 BVH2 packets)
+static int g_wide = 0;       // 1: 8-wide (LDS form), 2: quantised 4-wide, 3: quantised 8-wide (HBM forms)
 extern "C" void hh_set_wide(int on) { g_wide = on; }
 
 extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, float *t4, float *s4, mtr_counters *out)
@@ -70,6 +70,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.node_pairs = g_node_pairs;
     sv.wnodes = (g_wide == 1 && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.wnodes4 = (g_wide == 2 && !hs.wnodes4.empty()) ? hs.wnodes4.data() : nullptr;
+    sv.wnodes8q = (g_wide == 3 && !hs.wnodes8q.empty()) ? hs.wnodes8q.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -126,8 +127,10 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
                 if (h0.prim >= 0) path.dist = -h0.t;
             }
             bool alive = true;
+            const bool trace_log = getenv("HH_TRACE_LOG") != nullptr;       // debugging aid: the ray of every bounce
             while (alive) {
                 BounceStats bs{ 0, 0 };
+                if (trace_log) printf("s %u depth %u ray o %.9g %.9g %.9g d %.9g %.9g %.9g tmax %.9g\n", s, path.depth, path.ray.o.x, path.ray.o.y, path.ray.o.z, path.ray.d.x, path.ray.d.y, path.ray.d.z, path.ray.tmax);
                 alive = path_bounce(path, sv, hs.film, rc, st, sink, bs);
                 closest += bs.closest; shadow += bs.shadow; ++bounces;
             }
@@ -164,6 +167,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     sv.node_pairs = g_node_pairs;
     sv.wnodes = (g_wide == 1 && hs.has_wide && !hs.wnodes.empty()) ? hs.wnodes.data() : nullptr;
     sv.wnodes4 = (g_wide == 2 && !hs.wnodes4.empty()) ? hs.wnodes4.data() : nullptr;
+    sv.wnodes8q = (g_wide == 3 && !hs.wnodes8q.empty()) ? hs.wnodes8q.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
     sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
@@ -306,6 +310,23 @@ extern "C" int hh_check_wide(const mtr_scene_desc *d, uint32_t *n_wide8, uint32_
         std::sort(got.begin(), got.end());
         if (got != want) return -15;
         for (int v : seen) if (v != 1) return -16;
+    }
+    {   // the quantised 8-wide tree: every leaf exactly once, every node reached once
+        std::vector<int32_t> got; std::vector<int> seen(hs.wnodes8q.size(), 0);
+        std::vector<int32_t> st; if (!hs.wnodes8q.empty()) { st.push_back(0); seen[0] = 1; }
+        while (!st.empty()) {
+            const QNode8 &q = hs.wnodes8q[st.back()]; st.pop_back();
+            const uint32_t meta = fbits(q.q[0].w), count = (meta >> 26) & 0xfu;
+            if (count < 1 || count > 8 || ((meta >> 24) & 3u) > 2) return -32;
+            for (uint32_t c = 0; c < count; ++c) {
+                const int32_t ref = (int32_t)fbits((&q.q[4].x)[c]);
+                if (ref < 0) got.push_back(ref);
+                else { if ((size_t)ref >= seen.size() || seen[ref]++) return -34; st.push_back(ref); }
+            }
+        }
+        std::sort(got.begin(), got.end());
+        if (!hs.wnodes8q.empty() && got != want) return -35;
+        for (int v : seen) if (v != 1) return -36;
     }
     // containment: walk BVH2 and the 4-wide tree together is not possible (different shapes); instead check, for every
     // 4-wide node, that each decoded child box contains the union of the leaf boxes below it — cheap proxy: it must contain

@@ -283,7 +283,7 @@ def test_host_harness_specular_and_flags(oracle, host_harness, node_pairs):
     assert np.count_nonzero(t4) > 1000
 
 
-@pytest.mark.parametrize("wide", [0, 1, 2], ids=["bvh2", "wide-8", "wide-4"])
+@pytest.mark.parametrize("wide", [0, 1, 2, 3], ids=["bvh2", "wide-8", "wide-4", "wide-8q"])
 def test_host_harness_staircase_like(oracle, host_harness, wide):
     """BASELINE config-5 stand-in (procedural stair flight: conductor / dielectric / twosided mix, 852 triangles,
     BVH depth 13, max_depth 65, camera_unwarp): product arithmetic == oracle, bit for bit — through the BVH2, the

@@ -183,10 +183,15 @@ def check_cbox_steady(figures, s3):
     regions = {"floor": (slice(300, 345), slice(90, 200)), "back wall": (slice(90, 140), slice(110, 230)),
                "left (red) wall": (slice(140, 240), slice(8, 40)), "right (green) wall": (slice(140, 240), slice(330, 362)),
                "tall box front": (slice(180, 300), slice(115, 215))}
+    # per surface: the colour (chromaticity to 0.02) and, more loosely, the brightness — the canvas resampling blends band
+    # edges with black, the deeper inside the bands the closer the figure's values come (3-pixel erosion: 0.90 .. 0.99 of the
+    # render's on thin .. wide bands), so the level is held to 15 %
+    deep = binary_erosion(rgb.sum(-1) > 0.1, iterations=3) & (rgb.max(-1) < 0.98)
     for label, sl in regions.items():
-        sel = lit[sl]
+        sel = deep[sl]
         assert sel.sum() >= 100, label
-        a, b = rgb[sl][sel].mean(0), mine_full[sl][sel].mean(0)
+        a, b = rgb[sl][sel].mean(0), (mine_full / k)[sl][sel].mean(0)            # (the light is on a band: the figure's maximum is 1)
+        assert np.all(np.abs(a / a.sum() - b / b.sum()) <= 0.02), (label, a, b)
         assert np.all(np.abs(a - b) <= 0.03 + 0.15 * a), (label, a, b)
         assert np.argmax(a) == np.argmax(b), (label, a, b)                       # the surface's dominant colour
 

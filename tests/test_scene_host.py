@@ -130,7 +130,7 @@ def _hh_intersect(lib, sd, o, d, maxt=None):
     return t, prim, occ
 
 
-@pytest.mark.parametrize("pairs,wide", [(0, 0), (1, 0), (1, 1)], ids=["plane-selects", "plane-offsets", "wide-tree"])
+@pytest.mark.parametrize("pairs,wide", [(0, 0), (1, 0), (1, 1), (0, 2), (0, 3)], ids=["plane-selects", "plane-offsets", "wide-tree", "quantised-4", "quantised-8"])
 def test_product_bvh_equals_brute_force(oracle, host_harness, pairs, wide):
     host_harness.hh_set_node_pairs(pairs)
     host_harness.hh_set_wide(wide)
