@@ -244,3 +244,54 @@ def test_config4_full_row_length_properties(tmp_path):
     integ.accumulate(scene, sens, passes, 16, spp_range=(5, 16))
     s2, t2 = sens.film().develop()
     assert float((t2.torch() - keep).double().norm() / keep.double().norm()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_config5_full_size_properties_and_strips(oracle):
+    """BASELINE config 5 at its stated size — the staircase's 262,663 triangles, 512 x 512 px, 2048 bins over OPL 0 .. 40,
+    2048 spp, max_depth 65, camera_unwarp — rendered once (the full-size render had no check of any kind).
+    Properties of the whole film (sample count, finiteness, energy: the time window only cuts, it never adds; counters
+    repeat from render to render), and two pixel strips against the CPU oracle.  The strips are held to 1e-5 and to
+    counters within 1e-5 RELATIVE, not to the last ray: on grazing sliver triangles the f32 Moller-Trumbore distance can
+    leave the triangle's own box by more than its padding, and then which of two near-coincident slivers is 'closest'
+    depends on what was culled — brute force and ANY tree differ on about one ray in 1e8 (tools/find_tree_diff.py)."""
+    import torch
+    from mitransient_amd.scenes import staircase
+    W = H = 512
+    T, SPP = 2048, 2048
+    scene = staircase(width=W, height=H, temporal_bins=T, spp=SPP, max_depth=65)
+    film = scene.sensors()[0].film()
+    film.start_opl, film.bin_width_opl = 0.0, 40.0 / T
+    integ = scene.integrator()
+    integ.collect_stats = True
+    steady, transient = integ.render(scene, seed=0, spp=SPP)
+    torch.cuda.synchronize()
+    c1 = dict(integ.total_counters)
+    t = transient.torch()
+    assert tuple(t.shape) == (H, W, T, 3) and c1["paths"] == W * H * SPP
+    assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0.0
+    s = steady.torch()
+    tsum = t.sum(dim=2)
+    assert bool((tsum <= s * (1 + 1e-4) + 1e-6).all())                  # contributions beyond OPL 40 are in the steady image only
+    frac = float(tsum.sum() / s.sum())
+    assert 0.5 < frac <= 1.0 + 1e-5, frac
+    assert c1["rays_closest"] > 6 * c1["paths"] and c1["splats_issued"] > c1["paths"]      # long paths, as the scene's depth 65 allows
+    del t, tsum
+    # two strips of 4 pixels against the oracle (all 2048 samples), rendered into a fresh film by pixel range
+    for first in (260 * W + 254, 120 * W + 400):
+        st_s, st_t = integ.render(scene, seed=0, spp=SPP, pixel_range=(first, first + 4))
+        torch.cuda.synchronize()
+        got = dict(integ.total_counters)
+        y, x = divmod(first, W)
+        t_gpu = st_t.torch()[y, x:x + 4].cpu().numpy()
+        p = integ.render_params(film, 0, SPP, 0, SPP, first, first + 4)
+        # (the oracle's film is np.zeros: lazily mapped, only the strip's pages are ever touched)
+        t4, s4, cnt = oracle.render(scene.data(), p, use_bvh=True)
+        assert rel_l2(t_gpu, t4[y, x:x + 4, :, :3]) <= TOL
+        del t4, s4
+        for k in COUNTERS:
+            assert abs(got[k] - cnt[k]) <= max(2, 1e-5 * cnt[k]), (k, got[k], cnt[k])
+    # counters repeat exactly from render to render
+    integ.render(scene, seed=0, spp=SPP)
+    torch.cuda.synchronize()
+    assert dict(integ.total_counters) == c1

@@ -1,0 +1,9 @@
+#!/bin/bash
+# tools/profile_all.sh <round-tag> — the profile passes behind profiles/traffic.json: config 2 (k_fused + the wavefront leg) and
+# config 5 (staircase, one full-size render per pass).  Afterwards, in the authoring container:
+#   python tools/pmc_summary.py --merge gpurun_out/prof_<tag>_c2/traffic.json
+#   python tools/pmc_summary.py --merge gpurun_out/prof_<tag>_c5/traffic.json --section staircase
+TAG=$1
+tools/profile.sh ${TAG}_c2 > gpurun_out/prof_${TAG}_c2.log 2>&1
+STEPS=1 WARMUP=0 RENDERS=1 tools/profile.sh ${TAG}_c5 --scene staircase --no-scatter-leg > gpurun_out/prof_${TAG}_c5.log 2>&1
+tail -3 gpurun_out/prof_${TAG}_c2.log gpurun_out/prof_${TAG}_c5.log
