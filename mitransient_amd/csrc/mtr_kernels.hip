@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     bool alive = false;
     bool waiting = i < n_lanes;          // holds a sample index whose path has not started yet
     Path p;
+    p.L = mk(0, 0, 0);
     uint32_t q = 0, slot = 0;
+    bool carry = false;                  // the path that just ended leaves its radiance in p.L: this lane's next path is in the same pixel
     for (;;) {
         st.prof_mark(4);                 // (experiment builds) sections: 0 traversal, 1 shading, 2 path start, 3 end-of-path bookkeeping, 4 row flush, 5 idle
         if (__ballot(waiting) != 0ull) {
@@ -315,12 +317,14 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 if (__hip_atomic_load(s_owner + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == q) {
                     const uint32_t s = a.spp_begin + (i - q * a.spp_chunk);
                     const uint32_t pixel = pixel_of(q);
+                    const f3 L_carried = carry ? p.L : mk(0, 0, 0);
                     if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
                     else { path_begin(p, a.cam, a.film, a.rc, pixel, s); if (LdsStack::kPark) { st.park_inc(p.rng.inc); st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); } }
                     if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
                         Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
                         if (h0.prim >= 0) p.dist = -h0.t;
                     }
+                    p.L = L_carried; carry = false;
                     alive = true; waiting = false; started = true;
                 }
             }
@@ -369,24 +373,30 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
             if (!alive) {
-                // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+                // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200).  The lane takes its next sample first:
+                // when that is another sample of the SAME pixel (with 1024 spp a lane runs four in a row), the radiance simply
+                // keeps accumulating in p.L and is deposited with the last of them — three LDS float atomics per RUN of paths
+                // instead of per path (they retire at 3 clocks per lane on gfx950).  The pixel cannot close in between: this
+                // lane's next path of it has not ended.  Not for the order-independent rows (the runs depend on timing).
+                // The sample COUNT needs no atomic at all: the row is flushed when all spp_chunk paths of the pixel have ended
+                // (config 2: 68.7 -> 67.8 ms for that one atomic per path; fixed-point sums instead of f32: 67.7 -> 67.95, not kept).
+                i = atomicAdd(s_next, 1u);
+                waiting = i < n_lanes;
+                carry = !FIXED && waiting && fastdiv(i, a.div_spp) == q;
                 const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
-                if (fx < a.film.width && fy < a.film.height) {
+                if (fx < a.film.width && fy < a.film.height && !carry) {
                     if (FIXED) {
                         unsigned long long *sp = s_steady64 + 4 * slot;
-                        atomicAdd(sp, splat_to_fixed(p.L.x)); atomicAdd(sp + 1, splat_to_fixed(p.L.y));
-                        atomicAdd(sp + 2, splat_to_fixed(p.L.z)); atomicAdd(sp + 3, splat_to_fixed(1.0f));
+                        atomicAdd(sp, splat_to_fixed(p.L.x)); atomicAdd(sp + 1, splat_to_fixed(p.L.y)); atomicAdd(sp + 2, splat_to_fixed(p.L.z));
                     } else {
                         float *sp = s_steady + 4 * slot;
-                        lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z); lds_add(sp + 3, 1.0f);
+                        lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z);
                     }
                 }
                 // acq_rel: this lane's row / steady adds are performed before the count that may release the row.
                 // (One atomic per wave for the next samples and one per (wave, slot) for the count — ballots, readlanes and a
                 // leader lane — was measured: end-of-path bookkeeping 8.0 -> 11.0 % of the wave's time; not kept.)
                 closes = __hip_atomic_fetch_add(s_done + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == a.spp_chunk;
-                i = atomicAdd(s_next, 1u);
-                waiting = i < n_lanes;
             }
         }
         if (!NLOS) {          // one closest-hit ray per live lane (counted with w_bounce), at most one shadow ray, at most two contributions
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     // contiguous 12 bytes per lane — and neither a cleared film nor a develop pass is needed.  Written once,
                     // never read here: non-temporal, so the stream does not displace the waves' scratch lines from L2.
                     float *row3 = a.film_out + fpix * (size_t)T * 3u;
-                    for (uint32_t t = wl; t < T; t += 64u) {
+                    for (uint32_t t = wl; t < T; t += 64u) {      // (four bins per lane and pass, 16-byte accesses: no faster — 68.7 vs 68.7 ms — and two more spills)
                         float r, gc, b;
                         if (FIXED) {
                             unsigned long long *h = s_hist64 + fs * T;
@@ -485,6 +495,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     float v;
                     if (FIXED) { v = splat_from_fixed(s_steady64[4 * fs + wl]); s_steady64[4 * fs + wl] = 0ull; }
                     else { v = s_steady[4 * fs + wl]; s_steady[4 * fs + wl] = 0.0f; }
+                    if (wl == 3) v = (float)a.spp_chunk;          // every sample of the pixel of this launch has ended
                     if (v != 0.0f) a.steady_out[fpix * 4u + wl] += v;
                 }
             }
