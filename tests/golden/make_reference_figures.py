@@ -38,6 +38,19 @@ FIGURES = [
      dict(kind="hot", capture="exhaustive", t=60, laser=[15, 15], tick_step=0.02)),
     ("transient-nlos/1-simple-nlos-scenes.ipynb", 25, 2, "nlos_exhaustive_t60_l25_15",
      dict(kind="hot", capture="exhaustive", t=60, laser=[25, 15], tick_step=0.005)),
+    # examples/transient-nlos/2-complex-nlos-scenes.ipynb (llvm_ad_mono): transient_nlos_path behind a PERSPECTIVE camera,
+    # nlos-z-simple.xml (25 000 spp) and nlos-z-room.xml (250 000 spp), 32 x 32 px, 300 bins of 0.006 from 5.25; the colour
+    # bars carry a 1e-5 / 1e-6 offset (tick_step is the absolute spacing)
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 5, 0, "nlos_cam_simple_t130", dict(kind="hot", scene="nlos-z-simple", t=130, tick_step=1e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 5, 1, "nlos_cam_simple_t140", dict(kind="hot", scene="nlos-z-simple", t=140, tick_step=0.25e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 5, 2, "nlos_cam_simple_t150", dict(kind="hot", scene="nlos-z-simple", t=150, tick_step=0.2e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 11, 0, "nlos_cam_room_t130", dict(kind="hot", scene="nlos-z-room", t=130, tick_step=1e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 11, 1, "nlos_cam_room_t140", dict(kind="hot", scene="nlos-z-room", t=140, tick_step=0.5e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 11, 2, "nlos_cam_room_t150", dict(kind="hot", scene="nlos-z-room", t=150, tick_step=0.25e-5)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 13, 0, "nlos_cam_room_t110", dict(kind="hot", scene="nlos-z-room", t=110, tick_step=0.5e-6)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 13, 1, "nlos_cam_room_t120", dict(kind="hot", scene="nlos-z-room", t=120, tick_step=0.5e-6)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 13, 2, "nlos_cam_room_t200", dict(kind="hot", scene="nlos-z-room", t=200, tick_step=0.5e-6)),
+    ("transient-nlos/2-complex-nlos-scenes.ipynb", 13, 3, "nlos_cam_room_t210", dict(kind="hot", scene="nlos-z-room", t=210, tick_step=0.5e-6)),
     # examples/transient/4-rainbow_visualization.ipynb (llvm_ad_rgb, Mitsuba 3.6.4): cornell-box/cbox_diffuse.xml, 4096 spp
     ("transient/4-rainbow_visualization.ipynb", 10, 0, "cbox_rainbow_fusion",
      dict(kind="rgb", mode="rainbow_fusion", modulo=20, min_modulo=0, max_modulo=5, max_time_bins=200)),
@@ -71,8 +84,36 @@ def main():
         arrays[name] = rgb
         meta[name] = dict(info, notebook="examples/" + nb, cell=cell, ordinal=ordinal)
         print(name, rgb.shape)
+    for k in arrays:
+        if "capture" not in meta[k] and meta[k].get("kind") == "hot":
+            meta[k]["capture"] = "camera"
     np.savez_compressed(os.path.join(HERE, "reference_figures.npz"), meta=np.asarray(json.dumps(meta)), **arrays)
+    xml_scenes()
     print("wrote reference_figures.npz", os.path.getsize(os.path.join(HERE, "reference_figures.npz")), "bytes")
+
+
+def xml_scenes():
+    """examples/transient-nlos/nlos-z-simple.xml / nlos-z-room.xml as DATA: the dictionary form of the scene (this repo's XML
+    loader) with every `ply` mesh replaced by its triangles — the 8 / 18 triangles of the files under meshes/"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import load_ply
+    from mitransient_amd.scenes import _jsonable
+    mi.set_variant("llvm_ad_mono")
+    out = {}
+    for name in ("nlos-z-simple", "nlos-z-room"):
+        from mitransient_amd.xml_loader import xml_to_dict
+        d = _jsonable(xml_to_dict(f"{REF}/transient-nlos/{name}.xml"))
+        for key, v in d.items():
+            if isinstance(v, dict) and v.get("type") == "ply":
+                tris = load_ply(os.path.join(REF, "transient-nlos", v["filename"]))
+                out[f"{name}/{key}"] = np.asarray(tris, np.float32)
+                v["filename"] = f"{name}/{key}"
+        out[f"{name}/dict"] = np.asarray(json.dumps(d))
+    mi.set_variant("llvm_ad_rgb")
+    np.savez_compressed(os.path.join(HERE, "nlos_xml_scenes.npz"), **out)
+    print("wrote nlos_xml_scenes.npz", {k: (v.shape if v.ndim else "json") for k, v in out.items()})
 
 
 if __name__ == "__main__":
