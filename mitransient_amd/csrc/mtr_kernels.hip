@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 // (config 2: 68.7 -> 67.8 ms for that one atomic per path; fixed-point sums instead of f32: 67.7 -> 67.95, not kept).
                 i = atomicAdd(s_next, 1u);
                 waiting = i < n_lanes;
-                carry = !FIXED && waiting && fastdiv(i, a.div_spp) == q;
+                carry = !FIXED && waiting && (i - q * a.spp_chunk) < a.spp_chunk;      // the next sample is still in pixel q (i only grows)
                 const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
                 if (fx < a.film.width && fy < a.film.height && !carry) {
                     if (FIXED) {
