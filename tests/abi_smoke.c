@@ -85,6 +85,25 @@ int main(void)
            (unsigned long long)cnt.splats_issued, et, es, diff);
     int ok = cnt.paths == (unsigned long long)W * H * SPP && cnt.rays_closest >= cnt.paths && cnt.splats_issued > 0 &&
              es > 0 && diff <= 1e-4 * es;
+    /* ABI 9: the single-pass film lifecycle.  mtr_render_plan says which organisation runs and whether the row flush can store
+     * DEVELOPED rows; then ONE mtr_render writes the (H,W,T,3) tensor — filled with garbage beforehand — with no clear and no
+     * develop, and must give what clear + render + develop gave (f32 LDS sums: up to summation order) */
+    uint32_t mode = 99u, dev_ok = 0u;
+    CHECK(mtr_render_plan(scene, &p, &mode, &dev_ok));
+    ok = ok && (mode == MTR_MODE_FUSED || mode == MTR_MODE_WAVEFRONT);
+    if (dev_ok) {
+        float *ht2 = (float *)malloc(nt * 12);
+        if (hipMemset(t3, 0xff, nt * 12) || hipMemset(s4, 0, np * 16)) { fprintf(stderr, "memset failed\n"); return 1; }
+        p.flags = MTR_FLAG_DEVELOPED_ROWS;
+        CHECK(mtr_counters_reset(ctx));
+        CHECK(mtr_render(scene, &p, t3, s4, &cnt, NULL));
+        if (hipDeviceSynchronize() || hipMemcpy(ht2, t3, nt * 12, hipMemcpyDeviceToHost)) { fprintf(stderr, "copy back failed\n"); return 1; }
+        double num = 0, den = 0;
+        for (size_t i = 0; i < nt * 3; ++i) { const double dlt = (double)ht2[i] - ht[i]; num += dlt * dlt; den += (double)ht[i] * ht[i]; }
+        printf("developed rows: relative L2 against clear + render + develop %.3e (mode %u)\n", sqrt(num / (den > 0 ? den : 1)), mode);
+        ok = ok && num <= 1e-10 * den && cnt.paths == (unsigned long long)W * H * SPP;
+        free(ht2);
+    } else puts("developed rows: not offered for this plan");
     mtr_scene_destroy(scene); mtr_ctx_destroy(ctx);
     hipFree(t4); hipFree(s4); hipFree(t3); hipFree(s3); free(ht); free(hs);
     puts(ok ? "abi_smoke: PASS" : "abi_smoke: FAIL");
