@@ -344,7 +344,21 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     // tile = P pixels x S samples (2^25 slots); segment = G whole pixels (about 4096 slots: with the persistent
     // k_wf_trace a segment is drained once per launch, so longer segments waste less — staircase 1024: 425 ms,
     // 2048: 390, 4096: 360, 8192: 397)
-    uint32_t kTileSlots = 1u << 25; uint32_t kSegSlots = 4096u;      // tiles measured: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms per config-2 render
+    // Tile: as many slots as half of the free device memory holds, at most 2^28 (82 GB of workspace at 305 B per slot).  Every
+    // bounce of every tile costs four launches with ~0.1 ms of fixed cost each, and with max_depth 65 most of them run nearly
+    // empty: config 5 (2^29 slots) with tiles of 2^25 / 2^26 / 2^27 / 2^28 slots: 2.01 / 1.80 / 1.70 / 1.59 s per render
+    // (config 2 in this organisation: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms).
+    // Segment: scenes walked in HBM 8192 slots (config 5: 2048 / 4096 / 8192 / 16384 slots: 338 / 288 / 275 / 273 ms at 256 spp
+    // with the 8-wide tree), scenes staged in LDS 4096 (config 2: 141 against 169 ms with 8192).
+    uint32_t kTileSlots = 1u << 28; uint32_t kSegSlots = cfg.scene_lds ? 4096u : 8192u;
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t per_slot = 320;                                   // planes 112 + queues 44 + rays 96 + records 64 + occlusion 1, rounded up
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t budget = (free_b + (size_t)s->wf.n_slots * per_slot) / 2;     // (the workspace this scene already holds counts as free)
+            while (kTileSlots > (1u << 22) && (size_t)kTileSlots * per_slot > budget) kTileSlots >>= 1;
+        } else kTileSlots = 1u << 25;
+    }
     if (const char *e = getenv("MTR_WF_TILE_LOG2")) kTileSlots = 1u << atoi(e);      // experiments
     if (const char *e = getenv("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
     const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;

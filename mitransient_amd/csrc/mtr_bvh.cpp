@@ -256,6 +256,9 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     if (n == 0) return;
     Shared S; S.verts = verts;
     Builder B(S); B.prims = prims;
+    // leaves: two triangles for scenes staged in LDS (k_fused: 1 / 3 / 4 measured worse), four for the large scenes walked in
+    // HBM (config 5 at 256 spp, 8-wide tree: 1 / 2 / 3 / 4 triangles per leaf: 335 / 288 / 283 / 275 ms — fewer, fuller leaves)
+    if (n >= 1024) B.kLeafTarget = 4;
     if (const char *e = getenv("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     S.tmp.reserve(3 * (size_t)n);
     for (uint32_t i = 0; i < n;) {
