@@ -386,7 +386,9 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     if (s->nlos.on) a.nlos = s->nlos.k;
     const int grid_full = c->n_cu * 8;
     // NLOS paths end by the integrator's own rules (filter depth, roulette): the host polls the live count like an unbounded render
-    const bool unbounded = p->max_depth < 0 || p->max_depth > 256 || s->nlos.on;
+    // (deep bounded renders poll too: with max_depth 65 no path of config 5 is alive after some 35 bounces, and every bounce of
+    // every tile is four launches)
+    const bool unbounded = p->max_depth < 0 || p->max_depth > 16 || s->nlos.on;
     // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
     const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth + (s->nlos.on ? 2u : 0u));
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev, trace_ev;

@@ -332,6 +332,10 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
     wf_ticket_begin(a, tid);
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t n_live = any_hit ? a.seg_shadow[sg] : a.seg_live[(size_t)par * a.n_seg + sg];
+        if (n_live == 0u) {                  // an emptied segment (most of them in the deep bounces of max_depth 65): no barriers, no LDS
+            if (!any_hit && tid < (int)kWfKeys) a.seg_mat[(size_t)sg * kWfKeys + tid] = 0u;
+            continue;
+        }
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
         if (tid == 0) *s_fetch = 0u;
         __syncthreads();
@@ -438,9 +442,10 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
     const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     wf_ticket_begin(a, tid);
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
+        const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
+        if (n_k == 0u) { if (tid == 0) a.seg_shadow[sg] = 0u; continue; }       // (an emptied segment)
         if (tid == 0) *s_tail = 0u;
         __syncthreads();
-        const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
         const uint32_t *q = a.q_mat + (size_t)sg * a.seg;
         uint32_t *q_out = a.q_shadow + (size_t)sg * a.seg;
         float4 *r_out = a.r_shadow + 2 * (size_t)sg * a.seg;
@@ -503,6 +508,11 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const Wf
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
         const uint32_t npx = min(a.G, a.P - pl0);
+        {   // an emptied segment: nothing to shade, nothing survives
+            uint32_t n_all = 0u;
+            for (uint32_t k = 0; k < kWfKeys; ++k) n_all += a.seg_mat[(size_t)sg * kWfKeys + k];
+            if (n_all == 0u) { if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = 0u; continue; }
+        }
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) s_steady[t] = 0.0f;
         if (tid == 0) *s_next_p = 0u;
