@@ -81,7 +81,8 @@ struct Builder {
     std::vector<uint32_t> order;
     const BvhPrims *prims = nullptr;
 
-    static constexpr int kBins = 16;
+    static constexpr int kMaxBins = 64;
+    int kBins = 16;
     uint32_t kLeafTarget = 2, kLeafMax = 4;
 
     explicit Builder(Shared &s) : S(s) {}
@@ -152,7 +153,7 @@ struct Builder {
         for (int ax = 0; ax < 3; ++ax) {
             float ext = cb.hi[ax] - cb.lo[ax];
             if (!(ext > 0.0f)) continue;
-            Box bins[kBins]; uint32_t cnt[kBins];
+            Box bins[kMaxBins]; uint32_t cnt[kMaxBins];
             for (int k = 0; k < kBins; ++k) { bins[k].reset(); cnt[k] = 0; }
             float scale = (float)kBins / ext;
             for (uint32_t i = first; i < first + count; ++i) {
@@ -160,7 +161,7 @@ struct Builder {
                 int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + ax] - cb.lo[ax]) * scale)));
                 bins[k].grow(sbox[t]); cnt[k] += items[t].n_tris;
             }
-            float right_area[kBins]; uint32_t right_cnt[kBins];
+            float right_area[kMaxBins]; uint32_t right_cnt[kMaxBins];
             Box acc; acc.reset(); uint32_t c = 0;
             for (int k = kBins - 1; k > 0; --k) { acc.grow(bins[k]); c += cnt[k]; right_area[k] = acc.area(); right_cnt[k] = c; }
             acc.reset(); c = 0;
@@ -258,7 +259,8 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     Builder B(S); B.prims = prims;
     // leaves: two triangles for scenes staged in LDS (k_fused: 1 / 3 / 4 measured worse), four for the large scenes walked in
     // HBM (config 5 at 256 spp, 8-wide tree: 1 / 2 / 3 / 4 triangles per leaf: 335 / 288 / 283 / 275 ms — fewer, fuller leaves)
-    if (n >= 1024) B.kLeafTarget = 4;
+    if (n >= 1024) { B.kLeafTarget = 4; B.kBins = 32; }          // (SAH bins 8 / 16 / 32 / 64: 243 / 239 / 233 / 237 ms)
+    if (const char *e = getenv("MTR_BVH_BINS")) { B.kBins = atoi(e); if (B.kBins < 4) B.kBins = 4; if (B.kBins > Builder::kMaxBins) B.kBins = Builder::kMaxBins; }   // experiments
     if (const char *e = getenv("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     S.tmp.reserve(3 * (size_t)n);
     for (uint32_t i = 0; i < n;) {
