@@ -491,8 +491,11 @@ __global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
 // dwords (187 ms vs 215 ms per config-2 render)
 // EXT: the extended shading code (GGX lobes, interpolated normals) — only scenes that need it pay for it
 // (config 2, wavefront organisation: k_wf_shade 1.44 ms per launch without, 1.82 ms with)
+#ifndef MTR_WF_SHADE_WAVES
+#define MTR_WF_SHADE_WAVES 4
+#endif
 template <int STACK, bool SCENE_LDS, bool EXT>
-__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : 4) k_wf_shade(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_next_p = (uint32_t *)smem;                      // tail of the segment's next live list
