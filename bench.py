@@ -348,7 +348,7 @@ def main():
     path_taken = renderer.last_path
     # N > 1: the same steps with the film reduction ALONE (reduce-scatter, every rank keeps the developed rows it owns —
     # north_star's "single RCCL reduce"); the headline keeps the all-gather that hands every rank the whole tensor
-    rs_only = None
+    rs_only = rows_leg = None
     if world > 1:
         r2 = mdist.DistributedRenderer(scene, partition="spp", gather=False)
         e2, t2, *_ = timed_run(r2)
@@ -356,6 +356,14 @@ def main():
                    "unit": "Mray/s", "what": "reduce_scatter(film) only: every rank develops and keeps its rows of each band "
                                              "(3 GiB all-gather of the developed tensor left out)", "path": r2.last_path}
         del r2
+        # ... and the partition that needs no reduction at all: every rank renders ITS rows with all
+        # spp x N samples — the same work per rank — and only the developed rows are gathered
+        r3 = mdist.DistributedRenderer(scene, partition="rows", gather=True)
+        e3, t3, *_ = timed_run(r3)
+        rows_leg = {"ms_per_step": e3 / args.steps * 1e3, "value": (t3["rays_closest"] + t3["rays_shadow"]) / e3 / 1e6,
+                                  "unit": "Mray/s", "what": "pixel rows sharded instead of samples: no film reduction, all_gather of the developed rows",
+                                  "path": r3.last_path}
+        del r3
 
     # ---- untimed extra leg (rank 0, N=1): the same render in wavefront mode, to time the stand-alone
     # time-bin scatter-add kernel (k_wf_scatter) with HIP events on its stream
@@ -468,6 +476,7 @@ def main():
             res["comm_backend"] = backend
             res["render_path"] = path_taken
             res["reduce_scatter_only"] = rs_only
+            res["row_sharded"] = rows_leg
         if scatter:
             res["scatter_add"] = scatter
         if extra:

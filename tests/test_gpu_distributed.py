@@ -185,6 +185,7 @@ def test_bench_self_launches_its_ranks():
     assert res["render_path"] == "pipelined" and res["scaling"] == "weak"
     assert res["counters_per_step"]["paths"] == 128 * 128 * 8 * 2            # weak scaling: 8 spp per rank
     assert res["reduce_scatter_only"]["path"] == "pipelined" and res["reduce_scatter_only"]["ms_per_step"] > 0
+    assert res["row_sharded"]["path"] == "rows" and res["row_sharded"]["value"] > 0
     assert res["value"] > 0 and res["roofline"]["bound"] in ("hbm", "valu")
 
 
