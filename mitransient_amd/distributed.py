@@ -107,10 +107,22 @@ class DistributedRenderer:
         if world == 1:
             self.last_path = "single"
             return integ.render(scene, sens, seed=seed, spp=spp)      # (incl. the single-pass film lifecycle when it applies)
-        passes = integ.prepare(scene, sens, seed, spp, integ.aov_names())
-        total_spp = sum(s for _, s in passes)
         W, H = film.size()
         cw, ch = film.crop_size()
+        # sample shards through the band pipeline: when the fused kernel can store DEVELOPED rows (MTR_FLAG_DEVELOPED_ROWS), every
+        # rank renders its partial sums straight into an (H,W,T,3) tensor — developing is linear, the weight channel is 0 — so the
+        # film reduction moves 3 channels instead of 4 and neither the 4-channel clear nor a develop pass runs on any rank
+        nb = self.bands
+        pipelined = (self.partition == "spp" and nb > 1 and ch == H and cw == W and H % (nb * world) == 0
+                     and getattr(film, "frequencies_f32", None) is None)
+        n_spp = spp if spp != 0 else sens.sampler().sample_count()
+        dev3 = bool(pipelined and not film.exhaustive_scan and
+                    integ.developed_rows_ok(scene, sens, n_spp, shard_range(n_spp, world, rank), (0, (H // nb) * W)))
+        passes = integ.prepare(scene, sens, seed, spp, integ.aov_names(), _direct_develop=dev3)
+        total_spp = sum(s for _, s in passes)
+        if dev3 and len(passes) > 1:              # (a split render accumulates in the block)
+            dev3 = False
+            film._ensure_raw()
         self.last_path = self.partition
         # reject what the slab develop cannot do BEFORE any rendering (a phasor film has no time rows to scatter;
         # an exhaustive film's "steady" image is a mean over channels of the gathered tensor)
@@ -118,10 +130,9 @@ class DistributedRenderer:
             raise NotImplementedError("DistributedRenderer: phasor_hdr_film is single-GPU only")
         if self.partition == "spp":
             my_spp = shard_range(total_spp, world, rank)
-            nb = self.bands
-            if nb > 1 and ch == H and cw == W and H % (nb * world) == 0:
+            if pipelined:
                 self.last_path = "pipelined"
-                return self._render_pipelined(integ, sens, film, passes, total_spp, my_spp, nb, world)
+                return self._render_pipelined(integ, sens, film, passes, total_spp, my_spp, nb, world, dev3)
             integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp)
         else:
             r0, r1 = shard_range(ch, world, rank)
@@ -162,7 +173,7 @@ class DistributedRenderer:
             full_s = torch.cat([full_s, torch.zeros((H - full_s.shape[0],) + tuple(full_s.shape[1:]), dtype=full_s.dtype, device=full_s.device)])
         return TensorXf(full_t.mean(dim=-1) if exh else full_s), TensorXf(full_t)
 
-    def _render_pipelined(self, integ, sens, film, passes, total_spp, my_spp, nb, world):
+    def _render_pipelined(self, integ, sens, film, passes, total_spp, my_spp, nb, world, dev3=False):
         """bands of rows: render band b | reduce-scatter + develop + all-gather band b-1 on a side stream"""
         import torch
         import torch.distributed as dist
@@ -170,11 +181,13 @@ class DistributedRenderer:
         scene = self.scene
         W, H = film.size()
         T = film.temporal_bins
-        raw_t = film.transient_storage.torch_tensor()
+        # dev3: this rank's partial sums, already in the developed (H, W, T, 3) layout
+        raw_t = film.developed_storage() if dev3 else film.transient_storage.torch_tensor()
         raw_s = film.steady_accum()
         dev = raw_t.device
         rows_b = H // nb
         gather = self.gather
+        self.last_reduced_channels = 3 if dev3 else 4
         rank = dist.get_rank(self.group)
         per = rows_b // world                       # rows of a band this rank owns after the reduce-scatter
         # gather=False: "the single RCCL reduce" only — every rank keeps the developed rows it owns (band b: rows
@@ -219,7 +232,7 @@ class DistributedRenderer:
                 # every band owns its rows: they are still zero from prepare()'s clear when the band's only pass flushes them;
                 # no read-back per band (the launches stay asynchronous): counters sum on the device
                 integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W),
-                                 rows_are_zero=True, defer_stats="more")
+                                 rows_are_zero=True, defer_stats="more", developed_partial=dev3)
                 ready.record(lanes[b & 1])
             band_ev.append((begin, ready))
             with torch.cuda.stream(side):
@@ -228,12 +241,18 @@ class DistributedRenderer:
                     side.synchronize()              # gloo collectives are host-driven (CPU test path)
                 slab_t = reduce_scatter_rows(raw_t[r0:r1], self.group)          # THE film reduction, band b
                 slab_s = reduce_scatter_rows(raw_s[r0:r1], self.group)
-                if gather:
+                if dev3:                            # the sum of developed partial rows IS the developed row
+                    d_t, d_s = slab_t, film.develop_slab(None, slab_s)[1]
+                    if not gather:
+                        out_t[b * per:(b + 1) * per].copy_(d_t)
+                        out_s[b * per:(b + 1) * per].copy_(d_s)
+                elif gather:
                     d_t, d_s = film.develop_slab(slab_t, slab_s)
-                    out_t[r0:r1].copy_(all_gather_rows(d_t, rows_b, self.group))
-                    out_s[r0:r1].copy_(all_gather_rows(d_s, rows_b, self.group))
                 else:
                     film.develop_slab(slab_t, slab_s, out=(out_t[b * per:(b + 1) * per], out_s[b * per:(b + 1) * per]))
+                if gather:
+                    out_t[r0:r1].copy_(all_gather_rows(d_t, rows_b, self.group))
+                    out_s[r0:r1].copy_(all_gather_rows(d_s, rows_b, self.group))
         main.wait_stream(side)
         for st in lanes:
             main.wait_stream(st)
@@ -244,6 +263,9 @@ class DistributedRenderer:
             ms = [a.elapsed_time(b_) for a, b_ in band_ev]
             integ.total_times = {"total_ms": sum(ms), "trace_ms": sum(ms), "scatter_ms": 0.0, "trace_launches": nb,
                                  "scatter_launches": 0}
+        if dev3:                                 # the film held this rank's PARTIAL sums: not a result anyone should develop
+            film._developed = None
+            film.direct_develop = False
         if film.exhaustive_scan:                 # transient_hdr_film.py:213-214
             return TensorXf(out_t.mean(dim=-1)), TensorXf(out_t)
         return TensorXf(out_s), TensorXf(out_t)

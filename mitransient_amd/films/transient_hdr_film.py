@@ -261,6 +261,20 @@ class TransientHDRFilm:
         reduce-scatter, so that every GPU develops 1/N of the film.  ``out``: (transient, steady) contiguous
         destination tensors of the slab's developed shape (written in place), or None to allocate."""
         torch = require_gpu()
+        if raw_t is None:                         # the steady image alone (the transient rows came developed out of the render)
+            rows = int(raw_s.shape[0])
+            out_s = torch.empty((rows, self.size_[0], 3), dtype=torch.float32, device=raw_s.device) if out is None else out
+            if rows:
+                ctx = get_context(raw_s.device.index)
+                ctx.bind_current_stream()
+                fd = self.desc()
+                fd.height = rows
+                fd.crop_height = min(fd.crop_height, rows)
+                fd.crop_offset_y = 0
+                raw_s = raw_s.contiguous()
+                ctx.check(ctx.lib.mtr_film_develop(ctx.handle, C.byref(fd), None, None, C.c_void_p(raw_s.data_ptr()),
+                                                   C.c_void_p(out_s.data_ptr())), "mtr_film_develop")
+            return None, out_s
         rows = int(raw_t.shape[0])
         W = self.size_[0]
         if out is not None:

@@ -187,7 +187,7 @@ class TransientADIntegrator:
         return bool(ok.value)
 
     def accumulate(self, scene, sensor, samplers_spps, total_spp, spp_range=None, pixel_range=None,
-                   progress_callback=None, rows_are_zero=None, defer_stats=None):
+                   progress_callback=None, rows_are_zero=None, defer_stats=None, developed_partial=False):
         """The pass loop of render() (common.py:157-210) without prepare/develop: ADDS into the film.
         ``rows_are_zero``: the caller vouches that the film rows of ``pixel_range`` are untouched since clear() (a render
         split into disjoint row bands: every band's FIRST pass may store its rows instead of read-modify-write).
@@ -197,8 +197,10 @@ class TransientADIntegrator:
         ctx = get_context(film._device.index)
         ctx.bind_current_stream()
         handle = scene.gpu_handle(ctx, sensor)
+        # ``developed_partial``: the caller wants the developed (H,W,T,3) rows of THIS call's samples and pixels only — partial
+        # sums it reduces itself (multi-GPU: a 3-channel reduce-scatter instead of a 4-channel one, no clear, no develop)
         direct = film.developed_storage() if hasattr(film, "developed_storage") else None
-        if direct is not None and (len(samplers_spps) > 1 or spp_range is not None or pixel_range is not None):
+        if direct is not None and (len(samplers_spps) > 1 or ((spp_range is not None or pixel_range is not None) and not developed_partial)):
             direct = None
             film._ensure_raw()                    # (a direct-develop film asked to accumulate in parts: back to the block)
         tptr = C.c_void_p((direct if direct is not None else film.transient_storage.torch_tensor()).data_ptr())
@@ -236,6 +238,25 @@ class TransientADIntegrator:
                     self.total_times[k] += self.last_times[k]
             if progress_callback:
                 progress_callback((i + 1) / len(samplers_spps))
+
+    def developed_rows_ok(self, scene, sensor, total_spp, spp_range=None, pixel_range=None):
+        """would mtr_render honour MTR_FLAG_DEVELOPED_ROWS for this (partial) render of a plain transient_hdr_film?"""
+        film = sensor.film()
+        if not self.direct_develop or type(film) is not TransientHDRFilm:
+            return False
+        if tuple(film.crop_size()) != tuple(film.size()) or tuple(film.crop_offset()) != (0, 0):
+            return False
+        W, H = film.size()
+        if W * H * total_spp > self.max_wavefront_size:
+            return False
+        ctx = get_context()
+        handle = scene.gpu_handle(ctx, sensor)
+        s0, s1 = (0, total_spp) if spp_range is None else spp_range
+        p0, p1 = (0, None) if pixel_range is None else pixel_range
+        params = self.render_params(film, 0, total_spp, s0, s1, p0, p1)
+        mode, ok = C.c_uint32(0), C.c_uint32(0)
+        ctx.check(ctx.lib.mtr_render_plan(handle, C.byref(params), C.byref(mode), C.byref(ok)), "mtr_render_plan")
+        return bool(ok.value)
 
     def resolved_mode(self, scene, sensor, total_spp, spp_range=None, pixel_range=None):
         """the kernel organisation mtr_render would run (MTR_MODE_AUTO resolved by the library): "fused" | "wavefront".

@@ -42,6 +42,8 @@ def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
         torch.cuda.synchronize()
         np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
         np.save(os.path.join(tmp, f"s{rank}.npy"), np.array(steady))
+        with open(os.path.join(tmp, f"ch{rank}.txt"), "w") as fh:
+            fh.write(str(getattr(r, "last_reduced_channels", 0)))
         with open(os.path.join(tmp, f"info{rank}.txt"), "w") as fh:
             fh.write(f"{r.last_path} {getattr(r, 'last_band_streams', 0)} {' '.join(map(str, getattr(r, 'owned_rows', None) or []))}")
     finally:
@@ -136,9 +138,13 @@ def test_two_rank_pipelined_wavefront_bands_stay_on_one_stream(tmp_path):
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
         path, streams = (tmp_path / f"info{r}.txt").read_text().split()[:2]
         assert path == "pipelined" and streams == "1"
-    # ... and the fused organisation does use both
+        assert (tmp_path / f"ch{r}.txt").read_text() == "4"            # the wavefront organisation reduces the 4-channel block
+    # ... and the fused organisation does use both, and reduces DEVELOPED partial rows: 3 channels, no clear, no develop
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "spp", 32, "cornell"), nprocs=2, join=True)
     assert (tmp_path / "info0.txt").read_text().split()[:2] == ["pipelined", "2"]
+    assert (tmp_path / "ch0.txt").read_text() == "3"
+    for r in range(2):
+        assert rel_l2(np.load(tmp_path / f"t{r}.npy"), t_ref) <= 1e-6 and rel_l2(np.load(tmp_path / f"s{r}.npy"), s_ref) <= 1e-6
 
 
 def test_two_rank_reduce_scatter_only(tmp_path):
