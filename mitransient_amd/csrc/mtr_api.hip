@@ -43,7 +43,7 @@ struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one til
 struct NlosDev {                // NLOS tier: device tables + constants (mtr_scene_set_nlos)
     bool on = false;
     NlosConst k{};
-    void *shapes = nullptr, *tables = nullptr, *hg_tris = nullptr, *targets = nullptr;
+    void *shapes = nullptr, *tables = nullptr, *hg_tris = nullptr, *hg_vn = nullptr, *targets = nullptr;
     std::vector<mtr_shape> host_shapes;      // kept: the triangle -> shape table of the scene
 };
 
@@ -52,6 +52,7 @@ struct mtr_scene {
     WfWorkspace wf;
     NlosDev nlos;
     std::vector<float> tri_verts;            // host copy (NLOS tables are re-derived when the laser moves)
+    std::vector<float> tri_normals;          // ... and the vertex normals (empty without): Mesh::sample_position on hidden meshes
     uint32_t n_emitters_area = 0;
     SceneDev dev{};
     Camera cam{};
@@ -186,7 +187,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
 #define UP(vec, field)                                                       \
     do { rc = upload(s, vec, &s->dev.field); if (rc) { mtr_scene_destroy(s); return rc; } } while (0)
     UP(hs.nodes, nodes); UP(hs.tpairs, tpairs); UP(hs.tshade, tshade); UP(hs.mats, mats); UP(hs.ems, ems);
-    s->dev.samp_tris = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr; s->dev.vnormals = nullptr; s->dev.texels = s->dev.tex_info = s->dev.uvs = nullptr;
+    s->dev.samp_tris = nullptr; s->dev.samp_vn = nullptr; s->dev.face_pmf = s->dev.face_cdf = nullptr; s->dev.vnormals = nullptr; s->dev.texels = s->dev.tex_info = s->dev.uvs = nullptr;
     s->dev.wnodes = nullptr; s->dev.n_wnodes = (uint32_t)hs.wnodes.size();
     if (hs.has_wide) UP(hs.wnodes, wnodes);
     s->dev.wnodes4 = nullptr; s->dev.n_wnodes4 = (uint32_t)hs.wnodes4.size();
@@ -194,6 +195,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.wnodes8q = nullptr; s->dev.n_wnodes8q = (uint32_t)hs.wnodes8q.size();
     if (!hs.wnodes8q.empty()) UP(hs.wnodes8q, wnodes8q);
     if (!hs.samp_tris.empty()) { UP(hs.samp_tris, samp_tris); UP(hs.face_pmf, face_pmf); UP(hs.face_cdf, face_cdf); }
+    if (!hs.samp_vn.empty()) UP(hs.samp_vn, samp_vn);
     if (!hs.vnormals.empty()) UP(hs.vnormals, vnormals);
     if (!hs.texels.empty()) { UP(hs.texels, texels); UP(hs.tex_info, tex_info); UP(hs.uvs, uvs); }
 #undef UP
@@ -205,6 +207,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
+    if (d->tri_normals) s->tri_normals.assign(d->tri_normals, d->tri_normals + 9 * (size_t)d->n_tris);
     s->n_emitters_area = d->n_emitters;
     if (d->nlos) {
         rc = mtr_scene_set_nlos(s, d->nlos);
@@ -221,6 +224,7 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     HIP_TRY(c, hipSetDevice(c->device));
     mtr_scene_desc d{};
     d.n_tris = (uint32_t)(s->tri_verts.size() / 9); d.tri_verts = s->tri_verts.data(); d.n_emitters = s->n_emitters_area;
+    d.tri_normals = s->tri_normals.empty() ? nullptr : s->tri_normals.data();
     d.film = s->film_desc;
     memcpy(d.camera.sample_to_camera, s->cam.s2c, sizeof s->cam.s2c);
     memcpy(d.camera.to_world, s->cam.tw, sizeof s->cam.tw);
@@ -229,7 +233,7 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     HostNlos hn;
     if (const char *msg = derive_nlos(d, hn)) return fail(c, MTR_ERR_INVALID, std::string("mtr_scene_set_nlos: ") + msg);
     NlosDev &D = s->nlos;
-    void **old[] = { &D.shapes, &D.tables, &D.hg_tris, &D.targets };
+    void **old[] = { &D.shapes, &D.tables, &D.hg_tris, &D.hg_vn, &D.targets };
     for (void **p : old) if (*p) { (void)hipFree(*p); *p = nullptr; }
     const size_t ns = hn.shapes.size(), nt = hn.face_pmf.size();
     HIP_TRY(c, hipMalloc(&D.shapes, ns * sizeof(NlosShape)));
@@ -243,13 +247,17 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     HIP_TRY(c, hipMemcpy(D.tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc(&D.hg_tris, hn.hg_tris.size() * sizeof(q4)));
     HIP_TRY(c, hipMemcpy(D.hg_tris, hn.hg_tris.data(), hn.hg_tris.size() * sizeof(q4), hipMemcpyHostToDevice));
+    if (!hn.hg_vn.empty()) {
+        HIP_TRY(c, hipMalloc(&D.hg_vn, hn.hg_vn.size() * sizeof(q4)));
+        HIP_TRY(c, hipMemcpy(D.hg_vn, hn.hg_vn.data(), hn.hg_vn.size() * sizeof(q4), hipMemcpyHostToDevice));
+    }
     const size_t n_targets = nlos_target_count(hn.k);
     HIP_TRY(c, hipMalloc(&D.targets, n_targets * sizeof(q4)));
     D.k = hn.k;
     D.k.shapes = (const NlosShape *)D.shapes;
     D.k.shape_pmf = (const float *)D.tables; D.k.shape_cdf = D.k.shape_pmf + ns;
     D.k.face_pmf = D.k.shape_cdf + ns; D.k.face_cdf = D.k.face_pmf + nt;
-    D.k.hg_tris = (const q4 *)D.hg_tris; D.k.targets = (const q4 *)D.targets;
+    D.k.hg_tris = (const q4 *)D.hg_tris; D.k.hg_vn = (const q4 *)D.hg_vn; D.k.targets = (const q4 *)D.targets;
     HIP_TRY(c, launch_nlos_prepare(s->dev, D.k, (q4 *)D.targets, c->stream));    // scanned points + laser axis hit
     D.on = true;
     return MTR_OK;
@@ -263,7 +271,7 @@ void mtr_scene_destroy(mtr_scene *s)
     void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
-    void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.targets, s->d_freq };
+    void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.hg_vn, s->nlos.targets, s->d_freq };
     for (void *p : nl) if (p) (void)hipFree(p);
     delete s;
 }
@@ -499,13 +507,13 @@ static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pix
     mtr_ctx *c = s->ctx;
     const Film &f = s->film;
     uint32_t mode = *mode_io;
-    if (s->nlos.on && mode == MTR_MODE_AUTO) mode = MTR_MODE_FUSED;      // (wavefront = the second organisation, on request)
+    if (s->nlos.on && mode == MTR_MODE_AUTO)                             // (wavefront = the second organisation: on request, and for
+        mode = (s->dev.has_rough && (p->flags & MTR_FLAG_DETERMINISTIC)) ? MTR_MODE_WAVEFRONT : MTR_MODE_FUSED;      // deterministic rows with the extended shading)
     if (f.n_freq) {                      // phasor film: (opl, value) records -> wavefront pipeline by default; LDS (Re, Im) rows in the fused kernel on request
         if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: phasor_hdr_film is not available for the NLOS tier");
         if (mode == MTR_MODE_AUTO) mode = MTR_MODE_WAVEFRONT;
     }
-    if (s->dev.has_rough) {              // GGX lobes: transient_path with f32 rows only (fused), or the wavefront pipeline
-        if (s->nlos.on) return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles / bitmap textures are not available for the NLOS tier");
+    if (s->dev.has_rough) {              // GGX lobes / smooth normals / bitmaps: f32 rows only (fused), or the wavefront pipeline
         const bool fused_ok = !f.n_freq && !(p->flags & MTR_FLAG_DETERMINISTIC);
         if (mode == MTR_MODE_FUSED && !fused_ok)
             return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: rough BSDFs / smooth-shaded triangles with a phasor film or deterministic rows need the wavefront mode");

@@ -305,6 +305,7 @@ struct SceneView {
     // area sampling of triangle meshes (mesh emitters, NLOS hidden geometry), by ORIGINAL triangle index:
     // 3 quads (p0, e1.x) (e1.yz, e2.xy) (e2.z, n) and the face distribution normalised within the mesh
     const q4 *samp_tris;
+    const q4 *samp_vn;        // vertex normals of the sampled meshes (null unless one has them): mesh_sample_position
     const float *face_pmf, *face_cdf;
     const q4 *vnormals;       // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
     // bitmap textures (HBM; null without textures): all texels as RGBA f32, per texture (first texel, width, height, -),
@@ -325,8 +326,10 @@ MTR_HD uint32_t distr_sample_reuse(const float *cdf, const float *pmf, uint32_t 
 }
 
 // [mitsuba3: Mesh::sample_position] face by area (reusing sample.y), then warp::square_to_uniform_triangle
+// samp_vn (or null): three vertex normals per triangle, .w of the first = 1 on a mesh with vertex normals — then
+// ps.n = normalize(fmadd(n0, 1 - b.x - b.y, fmadd(n1, b.x, n2 * b.y))) instead of the face normal
 MTR_HD void mesh_sample_position(const q4 *samp_tris, const float *face_cdf, const float *face_pmf, uint32_t first_tri,
-                                 uint32_t n_tris, float u1, float u2, f3 &p, f3 &n)
+                                 uint32_t n_tris, float u1, float u2, f3 &p, f3 &n, const q4 *samp_vn = nullptr)
 {
     float sy = u2;
     uint32_t fi = 0;
@@ -337,6 +340,16 @@ MTR_HD void mesh_sample_position(const q4 *samp_tris, const float *face_cdf, con
     const float b0 = 1.0f - tt, b1 = tt * sy;
     p = mk(fmaf(a.w, b0, fmaf(b.z, b1, a.x)), fmaf(b.x, b0, fmaf(b.w, b1, a.y)), fmaf(b.y, b0, fmaf(cc.x, b1, a.z)));
     n = mk(cc.y, cc.z, cc.w);
+    if (samp_vn) {
+        const q4 *v = samp_vn + 3 * (size_t)(first_tri + fi);
+        const q4 n0 = v[0];
+        if (n0.w != 0.0f) {
+            const q4 n1 = v[1], n2 = v[2];
+            const float w0 = 1.0f - b0 - b1;
+            n = normalize(mk(fmaf(n0.x, w0, fmaf(n1.x, b0, n2.x * b1)), fmaf(n0.y, w0, fmaf(n1.y, b0, n2.y * b1)),
+                             fmaf(n0.z, w0, fmaf(n1.z, b0, n2.z * b1))));
+        }
+    }
 }
 
 // exact u32 division by an invariant divisor in 5 instructions (Granlund-Montgomery, the branch-free form):
@@ -1239,7 +1252,7 @@ MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderCo
 // Surface interaction rebuilt from (ray direction, primitive, barycentrics): cheap enough to
 // recompute on both sides of the shadow ray instead of keeping 15 registers alive across it.
 // sn / ss / stt: the SHADING frame (si.sh_frame); gn: the geometric normal (si.n), which keeps the ray offsets and the
-// emitter densities.  They differ only on smooth-shaded triangles.
+// hidden-geometry cosine of the NLOS tier.  They differ only on smooth-shaded triangles.
 struct HitCtx { f3 sp, sn, ss, stt, wi, gn; uint32_t mat, em_plus1; };
 
 // [mitsuba3: SurfaceInteraction::initialize_sh_frame] s = normalize(dp_du - n * dot(n, dp_du)), t = n x s
@@ -1357,7 +1370,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
         f3 dd = rel / dist;
         float em_pdf = 0.0f;
         if (!p.prev_delta) {
-            float dp = dot(dd, c.gn);
+            float dp = dot(dd, c.sn);                  // DirectionSample(scene, si, ref): ds.n = si.sh_frame.n
             if (dp < 0.0f) {
                 float adp = fabsf(dp);
                 em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
@@ -1388,7 +1401,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
         const Emitter &E = sc.ems[ei];
         f3 ep, en;
         if (E.is_mesh) {
-            mesh_sample_position(sc.samp_tris, sc.face_cdf, sc.face_pmf, E.first_tri, E.n_tris, u1, u2, ep, en);
+            mesh_sample_position(sc.samp_tris, sc.face_cdf, sc.face_pmf, E.first_tri, E.n_tris, u1, u2, ep, en, ROUGH ? sc.samp_vn : nullptr);
         } else {
             float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
             ep = mk(fmaf(E.du[0], a, fmaf(E.dv[0], b, E.center[0])),

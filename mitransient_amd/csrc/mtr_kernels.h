@@ -21,6 +21,7 @@ struct SceneDev {
     const mtr_material *mats; uint32_t n_mats;
     const Emitter *ems; uint32_t n_ems;
     const q4 *samp_tris; const float *face_pmf, *face_cdf;   // mesh-emitter sampling tables (HBM; null without mesh emitters)
+    const q4 *samp_vn;               // ... vertex normals of those meshes (null unless a mesh emitter has them)
     const q4 *vnormals;              // [3 * n_slots] vertex normals of smooth-shaded slots (HBM; null when every triangle is flat)
     const q4 *texels, *tex_info, *uvs;   // bitmap textures (HBM; null without): see SceneView
     uint32_t bvh_depth;

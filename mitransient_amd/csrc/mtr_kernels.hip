@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     uint32_t *s_next = (uint32_t *)(s_cnt + 6);
     SceneView sv;
     sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
-    sv.samp_tris = a.sc.samp_tris; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf; sv.vnormals = a.sc.vnormals;
+    sv.samp_tris = a.sc.samp_tris; sv.samp_vn = a.sc.samp_vn; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf; sv.vnormals = a.sc.vnormals;
     sv.texels = a.sc.texels; sv.tex_info = a.sc.tex_info; sv.uvs = a.sc.uvs;
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (fused_plan); the BVH2 packets stay in HBM, unused
@@ -355,19 +355,19 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
                              : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
                              : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
                              : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
@@ -635,10 +635,10 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
         if (!cfg.hist_lds || cfg.rough) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
         k = cfg.scene_lds ? k_fused<true, true, false, MTR_FUSED_MIN_WAVES, true> : k_fused<false, true, false, MTR_FUSED_MIN_WAVES, true>;
     }
-    else if (!NLOS && cfg.rough) {         // scenes with GGX lobes: the f32 organisations only, 168 registers for the larger shading
+    else if (cfg.rough) {                  // scenes with GGX lobes / smooth normals / bitmaps: the f32 organisations only, 168 registers for the larger shading
         if (cfg.fixed) return hipErrorInvalidValue;
-        k = cfg.scene_lds ? (cfg.hist_lds ? k_fused<true, true, false, 3, false, false, true> : k_fused<true, false, false, 3, false, false, true>)
-                          : (cfg.hist_lds ? k_fused<false, true, false, 3, false, false, true> : k_fused<false, false, false, 3, false, false, true>);
+        k = cfg.scene_lds ? (cfg.hist_lds ? k_fused<true, true, NLOS, 3, false, false, true> : k_fused<true, false, NLOS, 3, false, false, true>)
+                          : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
     }
     else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
     else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(kBlock) k_nlos_prepare(SceneDev sc, NlosConst 
     sv.wnodes = nullptr; sv.wnodes4 = nullptr; sv.wnodes8q = nullptr;
     sv.node_pairs = false;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
-    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
+    sv.samp_tris = sc.samp_tris; sv.samp_vn = sc.samp_vn; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
     sv.texels = sc.texels; sv.tex_info = sc.tex_info; sv.uvs = sc.uvs;
     const uint32_t total = nlos_target_count(nc);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {

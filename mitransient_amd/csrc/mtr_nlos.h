@@ -35,6 +35,7 @@ struct NlosConst {
     const float *shape_pmf, *shape_cdf;
     const float *face_pmf, *face_cdf;  // per ORIGINAL triangle index, normalised within its shape
     const q4 *hg_tris;                 // 3 quads per ORIGINAL triangle: (p0, e1.x) (e1.yz, e2.xy) (e2.z, n)
+    const q4 *hg_vn;                   // vertex normals of hidden meshes that have them (or null): mesh_sample_position
     // [W*H] scanned points (film order) | [1] the point the laser's axis hits (Single) | [laser_w*laser_h] the
     // illuminated points of an Exhaustive capture (transientnlospath.py:340-381)
     const q4 *targets;
@@ -149,23 +150,29 @@ MTR_HD Ray spawn_ray_to(f3 sp, f3 sn, f3 t)
     return r;
 }
 
-// diffuse eval (value * cos), the only smooth BSDF of the subset
-MTR_HD f3 bsdf_eval_cos(const mtr_material &m, f3 wi, f3 wo)
+// bsdf.eval (value * cos) of the smooth BSDFs: diffuse, and with EXT the GGX lobes; `albedo` = the reflectance at the hit
+// (the material's constant, or its bitmap: material_albedo)
+template <bool EXT>
+MTR_HD f3 bsdf_eval_cos(const mtr_material &m, f3 albedo, f3 wi, f3 wo)
 {
-    if (m.type != MTR_BSDF_DIFFUSE) return mk(0, 0, 0);
+    const bool rough = EXT && bsdf_is_rough(m.type);
+    if (m.type != MTR_BSDF_DIFFUSE && !rough) return mk(0, 0, 0);
     if ((m.flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (rough) { f3 val; float pdf; rough_eval_pdf(m, albedo, wi, wo, val, pdf); return val; }
     if (!(wi.z > 0.0f && wo.z > 0.0f)) return mk(0, 0, 0);
-    return mk((m.a[0] * kInvPi) * wo.z, (m.a[1] * kInvPi) * wo.z, (m.a[2] * kInvPi) * wo.z);
+    return mk((albedo.x * kInvPi) * wo.z, (albedo.y * kInvPi) * wo.z, (albedo.z * kInvPi) * wo.z);
 }
+template <bool EXT>
+MTR_HD bool nlos_bsdf_smooth(const mtr_material &m) { return m.type == MTR_BSDF_DIFFUSE || (EXT && bsdf_is_rough(m.type)); }
 
 // emitter_nee_sample (transientnlospath.py:432-509); `depth` is the reference's argument (not the loop depth)
-template <class Stack, class Sink>
-MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 beta, float distance, uint32_t depth,
+template <bool EXT, class Stack, class Sink>
+MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 beta, float distance, uint32_t depth,
                            bool focus_laser, uint32_t laser, const SceneView &sc, const NlosConst &nc, const Film &film,
                            const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats)
 {
     // visibility of the emitter origin (:441)
-    const Ray sr = spawn_ray_to(c.sp, c.sn, nc.l_origin);
+    const Ray sr = spawn_ray_to(c.sp, c.gn, nc.l_origin);
     stats.shadow++;
     if (traverse<true>(sc, sr.o, sr.d, sr.tmax, st).prim >= 0) return mk(0, 0, 0);
     (void)rng_f32(p.rng); (void)rng_f32(p.rng);                      // sampler.next_2d(active_e): only visible lanes draw
@@ -180,7 +187,7 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
     }
     const f3 dirn = normalize(nc.l_origin - c.sp);                   // :483
     const f3 wo = mk(dot(dirn, c.ss), dot(dirn, c.stt), dot(dirn, c.sn));
-    const f3 bv = bsdf_eval_cos(mat, c.wi, wo);
+    const f3 bv = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);
     if (nc.filter_depth != -1 && depth != (uint32_t)nc.filter_depth) return mk(0, 0, 0);      // :489-490
     if ((nc.flags & MTR_NLOS_DISCARD_DIRECT) && !(depth > 2)) return mk(0, 0, 0);             // :491-492
     const f3 Lr = mk((beta.x * bv.x) * w.x, (beta.y * bv.y) * w.y, (beta.z * bv.z) * w.z);    // :493
@@ -195,34 +202,36 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
 }
 
 // emitter_laser_targets_sample (:511-564)
-template <class Stack, class Sink>
-MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 lt, uint32_t depth, uint32_t laser,
+template <bool EXT, class Stack, class Sink>
+MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 lt, uint32_t depth, uint32_t laser,
                              const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
                              Stack &st, Sink &sink, BounceStats &stats)
 {
     f3 dd = lt - c.sp;
     const float dl = sqrtf(dot(dd, dd));
     dd = dd / dl;
-    Ray rb = spawn_ray_to(c.sp, c.sn, lt);
+    Ray rb = spawn_ray_to(c.sp, c.gn, lt);
     stats.shadow++;
     if (traverse<true>(sc, rb.o, rb.d, rb.tmax, st).prim >= 0) return mk(0, 0, 0);             // :528
     const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
-    const f3 bs = bsdf_eval_cos(mat, c.wi, wo);                                               // :531-533
+    const f3 bs = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);                                  // :531-533
     const Hit h2 = traverse<false>(sc, rb.o, rb.d, kInf, st);                                  // :535-537
     stats.closest++;
     if (h2.prim < 0) return mk(0, 0, 0);
     if (!(bs.x > kDrEps || bs.y > kDrEps || bs.z > kDrEps)) return mk(0, 0, 0);               // :539-540
-    const HitCtx c2 = hit_ctx<false>(sc, rb.d, h2);
+    const HitCtx c2 = hit_ctx<EXT>(sc, rb.d, h2);
     const f3 md = -dd;
     const float wlz = dot(md, c2.sn);                                                          // cos_theta(si_bsdf.to_local(-d))
     if (!(wlz > 0.0f)) return mk(0, 0, 0);                                                     // :543
     const float pdf_ls = (dl * dl) / wlz;                                                      // :546-551
     const f3 b2 = mk(p.beta.x * (bs.x / pdf_ls), p.beta.y * (bs.y / pdf_ls), p.beta.z * (bs.z / pdf_ls));
-    return nlos_emitter_nee(p, c2, sc.mats[c2.mat], b2, p.dist + dl * p.eta, depth + 1, true, laser, sc, nc, film, rc, st, sink, stats);
+    return nlos_emitter_nee<EXT>(p, c2, sc.mats[c2.mat], material_albedo<EXT>(sc, sc.mats[c2.mat], h2), b2, p.dist + dl * p.eta, depth + 1, true,
+                                 laser, sc, nc, film, rc, st, sink, stats);
 }
 
 // hidden_geometry_sample (:637-670) incl. _sample_hidden_geometry_position (:385-430)
-MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat, float ua, float ub, const NlosConst &nc)
+template <bool EXT>
+MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat, f3 albedo, float ua, float ub, const NlosConst &nc)
 {
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
@@ -234,19 +243,19 @@ MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat,
         pp = rect_point(ld3(S.center), ld3(S.du), ld3(S.dv), reused, ub);
         pn = ld3(S.n);
     } else {                                               // [mitsuba3: Mesh::sample_position]
-        mesh_sample_position(nc.hg_tris, nc.face_cdf, nc.face_pmf, S.first_tri, S.n_tris, reused, ub, pp, pn);
+        mesh_sample_position(nc.hg_tris, nc.face_cdf, nc.face_pmf, S.first_tri, S.n_tris, reused, ub, pp, pn, EXT ? nc.hg_vn : nullptr);
     }
     const float ppdf = S.inv_area * spmf;
     f3 dd = pp - c.sp;
     const float dist = sqrtf(dot(dd, dd));
     dd = dd / dist;
-    const float cos_i = dot(c.sn, dd), cos_g = dot(pn, -dd);
+    const float cos_i = dot(c.gn, dd), cos_g = dot(pn, -dd);               // si.n: the geometric normal
     const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
     bs.wo = wo;
     bs.pdf = ppdf * (dist * dist) / fabsf(cos_g);
     if (!(cos_i > kDrEps && cos_g > kDrEps)) return bs;
     if (!(bs.pdf > kDrEps)) return bs;
-    const f3 val = bsdf_eval_cos(mat, c.wi, wo);
+    const f3 val = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);
     bs.w = mk(val.x / bs.pdf, val.y / bs.pdf, val.z / bs.pdf);
     return bs;
 }
@@ -260,7 +269,7 @@ MTR_HD f3 nlos_laser_target(const NlosConst &nc, uint32_t px, uint32_t py)
 }
 
 // One iteration of TransientNLOSPath.sample (:740-918).  Returns active_next.
-template <class Stack, class Sink>
+template <bool EXT = false, class Stack, class Sink>
 MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
                         Stack &st, Sink &sink, BounceStats &stats)
 {
@@ -272,24 +281,26 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     f3 Lr = mk(0, 0, 0);
     HitCtx c;
     c.sp = mk(0, 0, 0); c.sn = mk(0, 0, 1); c.gn = mk(0, 0, 1); c.ss = mk(1, 0, 0); c.stt = mk(0, 1, 0); c.wi = mk(0, 0, 0); c.mat = 0; c.em_plus1 = 0;
-    if (valid) c = hit_ctx<false>(sc, p.ray.d, h);
+    if (valid) c = hit_ctx<EXT>(sc, p.ray.d, h);
+    const mtr_material &mat = sc.mats[c.mat];
+    const f3 albedo = valid ? material_albedo<EXT>(sc, mat, h) : mk(0, 0, 0);
     // the only emitter is the projector (not a surface): Le = 0 (:757-777)
-    if (active_next && sc.mats[c.mat].type == MTR_BSDF_DIFFUSE) {                                 // active_em :785-786
+    if (active_next && nlos_bsdf_smooth<EXT>(mat)) {                                 // active_em :785-786
         if ((nc.flags & MTR_NLOS_LASER_SAMPLING) && nc.capture_type == MTR_CAPTURE_EXHAUSTIVE) {
             // every illuminated point in turn (:597-621); target i lands in film cell laser_x = i / Ly, laser_y = i % Ly,
             // i.e. row offset i * T; the steady estimate is the mean over the grid
             const uint32_t nl = nc.laser_w * nc.laser_h, t0 = nc.film_w * nc.film_h + 1u;
             for (uint32_t i = 0; i < nl; ++i) {
                 const q4 t = nc.targets[t0 + i];
-                const f3 li = nlos_laser_targets(p, c, sc.mats[c.mat], mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats);
+                const f3 li = nlos_laser_targets<EXT>(p, c, mat, albedo, mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats);
                 Lr = mk(Lr.x + li.x, Lr.y + li.y, Lr.z + li.z);
             }
             const float nlf = (float)nl;
             Lr = mk(Lr.x / nlf, Lr.y / nlf, Lr.z / nlf);
         } else if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                            // emitter_laser_sample: depth + 1
-            Lr = nlos_laser_targets(p, c, sc.mats[c.mat], nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats);
+            Lr = nlos_laser_targets<EXT>(p, c, mat, albedo, nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats);
         else
-            Lr = nlos_emitter_nee(p, c, sc.mats[c.mat], p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats);
+            Lr = nlos_emitter_nee<EXT>(p, c, mat, albedo, p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats);
     }
     // hidden-geometry / BSDF sampling (:797-833)
     const bool hg = (nc.flags & MTR_NLOS_HG_SAMPLING) != 0;
@@ -303,12 +314,12 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
     if (active_next) {
-        if (do_hg) bs = nlos_hidden_geometry(c, sc.mats[c.mat], a2a, a2b, nc);
-        else bs = bsdf_sample<false>(sc.mats[c.mat], c.wi, b1, b2a, b2b, mk(0, 0, 0));
+        if (do_hg) bs = nlos_hidden_geometry<EXT>(c, mat, albedo, a2a, a2b, nc);
+        else bs = bsdf_sample<EXT>(mat, c.wi, b1, b2a, b2b, albedo);
         const f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                            fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                            fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
-        p.ray.o = offset_point(c.sp, c.sn, wo_w); p.ray.d = wo_w; p.ray.tmax = kInf;
+        p.ray.o = offset_point(c.sp, c.gn, wo_w); p.ray.d = wo_w; p.ray.tmax = kInf;
     }
     p.L = mk(p.L.x + Lr.x, p.L.y + Lr.y, p.L.z + Lr.z);
     p.eta *= bs.eta;

@@ -46,6 +46,21 @@ static double fill_mesh_tables(const float *tri_verts, uint32_t first, uint32_t 
     return a;
 }
 
+// vertex normals of the same triangles for Mesh::sample_position (has_vertex_normals): three quads per ORIGINAL triangle,
+// .w of the first = 1 where the scene holds normals for it; `quads` is sized (3 * n_total) on first use
+static void fill_mesh_normals(const float *tri_normals, uint32_t first, uint32_t n, uint32_t n_total, std::vector<q4> &quads)
+{
+    if (!tri_normals) return;
+    for (uint32_t t = 0; t < n; ++t) {
+        const float *vn = tri_normals + 9 * (size_t)(first + t);
+        bool smooth = false;
+        for (int k = 0; k < 9; ++k) smooth = smooth || vn[k] != 0.0f;
+        if (!smooth) continue;
+        if (quads.empty()) quads.assign(3 * (size_t)n_total, q4{ 0, 0, 0, 0 });
+        for (int k = 0; k < 3; ++k) quads[3 * (size_t)(first + t) + k] = q4{ vn[3 * k], vn[3 * k + 1], vn[3 * k + 2], k == 0 ? 1.0f : 0.0f };
+    }
+}
+
 // [mitsuba3: coordinate_system(n)] (Duff et al. 2017), first vector: the tangent of a mesh triangle without UVs
 static f3 coordinate_system_s(f3 n)
 {
@@ -166,7 +181,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     if (!getenv("MTR_NO_WIDE8Q")) s.wide8q_levels = build_wide8q(bvh, s.wnodes8q);      // (experiments: without it the HBM walk uses the 4-wide tree)
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
-    s.vnormals.clear();
+    s.vnormals.clear(); s.samp_vn.clear();
     // bitmap textures: texels to RGBA f32, texture coordinates by slot (filled in the slot loop below)
     s.texels.clear(); s.tex_info.clear(); s.uvs.clear();
     bool textured = false;
@@ -273,6 +288,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
                 s.face_pmf.assign(d.n_tris, 0.0f); s.face_cdf.assign(d.n_tris, 0.0f);
             }
             const double a = fill_mesh_tables(d.tri_verts, e.first_tri, e.n_tris, s.face_pmf.data(), s.face_cdf.data(), s.samp_tris.data());
+            fill_mesh_normals(d.tri_normals, e.first_tri, e.n_tris, d.n_tris, s.samp_vn);
             for (int k = 0; k < 3; ++k) { E.center[k] = E.du[k] = E.dv[k] = E.n[k] = 0.0f; E.radiance[k] = e.radiance[k]; }
             E.inv_area = (float)(1.0 / a);
             continue;
@@ -356,6 +372,7 @@ const char *derive_nlos(const mtr_scene_desc &d, HostNlos &o)
         NlosShape &D = o.shapes[s];
         D.first_tri = S.first_tri; D.n_tris = S.n_tris; D.is_rect = S.is_rectangle;
         double a = fill_mesh_tables(d.tri_verts, S.first_tri, S.n_tris, o.face_pmf.data(), o.face_cdf.data(), o.hg_tris.data());
+        if (!S.is_rectangle) fill_mesh_normals(d.tri_normals, S.first_tri, S.n_tris, d.n_tris, o.hg_vn);
         if (S.is_rectangle) {
             for (int c = 0; c < 3; ++c) { D.center[c] = S.center[c]; D.du[c] = S.du[c]; D.dv[c] = S.dv[c]; }
             const f3 cr = cross(ld3(S.du), ld3(S.dv));

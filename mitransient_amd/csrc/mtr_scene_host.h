@@ -22,6 +22,7 @@ struct HostScene {
     std::vector<mtr_material> mats;
     std::vector<Emitter> ems;
     std::vector<q4> samp_tris;                 // mesh emitters only (empty otherwise): see SceneView
+    std::vector<q4> samp_vn;                   // ... their vertex normals (empty unless a mesh emitter has them): mesh_sample_position
     std::vector<q4> vnormals;                  // [3 * n_slots] vertex normals, when a triangle is smooth-shaded (empty otherwise)
     // bitmap textures (empty without): texels as RGBA f32 of all textures, (first texel, width, height, 0) per texture, and
     // the corner texture coordinates by slot, two quads each
@@ -39,6 +40,7 @@ struct HostNlos {
     std::vector<NlosShape> shapes;
     std::vector<float> shape_pmf, shape_cdf, face_pmf, face_cdf;
     std::vector<q4> hg_tris;
+    std::vector<q4> hg_vn;                     // vertex normals of hidden meshes that have them (empty otherwise): mesh_sample_position
     NlosConst k{};            // pointers left null: the caller points them at its copies
 };
 const char *derive_nlos(const mtr_scene_desc &d, HostNlos &out);

@@ -73,7 +73,7 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     // not by the STACK class, so that a depth-27 tree leaves room for 5 workgroups per CU instead of 4
     int32_t *s_stack = (int32_t *)(smem + off); off += wf_stack_rows(sc, SCENE_LDS) * kBlock * 4u;
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
-    sv.samp_tris = sc.samp_tris; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
+    sv.samp_tris = sc.samp_tris; sv.samp_vn = sc.samp_vn; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
     sv.texels = sc.texels; sv.tex_info = sc.tex_info; sv.uvs = sc.uvs;
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (wf_plan), as in k_fused
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
 // k_wf_scatter, survivors are compacted into the next live list.  It is the second, independent organisation of this tier
 // (k_fused<NLOS> being the first): same per-path arithmetic (mtr_nlos.h), different machinery around it — state in HBM
 // instead of registers, records + the stand-alone scatter-add instead of LDS row histograms, host loop over bounces.
-template <int STACK, bool SCENE_LDS>
+template <int STACK, bool SCENE_LDS, bool EXT>
 __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
                 sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = p.lane;
                 sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
                 BounceStats bs; bs.closest = 0; bs.shadow = 0;
-                alive = nlos_bounce(p, sv, a.nlos, a.film, a.rc, st, sink, bs);
+                alive = nlos_bounce<EXT>(p, sv, a.nlos, a.film, a.rc, st, sink, bs);
                 n_closest += bs.closest; n_shadow += bs.shadow; ++n_bounce;
                 n_splats += sink.n_splats; n_over += sink.n_overflow;
                 store_state(P, slot, p, false);
@@ -886,7 +886,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
     const bool ext = a.sc.has_rough != 0u;
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
                             : which == 4 ? (ext ? k_wf_shadow_gen<STACK, SL, true> : k_wf_shadow_gen<STACK, SL, false>)
-                            : which == 5 ? k_wf_nlos_bounce<STACK, SL>
+                            : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -204,12 +204,6 @@ class Scene:
                 raise AssertionError(f"You have defined multiple ({len(self.emitters_)}) emitters in the scene with a "
                                      "NLOS capture meter. You should have only 1.")
             sd.nlos = nlos_desc_from(self.integrator_, sensor, self.emitters_[0], sd.relay_shape)
-            sd.tri_normals = None          # the NLOS tier shades flat (documented: DESIGN.md section 10); vertex normals are not passed on
-            # ... and with constant reflectances: a bitmap falls back to its mean colour, which the loader already stored
-            # in mtr_material.a (Texture::mean())
-            for i in range(sd.n_materials):
-                sd.materials[i].albedo_texture = 0
-            sd.textures = []
         return sd
 
     def gpu_handle(self, ctx, sensor=0):

@@ -524,7 +524,7 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
 typedef struct {
     int valid; float t; v3 p, n, s, tt, wi; int prim;       /* n, s, tt: the shading frame (si.sh_frame) */
     float uv[2];                                               /* si.uv */
-    v3 ng;                                                     /* si.n: the geometric normal (ray offsets, emitter densities) */
+    v3 ng;                                                     /* si.n: the geometric normal (ray offsets, hidden_geometry_sample's cos_theta_i) */
 } sinter;
 
 static sinter make_si(const orc_scene *sc, const ray3 *r, hit_t h)
@@ -1024,7 +1024,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
             /* pdf_emitter_direction(prev_si, ds, ~prev_bsdf_delta) [AreaLight::pdf_direction, Shape::pdf_direction] */
             float em_pdf = 0.0f;
             if (!prev_delta) {
-                float dp = vdot(dd, si.ng);
+                float dp = vdot(dd, si.n);          /* DirectionSample3f(scene, si, ref): ds.n = si.sh_frame.n [PositionSample(si)] */
                 if (dp < 0.0f) {
                     float adp = fabsf(dp);
                     em_pdf = sc->em_inv_area[em] * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
@@ -1063,6 +1063,12 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
                 ep = V(fmaf(T->e1.x, b0, fmaf(T->e2.x, b1, T->p0.x)), fmaf(T->e1.y, b0, fmaf(T->e2.y, b1, T->p0.y)),
                        fmaf(T->e1.z, b0, fmaf(T->e2.z, b1, T->p0.z)));
                 en = T->n;
+                if (T->smooth) {                /* has_vertex_normals: ps.n = normalize(fmadd(n0, 1 - b.x - b.y, fmadd(n1, b.x, n2 * b.y))) */
+                    const float *vn = d->tri_normals + 9 * (size_t)(E->first_tri + fi);
+                    float w0 = 1.0f - b0 - b1;
+                    en = vnormalize(V(fmaf(vn[0], w0, fmaf(vn[3], b0, vn[6] * b1)), fmaf(vn[1], w0, fmaf(vn[4], b0, vn[7] * b1)),
+                                      fmaf(vn[2], w0, fmaf(vn[5], b0, vn[8] * b1))));
+                }
             } else {                            /* [Rectangle::sample_position] */
                 float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
                 ep = V(fmaf(E->du[0], a, fmaf(E->dv[0], b, E->center[0])),
@@ -1412,8 +1418,8 @@ static void nlos_laser_targets(const orc_scene *sc, const nlos_scene *N, film_t 
     float pdf_ls = (dl * dl) / wl.z;                                          /* :546-551 */
     float b2[3];
     for (int k = 0; k < 3; ++k) b2[k] = beta[k] * (bs[k] / pdf_ls);
-    const mtr_material *m2 = &sc->d->materials[sc->d->tri_material[s2.prim]];
-    int smooth_ok = 1; (void)smooth_ok;
+    mtr_material m2copy;
+    const mtr_material *m2 = material_at(sc->d, &sc->d->materials[sc->d->tri_material[s2.prim]], &s2, &m2copy);
     nlos_emitter_nee(sc, N, F, rng, &s2, m2, b2, distance + dl * eta, eta, depth + 1, 1, 1, px, py, sample_scale, lane,
                      loop_depth, use_bvh, C, Lr, laser_x, laser_y);
 }
@@ -1445,12 +1451,18 @@ static void nlos_hidden_geometry(const orc_scene *sc, const nlos_scene *N, const
         pp = V(fmaf(T->e1.x, b0, fmaf(T->e2.x, b1, T->p0.x)), fmaf(T->e1.y, b0, fmaf(T->e2.y, b1, T->p0.y)),
                fmaf(T->e1.z, b0, fmaf(T->e2.z, b1, T->p0.z)));
         pn = T->n;
+        if (T->smooth) {                            /* has_vertex_normals: ps.n = normalize(fmadd(n0, 1 - b.x - b.y, fmadd(n1, b.x, n2 * b.y))) */
+            const float *vn = d->tri_normals + 9 * (size_t)(S->first_tri + fi);
+            float w0 = 1.0f - b0 - b1;
+            pn = vnormalize(V(fmaf(vn[0], w0, fmaf(vn[3], b0, vn[6] * b1)), fmaf(vn[1], w0, fmaf(vn[4], b0, vn[7] * b1)),
+                              fmaf(vn[2], w0, fmaf(vn[5], b0, vn[8] * b1))));
+        }
     }
     ppdf = N->shape_inv_area[s] * spmf;
     v3 dd = vsub(pp, si->p);
     float dist = sqrtf(vdot(dd, dd));
     dd = vdivs(dd, dist);
-    float cos_i = vdot(si->n, dd), cos_g = vdot(pn, vneg(dd));
+    float cos_i = vdot(si->ng, dd), cos_g = vdot(pn, vneg(dd));          /* si.n: the geometric normal */
     if (!(cos_i > ORC_EPS && cos_g > ORC_EPS)) { bs->wo = to_local(si, dd); bs->pdf = ppdf * (dist * dist) / fabsf(cos_g); return; }
     v3 wo = to_local(si, dd);
     float val[3]; bsdf_eval(mat, si->wi, wo, val);
@@ -1494,7 +1506,8 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
         hit_t h = intersect(sc, &ray, use_bvh); C->closest++;
         sinter si = make_si(sc, &ray, h);
         if ((n->flags & MTR_NLOS_ACCOUNT_FIRST_LAST) || depth > 0) distance += si.t * eta;       /* :751-752 */
-        const mtr_material *mat = si.valid ? &d->materials[d->tri_material[si.prim]] : NULL;
+        mtr_material matcopy;
+        const mtr_material *mat = si.valid ? material_at(d, &d->materials[d->tri_material[si.prim]], &si, &matcopy) : NULL;
         /* direct emission (:757-777): the only emitter is the projector, which is not a surface: Le = 0 */
         active_next &= (depth + 1 < max_depth) && si.valid;                                       /* :782 */
         int active_em = active_next && bsdf_is_smooth(mat);

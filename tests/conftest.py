@@ -94,7 +94,10 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
     idict.update(integ)
     d = {"type": "scene", "integrator": idict, "laser": laser, "relay_wall": relay}
     white = hidden_bsdf or {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}
-    if hidden == "quad":
+    if isinstance(hidden, dict):                # a shape dict (tests of meshes with vertex normals); its BSDF unless it names one
+        d["hidden"] = dict(hidden)
+        d["hidden"].setdefault("bsdf", white)
+    elif hidden == "quad":
         d["hidden"] = {"type": "rectangle", "to_world": T().translate([0, 0, 1]).rotate([0, 1, 0], 180).scale(0.4), "bsdf": white}
     else:   # three bars of a 'Z' facing the wall (-z normals), as cubes squashed flat: 36 triangles
         d["z_top"] = {"type": "cube", "to_world": T().translate([0.0, 0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}

@@ -68,9 +68,28 @@ FIGURES = [
 ]
 
 
+# images the reference's README / docs show of its own renders (/root/reference/.images): the steady Cornell box — the scene of
+# mitransient.cornell_box(), BASELINE configs 1-3 — and the steady image of examples/diff-transient/staircase (config 5's
+# scene; NOT the Tungsten render that ships with the scene file, which is lit and toned differently)
+README_IMAGES = [
+    (".images/cornell-box.png", "readme_cornell_box", dict(kind="steady", scene="cornell_box()", shown_in="README.md:20, docs/index.rst:1")),
+    (".images/staircase_steady.png", "readme_staircase_steady", dict(kind="steady", scene="diff-transient/staircase/scene.xml", shown_in="README.md:26")),
+]
+
+
+def composite_on_white(im):
+    a = np.asarray(im.convert("RGBA"))
+    alpha = a[..., 3:4].astype(np.float32) / 255.0
+    return np.rint(a[..., :3].astype(np.float32) * alpha + 255.0 * (1.0 - alpha)).astype(np.uint8)
+
+
 def main():
     books = {}
     arrays, meta = {}, {}
+    for rel, name, info in README_IMAGES:
+        arrays[name] = composite_on_white(Image.open(os.path.join(os.path.dirname(REF), rel)))
+        meta[name] = dict(info, file=rel)
+        print(name, arrays[name].shape)
     for nb, cell, ordinal, name, info in FIGURES:
         if nb not in books:
             books[nb] = json.load(open(os.path.join(REF, nb)))

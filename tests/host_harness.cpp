@@ -73,7 +73,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     sv.wnodes8q = (g_wide == 3 && !hs.wnodes8q.empty()) ? hs.wnodes8q.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
-    sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
+    sv.samp_tris = hs.samp_tris.data(); sv.samp_vn = hs.samp_vn.empty() ? nullptr : hs.samp_vn.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
     sv.texels = hs.texels.empty() ? nullptr : hs.texels.data(); sv.tex_info = hs.tex_info.empty() ? nullptr : hs.tex_info.data();
     sv.uvs = hs.uvs.empty() ? nullptr : hs.uvs.data();
@@ -84,11 +84,14 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
     // NLOS tier: tables + scanned points (the product computes the latter in k_nlos_prepare)
     HostNlos hn; std::vector<q4> targets;
     const bool nlos = d->nlos != nullptr;
+    // the product's rule for the extended shading code (mtr_api.hip: has_rough): a GGX lobe, a smooth-shaded triangle, a bitmap
+    bool ext = !hs.vnormals.empty() || !hs.texels.empty();
+    for (uint32_t i = 0; i < d->n_materials; ++i) ext = ext || bsdf_is_rough(d->materials[i].type);
     if (nlos) {
         if (derive_nlos(*d, hn)) return -2;
         NlosConst &k = hn.k;
         k.shapes = hn.shapes.data(); k.shape_pmf = hn.shape_pmf.data(); k.shape_cdf = hn.shape_cdf.data();
-        k.face_pmf = hn.face_pmf.data(); k.face_cdf = hn.face_cdf.data(); k.hg_tris = hn.hg_tris.data();
+        k.face_pmf = hn.face_pmf.data(); k.face_cdf = hn.face_cdf.data(); k.hg_tris = hn.hg_tris.data(); k.hg_vn = hn.hg_vn.empty() ? nullptr : hn.hg_vn.data();
         const uint32_t n = nlos_target_count(k);
         targets.resize(n);
         for (uint32_t i = 0; i < n; ++i) {
@@ -109,7 +112,7 @@ extern "C" int hh_render(const mtr_scene_desc *d, const mtr_render_params *p, fl
                 bool alive = true;
                 while (alive) {
                     BounceStats bs{ 0, 0 };
-                    alive = nlos_bounce(path, sv, hn.k, hs.film, rc, st, sink, bs);
+                    alive = ext ? nlos_bounce<true>(path, sv, hn.k, hs.film, rc, st, sink, bs) : nlos_bounce<false>(path, sv, hn.k, hs.film, rc, st, sink, bs);
                     closest += bs.closest; shadow += bs.shadow; ++bounces;
                 }
                 uint32_t fx = path.px - hs.film.crop_x, fy = path.py - hs.film.crop_y;
@@ -170,7 +173,7 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     sv.wnodes8q = (g_wide == 3 && !hs.wnodes8q.empty()) ? hs.wnodes8q.data() : nullptr;
     sv.mats = hs.mats.data(); sv.ems = hs.ems.data();
     sv.n_emitters = (uint32_t)hs.ems.size(); sv.n_slots = (uint32_t)hs.tshade.size();
-    sv.samp_tris = hs.samp_tris.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
+    sv.samp_tris = hs.samp_tris.data(); sv.samp_vn = hs.samp_vn.empty() ? nullptr : hs.samp_vn.data(); sv.face_pmf = hs.face_pmf.data(); sv.face_cdf = hs.face_cdf.data();
     sv.vnormals = hs.vnormals.empty() ? nullptr : hs.vnormals.data();
     sv.texels = hs.texels.empty() ? nullptr : hs.texels.data(); sv.tex_info = hs.tex_info.empty() ? nullptr : hs.tex_info.data();
     sv.uvs = hs.uvs.empty() ? nullptr : hs.uvs.data();

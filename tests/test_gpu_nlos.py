@@ -199,3 +199,63 @@ def test_is_confocal_capture_meter_gpu(oracle):
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
+
+
+# ---- the extended shading code in the NLOS tier (VERDICT r2 task 8): vertex normals, GGX lobes, bitmaps on hidden geometry -------
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("capture,integ", [("confocal", {}), ("single", {"nlos_hidden_geometry_sampling": False}), ("exhaustive", {})])
+@pytest.mark.parametrize("bsdf", ["diffuse", "roughconductor", "roughplastic", "twosided-roughplastic"])
+def test_hidden_mesh_with_vertex_normals_and_rough_lobes_gpu(oracle, tmp_path, bsdf, capture, integ, mode):
+    from test_nlos import ROUGH_HIDDEN, _hidden_sphere
+    kw = dict(sx=6, sy=5, capture=capture, hidden=_hidden_sphere(tmp_path, ROUGH_HIDDEN[bsdf]), **integ)
+    if capture == "exhaustive":
+        kw.update(film={"exhaustive_scan": True, "laser_scan_width": 6, "laser_scan_height": 5}, bins=48, bin_width=0.05, start=1.8,
+                  force_equal_illumination_scanning=True)
+    scene = make_nlos(**kw)
+    assert scene.data().tri_normals is not None
+    scene.integrator().mode = mode
+    s_gpu, t_gpu = _gpu(scene, 64)
+    if capture == "exhaustive":
+        sd = scene.data()
+        t6, s4, cnt = oracle.render(sd, scene.integrator().render_params(scene.sensors()[0].film(), 0, 64), use_bvh=True)
+        t_ref, s_ref = oracle.develop(sd.film, t6, None)[0], None
+    else:
+        s_ref, t_ref, cnt = _oracle(oracle, scene, 64)
+    assert np.count_nonzero(t_ref) > 20 and rel_l2(t_gpu, t_ref) <= TOL
+    if capture != "exhaustive":              # (an exhaustive film's steady image is the mean over time: test_exhaustive_matches_oracle)
+        assert np.linalg.norm(s_ref) == 0 or rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_textured_hidden_geometry_gpu(oracle, tmp_path, mode):
+    from test_textures import make_texture
+    make_texture(str(tmp_path / "tex.png"))
+    tex = {"type": "diffuse", "reflectance": {"type": "bitmap", "filename": str(tmp_path / "tex.png")}}
+    scene = make_nlos(sx=8, sy=8, capture="confocal", hidden="quad", hidden_bsdf=tex)
+    assert len(scene.data().textures) == 1
+    scene.integrator().mode = mode
+    s_gpu, t_gpu = _gpu(scene, 64)
+    s_ref, t_ref, cnt = _oracle(oracle, scene, 64)
+    assert np.count_nonzero(t_ref) > 50 and rel_l2(t_gpu, t_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
+def test_extended_nlos_deterministic_rows_take_the_wavefront_pipeline(tmp_path):
+    """deterministic rows + the extended shading: AUTO resolves to the wavefront organisation (the fused kernel's fixed-point
+    rows are built without the extended code), two renders are bit-identical; asking for the fused kernel is refused"""
+    from test_nlos import ROUGH_HIDDEN, _hidden_sphere
+    from mitransient_amd._cabi import MitransientAMDError
+    def build(**kw):
+        return make_nlos(sx=4, sy=4, capture="confocal", hidden=_hidden_sphere(tmp_path, ROUGH_HIDDEN["roughplastic"]), **kw)
+    a = build(amd_deterministic=True); b = build(amd_deterministic=True)
+    ta, tb = _gpu(a, 32)[1], _gpu(b, 32)[1]
+    assert np.array_equal(ta, tb) and np.count_nonzero(ta) > 20
+    assert a.integrator().resolved_mode(a, a.sensors()[0], 32) == "wavefront"
+    c = build(amd_deterministic=True, amd_mode="fused")
+    with pytest.raises(MitransientAMDError, match="wavefront"):
+        _gpu(c, 8)

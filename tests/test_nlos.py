@@ -316,23 +316,92 @@ def test_is_confocal_capture_meter(oracle, host_harness):
         make_nlos(sx=4, sy=4, capture="single", sensor_extra={"original_film_width": 8, "original_film_height": 8})
 
 
-def test_textured_hidden_geometry_uses_the_mean_colour(oracle, host_harness, tmp_path):
-    """the NLOS tier shades with constant reflectances — a bitmap on the hidden object is replaced by its mean
-    colour (Texture::mean(), which the loader stores in mtr_material.a) instead of refusing the scene"""
+def test_textured_hidden_geometry_is_shaded_with_its_bitmap(oracle, host_harness, tmp_path):
+    """VERDICT r2 task 8: the NLOS tier runs the extended shading code — a bitmap reflectance on the hidden object is looked up
+    at the hit (BitmapTexture::eval at si.uv), in emitter_nee_sample's bsdf.eval, hidden_geometry_sample and bsdf.sample alike;
+    product == oracle bit for bit, and the result is NOT the mean-colour render (what rounds 1-2 fell back to)"""
     from test_textures import make_texture
-    import mitransient_amd.mi as mi
     a = make_texture(str(tmp_path / "tex.png"))
     tex = {"type": "diffuse", "reflectance": {"type": "bitmap", "filename": str(tmp_path / "tex.png")}}
     scene = make_nlos(capture="confocal", hidden="quad", hidden_bsdf=tex)
     sd = scene.data()
-    assert sd.nlos is not None and not sd.textures and all(sd.materials[i].albedo_texture == 0 for i in range(sd.n_materials))
+    assert sd.nlos is not None and len(sd.textures) == 1 and any(sd.materials[i].albedo_texture for i in range(sd.n_materials))
     from mitransient_amd.scene import _srgb_to_linear as srgb_to_linear
     mean = srgb_to_linear(a.astype(np.float64) / 255.0).reshape(-1, 3).mean(axis=0)
-    flat = scene_with_mean = make_nlos(capture="confocal", hidden="quad",
-                                       hidden_bsdf={"type": "diffuse", "reflectance": {"type": "rgb", "value": [float(x) for x in mean]}})
+    flat = make_nlos(capture="confocal", hidden="quad",
+                     hidden_bsdf={"type": "diffuse", "reflectance": {"type": "rgb", "value": [float(x) for x in mean]}})
     p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 24)
     t4, s4, c = oracle.render(sd, p, n_threads=1)
     ht, hs, hc = hh_render(host_harness, sd, p)
-    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs) and hc["bounces"] == c["bounces"]
     t4m, s4m, cm = oracle.render(flat.data(), p, n_threads=1)
-    assert np.count_nonzero(t4) > 50 and rel_l2(t4, t4m) <= 1e-5
+    assert np.count_nonzero(t4) > 50 and rel_l2(t4, t4m) > 1e-2
+    # same geometry, same random numbers: the same cells are touched; per channel the energy is that of the mean colour to
+    # within the texture's contrast
+    assert np.array_equal(t4[..., 3] != 0, t4m[..., 3] != 0)
+    for ch in range(3):
+        if t4m[..., ch].sum() > 0:
+            assert 0.3 < t4[..., ch].sum() / t4m[..., ch].sum() < 3.0
+
+
+def _hidden_sphere(tmp_path, bsdf=None, face_normals=False, with_vn=True):
+    from test_smooth_normals import write_sphere_obj
+    path = str(tmp_path / f"hidden_sphere_{int(with_vn)}.obj")
+    write_sphere_obj(path, n_lat=5, n_lon=8, r=0.35, c=(0.0, 0.0, 1.0), with_vn=with_vn)
+    d = {"type": "obj", "filename": path, "face_normals": face_normals}
+    if bsdf is not None:
+        d["bsdf"] = bsdf
+    return d
+
+
+ROUGH_HIDDEN = {
+    "diffuse": None,
+    "roughconductor": {"type": "roughconductor", "distribution": "ggx", "alpha": 0.3, "eta": {"type": "rgb", "value": [0.2, 0.9, 1.1]},
+                       "k": {"type": "rgb", "value": [3.9, 2.4, 2.2]}},
+    "roughplastic": {"type": "roughplastic", "distribution": "ggx", "alpha": 0.25, "diffuse_reflectance": {"type": "rgb", "value": [0.8, 0.5, 0.3]}},
+    "twosided-roughplastic": {"type": "twosided", "bsdf": {"type": "roughplastic", "distribution": "ggx", "alpha": 0.4,
+                                                           "diffuse_reflectance": {"type": "rgb", "value": [0.6, 0.6, 0.6]}}},
+}
+
+
+@pytest.mark.parametrize("capture,integ", [("confocal", {}), ("single", {}), ("single", {"nlos_hidden_geometry_sampling": False}),
+                                           ("confocal", {"nlos_laser_sampling": False, "nlos_hidden_geometry_sampling_do_rroulette": True, "laser_fov": 70.0}),
+                                           ("exhaustive", {})])
+@pytest.mark.parametrize("bsdf", list(ROUGH_HIDDEN))
+def test_hidden_mesh_with_vertex_normals_and_rough_lobes(oracle, host_harness, tmp_path, bsdf, capture, integ):
+    """VERDICT r2 task 8: hidden geometry that is a mesh with vertex normals (interpolated shading frame at the hit, si.n = the
+    geometric normal in hidden_geometry_sample's cos_theta_i, Mesh::sample_position's interpolated ps.n in cos_theta_g) and / or
+    carries a GGX lobe (a smooth BSDF: it takes part in laser sampling, bsdf.eval at the sampled point): product == oracle bit
+    for bit, counters included"""
+    kw = dict(sx=4, sy=4, capture=capture, hidden=_hidden_sphere(tmp_path, ROUGH_HIDDEN[bsdf]), **integ)
+    if capture == "exhaustive":
+        kw.update(film={"exhaustive_scan": True, "laser_scan_width": 4, "laser_scan_height": 4}, bins=48, bin_width=0.05, start=1.8,
+                  force_equal_illumination_scanning=True)
+    scene = make_nlos(**kw)
+    sd = scene.data()
+    assert sd.tri_normals is not None and np.any(sd.tri_normals != 0)
+    spp = 48 if integ.get("nlos_laser_sampling", True) else 1500         # plain emitter sampling: few paths see the projector's cone
+    p = scene.integrator().render_params(scene.sensors()[0].film(), 0, spp)
+    t4, s4, c = oracle.render(sd, p, n_threads=1)
+    ht, hs, hc = hh_render(host_harness, sd, p)
+    assert np.array_equal(t4, ht) and np.array_equal(s4, hs)
+    for k in ("paths", "rays_closest", "rays_shadow", "bounces"):
+        assert hc[k] == c[k], k
+    assert np.count_nonzero(t4) > 8
+
+
+def test_vertex_normals_change_the_hidden_sphere_and_both_estimators_agree(oracle, tmp_path):
+    """smooth vs flat shading of the same coarse hidden sphere differ; with vertex normals the hidden-geometry estimator
+    and plain BSDF sampling are two estimators of the same integral (their totals agree statistically)"""
+    kw = dict(sx=2, sy=2, capture="confocal", bins=64, max_depth=4)
+    spp = 6000
+    def total(scene):
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, spp)
+        t4, _, _ = oracle.render(scene.data(), p)
+        return t4
+    smooth_hg = total(make_nlos(hidden=_hidden_sphere(tmp_path), **kw))
+    flat_hg = total(make_nlos(hidden=_hidden_sphere(tmp_path, face_normals=True), **kw))
+    smooth_bs = total(make_nlos(hidden=_hidden_sphere(tmp_path), nlos_hidden_geometry_sampling=False, **kw))
+    assert rel_l2(smooth_hg, flat_hg) > 1e-2
+    a, b = float(smooth_hg[..., 0].sum()), float(smooth_bs[..., 0].sum())
+    assert a > 0 and abs(a - b) <= 0.1 * a
