@@ -272,6 +272,129 @@ def check_cbox_freq(figures, phasors, ncc_min):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU: the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+# the README's images of the reference's own renders (/root/reference/.images): steady Cornell box, steady staircase
+LUMA = np.array([0.2126, 0.7152, 0.0722])
+
+
+def display(steady):
+    """what a viewer shows of a linear image: clipped, gamma 2.2 (the curve the two README images are consistent with)"""
+    return np.clip(np.asarray(steady, np.float64), 0.0, 1.0) ** (1.0 / 2.2)
+
+
+def figure_content(rgb, bright_margin):
+    """the image inside the figure's margin (white for the staircase; white, then a black frame, for the Cornell box)"""
+    a = rgb.astype(np.float64) / 255.0 if rgb.dtype == np.uint8 else rgb
+    edge = (a.min(-1) > 0.97) if bright_margin else (a.sum(-1) < 0.15)
+    rows, cols = np.where(edge.mean(1) < 0.5)[0], np.where(edge.mean(0) < 0.5)[0]
+    return a[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]
+
+
+def resized(img, shape):
+    from PIL import Image
+    u8 = np.rint(np.clip(img, 0, 1) * 255).astype(np.uint8)
+    return np.asarray(Image.fromarray(u8).resize((shape[1], shape[0]), Image.BOX if shape[0] < img.shape[0] else Image.BILINEAR)).astype(np.float64) / 255.0
+
+
+def best_shift(ref, mine, reach=4, margin=8):
+    best = (-2.0, 0, 0)
+    for dy in range(-reach, reach + 1):
+        for dx in range(-reach, reach + 1):
+            c = ft.ncc(ref[margin:-margin, margin:-margin], np.roll(np.roll(mine, dy, 0), dx, 1)[margin:-margin, margin:-margin])
+            best = max(best, (c, dy, dx))
+    return best
+
+
+def check_readme_staircase(figures, steady, ncc_min, interior_min, mean_tol):
+    """`.images/staircase_steady.png` (README.md:26) against a steady render of BASELINE config 5's scene AS ITS FILE DESCRIBES
+    IT (GGX lobes, vertex normals, bitmap textures): the same picture — structure (luminance correlation, best alignment at
+    zero shift, mirrored hypotheses clearly worse) and RADIOMETRY: the mean linear colour of the whole image, which the camera,
+    every material, the textures and the light's radiance enter (measured on the GPU: (0.239, 0.146, 0.080) against the
+    figure's (0.239, 0.144, 0.081))"""
+    fig = figures[0]["readme_staircase_steady"]
+    ref = figure_content(fig, bright_margin=True)
+    assert abs(ref.shape[1] / ref.shape[0] - 9.0 / 16.0) < 0.01
+    small = steady.shape[0] < ref.shape[0]
+    a, b = (resized(ref, steady.shape[:2]), display(steady)) if small else (ref, resized(display(steady), ref.shape[:2]))
+    la, lb = a @ LUMA, b @ LUMA
+    c = ft.ncc(la, lb)
+    assert c >= ncc_min, c
+    assert ft.ncc(la, lb[:, ::-1]) <= c - 0.12 and ft.ncc(la, lb[::-1]) <= c - 0.5
+    m = 8 if not small else 3
+    ci, dy, dx = best_shift(la, lb, reach=3, margin=m)
+    assert (dy, dx) == (0, 0) and ci >= interior_min, (ci, dy, dx)
+    mean_ref, mean_mine = (a ** 2.2).reshape(-1, 3).mean(0), (b ** 2.2).reshape(-1, 3).mean(0)
+    assert np.all(np.abs(mean_mine / mean_ref - 1.0) <= mean_tol), (mean_ref, mean_mine)
+    return c, mean_mine / mean_ref
+
+
+# regions of the Cornell box image in units of its side: (y0, y1, x0, x1)
+CBOX_REGIONS = {"left wall": (0.31, 0.70, 0.03, 0.125), "right wall": (0.31, 0.70, 0.875, 0.97), "back wall": (0.31, 0.39, 0.31, 0.70),
+                "floor": (0.92, 0.985, 0.23, 0.47), "ceiling": (0.025, 0.08, 0.16, 0.31), "tall box front": (0.55, 0.78, 0.33, 0.47)}
+
+
+def check_readme_cornell_box(figures, steady, ncc_min, interior_min, level_tol):
+    """`.images/cornell-box.png` (README.md:20, docs/index.rst:1): the steady image of mitransient.cornell_box() — the scene of
+    BASELINE configs 1-3.  Structure per channel (correlation, best alignment at zero shift: camera pose and field of view;
+    mirrored / transposed hypotheses clearly worse) and the LEVEL of the red and green channels on the six large surfaces
+    (figure^2.2 against the linear render: measured 0.88 ... 1.13 and 0.85 ... 0.90).  The figure's BLUE channel reads 0.3 - 0.4
+    of this render's on every surface — a uniform per-channel factor (white balance / a spectral variant?) that nothing in
+    mitransient.cornell_box() explains; recorded in DESIGN.md, not asserted"""
+    fig = figures[0]["readme_cornell_box"]
+    ref = figure_content(figure_content(fig, bright_margin=True), bright_margin=False)      # white margin, then the black frame
+    assert abs(ref.shape[0] - ref.shape[1]) <= 4
+    n = steady.shape[0]
+    a, b = resized(ref, (n, n)), display(steady)
+    for ch, least in ((0, ncc_min), (1, ncc_min), (2, ncc_min - 0.08)):
+        c = ft.ncc(a[..., ch], b[..., ch])
+        assert c >= least, (ch, c)
+        assert max(ft.ncc(a[..., ch], b[:, ::-1, ch]), ft.ncc(a[..., ch], b[::-1, :, ch]), ft.ncc(a[..., ch], b[..., ch].T)) <= c - 0.15, ch
+    ci, dy, dx = best_shift(a[..., 0], b[..., 0], reach=3, margin=max(4, n // 16))
+    assert (dy, dx) == (0, 0) and ci >= interior_min, (ci, dy, dx)
+    lin = np.asarray(steady, np.float64)
+    ratios = {}
+    for name, (y0, y1, x0, x1) in CBOX_REGIONS.items():
+        sl = (slice(int(y0 * n), int(y1 * n)), slice(int(x0 * n), int(x1 * n)))
+        f, m = (a[sl] ** 2.2).reshape(-1, 3).mean(0), lin[sl].reshape(-1, 3).mean(0)
+        ratios[name] = f / m
+        dominant = (0, 1) if name != "left wall" else (0,)         # (the red wall's green is 3 % of its red: below the figure's precision)
+        for ch in dominant:
+            assert abs(f[ch] / m[ch] - 1.0) <= level_tol, (name, ch, f, m)
+    # colours name the walls: red left, green right, the rest warm white
+    assert ratios and a[int(0.5 * n), int(0.07 * n), 0] > 3 * a[int(0.5 * n), int(0.07 * n), 1]
+    assert a[int(0.5 * n), int(0.93 * n), 1] > a[int(0.5 * n), int(0.93 * n), 0] and b[int(0.5 * n), int(0.93 * n), 1] > b[int(0.5 * n), int(0.93 * n), 0]
+    return ratios
+
+
+def readme_staircase_scene(width, height, spp, **kw):
+    from mitransient_amd.scenes import staircase
+    return staircase(width=width, height=height, spp=spp, temporal_bins=64, materials="rough", vertex_normals=True, textures=True, **kw)
+
+
+def readme_cornell_scene(n, spp):
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=n, height=n, temporal_bins=16)
+    d["sensor"]["sampler"]["sample_count"] = spp
+    return mi.load_dict(d)
+
+
+def test_oracle_matches_the_readme_images(oracle, figures):
+    """the ORACLE against the two images of its own renders the reference shows in its README"""
+    scene = readme_cornell_scene(128, 128)
+    sd, film = scene.data(), scene.sensors()[0].film()
+    t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 128), use_bvh=True)
+    _, s3 = oracle.develop(sd.film, t4, s4)
+    check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, level_tol=0.2)
+    scene = readme_staircase_scene(54, 96, 32)
+    sd, film = scene.data(), scene.sensors()[0].film()
+    t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 32), use_bvh=True)
+    _, s3 = oracle.develop(sd.film, t4, s4)
+    check_readme_staircase(figures, s3, ncc_min=0.95, interior_min=0.95, mean_tol=0.12)
+
+
 @pytest.mark.parametrize("capture", ["single", "confocal"])
 def test_oracle_nlos_frames_match_the_notebook(oracle, figures, capture):
     scene = nlos_notebook_scene(capture, 1024)
@@ -391,3 +514,24 @@ def test_product_phasor_film_matches_the_frequency_figures(figures):
     ph, steady = product_render(scene, 128)
     assert ph.shape == (200, 200, 41, 2) and steady.shape == (200, 200, 1)
     check_cbox_freq(figures, ph, ncc_min={0: 0.93, 10: 0.88, 20: 0.85, 30: 0.8, 40: 0.75})
+
+
+@pytest.mark.gpu
+def test_product_matches_the_readme_images(figures):
+    """the PRODUCT against `.images/cornell-box.png` (configs 1-3's scene) and `.images/staircase_steady.png` (config 5's scene as
+    its file describes it; the bench's smooth-material approximation of the same scene is measurably NOT that picture)"""
+    scene = readme_cornell_scene(356, 1024)
+    _, s3 = product_render(scene, 1024)
+    check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, level_tol=0.17)
+    scene = readme_staircase_scene(216, 384, 512)
+    _, s3 = product_render(scene, 512)
+    c_full, ratio = check_readme_staircase(figures, s3, ncc_min=0.94, interior_min=0.98, mean_tol=0.05)
+    from mitransient_amd.scenes import staircase
+    approx = staircase(width=216, height=384, spp=256, temporal_bins=64)
+    _, s3a = product_render(approx, 256)
+    with pytest.raises(AssertionError):
+        check_readme_staircase(figures, s3a, ncc_min=0.94, interior_min=0.98, mean_tol=0.05)
+    fig = figures[0]["readme_staircase_steady"]
+    ref = figure_content(fig, bright_margin=True)
+    mean_a = (resized(display(s3a), ref.shape[:2]) ** 2.2).reshape(-1, 3).mean(0) / (ref ** 2.2).reshape(-1, 3).mean(0)
+    assert mean_a[0] > 1.4 and np.all(np.abs(ratio - 1.0) <= 0.05)
