@@ -77,6 +77,22 @@ README_IMAGES = [
 ]
 
 
+# .images/staircase_transient.gif (README.md:27): the transient video of the same scene — 279 frames at 60 ms.  Kept as DATA:
+# every second frame of the first 130, the picture inside the white margin box-averaged to 54 x 96 (8-bit RGB)
+README_VIDEO = (".images/staircase_transient.gif", "readme_staircase_transient", list(range(0, 130, 2)), (96, 54))
+
+
+def video_frames(rel, frames, shape):
+    im = Image.open(os.path.join(os.path.dirname(REF), rel))
+    out = []
+    for k in frames:
+        im.seek(k)
+        a = np.asarray(im.convert("RGB"))
+        c = a[8:377, 7:216]                # inside the white margin (that of staircase_steady.png; the first frames are black)
+        out.append(np.asarray(Image.fromarray(c).resize((shape[1], shape[0]), Image.BOX)))
+    return np.stack(out), im.n_frames, im.info.get("duration")
+
+
 def composite_on_white(im):
     a = np.asarray(im.convert("RGBA"))
     alpha = a[..., 3:4].astype(np.float32) / 255.0
@@ -90,6 +106,11 @@ def main():
         arrays[name] = composite_on_white(Image.open(os.path.join(os.path.dirname(REF), rel)))
         meta[name] = dict(info, file=rel)
         print(name, arrays[name].shape)
+    rel, name, frames, shape = README_VIDEO
+    arrays[name], n_frames, duration = video_frames(rel, frames, shape)
+    meta[name] = dict(kind="video", scene="diff-transient/staircase/scene.xml", file=rel, frames=frames, n_frames=n_frames,
+                      duration_ms=duration, shown_in="README.md:27")
+    print(name, arrays[name].shape)
     for nb, cell, ordinal, name, info in FIGURES:
         if nb not in books:
             books[nb] = json.load(open(os.path.join(REF, nb)))

@@ -366,9 +366,46 @@ def check_readme_cornell_box(figures, steady, ncc_min, interior_min, level_tol):
     return ratios
 
 
+def check_readme_staircase_video(figures, transient, least_ncc, min_exact, last_exact=66, late_tol=3):
+    """`.images/staircase_transient.gif` (README.md:27; 279 frames) against the transient tensor of the scene file's own film
+    (400 bins of 0.1 from OPL 0, camera_unwarp): every frame of the video is found among the time bins by normalised
+    cross-correlation of the tone-mapped frames (mitr.vis.tonemap_transient: value / quantile(|value|, 0.99), clipped) — and
+    frame k is bin k + 20: exactly, in every one of the frames 6 ... 66 (the GPU render; first light to the wavefront reaching the
+    floor), and within 3 bins up to k = 110, where the room has filled with light and consecutive frames are hard to tell apart.  Start of the time axis, bin width, camera_unwarp and the speed of the
+    wavefront through config 5's scene: an offset, a slope or an unwarp error of ONE bin (0.1 units) would show"""
+    frames, meta = figures[0]["readme_staircase_transient"], figures[1]["readme_staircase_transient"]
+    H, W = frames.shape[1:3]
+    t = np.asarray(transient, np.float64)
+    fy, fx = t.shape[0] // H, t.shape[1] // W
+    t = t[:H * fy, :W * fx].reshape(H, fy, W, fx, t.shape[2], 3).mean((1, 3))
+    video = np.clip(t / np.quantile(np.abs(t), 0.99), 0.0, 1.0).sum(-1)            # (H, W, T)
+    v = video - video.mean((0, 1), keepdims=True)
+    vn = np.sqrt((v * v).sum((0, 1)))
+    ks, bins, scores = [], [], []
+    for k, f in zip(meta["frames"], frames.astype(np.float64).sum(-1) / 255.0):
+        if not 6 <= k <= 110:
+            continue
+        g = f - f.mean()
+        c = np.einsum("hw,hwt->t", g, v) / (np.sqrt((g * g).sum()) * np.where(vn > 0, vn, 1.0))
+        ks.append(k); bins.append(int(np.argmax(c))); scores.append(float(c.max()))
+    ks, bins, scores = np.array(ks), np.array(bins), np.array(scores)
+    off = bins - ks
+    early = ks <= last_exact         # the wavefront is still crossing the room: consecutive frames differ visibly
+    if late_tol is None:             # (a noisy render: the late, slowly changing frames cannot be told apart)
+        ks, bins, scores, off = ks[early], bins[early], scores[early], off[early]
+        early = early[early]
+    assert np.median(off) == 20 and np.mean(off[early] == 20) >= min_exact and np.all(np.abs(off[early] - 20) <= 1), list(zip(ks, bins))
+    assert np.all(np.abs(off[~early] - 20) <= (late_tol or 0)), list(zip(ks, bins))
+    slope, intercept = np.polyfit(ks[early], bins[early], 1)
+    assert abs(slope - 1.0) <= 0.01 and abs(intercept - 20.0) <= 0.5, (slope, intercept)
+    assert scores.min() >= least_ncc and np.median(scores) >= least_ncc + 0.05, (scores.min(), np.median(scores))
+    return off, scores
+
+
 def readme_staircase_scene(width, height, spp, **kw):
     from mitransient_amd.scenes import staircase
-    return staircase(width=width, height=height, spp=spp, temporal_bins=64, materials="rough", vertex_normals=True, textures=True, **kw)
+    return staircase(width=width, height=height, spp=spp, temporal_bins=kw.pop("temporal_bins", 64), materials="rough", vertex_normals=True,
+                     textures=True, **kw)
 
 
 def readme_cornell_scene(n, spp):
@@ -388,11 +425,13 @@ def test_oracle_matches_the_readme_images(oracle, figures):
     t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 128), use_bvh=True)
     _, s3 = oracle.develop(sd.film, t4, s4)
     check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, level_tol=0.2)
-    scene = readme_staircase_scene(54, 96, 32)
+    scene = readme_staircase_scene(54, 96, 160, temporal_bins=400)        # the scene file's own film: 400 bins of 0.1 from 0
     sd, film = scene.data(), scene.sensors()[0].film()
-    t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 32), use_bvh=True)
-    _, s3 = oracle.develop(sd.film, t4, s4)
+    assert (film.temporal_bins, film.bin_width_opl, film.start_opl, scene.integrator().camera_unwarp) == (400, 0.1, 0.0, True)
+    t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 160), use_bvh=True)
+    t3, s3 = oracle.develop(sd.film, t4, s4)
     check_readme_staircase(figures, s3, ncc_min=0.95, interior_min=0.95, mean_tol=0.12)
+    check_readme_staircase_video(figures, t3, least_ncc=0.6, min_exact=0.8, last_exact=64, late_tol=None)
 
 
 @pytest.mark.parametrize("capture", ["single", "confocal"])
@@ -535,3 +574,19 @@ def test_product_matches_the_readme_images(figures):
     ref = figure_content(fig, bright_margin=True)
     mean_a = (resized(display(s3a), ref.shape[:2]) ** 2.2).reshape(-1, 3).mean(0) / (ref ** 2.2).reshape(-1, 3).mean(0)
     assert mean_a[0] > 1.4 and np.all(np.abs(ratio - 1.0) <= 0.05)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unwarp", [True, False])
+def test_product_matches_the_readme_video_of_the_staircase(figures, unwarp):
+    """config 5's TIME AXIS against the reference's own transient video: GIF frame k == time bin k + 20, exactly, in all 31
+    sampled frames from the first light to the wavefront reaching the floor; without camera_unwarp (the camera-to-surface leg
+    counted) the same check must fail — the video was rendered with the scene file's `camera_unwarp = true`"""
+    scene = readme_staircase_scene(216, 384, 256, temporal_bins=400, camera_unwarp=unwarp)
+    t3, _ = product_render(scene, 256)
+    if unwarp:
+        off, scores = check_readme_staircase_video(figures, t3, least_ncc=0.8, min_exact=1.0)
+        assert scores[1:12].min() >= 0.9            # (the frames after the very first light: 0.92 ... 0.98)
+    else:
+        with pytest.raises(AssertionError):
+            check_readme_staircase_video(figures, t3, least_ncc=0.8, min_exact=1.0)
