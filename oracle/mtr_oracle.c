@@ -21,8 +21,17 @@
  * for this path (tests/integration/test_nlos.py:117-118 asserts shapes only).
  * What IS pinned: the official PCG32 known-answer stream, the f32 bin mapping
  * of transient_hdr_film.py:263-265, the energy identity transient.sum(2) ==
- * steady (examples/transient-nlos/1-simple-nlos-scenes.ipynb, md cell 8) and
- * an analytic direct-illumination quadrature (tests/).
+ * steady (examples/transient-nlos/1-simple-nlos-scenes.ipynb, md cell 8), an
+ * analytic direct-illumination quadrature (tests/) — and, at FIGURE precision,
+ * outputs of the reference itself (tests/test_reference_figures.py, fixtures
+ * decoded by tests/golden/make_reference_figures.py): the figures embedded in
+ * its notebooks (NLOS frames and a pixel's time response with absolute sums
+ * within 0.1 - 3.5 %, the Cornell box's iso-time bands, the phasor film) and
+ * the README's own renders — the steady staircase (mean linear colour within
+ * 9 % here, 1 - 3 % for the product at full sample counts), the steady Cornell
+ * box, and the staircase's transient video, whose frame k is time bin k + 20 of
+ * this oracle's render.  No sample-for-sample comparison with Mitsuba exists:
+ * in that strict sense parity stays unpinned.
  *
  * Numerics contract shared with the HIP path: IEEE f32,
  * no contraction (-ffp-contract=off), fmaf() only where written, 1/x and
