@@ -6,4 +6,4 @@
 TAG=$1
 tools/profile.sh ${TAG}_c2 > gpurun_out/prof_${TAG}_c2.log 2>&1
 STEPS=1 WARMUP=0 RENDERS=1 tools/profile.sh ${TAG}_c5 --scene staircase --no-scatter-leg > gpurun_out/prof_${TAG}_c5.log 2>&1
-tail -3 gpurun_out/prof_${TAG}_c2.log gpurun_out/prof_${TAG}_c5.log
+tail -n 3 gpurun_out/prof_${TAG}_c2.log; tail -n 3 gpurun_out/prof_${TAG}_c5.log
