@@ -65,13 +65,17 @@ def self_launch(n):
 
 
 MATERIALS = "smooth"       # --materials (staircase only): "smooth" = the SURVEY section-8d mapping (default) | "rough" = GGX lobes kept
-SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry)
+SCENE = "cornell"          # --scene: "cornell" (BASELINE configs[1], the default) | "staircase" (configs[4] geometry) | "nlos" (configs[3]: one GPU's share)
 
 
 def build_scene(width, height, bins, max_depth=8, mode=None):
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
+    if SCENE == "nlos":          # BASELINE configs[3]: NLOS confocal Z scene, 256^2 x 4096 bins; --spp = one GPU's share of the 4096
+        from mitransient_amd.scenes import nlos_z
+        kw = {"amd_mode": mode} if mode else {}
+        return nlos_z(width=width, height=height, temporal_bins=bins, **kw)
     if SCENE == "staircase":
         from mitransient_amd.scenes import staircase
         kw = {"amd_mode": mode} if mode else {}
@@ -243,9 +247,10 @@ def main():
     ap.add_argument("--materials", default="smooth", choices=["smooth", "rough"],
                     help="staircase only: 'smooth' = roughplastic -> diffuse, roughconductor -> conductor (the SURVEY section-8d "
                          "workload); 'rough' = the scene as its file describes it: GGX lobes (roughplastic, roughconductor), vertex normals, bitmap textures")
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "staircase", "nlos"],
                     help="staircase: BASELINE configs[4] (512x512, 2048 bins over OPL 0..40, 2048 spp, max_depth 65; "
-                         "the reference's scene.xml geometry with approximate materials)")
+                         "the reference's scene.xml geometry with approximate materials); nlos: BASELINE configs[3] (NLOS confocal Z scene, "
+                         "256x256, 4096 bins of 2^-11 from 1.85; 512 spp per GPU = one GPU's share of 4096 over 8)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bins", type=int, default=None)
@@ -261,7 +266,7 @@ def main():
     global SCENE, MATERIALS
     SCENE = args.scene
     MATERIALS = args.materials
-    dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (512, 512, 2048, 2048)}[SCENE]
+    dflt = {"cornell": (512, 512, 1024, 1024), "staircase": (512, 512, 2048, 2048), "nlos": (256, 256, 4096, 512)}[SCENE]
     args.width, args.height, args.bins, args.spp = [d if a is None else a
                                                     for a, d in zip((args.width, args.height, args.bins, args.spp), dflt)]
 
@@ -407,6 +412,7 @@ def main():
         kname = "k_fused" if fused else "k_wf_trace+k_wf_shade+k_wf_scatter (whole render)"
         res = {
             "metric": ("Mray/s (closest-hit + shadow rays), Cornell-box 512^2 x 1024 bins x 1024 spp per GPU" if SCENE == "cornell"
+                       else "Mray/s (closest-hit + shadow rays), NLOS confocal Z scene 256^2 x 4096 bins x 512 spp per GPU" if SCENE == "nlos"
                        else "Mray/s (closest-hit + shadow rays), staircase 512^2 x 2048 bins x 2048 spp per GPU"),
             "value": rays / elapsed / 1e6,
             "unit": "Mray/s",
@@ -419,12 +425,15 @@ def main():
             "config": {"workload": (f"cornell_box() diffuse, {args.width}x{args.height} px, {args.bins} time bins "
                                     f"(start_opl 3.5, width 6/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 8, rr_depth 5, seed 0") if SCENE == "cornell" else
+                                   (f"NLOS confocal Z scene (the reference's Z.obj behind a 2 x 2 relay wall, nlos_capture_meter + projector, laser and "
+                                    f"hidden-geometry sampling), {args.width}x{args.height} px, {args.bins} time bins (start_opl 1.85, width 2^-11), "
+                                    f"{args.spp} spp per GPU ({spp_total} spp total), max_depth -1, rr_depth 5, seed 0") if SCENE == "nlos" else
                                    (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes, vertex normals and (256-px) bitmap textures as in the scene file") + f"), "
                                     f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
                        "parallelism": (f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather, 8 row bands pipelined against the path kernel"
                                        if world > 1 else "1 GPU"),
-                       "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE == "cornell"
+                       "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE in ("cornell", "nlos")
                                              else "auto (wavefront: scene in HBM)")},
             # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
             # `scatter_add` below is the stand-alone scatter-add kernel of the wavefront organisation
@@ -434,7 +443,7 @@ def main():
         default_wl = (args.width, args.height, args.bins, args.spp) == dflt and args.mode in (None, "auto")
         hbm_line = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic_from_profiles("k_fused") if (kname == "k_fused" and SCENE == "cornell" and default_wl) else None,
+                    "traffic": traffic_from_profiles("k_fused", {"cornell": None, "nlos": "nlos"}[SCENE]) if (kname == "k_fused" and SCENE in ("cornell", "nlos") and default_wl) else None,
                     "avg_launch_ms": avg_ms, "launches_per_step": n_launch / args.steps,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         # the dominant kernel's bound: k_fused keeps the scatter-add in LDS, so the HBM line only says how little it moves;
@@ -442,6 +451,8 @@ def main():
         vline = None
         if fused and SCENE == "cornell":
             vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps)
+        elif fused and SCENE == "nlos":       # k_fused<NLOS>: counters of `tools/profile.sh <tag> --scene nlos`, section "nlos"
+            vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps, section="nlos")
         elif not fused and SCENE == "staircase" and MATERIALS == "smooth" and wft_n:
             # config 5: the dominant kernel is k_wf_trace (closest-hit and any-hit runs); its launches are timed alone with HIP
             # events; the PMC passes (tools/profile.sh ... --scene staircase) ran the SAME command, so instructions per RENDER
@@ -467,6 +478,7 @@ def main():
         else:
             res["roofline"] = hbm_line
             if (SCENE == "cornell" and fused and default_wl and not profile_is_current()) or \
+               (SCENE == "nlos" and fused and default_wl and not profile_is_current("nlos")) or \
                (SCENE == "staircase" and default_wl and not profile_is_current("staircase")):
                 res["roofline_stale"] = True      # profiles/traffic.json was collected from other sources: counter-based lines omitted
         if not fused and wft_n:

@@ -312,7 +312,7 @@ class _SceneBuilder:
             if not os.path.isabs(fn):
                 fn = os.path.join(self.base_dir, fn)
             if fn not in self.mesh_cache:
-                self.mesh_cache[fn] = load_obj(fn, with_uv=True, with_normals=True) if t == "obj" else (load_ply(fn), None, None)
+                self.mesh_cache[fn] = load_obj(fn, with_uv=True, with_normals=True) if t == "obj" else load_ply(fn, with_attributes=True)
             v, uv, vn = self.mesh_cache[fn]
             tris = tw.transform_affine(v.reshape(-1, 3)).reshape(-1, 3, 3)
             # shading normals [mitsuba3: Mesh::compute_surface_interaction]: interpolated vertex normals unless face_normals;
@@ -495,9 +495,13 @@ _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int":
               "float32": "f4", "float64": "f8"}
 
 
-def load_ply(path: str) -> np.ndarray:
+def load_ply(path: str, with_attributes: bool = False):
     """Stanford PLY (ascii / binary_little_endian / binary_big_endian) -> (n,3,3) float64 triangle soup:
-    vertex x/y/z and the face index list; every other property is skipped; polygons are fan-triangulated."""
+    vertex x/y/z and the face index list; polygons are fan-triangulated.  ``with_attributes``: also the corner texture
+    coordinates (n,6) float32 from the vertex properties ``u v`` / ``s t`` (None without) and the corner normals (n,3,3)
+    from ``nx ny nz`` — or, when the file has none, the vertex normals mitsuba computes in that case
+    (Mesh::recompute_vertex_normals) [mitsuba3: src/shapes/ply.cpp]; returns (tris, uv, normals).  Other properties are
+    skipped."""
     with open(path, "rb") as fh:
         if fh.readline().strip() != b"ply":
             raise ValueError(f"{path}: not a PLY file")
@@ -519,6 +523,7 @@ def load_ply(path: str) -> np.ndarray:
                 break
         body = fh.read()
     verts, faces = None, []
+    vattr = {}                       # vertex properties beside the position, by name
     if fmt == "ascii":
         lines = body.decode("ascii", "replace").split("\n")
         li = 0
@@ -529,6 +534,9 @@ def load_ply(path: str) -> np.ndarray:
                 names = [p[-1] for p in props]
                 ix = [names.index(a) for a in "xyz"]
                 verts = np.asarray([[float(r[i]) for i in ix] for r in rows], dtype=np.float64)
+                for a in ("nx", "ny", "nz", "u", "v", "s", "t"):
+                    if a in names:
+                        vattr[a] = np.asarray([float(r[names.index(a)]) for r in rows], dtype=np.float64)
             elif name == "face":
                 for r in rows:
                     n = int(r[0])
@@ -544,6 +552,9 @@ def load_ply(path: str) -> np.ndarray:
                 off += dt.itemsize * count
                 if name == "vertex":
                     verts = np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float64)
+                    for a in ("nx", "ny", "nz", "u", "v", "s", "t"):
+                        if a in arr.dtype.names:
+                            vattr[a] = arr[a].astype(np.float64)
             else:
                 if len(props) != 1:
                     raise ValueError(f"{path}: face element with extra properties is not supported")
@@ -572,7 +583,18 @@ def load_ply(path: str) -> np.ndarray:
     if verts is None:
         raise ValueError(f"{path}: no vertex element")
     t = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
-    return verts[t]
+    if not with_attributes:
+        return verts[t]
+    uv = None
+    for a, b in (("u", "v"), ("s", "t")):
+        if a in vattr and b in vattr:
+            uv = np.stack([vattr[a], vattr[b]], axis=1).astype(np.float32)[t].reshape(-1, 6)
+            break
+    if all(a in vattr for a in ("nx", "ny", "nz")):
+        normals = np.stack([vattr["nx"], vattr["ny"], vattr["nz"]], axis=1)[t]
+    else:
+        normals = vertex_normals(verts, t)
+    return verts[t], uv, normals
 
 
 # -- sensor ---------------------------------------------------------------

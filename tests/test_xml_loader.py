@@ -153,6 +153,22 @@ def test_ply_binary_and_obj_readers(tmp_path):
     body = b"".join(struct.pack("<ddd", *v) for v in verts) + struct.pack("<BIII", 3, 0, 1, 4) + struct.pack("<BIII", 3, 1, 2, 4)
     (tmp_path / "u.ply").write_bytes(hdr + body)
     assert np.array_equal(load_ply(str(tmp_path / "u.ply"))[1], verts[[1, 2, 4]].astype(np.float64))
+    # vertex normals and texture coordinates of a PLY (ply.cpp): nx ny nz / s t are kept; without normals the loader
+    # computes mitsuba's vertex normals, as for an OBJ
+    t3, uv, nn = load_ply(str(tmp_path / "u.ply"), with_attributes=True)
+    assert uv is None and nn.shape == (2, 3, 3) and np.allclose(np.linalg.norm(nn, axis=2), 1.0)
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+           "property float nx\nproperty float ny\nproperty float nz\nproperty float s\nproperty float t\n"
+           "element face 1\nproperty list uchar int vertex_indices\nend_header\n").encode()
+    rows = [(0, 0, 0, 0, 0.6, 0.8, 0.0, 0.0), (1, 0, 0, 0, 0, 1, 1.0, 0.0), (0, 1, 0, 0.6, 0, 0.8, 0.0, 1.0)]
+    (tmp_path / "n.ply").write_bytes(hdr + b"".join(struct.pack("<8f", *r) for r in rows) + struct.pack("<Biii", 3, 0, 1, 2))
+    t3, uv, nn = load_ply(str(tmp_path / "n.ply"), with_attributes=True)
+    assert np.allclose(nn[0], [[0, 0.6, 0.8], [0, 0, 1], [0.6, 0, 0.8]]) and np.allclose(uv[0], [0, 0, 1, 0, 0, 1])
+    import mitransient_amd.mi as mi
+    sd = mi.load_dict({"type": "scene", "integrator": {"type": "transient_path"},
+                       "sensor": {"type": "perspective", "fov": 40.0, "film": {"type": "transient_hdr_film", "width": 4, "height": 4, "temporal_bins": 4}},
+                       "m": {"type": "ply", "filename": str(tmp_path / "n.ply")}}).data()
+    assert sd.tri_normals is not None and np.allclose(sd.tri_normals[0].reshape(3, 3), nn[0], atol=1e-6)
     (tmp_path / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\n")
     assert load_obj(str(tmp_path / "neg.obj")).shape == (1, 3, 3)
 
