@@ -195,6 +195,17 @@ def test_bench_self_launches_its_ranks():
     assert res["value"] > 0 and res["roofline"]["bound"] in ("hbm", "valu")
 
 
+def test_bench_config4_share_two_ranks():
+    """`bench.py --scene nlos` — BASELINE config 4's per-GPU share as a bench workload — with two ranks sharing this GPU: the NLOS
+    film goes through the same sample-sharded reduce as config 3's"""
+    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0"},
+                      ["--gpus", "2", "--scene", "nlos", "--steps", "2", "--warmup", "1", "--width", "32", "--height", "32", "--bins", "512",
+                       "--spp", "16", "--no-cpu-baseline", "--no-scatter-leg"])
+    assert res["n_gpus"] == 2 and "NLOS" in res["metric"] and "nlos_capture_meter" in res["config"]["workload"]
+    assert res["counters_per_step"]["paths"] == 32 * 32 * 16 * 2 and res["counters_per_step"]["splats_issued"] > 0
+    assert res["value"] > 0 and res["render_path"] in ("pipelined", "whole")
+
+
 def test_bench_under_torchrun_matches_the_contract():
     """the same branch launched as the driver launches it: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
     import json
