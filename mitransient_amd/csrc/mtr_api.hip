@@ -332,7 +332,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     HIP_TRY(c, hipMalloc(&w.q_shadow, (size_t)n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.r_shadow, (size_t)n_slots * 32));
     HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots));
-    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (3 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total
+    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (5 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total + seg_list_n[2] (16 words), seg_list[2][n_seg]
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
     if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
@@ -428,6 +428,8 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             a.seg_shadow = (uint32_t *)w.counts + (size_t)(2 + kWfKeys) * a.n_seg;
             uint32_t *live_total = (uint32_t *)w.counts + (size_t)(3 + kWfKeys) * a.n_seg;
             a.live_total = unbounded ? live_total : nullptr;
+            a.seg_list_n = live_total + 4;
+            a.seg_list = live_total + 16;
             const int grid = (int)std::min<uint32_t>(a.n_seg, (uint32_t)grid_full);
             const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
             HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
@@ -435,9 +437,11 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             a.ticket = c->d_ticket + 16; a.ticket_cur = 0u;                          // segment tickets (k_wf_trace / shadow_gen / shade)
             HIP_TRY(c, hipMemsetAsync(a.ticket, 0, 2 * sizeof(uint32_t), c->stream));
             HIP_TRY(c, launch_wf(a, cfg, 0, grid_gen, c->stream));                   // raygen (writes live list 0)
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)a.seg_list_n, (int)a.n_seg, 1, c->stream));     // bounce 0 walks every segment
             uint32_t depth = 0;
             while (depth < max_depth) {
                 if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
+                HIP_TRY(c, hipMemsetAsync(a.seg_list_n + (a.parity ^ 1u), 0, 4, c->stream));     // the list this bounce's survivors build
                 if (a.nlos_on) {          // NLOS tier: the whole loop iteration of transient_nlos_path in one launch per bounce
                     HIP_TRY(c, launch_wf(a, cfg, 5, grid, c->stream)); a.ticket_cur ^= 1u;
                     *n_trace += 1;

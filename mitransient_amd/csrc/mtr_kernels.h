@@ -97,6 +97,8 @@ struct WfArgs {
     uint32_t *q_live;                    // [2][n_slots] ping-pong live lists (slot indices), segment sg at sg * seg
     float4 *q_ray;                       // [2][n_slots][2] the rays of the live lists IN LIST ORDER: (o, tmax) (d, eta)
     uint32_t *seg_live;                  // [2][n_seg]   their lengths
+    uint32_t *seg_list;                  // [2][n_seg]   the segments that HOLD live paths, per parity (the kernels of a bounce walk this list:
+    uint32_t *seg_list_n;                // [2]          its length        a deep bounce of max_depth 65 touches a handful of 32768 segments)
     uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit lists, same segmentation
     uint32_t *q_shadow;                  // [n_slots] slots whose vertex emits a shadow ray this bounce, same segmentation
     float4 *r_shadow;                    // [n_slots][2] those shadow rays, in list order: (o, tmax) (d, -)

@@ -107,14 +107,28 @@ __device__ __forceinline__ void wf_ticket_begin(const WfArgs &a, int tid)
 }
 // A workgroup's FIRST segment is its own index (no atomic: 2048 workgroups hitting one counter at launch cost a launch of
 // a late, nearly empty bounce 90 us), the following ones come from the counter, which therefore counts from gridDim.
+// The index runs over the bounce's list of segments that still hold live paths (written by raygen / by the previous bounce's
+// shading kernel): with max_depth 65 most launches find a handful of the 32768 segments of a tile alive, and walking all of
+// them — a ticket and two barriers each — was 0.37 ms per launch, 520 launches per render.
 __device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned char *smem, int tid, bool first)
 {
-    if (first) return blockIdx.x;
-    uint32_t *s_sg = (uint32_t *)smem + 15;
-    __syncthreads();                      // the previous segment's LDS state is no longer in use
-    if (tid == 0) *s_sg = gridDim.x + atomicAdd(a.ticket + a.ticket_cur, 1u);
-    __syncthreads();
-    return *s_sg;
+    uint32_t k;
+    if (first) k = blockIdx.x;
+    else {
+        uint32_t *s_sg = (uint32_t *)smem + 15;
+        __syncthreads();                  // the previous segment's LDS state is no longer in use
+        if (tid == 0) *s_sg = gridDim.x + atomicAdd(a.ticket + a.ticket_cur, 1u);
+        __syncthreads();
+        k = *s_sg;
+    }
+    return k < a.seg_list_n[a.parity] ? a.seg_list[(size_t)a.parity * a.n_seg + k] : 0xffffffffu;
+}
+// the segment keeps `n` live paths for the next bounce: its length, and its place in the next bounce's list
+__device__ __forceinline__ void wf_segment_survivors(const WfArgs &a, uint32_t sg, uint32_t n)
+{
+    const uint32_t nxt = a.parity ^ 1u;
+    a.seg_live[(size_t)nxt * a.n_seg + sg] = n;
+    if (n) a.seg_list[(size_t)nxt * a.n_seg + atomicAdd(a.seg_list_n + nxt, 1u)] = sg;
 }
 
 // ---- SoA-of-quads state: 7 planes of float4 (16 B per lane per access, the coalescing sweet spot;
@@ -147,14 +161,15 @@ __device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s, float &eta)
     return r;
 }
 template <class Planes>
-__device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_inc)
+// with_origin: also the (origin, tmax) plane.  Only a kernel that traces from the planes reads it (k_wf_nlos_bounce); the
+// closest-hit kernel takes its rays from the list in list order, shading needs the direction alone
+__device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_origin)
 {
-    P.st(Q_RAY0, s, make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax));
+    if (with_origin) P.st(Q_RAY0, s, make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax));
     P.st(Q_RAY1, s, make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta));
     P.st(Q_BETA, s, make_float4(p.beta.x, p.beta.y, p.beta.z, p.dist));
     P.st(Q_RAD, s, make_float4(p.L.x, p.L.y, p.L.z, p.prev_pdf));
     P.st(Q_PREV, s, make_float4(p.prev_p.x, p.prev_p.y, p.prev_p.z, __uint_as_float(p.depth | (p.prev_delta << 31))));
-    (void)with_inc;
     P.st(Q_RNG, s, make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)),
                                 __uint_as_float((uint32_t)p.rng.inc), __uint_as_float((uint32_t)(p.rng.inc >> 32))));
 }
@@ -286,8 +301,10 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
         a.q_ray[2 * (size_t)slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax);
         a.q_ray[2 * (size_t)slot + 1] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta);
     }
-    for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock)
+    for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock) {
         a.seg_live[sg] = min(a.seg, a.n_slots - sg * a.seg);    // every slot of the segment is live
+        a.seg_list[sg] = sg;                                    // ... and every segment is on bounce 0's list (its length: the host)
+    }
     if (a.counters) {
         if (n_closest) atomicAdd(&a.counters->rays_closest, (unsigned long long)n_closest);
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&a.counters->paths, (unsigned long long)a.n_slots);
@@ -514,7 +531,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
         {   // an emptied segment: nothing to shade, nothing survives
             uint32_t n_all = 0u;
             for (uint32_t k = 0; k < kWfKeys; ++k) n_all += a.seg_mat[(size_t)sg * kWfKeys + k];
-            if (n_all == 0u) { if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = 0u; continue; }
+            if (n_all == 0u) { if (tid == 0) wf_segment_survivors(a, sg, 0u); continue; }
         }
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) s_steady[t] = 0.0f;
@@ -562,9 +579,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     alive = shade_finish<EXT>(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
-                    store_state(P, slot, p, false);
                     ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
-                    if (alive) ++n_alive;
+                    if (alive) { ++n_alive; store_state(P, slot, p, false); }      // (a path that ended leaves nothing to read)
                     else {
                         // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
                         float *sp = s_steady + 4 * (pl - pl0);
@@ -586,7 +602,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
             }
         }
         __syncthreads();
-        if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
+        if (tid == 0) wf_segment_survivors(a, sg, *s_next_p);
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
             const float v = s_steady[t];
@@ -670,8 +686,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
                 alive = nlos_bounce<EXT>(p, sv, a.nlos, a.film, a.rc, st, sink, bs);
                 n_closest += bs.closest; n_shadow += bs.shadow; ++n_bounce;
                 n_splats += sink.n_splats; n_over += sink.n_overflow;
-                store_state(P, slot, p, false);
-                if (alive) ++n_alive;
+                if (alive) { ++n_alive; store_state(P, slot, p, true); }
                 else {
                     const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
                     if (fx < a.film.width && fy < a.film.height) {
@@ -689,7 +704,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
             }
         }
         __syncthreads();
-        if (tid == 0) a.seg_live[(size_t)(par ^ 1u) * a.n_seg + sg] = *s_next_p;
+        if (tid == 0) wf_segment_survivors(a, sg, *s_next_p);
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {
             const float v = s_steady[t];
