@@ -1586,6 +1586,7 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
 /* ------------------------------------------------------------------ */
 /* Public entry points                                                 */
 /* ------------------------------------------------------------------ */
+static int g_default_threads = 0;
 int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *transient_hwt4, float *steady_hw4,
                mtr_counters *out, int n_threads, int use_bvh,
                orc_splat_rec *log, uint64_t log_cap, uint64_t *log_n)
@@ -1607,7 +1608,10 @@ int orc_render(const mtr_scene_desc *d, const mtr_render_params *P, float *trans
     const int64_t n_pix = (int64_t)P->pixel_end - (int64_t)P->pixel_begin;
     const uint32_t s0 = P->spp_begin, s1 = P->spp_end;
 #ifdef _OPENMP
-    if (n_threads > 0) omp_set_num_threads(n_threads);
+    /* n_threads <= 0: the process's default team (OMP_NUM_THREADS or every core) — also after an earlier call asked for fewer
+     * (omp_set_num_threads persists: a test that rendered on one thread left every later render on one thread) */
+    if (!g_default_threads) g_default_threads = omp_get_max_threads();
+    omp_set_num_threads(n_threads > 0 ? n_threads : g_default_threads);
 #else
     (void)n_threads;
 #endif
@@ -1714,7 +1718,7 @@ void orc_camera_ray(const mtr_scene_desc *d, uint32_t px, uint32_t py, float j1,
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    return g_default_threads ? g_default_threads : omp_get_max_threads();
 #else
     return 1;
 #endif
