@@ -199,8 +199,8 @@ typedef struct mtr_scene_desc {
     /* Per-corner SHADING normals (host, n_tris*9 floats: n0 n1 n2, unit length, world space; optional; ABI 8).  A triangle
      * whose nine floats are all zero — and every triangle when this is NULL — is flat-shaded (face_normals = true, cube,
      * rectangle).  Otherwise, as in mitsuba's Mesh::compute_surface_interaction: sh_frame.n = normalize(b0 n0 + b1 n1 +
-     * b2 n2), the tangent from dp_du by initialize_sh_frame; the geometric normal keeps the ray offsets and the emitter
-     * densities. */
+     * b2 n2), the tangent from dp_du by initialize_sh_frame; the geometric normal (si.n) keeps the ray offsets.  Meshes that are
+     * SAMPLED (area emitters, NLOS hidden geometry) interpolate the same normals in Mesh::sample_position. */
     const float    *tri_normals;
     /* Bitmap textures referenced by mtr_material.albedo_texture (host; optional).  The lookup uses tri_uv exactly as given:
      * uv = fmadd(uv2, b2, fmadd(uv1, b1, uv0 b0)) (a rectangle: (prim_uv + 1) / 2); mitsuba's OBJ loader flips v
