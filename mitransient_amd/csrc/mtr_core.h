@@ -56,6 +56,7 @@ constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kRayEps = 1500.0f * 5.9604644775390625e-8f;
 constexpr float kShadowEps = kRayEps * 10.0f;
 constexpr float kInf = __builtin_huge_valf();
+constexpr float kEdgeEps = 1.9073486328125e-06f;     // 2^-19: how far a barycentric coordinate may undershoot a triangle edge (trav_leaf_test)
 
 // ---------------------------------------------------------------- sampler
 struct Rng { uint64_t state, inc; };
@@ -524,6 +525,11 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     // Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]: pvec = cross(d, e2); inv_det = 1 / dot(e1, pvec);
     // tvec = o - p0; u = dot(tvec, pvec) * inv_det; qvec = cross(tvec, e1); v = dot(d, qvec) * inv_det;
     // t = dot(e2, qvec) * inv_det; hit iff 0 <= u <= 1, v >= 0, u + v <= 1, 0 <= t <= tmax  (cross and dot as fma chains).
+    // Shared edges are CLOSED (kEdgeEps = 2^-19 of the triangle): the two triangles of an edge evaluate it with different
+    // operation orders, so a ray aimed exactly at it can fail both tests by one rounding — which is no measure-zero event
+    // when millions of paths connect to ONE point (the laser spot at the centre of a two-triangle relay wall lies on its
+    // diagonal: 11 % of the NLOS connections of nlos-z-simple.xml fell through; the reference's Embree evaluates a quad's
+    // diagonal with one expression for both triangles).  A ray on the edge hits both at the same t; the tie rule decides.
     // Two triangles of the leaf per pass, one in each half of a register pair (v_pk_mul/add/fma_f32): either half is bit
     // for bit what a scalar evaluation gives; a leaf with an odd count has its last triangle repeated in the pad slot,
     // whose result is ignored.
@@ -550,7 +556,7 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
         const f2 t = mul2(fma2(e2x, qx, fma2(e2y, qy, mul2(e2z, qz))), inv_det);       // dot(e2, qvec) * inv_det
         const f2 uv = add2(u, v);
         {
-            const bool hit = (u.x >= 0.0f) && (u.x <= 1.0f) && (v.x >= 0.0f) && (uv.x <= 1.0f) && (t.x >= 0.0f) && (t.x <= tr.tmax);
+            const bool hit = (u.x >= -kEdgeEps) && (u.x <= 1.0f + kEdgeEps) && (v.x >= -kEdgeEps) && (uv.x <= 1.0f + kEdgeEps) && (t.x >= 0.0f) && (t.x <= tr.tmax);
             const bool closer = (t.x < tr.h.t) | ((t.x == tr.h.t) & (orig_a < tr.best_orig));      // bitwise: no branches for three compares
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;
@@ -558,7 +564,7 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
             tr.h.prim = better ? pa : tr.h.prim; tr.best_orig = better ? orig_a : tr.best_orig;
         }
         {
-            const bool hit = two && (u.y >= 0.0f) && (u.y <= 1.0f) && (v.y >= 0.0f) && (uv.y <= 1.0f) && (t.y >= 0.0f) && (t.y <= tr.tmax);
+            const bool hit = two && (u.y >= -kEdgeEps) && (u.y <= 1.0f + kEdgeEps) && (v.y >= -kEdgeEps) && (uv.y <= 1.0f + kEdgeEps) && (t.y >= 0.0f) && (t.y <= tr.tmax);
             const bool closer = (t.y < tr.h.t) | ((t.y == tr.h.t) & (orig_b < tr.best_orig));
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;

@@ -417,6 +417,16 @@ static void free_scene(orc_scene *sc)
 typedef struct { v3 o, d; float maxt; } ray3;
 typedef struct { float t, u, v; int prim; } hit_t;
 
+/* Shared edges are CLOSED: a barycentric coordinate may undershoot its edge by MTR_EDGE_EPS (2^-19 of the triangle).
+ * Moller-Trumbore evaluates the two triangles of an edge with different operation orders, so a ray aimed exactly at the
+ * edge can fail both tests by one rounding.  That is no measure-zero event when a render connects millions of paths to ONE
+ * point: the laser spot of examples/transient-nlos/nlos-z-simple.xml is the centre of a two-triangle wall, i.e. ON its
+ * diagonal, and 11 % of the connections of emitter_laser_targets_sample (transientnlospath.py:511-564) fell through
+ * (frames 0.886 of the reference's notebook figure; with closed edges 0.985 ... 1.0).  The reference
+ * traces with Embree, whose Moller-Trumbore variant evaluates an edge at the triangles' common first vertex with the same
+ * expression for both (U = dot(cross(v0 - o, d), e2) of one is -V of the other: no gap on a quad's diagonal).  A ray on
+ * the edge now hits BOTH triangles at the same t; the tie goes to the lower original index as always. */
+#define MTR_EDGE_EPS 1.9073486328125e-06f
 static inline int tri_test(const orc_tri *T, const ray3 *r, float *t, float *u, float *v)
 {
     v3 pvec = vcross(r->d, T->e2);
@@ -424,10 +434,10 @@ static inline int tri_test(const orc_tri *T, const ray3 *r, float *t, float *u, 
     float inv_det = 1.0f / det;
     v3 tvec = vsub(r->o, T->p0);
     float uu = vdot(tvec, pvec) * inv_det;
-    if (!(uu >= 0.0f && uu <= 1.0f)) return 0;
+    if (!(uu >= -MTR_EDGE_EPS && uu <= 1.0f + MTR_EDGE_EPS)) return 0;
     v3 qvec = vcross(tvec, T->e1);
     float vv = vdot(r->d, qvec) * inv_det;
-    if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
+    if (!(vv >= -MTR_EDGE_EPS && uu + vv <= 1.0f + MTR_EDGE_EPS)) return 0;
     float tt = vdot(T->e2, qvec) * inv_det;
     if (!(tt >= 0.0f && tt <= r->maxt)) return 0;
     *t = tt; *u = uu; *v = vv;

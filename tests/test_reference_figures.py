@@ -91,11 +91,11 @@ CAMERA_NCC = {"nlos_cam_simple_t130": 0.95, "nlos_cam_simple_t140": 0.9, "nlos_c
 def check_nlos_camera_frames(figures, name, tr):
     """2-complex-nlos-scenes.ipynb, cells 5 / 11 / 13: frames of the 32 x 32 x 300 tensor.  Structure, the left-right orientation
     (the scenes are symmetric top to bottom), and the absolute scale — values of 1e-5 / 1e-6 here, five orders of magnitude
-    below the capture-meter scenes of notebook 1: the camera's pixel measure instead of the relay wall's.
-    nlos-z-room: every frame sum within 8 % (measured 0.98 .. 1.06).  nlos-z-simple: the frames correlate 0.94 .. 0.99 but are
-    a UNIFORM 0.88 .. 0.91 of the figure's, in bright and dim pixels alike, with hidden-geometry sampling on or off — although the
-    room scene contains the same wall, the same Z and the same laser.  Unexplained (the embedded figure may predate the XML);
-    held to 15 % and recorded in DESIGN.md."""
+    below the capture-meter scenes of notebook 1: the camera's pixel measure instead of the relay wall's.  Every frame sum of
+    BOTH scenes within 8 % (measured: nlos-z-room 0.98 .. 1.06, nlos-z-simple 0.987 .. 1.000).  Round 3 had nlos-z-simple at a
+    uniform 0.886 .. 0.897: its laser points at the CENTRE of a two-triangle wall, i.e. at the triangles' shared diagonal, and
+    one connection ray in nine of emitter_laser_targets_sample fell between them (a Moller-Trumbore crack; closed since round
+    4: mtr_core.h kEdgeEps, tests/test_scene_host.py::test_shared_edges_are_closed); the room's wall is centred elsewhere."""
     figs, meta = figures
     for fig, m in meta.items():
         if m.get("scene") != name:
@@ -107,7 +107,7 @@ def check_nlos_camera_frames(figures, name, tr):
         c = ft.ncc(ref, mine)
         assert c >= CAMERA_NCC[fig], (fig, c)
         assert ft.ncc(ref, mine[:, ::-1]) <= c - 0.15 and ft.ncc(ref, mine.T) <= c - 0.3, fig
-        assert abs(mine.sum() / ref.sum() - 1.0) <= (0.08 if name == "nlos-z-room" else 0.15), (fig, mine.sum(), ref.sum())
+        assert abs(mine.sum() / ref.sum() - 1.0) <= 0.08, (fig, mine.sum(), ref.sum())
 
 
 def oracle_render(oracle, scene, spp, seeds=(0,)):
@@ -331,37 +331,67 @@ def check_readme_staircase(figures, steady, ncc_min, interior_min, mean_tol):
 # regions of the Cornell box image in units of its side: (y0, y1, x0, x1)
 CBOX_REGIONS = {"left wall": (0.31, 0.70, 0.03, 0.125), "right wall": (0.31, 0.70, 0.875, 0.97), "back wall": (0.31, 0.39, 0.31, 0.70),
                 "floor": (0.92, 0.985, 0.23, 0.47), "ceiling": (0.025, 0.08, 0.16, 0.31), "tall box front": (0.55, 0.78, 0.33, 0.47)}
+# ... of which these lie BEHIND the luminaire's front edge (z > 238 of the box's 559): their level is held tightly (see below)
+CBOX_INTERIOR = ("back wall", "tall box front")
 
 
-def check_readme_cornell_box(figures, steady, ncc_min, interior_min, level_tol):
-    """`.images/cornell-box.png` (README.md:20, docs/index.rst:1): the steady image of mitransient.cornell_box() — the scene of
-    BASELINE configs 1-3.  Structure per channel (correlation, best alignment at zero shift: camera pose and field of view;
-    mirrored / transposed hypotheses clearly worse) and the LEVEL of the red and green channels on the six large surfaces
-    (figure^2.2 against the linear render: measured 0.88 ... 1.13 and 0.85 ... 0.90).  The figure's BLUE channel reads 0.3 - 0.4
-    of this render's on every surface — a uniform per-channel factor (white balance / a spectral variant?) that nothing in
-    mitransient.cornell_box() explains; recorded in DESIGN.md, not asserted"""
+def srgb_to_linear(x):
+    x = np.asarray(x, np.float64)
+    return np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
+def linear_to_srgb(x):
+    x = np.clip(np.asarray(x, np.float64), 0.0, 1.0)
+    return np.where(x <= 0.0031308, 12.92 * x, 1.055 * x ** (1.0 / 2.4) - 0.055)
+
+
+def resized_linear(img, n):
+    """float image -> n x n, channel by channel (box filter going down, bilinear going up): averages LINEAR values"""
+    from PIL import Image
+    how = Image.BOX if n < img.shape[0] else Image.BILINEAR
+    return np.stack([np.asarray(Image.fromarray(np.ascontiguousarray(img[..., c], np.float32), mode="F").resize((n, n), how)) for c in range(3)],
+                    -1).astype(np.float64)
+
+
+def check_readme_cornell_box(figures, steady, ncc_min, interior_min, chroma_tol, level_tol):
+    """`.images/cornell-box.png` (README.md:20, docs/index.rst:1).  WHICH scene it shows was the open question of round 3 (blue
+    0.3 - 0.4 x, green 0.85 x of a render of mitransient.cornell_box()).  Answered in round 4: it is a render of
+    examples/transient/cornell-box/cbox_diffuse.xml — the light's radiance (18.387, 10.9873, 2.75357) of :59 instead of
+    utils.py:156-160's (18.387, 13.9873, 6.75357), GRAY boxes (0.85, :41-43) instead of white ones — written through the sRGB
+    transfer curve (not a 2.2 power: only with the true curve do values of 0.0015 and of 0.38 agree at once).  Against a
+    render of that file every surface reads the SAME ratio in red, green and blue — e.g. left wall 1.096 / 1.083 / 1.092,
+    tall box front 0.991 / 1.007 / 1.003, blue spanning 0.0015 ... 0.035 — asserted to `chroma_tol`; the LEVEL is 1.00 - 1.02 on
+    the surfaces behind the luminaire's front edge (`level_tol`) and an achromatic 1.08 ... 1.21 on the parts of walls, floor
+    and ceiling in front of it (z < 238 of 559), which the reference's own notebook render of the same file
+    (4-rainbow_visualization.ipynb, `cbox_sparse_fusion`: no such ring against this render) does not show: an exposure
+    gradient of that one image, recorded in DESIGN.md section 2 and bounded here.  A render of mitransient.cornell_box() fails
+    this check (asserted by the callers)."""
     fig = figures[0]["readme_cornell_box"]
     ref = figure_content(figure_content(fig, bright_margin=True), bright_margin=False)      # white margin, then the black frame
     assert abs(ref.shape[0] - ref.shape[1]) <= 4
     n = steady.shape[0]
-    a, b = resized(ref, (n, n)), display(steady)
+    lin = np.asarray(steady, np.float64)
+    fig_lin = resized_linear(srgb_to_linear(ref), n)
+    a, b = linear_to_srgb(fig_lin), linear_to_srgb(lin)
     for ch, least in ((0, ncc_min), (1, ncc_min), (2, ncc_min - 0.08)):
         c = ft.ncc(a[..., ch], b[..., ch])
         assert c >= least, (ch, c)
         assert max(ft.ncc(a[..., ch], b[:, ::-1, ch]), ft.ncc(a[..., ch], b[::-1, :, ch]), ft.ncc(a[..., ch], b[..., ch].T)) <= c - 0.15, ch
     ci, dy, dx = best_shift(a[..., 0], b[..., 0], reach=3, margin=max(4, n // 16))
     assert (dy, dx) == (0, 0) and ci >= interior_min, (ci, dy, dx)
-    lin = np.asarray(steady, np.float64)
     ratios = {}
     for name, (y0, y1, x0, x1) in CBOX_REGIONS.items():
         sl = (slice(int(y0 * n), int(y1 * n)), slice(int(x0 * n), int(x1 * n)))
-        f, m = (a[sl] ** 2.2).reshape(-1, 3).mean(0), lin[sl].reshape(-1, 3).mean(0)
-        ratios[name] = f / m
-        dominant = (0, 1) if name != "left wall" else (0,)         # (the red wall's green is 3 % of its red: below the figure's precision)
-        for ch in dominant:
-            assert abs(f[ch] / m[ch] - 1.0) <= level_tol, (name, ch, f, m)
+        f, m = fig_lin[sl].reshape(-1, 3).mean(0), lin[sl].reshape(-1, 3).mean(0)
+        r = ratios[name] = f / m
+        # the COLOUR of every surface, in all three channels (blue included: it is 1 / 100 of red on the left wall)
+        assert r.max() / r.min() - 1.0 <= chroma_tol, (name, r, f, m)
+        if name in CBOX_INTERIOR:
+            assert np.all(np.abs(r - 1.0) <= level_tol), (name, r)
+        else:
+            assert 1.0 - level_tol <= r.mean() <= 1.27, (name, r)
     # colours name the walls: red left, green right, the rest warm white
-    assert ratios and a[int(0.5 * n), int(0.07 * n), 0] > 3 * a[int(0.5 * n), int(0.07 * n), 1]
+    assert a[int(0.5 * n), int(0.07 * n), 0] > 3 * a[int(0.5 * n), int(0.07 * n), 1]
     assert a[int(0.5 * n), int(0.93 * n), 1] > a[int(0.5 * n), int(0.93 * n), 0] and b[int(0.5 * n), int(0.93 * n), 1] > b[int(0.5 * n), int(0.93 * n), 0]
     return ratios
 
@@ -408,10 +438,18 @@ def readme_staircase_scene(width, height, spp, **kw):
                      textures=True, **kw)
 
 
-def readme_cornell_scene(n, spp):
+def readme_cornell_scene(n, spp, which="xml"):
+    """the scene of `.images/cornell-box.png`: examples/transient/cornell-box/cbox_diffuse.xml (data fixture
+    tests/golden/cbox_diffuse_scene.npz) at n x n pixels — or, `which="dict"`, mitransient.cornell_box() (BASELINE configs 1-3),
+    which the image is NOT (other radiance, white boxes)"""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
+    if which == "xml":
+        import os
+        from mitransient_amd.scenes import from_fixture
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cbox_diffuse_scene.npz")
+        return from_fixture(path, spp=spp, film={"width": n, "height": n, "temporal_bins": 16, "bin_width_opl": 200.0})
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=n, height=n, temporal_bins=16)
     d["sensor"]["sampler"]["sample_count"] = spp
@@ -420,11 +458,16 @@ def readme_cornell_scene(n, spp):
 
 def test_oracle_matches_the_readme_images(oracle, figures):
     """the ORACLE against the two images of its own renders the reference shows in its README"""
-    scene = readme_cornell_scene(128, 128)
-    sd, film = scene.data(), scene.sensors()[0].film()
-    t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 128), use_bvh=True)
-    _, s3 = oracle.develop(sd.film, t4, s4)
-    check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, level_tol=0.2)
+    for which in ("xml", "dict"):
+        scene = readme_cornell_scene(128, 512, which)
+        sd, film = scene.data(), scene.sensors()[0].film()
+        t4, s4, _ = oracle.render(sd, scene.integrator().render_params(film, 0, 512), use_bvh=True)
+        _, s3 = oracle.develop(sd.film, t4, s4)
+        if which == "xml":
+            check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, chroma_tol=0.05, level_tol=0.06)
+        else:               # mitransient.cornell_box() is another picture: its light is 1.27 x greener and 2.45 x bluer, its boxes are white
+            with pytest.raises(AssertionError):
+                check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, chroma_tol=0.05, level_tol=0.06)
     scene = readme_staircase_scene(54, 96, 160, temporal_bins=400)        # the scene file's own film: 400 bins of 0.1 from 0
     sd, film = scene.data(), scene.sensors()[0].film()
     assert (film.temporal_bins, film.bin_width_opl, film.start_opl, scene.integrator().camera_unwarp) == (400, 0.1, 0.0, True)
@@ -557,11 +600,16 @@ def test_product_phasor_film_matches_the_frequency_figures(figures):
 
 @pytest.mark.gpu
 def test_product_matches_the_readme_images(figures):
-    """the PRODUCT against `.images/cornell-box.png` (configs 1-3's scene) and `.images/staircase_steady.png` (config 5's scene as
-    its file describes it; the bench's smooth-material approximation of the same scene is measurably NOT that picture)"""
+    """the PRODUCT against `.images/cornell-box.png` (a render of cbox_diffuse.xml: all three channels of six surfaces) and
+    `.images/staircase_steady.png` (config 5's scene as its file describes it; the bench's smooth-material approximation of the
+    same scene is measurably NOT that picture)"""
     scene = readme_cornell_scene(356, 1024)
     _, s3 = product_render(scene, 1024)
-    check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, level_tol=0.17)
+    ratios = check_readme_cornell_box(figures, s3, ncc_min=0.8, interior_min=0.9, chroma_tol=0.04, level_tol=0.05)
+    print("README cornell-box.png / render of cbox_diffuse.xml, per surface (r, g, b):", {k: np.round(v, 3).tolist() for k, v in ratios.items()})
+    _, s3d = product_render(readme_cornell_scene(356, 1024, "dict"), 1024)
+    with pytest.raises(AssertionError):             # mitransient.cornell_box() is not that picture
+        check_readme_cornell_box(figures, s3d, ncc_min=0.8, interior_min=0.9, chroma_tol=0.04, level_tol=0.05)
     scene = readme_staircase_scene(216, 384, 512)
     _, s3 = product_render(scene, 512)
     c_full, ratio = check_readme_staircase(figures, s3, ncc_min=0.94, interior_min=0.98, mean_tol=0.05)

@@ -280,6 +280,55 @@ def test_bvh_degenerate_inputs(oracle, host_harness):
             assert p0[0] == 0                                   # coincident triangles: lowest index wins
 
 
+def test_shared_edges_are_closed(oracle, host_harness):
+    """Rays aimed AT the shared diagonal of a two-triangle quad never slip between the triangles (mtr_core.h: kEdgeEps,
+    oracle: MTR_EDGE_EPS).  Moller-Trumbore evaluates the two sides of an edge with different operation orders; with the
+    plain 0 <= u, v, u + v <= 1 test about one ray in nine aimed at the centre of examples/transient-nlos/nlos-z-simple.xml's
+    relay wall — where its laser points — missed both triangles: every NLOS frame came out 0.886 of the reference's figure
+    (DESIGN.md section 2).  Oracle and product agree bit for bit on every ray, hit or not."""
+    from mitransient_amd.scene import SceneData
+    base = make_cornell().data()
+    # Plane.ply of the reference's scene: (-1,-1) (1,-1) (1,1) | (-1,-1) (1,1) (-1,1), and a rotated, shifted, scaled copy
+    quad = np.array([[-1, -1, 0, 1, -1, 0, 1, 1, 0], [-1, -1, 0, 1, 1, 0, -1, 1, 0]], np.float64).reshape(2, 3, 3)
+    c, s_ = np.cos(0.7), np.sin(0.7)
+    rot = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) @ np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    rng = np.random.default_rng(11)
+    for verts, origin in ((quad, np.zeros(3)), (quad @ rot.T * 0.37 + np.array([3.1, -2.2, 5.3]), np.array([3.1, -2.2, 5.3]))):
+        sd = SceneData()
+        sd.tri_verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+        sd.tri_material = np.zeros(2, np.uint32)
+        sd.tri_emitter = np.full(2, -1, np.int32)
+        sd.materials, sd.n_materials = base.materials, 1
+        sd.camera, sd.film = base.camera, base.film
+        v = sd.tri_verts.reshape(2, 3, 3).astype(np.float64)
+        n = 200000
+        # targets: the quad's centre (the laser spot) for half of the rays, random points of the diagonal for the rest
+        lam = np.where(np.arange(n) < n // 2, 0.5, rng.uniform(0.02, 0.98, n))[:, None]
+        target = v[0, 0] * (1 - lam) + v[0, 2] * lam
+        nrm = np.cross(v[0, 1] - v[0, 0], v[0, 2] - v[0, 0]); nrm /= np.linalg.norm(nrm)
+        dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        dirs = np.where((dirs @ nrm)[:, None] < 0, -dirs, dirs)            # origins on the normal's side ...
+        dirs = dirs[np.abs(dirs @ nrm) > 0.05]                             # ... and not grazing
+        o = (target[:len(dirs)] + dirs * rng.uniform(0.5, 4.0, (len(dirs), 1))).astype(np.float32)
+        d = (target[:len(dirs)] - o.astype(np.float64))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        t0, p0, occ0 = oracle.intersect(sd, o, d)
+        t1, p1, occ1 = _hh_intersect(host_harness, sd, o, d)
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(p0, p1) and np.array_equal(occ0, occ1)
+        # the plain 0 <= u, v test loses 8 - 12 % of these rays.  The reference's wall: none may miss.  The small, rotated quad far
+        # from the origin, seen from up to 11 of its side lengths away at down to 3 degrees: the rounding of u, v grows with
+        # distance / (size * cos) and passes the tolerance for a few grazing rays in 10^4 — a ray that misses there is within
+        # 10^-6 of the edge of a triangle it sees under a few degrees
+        miss = p0 < 0
+        assert miss.mean() <= (0.0 if origin[0] == 0.0 else 5e-4), (int(miss.sum()), len(p0))
+        assert not np.any(miss & (np.abs(d.astype(np.float64) @ nrm) > 0.3))
+    # ... and a ray that passes OUTSIDE the quad by more than the tolerance still misses
+    sd.tri_verts = np.ascontiguousarray(quad, np.float32).reshape(-1, 9)
+    o = np.array([[1.0 + 1e-4, 0.3, 2.0], [0.2, -1.0 - 1e-4, 2.0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -1]], np.float32)
+    assert np.all(oracle.intersect(sd, o, d)[1] < 0) and np.all(_hh_intersect(host_harness, sd, o, d)[1] < 0)
+
+
 def test_obj_loader(tmp_path):
     from mitransient_amd.scene import load_obj
     p = tmp_path / "q.obj"
