@@ -201,40 +201,122 @@ def valu_roofline(kernel, avg_launch_ms, workload_matches, launches_per_render=1
                       + str(c.get("profile", "")) + "; same source hash as the library that ran) over the launch time measured live (HIP events)"}
 
 
+WF_STATE_BYTES_PER_BOUNCE = 216.0      # un-fused wavefront state per live path and bounce
+WF_SHADOW_RAY_BYTES = 48.0             # ... + 48 B per shadow ray
+
+
+def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
+    """Roofline blocks of a render in the wavefront organisation (config 5): the dominant kernel k_wf_trace (VALU issue x active
+    lanes: instructions of the committed PMC pass of the SAME workload and sources over its own live HIP-event time), the
+    HBM-bound pair k_wf_shadow_gen + k_wf_shade (SURVEY section 8d's algorithmic bytes over their live time) and the time-bin
+    scatter-add k_wf_scatter (24 B per contribution over its live time).  counters / times: sums over ``n_renders`` renders."""
+    out = {}
+    trace_ms = times.get("wf_trace_ms", 0.0) / n_renders
+    shade_ms = times.get("wf_shade_ms", 0.0) / n_renders
+    scat_ms = times.get("scatter_ms", 0.0) / n_renders
+    c5 = pmc_from_profiles("k_wf_trace", "staircase")
+    if trace_ms > 0:
+        blk = {"kernel": "k_wf_trace", "bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "kernel_ms_per_render": trace_ms,
+               "launches_per_render": times.get("wf_trace_kernel_launches", 0) / n_renders, "share_of_render": trace_ms / ms_per_render}
+        if profile_ok and c5.get("valu_insts_per_render"):
+            lane_ops = c5["valu_insts_per_render"] * c5["valu_lanes_per_inst"]
+            ach = lane_ops / (trace_ms * 1e-3) / 1e12
+            blk.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS,
+                        "valu_issue_frac": c5["valu_insts_per_render"] * 2.0 / (1024 * trace_ms * 1e-3 * 2.4e9),
+                        "lanes_per_valu_inst": c5["valu_lanes_per_inst"], "valu_insts_per_render": c5["valu_insts_per_render"],
+                        "traffic": c5.get("hbm_bytes_per_render"), "wait_any_frac": c5.get("wait_any_frac"),
+                        "profile_source_hash": source_hash(),
+                        "note": "k_wf_trace waits on divergent 16-byte loads from L1/L2 (wait_any_frac), so its issue fraction is the "
+                                "honest utilisation figure; HBM traffic is a small fraction of the roof (scene resident in L2)",
+                        "source": "profiles/traffic.json[staircase] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"})
+        else:
+            blk.update({"achieved": None, "frac": None, "roofline_stale": True,
+                        "note": "instruction counts need the PMC pass of THESE sources (tools/profile.sh ... --scene staircase); the live kernel time stands"})
+        out["roofline"] = blk
+    if shade_ms > 0:
+        alg = WF_STATE_BYTES_PER_BOUNCE * counters["bounces"] / n_renders + WF_SHADOW_RAY_BYTES * counters["rays_shadow"] / n_renders
+        ach = alg / (shade_ms * 1e-3) / 1e9
+        traffic = None
+        if profile_ok:
+            tr = [pmc_from_profiles(k, "staircase").get("hbm_bytes_per_render") for k in ("k_wf_shade", "k_wf_shadow_gen")]
+            traffic = sum(tr) if all(t is not None for t in tr) else None
+        out["roofline_shade"] = {"kernel": "k_wf_shadow_gen + k_wf_shade", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms_per_render": shade_ms,
+                                 "algorithmic_bytes_per_render": alg, "share_of_render": shade_ms / ms_per_render,
+                                 "note": "algorithmic bytes = SURVEY section 8d: 216 B per live path and bounce + 48 B per shadow ray; "
+                                         "traffic = 2 x FETCH_SIZE + WRITE_SIZE of both kernels per render (PMC passes)"}
+    if scat_ms > 0:
+        alg = SPLAT_BYTES * counters["splats_issued"] / n_renders
+        ach = alg / (scat_ms * 1e-3) / 1e9
+        out["scatter_add"] = {"kernel": "k_wf_scatter", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": (pmc_from_profiles("k_wf_scatter", "staircase").get("hbm_bytes_per_render") if profile_ok else None),
+                              "kernel_ms_per_render": scat_ms, "algorithmic_bytes_per_render": alg,
+                              "launches_per_render": times.get("scatter_launches", 0) / n_renders}
+    return out
+
+
 def extra_config_legs(spp4, spp5):
-    """Untimed side legs (rank 0, N = 1): BASELINE configs[3] (NLOS confocal Z scene, one GPU's share of the 4096 spp) and
-    configs[4] (the staircase) at reduced sample counts, each with its own HIP-event time and counters, so that the
-    driver-run line carries them next to the headline."""
+    """Side legs of the driver-run line (rank 0, N = 1), each with its own HIP-event times, counters and roofline blocks:
+    BASELINE configs[3] — the NLOS confocal Z scene, ONE GPU's share (512 of the 4096 spp; the config is stated for 8 GPUs) —
+    and configs[4] — the staircase AT ITS STATED SIZE (512^2 x 2048 bins x 2048 spp, max_depth 65).  The staircase's wavefront
+    workspace is sized by the library from the free device memory (up to 82 GB for a 2^28-slot tile)."""
     import torch
     import mitransient_amd.mi as mi
     from mitransient_amd.scenes import nlos_z, staircase
     out = {}
 
-    def run(scene, spp, reps=2):
+    def run(scene, spp, reps):
         integ = scene.integrator()
         integ.collect_stats = True
-        for _ in range(reps):                                  # the first render pays the workspace allocation
-            integ.render(scene, spp=spp, seed=0)
+        integ.render(scene, spp=spp, seed=0)                   # the first render pays the workspace allocation: not counted
         torch.cuda.synchronize()
-        c, tm = integ.total_counters, integ.total_times
-        rays = c["rays_closest"] + c["rays_shadow"]
-        r = {"ms": tm["total_ms"], "Mray_per_s": rays / tm["total_ms"] / 1e3, "time_bins_per_s": c["splats_issued"] / tm["total_ms"] * 1e3,
-             "counters": {k: c[k] for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")},
-             "mode": "wavefront" if tm["scatter_launches"] else "fused"}
-        if tm.get("wf_trace_kernel_launches"):
-            r["k_wf_trace_ms"] = tm["wf_trace_ms"]
-        return r
+        acc_c, acc_t, wall = None, None, 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            integ.render(scene, spp=spp, seed=0)
+            torch.cuda.synchronize()
+            wall += time.perf_counter() - t0
+            c, tm = integ.total_counters, integ.total_times
+            acc_c = dict(c) if acc_c is None else {k: acc_c[k] + c[k] for k in acc_c}
+            acc_t = dict(tm) if acc_t is None else {k: acc_t[k] + tm[k] for k in acc_t}
+        rays = acc_c["rays_closest"] + acc_c["rays_shadow"]
+        ms = acc_t["total_ms"] / reps
+        r = {"ms": ms, "wall_ms": wall / reps * 1e3, "renders_timed": reps, "Mray_per_s": rays / acc_t["total_ms"] / 1e3,
+             "time_bins_per_s": acc_c["splats_issued"] / acc_t["total_ms"] * 1e3,
+             "counters": {k: acc_c[k] / reps for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces")},
+             "mode": "wavefront" if acc_t["scatter_launches"] else "fused"}
+        return r, acc_c, acc_t
     mi.set_variant("llvm_ad_rgb")
     t0 = time.perf_counter()
     sc4 = nlos_z(width=256, height=256, temporal_bins=4096, spp=spp4)
-    out["config4_share"] = dict(run(sc4, spp4), workload=f"NLOS confocal Z scene (reference Z.obj), 256x256 px, 4096 time bins (start_opl 1.85, "
-                                f"width 2^-11), {spp4} of 4096 spp (one GPU's share of 8), max_depth -1, rr_depth 5")
+    r4, c4, t4 = run(sc4, spp4, 3)
+    r4["workload"] = (f"NLOS confocal Z scene (reference Z.obj), 256x256 px, 4096 time bins (start_opl 1.85, width 2^-11), {spp4} of 4096 spp "
+                      f"(one GPU's share of 8), max_depth -1, rr_depth 5")
+    if r4["mode"] == "fused":
+        avg = t4["trace_ms"] / max(1, t4["trace_launches"])
+        v = valu_roofline("k_fused", avg, spp4 == 512, 1.0, section="nlos")
+        alg = SPLAT_BYTES * c4["splats_issued"] / max(1, t4["trace_launches"])
+        hbm = {"kernel": "k_fused<NLOS>", "bound": "hbm", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": avg, "algorithmic_bytes_per_launch": alg,
+               "traffic": traffic_from_profiles("k_fused", "nlos") if spp4 == 512 else None}
+        if v is not None:
+            r4["roofline"], r4["roofline_hbm"] = v, hbm
+        else:
+            r4["roofline"] = hbm
+            r4["roofline_stale"] = not profile_is_current("nlos")
+    out["config4_share"] = r4
     del sc4
+    torch.cuda.empty_cache()
     sc5 = staircase(width=512, height=512, temporal_bins=2048, max_depth=65, materials="smooth")
     film = sc5.sensors()[0].film()
     film.start_opl, film.bin_width_opl = 0.0, 40.0 / 2048
-    out["config5_reduced"] = dict(run(sc5, spp5), workload=f"staircase scene.xml geometry (262,663 triangles, approximate materials), 512x512 px, "
-                                  f"2048 time bins (start_opl 0, width 40/2048), {spp5} of 2048 spp, max_depth 65, camera_unwarp")
+    r5, c5, t5 = run(sc5, spp5, 2)
+    r5["workload"] = (f"staircase scene.xml geometry (262,663 triangles, approximate materials), 512x512 px, 2048 time bins (start_opl 0, "
+                      f"width 40/2048), {spp5} of 2048 spp, max_depth 65, camera_unwarp")
+    r5.update(wavefront_rooflines(c5, t5, 2, r5["ms"], spp5 == 2048 and profile_is_current("staircase")))
+    out["config5" if spp5 == 2048 else "config5_reduced"] = r5
+    del sc5
+    torch.cuda.empty_cache()
     out["wall_s"] = time.perf_counter() - t0
     return out
 
@@ -258,8 +340,16 @@ def main():
     ap.add_argument("--mode", default=None, choices=[None, "auto", "fused", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scatter-leg", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the untimed config-4 / config-5 side legs")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config-4 / config-5 side legs")
+    ap.add_argument("--reduced-config5", action="store_true", help="config-5 side leg at 128 of its 2048 spp (quick runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="compute units the persistent path kernel leaves free for RCCL's kernels (mtr_render_params.reserve_cus); "
+                         "default: 8 with N > 1, 0 with one GPU")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="N > 1: time ONLY the communication of a step (reduce-scatter + all-gather of a film-sized tensor in 8 row "
+                         "bands + the steady all-reduce, no path kernel) and print that as the line's value; without the flag the same "
+                         "measurement rides along as `comm_only`")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -318,9 +408,10 @@ def main():
 
     def timed_run(renderer):
         """W untimed + K timed steps of `renderer`, fenced on both sides; returns (elapsed s = max over ranks, counters summed
-        over ranks, per-step kernel ms of this rank, launches, wavefront seen, k_wf_trace ms / launches of this rank)"""
+        over ranks, per-step kernel ms of this rank, launches, wavefront seen, sums of this rank's per-kernel HIP-event times)"""
         totals = {"paths": 0, "rays_closest": 0, "rays_shadow": 0, "splats_issued": 0, "bounces": 0}
-        kernel_ms, launches, wf_seen, wft_ms, wft_n = [], 0, False, 0.0, 0
+        kernel_ms, launches, wf_seen = [], 0, False
+        wf = {"wf_trace_ms": 0.0, "wf_trace_kernel_launches": 0, "wf_shade_ms": 0.0, "scatter_ms": 0.0, "scatter_launches": 0}
         for _ in range(args.warmup):
             renderer.render(spp=spp_total, seed=0)
         fence()
@@ -333,11 +424,12 @@ def main():
             kernel_ms.append(integ.total_times["trace_ms"])          # sum over the launches of this step
             launches += integ.total_times["trace_launches"]
             wf_seen = wf_seen or integ.total_times["scatter_launches"] > 0
-            wft_ms += integ.total_times.get("wf_trace_ms", 0.0)
-            wft_n += integ.total_times.get("wf_trace_kernel_launches", 0)
+            for k in wf:
+                wf[k] += integ.total_times.get(k, 0)
         fence()
         elapsed = time.perf_counter() - t0
         del out
+        rank_totals = dict(totals)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -346,11 +438,67 @@ def main():
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             for k, v in zip(sorted(totals), c.tolist()):
                 totals[k] = int(v)
-        return elapsed, totals, kernel_ms, launches, wf_seen, wft_ms, wft_n
+        wf["rank_totals"] = rank_totals
+        return elapsed, totals, kernel_ms, launches, wf_seen, wf
+
+    reserve = args.reserve_cus if args.reserve_cus is not None else (8 if world > 1 else 0)
+    integ.reserve_cus = reserve
+
+    def comm_only_leg(gather):
+        """the communication of one step WITHOUT the path kernel: per band one reduce-scatter of a (rows, W, T, 3) slab of a
+        film-sized tensor (+ one all-gather of the reduced rows), then the all-reduce of the (H, W, 4) steady sums — what
+        `DistributedRenderer._render_pipelined` issues, on one stream, nothing to overlap with.  step - comm_only = the part of
+        the communication the pipeline hides (or fails to)."""
+        H, W, T, nb = args.height, args.width, args.bins, 8
+        if H % (nb * world):
+            return None
+        buf = torch.zeros((H, W, T, 3), dtype=torch.float32, device="cuda")
+        outb = torch.empty_like(buf) if gather else None
+        steady = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rows_b = H // nb
+
+        def step():
+            for b in range(nb):
+                slab = mdist.reduce_scatter_rows(buf[b * rows_b:(b + 1) * rows_b])
+                if gather:
+                    outb[b * rows_b:(b + 1) * rows_b].copy_(mdist.all_gather_rows(slab, rows_b))
+            dist.all_reduce(steady)
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / args.steps * 1e3
+        gib = buf.numel() * 4 / 2 ** 30
+        return {"ms_per_step": ms, "bands": nb, "collectives_per_step": nb * (2 if gather else 1) + 1, "film_GiB": gib,
+                "reduce_scatter_GBps_per_rank": (world - 1) / world * buf.numel() * 4 / (ms * 1e-3) / 1e9 if not gather else None,
+                "what": "reduce_scatter" + (" + all_gather" if gather else "") + " of a film-sized f32 tensor in 8 row bands + all_reduce of the "
+                        "steady sums; no path kernel"}
+
+    if world > 1 and args.comm_only:
+        c_full, c_rs = comm_only_leg(True), comm_only_leg(False)
+        if rank == 0:
+            print(json.dumps({"metric": "ms per step, communication only (no path kernel)", "value": c_full["ms_per_step"] if c_full else None,
+                              "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": c_full["ms_per_step"] if c_full else None,
+                              "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"film {args.height}x{args.width}x{args.bins}x3 f32, 8 row bands"},
+                              "comm_only": c_full, "comm_only_reduce_scatter": c_rs,
+                              "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "comm_backend": backend}))
+        dist.destroy_process_group()
+        return
 
     renderer = mdist.DistributedRenderer(scene, partition="spp", gather=True)
-    elapsed, totals, kernel_ms, trace_launches, wf_seen, wft_ms, wft_n = timed_run(renderer)
+    elapsed, totals, kernel_ms, trace_launches, wf_seen, wf_t = timed_run(renderer)
+    wft_ms, wft_n, wfs_ms, wsc_ms, wsc_n = (wf_t["wf_trace_ms"], wf_t["wf_trace_kernel_launches"], wf_t["wf_shade_ms"], wf_t["scatter_ms"],
+                                            wf_t["scatter_launches"])
+    totals_rank0 = wf_t["rank_totals"]
     path_taken = renderer.last_path
+    renderer_collectives = renderer.last_collectives
     # N > 1: the same steps with the film reduction ALONE (reduce-scatter, every rank keeps the developed rows it owns —
     # north_star's "single RCCL reduce"); the headline keeps the all-gather that hands every rank the whole tensor
     rs_only = rows_leg = None
@@ -369,6 +517,7 @@ def main():
                                   "unit": "Mray/s", "what": "pixel rows sharded instead of samples: no film reduction, all_gather of the developed rows",
                                   "path": r3.last_path}
         del r3
+        comm_full, comm_rs = comm_only_leg(True), comm_only_leg(False)
 
     # ---- untimed extra leg (rank 0, N=1): the same render in wavefront mode, to time the stand-alone
     # time-bin scatter-add kernel (k_wf_scatter) with HIP events on its stream
@@ -396,7 +545,7 @@ def main():
     if rank == 0 and world == 1 and SCENE == "cornell" and not args.no_extra_configs:
         del renderer, scene
         torch.cuda.empty_cache()
-        extra = extra_config_legs(512, 128)
+        extra = extra_config_legs(512, 2048 if not args.reduced_config5 else 128)
 
     if rank == 0:
         rays = totals["rays_closest"] + totals["rays_shadow"]
@@ -431,8 +580,8 @@ def main():
                                    (f"examples/diff-transient/staircase/scene.xml geometry (262,663 triangles, " + ("approximate materials" if MATERIALS == "smooth" else "GGX lobes, vertex normals and (256-px) bitmap textures as in the scene file") + f"), "
                                     f"{args.width}x{args.height} px, {args.bins} time bins (start_opl 0, width 40/{args.bins}), {args.spp} spp per GPU "
                                     f"({spp_total} spp total), max_depth 65, rr_depth 5, camera_unwarp, seed 0"),
-                       "parallelism": (f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather, 8 row bands pipelined against the path kernel"
-                                       if world > 1 else "1 GPU"),
+                       "parallelism": (f"spp-shard x{world} + RCCL reduce_scatter(film) + all_gather, 8 row bands pipelined against the path kernel "
+                                       f"({reserve} CUs left to RCCL)" if world > 1 else "1 GPU"),
                        "mode": args.mode or ("auto (fused: scene + per-pixel time histograms in LDS)" if SCENE in ("cornell", "nlos")
                                              else "auto (wavefront: scene in HBM)")},
             # the fused kernel absorbs the scatter-add in LDS: its HBM fraction is small BY DESIGN;
@@ -440,6 +589,8 @@ def main():
             "counters_per_step": {k: v / args.steps for k, v in totals.items()},
             "source_hash": source_hash(),
         }
+        if reserve:
+            res["reserve_cus"] = reserve
         default_wl = (args.width, args.height, args.bins, args.spp) == dflt and args.mode in (None, "auto")
         hbm_line = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
@@ -454,23 +605,16 @@ def main():
         elif fused and SCENE == "nlos":       # k_fused<NLOS>: counters of `tools/profile.sh <tag> --scene nlos`, section "nlos"
             vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps, section="nlos")
         elif not fused and SCENE == "staircase" and MATERIALS == "smooth" and wft_n:
-            # config 5: the dominant kernel is k_wf_trace (closest-hit and any-hit runs); its launches are timed alone with HIP
-            # events; the PMC passes (tools/profile.sh ... --scene staircase) ran the SAME command, so instructions per RENDER
-            # divide by the k_wf_trace time per render
-            c5 = pmc_from_profiles("k_wf_trace", "staircase")
-            per_render_ms = wft_ms / args.steps
-            if default_wl and profile_is_current("staircase") and c5.get("valu_insts_per_render"):
-                lane_ops = c5["valu_insts_per_render"] * c5["valu_lanes_per_inst"]
-                ach = lane_ops / (per_render_ms * 1e-3) / 1e12
-                vline = {"kernel": "k_wf_trace", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                         "frac": ach / VALU_PEAK_TLANEOPS, "valu_issue_frac": c5["valu_insts_per_render"] * 2.0 / (1024 * per_render_ms * 1e-3 * 2.4e9),
-                         "lanes_per_valu_inst": c5["valu_lanes_per_inst"], "valu_insts_per_render": c5["valu_insts_per_render"],
-                         "kernel_ms_per_render": per_render_ms, "launches_per_render": wft_n / args.steps,
-                         "share_of_step": per_render_ms / ms_per_step, "traffic": c5.get("hbm_bytes_per_render"),
-                         "wait_any_frac": c5.get("wait_any_frac"), "profile_source_hash": source_hash(),
-                         "note": "k_wf_trace waits on divergent 16-byte loads from L1/L2 (wait_any_frac), so its issue fraction is the "
-                                 "honest utilisation figure; HBM traffic is a small fraction of the roof (scene resident in L2)",
-                         "source": "profiles/traffic.json[staircase] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"}
+            # config 5: the dominant kernel is k_wf_trace (closest-hit and any-hit runs), timed alone with HIP events; beside it the
+            # HBM-bound pair k_wf_shadow_gen + k_wf_shade and the scatter-add
+            blocks = wavefront_rooflines(totals_rank0, {"wf_trace_ms": wft_ms, "wf_trace_kernel_launches": wft_n, "wf_shade_ms": wfs_ms,
+                                                        "scatter_ms": wsc_ms, "scatter_launches": wsc_n},
+                                         args.steps, ms_per_step, default_wl and profile_is_current("staircase"))
+            if blocks.get("roofline", {}).get("frac") is not None:
+                vline = blocks["roofline"]
+            for k in ("roofline_shade", "scatter_add"):
+                if k in blocks:
+                    res[k] = blocks[k]
         if vline is not None:
             vline["launches_per_step"] = n_launch / args.steps
             res["roofline"] = vline
@@ -489,6 +633,10 @@ def main():
             res["render_path"] = path_taken
             res["reduce_scatter_only"] = rs_only
             res["row_sharded"] = rows_leg
+            res["comm_only"] = comm_full
+            res["comm_only_reduce_scatter"] = comm_rs
+            res["reserve_cus"] = reserve
+            res["collectives_per_step"] = renderer_collectives
         if scatter:
             res["scatter_add"] = scatter
         if extra:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 9
+#define MTR_ABI_VERSION 10
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -258,7 +258,12 @@ typedef struct mtr_render_params {
     uint32_t spp_scale;     /* 0, or the sample count of the WHOLE multi-pass render (common.py:56-85: above 2^32 lanes
                                the reference renders passes of their own sampler each — lanes of a pass are indexed with
                                spp_total = the PASS's samples — while sample_scale stays 1/total_spp, :173-175)       */
-    uint32_t reserved[5];
+    uint32_t reserve_cus;   /* (ABI 10) fused organisation: leave this many compute units WITHOUT a resident workgroup of the
+                               persistent path kernel (grid = (CUs - reserve_cus) x workgroups per CU; at least one CU is
+                               used).  The kernel otherwise owns every CU's LDS for the whole launch, so kernels of other
+                               streams — RCCL's reduce-scatter of the previous row band — could only start between two
+                               launches.  0 = use every CU (one GPU; the measured cost of 8 / 16 is in DESIGN.md section 7) */
+    uint32_t reserved[4];
 } mtr_render_params;
 
 /* in-kernel counters */
@@ -291,7 +296,7 @@ typedef struct mtr_kernel_times {
     uint32_t scatter_launches;
     float    wf_trace_ms;     /* wavefront (ABI 9): sum of the k_wf_trace launches alone (closest-hit and any-hit runs) */
     uint32_t wf_trace_kernel_launches; /* ... and their number                                   */
-    uint32_t reserved[1];
+    float    wf_shade_ms;     /* wavefront (ABI 10): sum of the k_wf_shadow_gen + k_wf_shade launches (the HBM-bound pair of scenes in HBM) */
 } mtr_kernel_times;
 
 typedef struct mtr_ctx   mtr_ctx;

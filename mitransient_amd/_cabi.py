@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 9
+MTR_ABI_VERSION = 10
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC = 4, 5
@@ -108,7 +108,8 @@ class mtr_render_params(C.Structure):
     _fields_ = [("spp_total", C.c_uint32), ("spp_begin", C.c_uint32), ("spp_end", C.c_uint32),
                 ("pixel_begin", C.c_uint32), ("pixel_end", C.c_uint32),
                 ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
-                ("flags", C.c_uint32), ("mode", C.c_uint32), ("spp_scale", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("flags", C.c_uint32), ("mode", C.c_uint32), ("spp_scale", C.c_uint32), ("reserve_cus", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
 
 
 class mtr_counters(C.Structure):
@@ -133,13 +134,13 @@ class mtr_kernel_times(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("trace_ms", C.c_float), ("scatter_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("scatter_launches", C.c_uint32),
                 ("wf_trace_ms", C.c_float), ("wf_trace_kernel_launches", C.c_uint32),
-                ("reserved", C.c_uint32 * 1)]
+                ("wf_shade_ms", C.c_float)]
 
     def as_dict(self):
         return {"total_ms": float(self.total_ms), "trace_ms": float(self.trace_ms),
                 "scatter_ms": float(self.scatter_ms), "trace_launches": int(self.trace_launches),
                 "scatter_launches": int(self.scatter_launches), "wf_trace_ms": float(self.wf_trace_ms),
-                "wf_trace_kernel_launches": int(self.wf_trace_kernel_launches)}
+                "wf_trace_kernel_launches": int(self.wf_trace_kernel_launches), "wf_shade_ms": float(self.wf_shade_ms)}
 
 
 # Every symbol include/mitransient_amd.h declares (checked by tests/test_abi.py).

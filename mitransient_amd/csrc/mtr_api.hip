@@ -4,6 +4,7 @@
 // BVH2 build, upload), render planning and launches, film develop/clear, the stand-alone
 // scatter-add.  There is no CPU execution path: without a HIP device every entry point fails.
 #include "../../include/mitransient_amd.h"
+#include "mtr_knobs.h"
 #include "mtr_scene_host.h"
 #include "mtr_core.h"
 #include "mtr_kernels.h"
@@ -72,6 +73,13 @@ static int fail(mtr_ctx *c, int code, const std::string &msg)
     if (c) c->err = msg; else g_err = msg;
     return code;
 }
+// CUs the persistent fused kernel may occupy (mtr_render_params.reserve_cus: the rest stays free for other streams' kernels)
+static int usable_cus(const mtr_ctx *c, const mtr_render_params *p)
+{
+    const int keep = (int)std::min<uint32_t>(p->reserve_cus, (uint32_t)(c->n_cu > 1 ? c->n_cu - 1 : 0));
+    return c->n_cu - keep;
+}
+
 #define HIP_TRY(c, expr)                                                                       \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -341,7 +349,8 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
 }
 
 static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4, const RenderConst &rc,
-                     float *trace_ms, float *scatter_ms, uint32_t *n_trace, uint32_t *n_scatter, bool timed, uint32_t *n_trace_kernel)
+                     float *trace_ms, float *scatter_ms, uint32_t *n_trace, uint32_t *n_scatter, bool timed, uint32_t *n_trace_kernel,
+                     bool may_block, float *shade_ms)
 {
     mtr_ctx *c = s->ctx;
     const Film &f = s->film;
@@ -363,23 +372,32 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
         size_t free_b = 0, total_b = 0;
         const size_t per_slot = 320;                                   // planes 112 + queues 44 + rays 96 + records 64 + occlusion 1, rounded up
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t budget = (free_b + (size_t)s->wf.n_slots * per_slot) / 2;     // (the workspace this scene already holds counts as free)
+            // half of what is free now (the workspace this scene already holds counts as free), and never more than a third of
+            // the device: the caller's allocator (films, all-gather buffers, a second scene) needs room the driver cannot see
+            size_t budget = (free_b + (size_t)s->wf.n_slots * per_slot) / 2;
+            if (budget > total_b / 3) budget = total_b / 3;
             while (kTileSlots > (1u << 22) && (size_t)kTileSlots * per_slot > budget) kTileSlots >>= 1;
         } else kTileSlots = 1u << 25;
     }
-    if (const char *e = getenv("MTR_WF_TILE_LOG2")) kTileSlots = 1u << atoi(e);      // experiments
-    if (const char *e = getenv("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
+    if (const char *e = mtr::knob("MTR_WF_TILE_LOG2")) kTileSlots = 1u << atoi(e);      // experiments
+    if (const char *e = mtr::knob("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
     const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
     const uint32_t G = (kSegSlots + S - 1) / S;
     uint32_t P = kTileSlots / S; if (P < G) P = G; if (P > n_pixels) P = n_pixels;
     const uint32_t n_slots_max = P * S;
     const uint32_t seg = G * S;
-    const uint32_t n_seg_max = (P + G - 1) / G;
+    const uint32_t n_seg_max = (P + G - 1) / G;      // (of the first attempt; wf_alloc below may settle for a smaller tile)
     // time-bin records: per-pixel lists sized for 4 contributions per path; the rest (and rows that do not
     // fit LDS) fall back to f32 atomics on the film
     const bool rows_fit = (size_t)f.bins * 12u <= 150u * 1024u;
     const uint32_t rec_cap = rows_fit ? S * 4u : 0u;
     int rc_ = wf_alloc(s, n_slots_max, P, n_seg_max, rec_cap);
+    // out of memory (someone else took it between hipMemGetInfo and here): halve the tile until the workspace fits
+    while (rc_ == MTR_ERR_OOM && P > G && (size_t)P * S > (1u << 22)) {
+        (void)hipGetLastError();                       // (the failed hipMalloc must not surface at the next launch check)
+        P = std::max(G, ((P / 2 + G - 1) / G) * G);
+        rc_ = wf_alloc(s, P * S, P, (P + G - 1) / G, rec_cap);
+    }
     if (rc_) return rc_;
     WfWorkspace &w = s->wf;
 
@@ -396,12 +414,15 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     // NLOS paths end by the integrator's own rules (filter depth, roulette): the host polls the live count like an unbounded render
     // (deep bounded renders poll too: with max_depth 65 no path of config 5 is alive after some 35 bounces, and every bounce of
     // every tile is four launches)
-    const bool unbounded = p->max_depth < 0 || p->max_depth > 16 || s->nlos.on;
+    // ... but only in calls that block anyway (counters / timings requested): a caller that keeps mtr_render asynchronous —
+    // row bands overlapped with collectives — is not stalled inside it; its empty bounces cost 4 us per launch (live segment list)
+    const bool unbounded = p->max_depth < 0 || s->nlos.on || (p->max_depth > 16 && may_block);
     // the reference loop always runs its first iteration (emission of the camera-ray hit), also at max_depth 0
     const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth + (s->nlos.on ? 2u : 0u));
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev, trace_ev;
-    // (timed renders only) events around every k_wf_trace launch: the dominant kernel of scenes in HBM is timed alone
-    auto trace_timed = [&](int which, int grid_) -> hipError_t {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev, trace_ev, shade_ev;
+    // (timed renders only) events around every k_wf_trace launch — the dominant kernel of scenes in HBM is timed alone — and
+    // around the HBM-bound pair k_wf_shadow_gen + k_wf_shade (their sum: mtr_kernel_times.wf_shade_ms)
+    auto launch_timed = [&](int which, int grid_, std::vector<std::pair<hipEvent_t, hipEvent_t>> &bucket) -> hipError_t {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) {
             hipError_t e = hipEventCreate(&e0); if (e != hipSuccess) return e;
@@ -410,9 +431,10 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
         }
         hipError_t e = launch_wf(a, cfg, which, grid_, c->stream);
         if (e != hipSuccess) return e;
-        if (timed) { e = hipEventRecord(e1, c->stream); if (e != hipSuccess) return e; trace_ev.push_back({ e0, e1 }); }
+        if (timed) { e = hipEventRecord(e1, c->stream); if (e != hipSuccess) return e; bucket.push_back({ e0, e1 }); }
         return hipSuccess;
     };
+    auto trace_timed = [&](int which, int grid_) -> hipError_t { return launch_timed(which, grid_, trace_ev); };
 
     for (uint32_t s0 = 0; s0 < spp_chunk; s0 += S) {
         const uint32_t Scur = std::min(S, spp_chunk - s0);
@@ -457,12 +479,12 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                 a.trace_any = 0u;
                 HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                // closest hit + material lists
                 if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
-                    HIP_TRY(c, launch_wf(a, cfg, 4, grid, c->stream)); a.ticket_cur ^= 1u;   // shadow rays of the emitter samples
+                    HIP_TRY(c, launch_timed(4, grid, shade_ev)); a.ticket_cur ^= 1u;         // shadow rays of the emitter samples
                     a.trace_any = 1u;
                     HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                   // their occlusion
                     *n_trace += 2;
                 }
-                HIP_TRY(c, launch_wf(a, cfg, 2, grid, c->stream)); a.ticket_cur ^= 1u;  // shade (+ inline shadow rays when the scene is in LDS) + compaction
+                HIP_TRY(c, launch_timed(2, grid, shade_ev)); a.ticket_cur ^= 1u;        // shade (+ inline shadow rays when the scene is in LDS) + compaction
                 *n_trace += 2;
                 a.parity ^= 1u;
                 ++depth;
@@ -499,7 +521,14 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
         acc_trace += ms;
         (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
     }
-    *scatter_ms = acc_scatter; *trace_ms = acc_trace; *n_trace_kernel = (uint32_t)trace_ev.size();
+    float acc_shade = 0.0f;
+    for (auto &pr : shade_ev) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+        acc_shade += ms;
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    *scatter_ms = acc_scatter; *trace_ms = acc_trace; *n_trace_kernel = (uint32_t)trace_ev.size(); *shade_ms = acc_shade;
     return MTR_OK;
 }
 
@@ -526,7 +555,7 @@ static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pix
     if (mode == MTR_MODE_AUTO) {
         FusedArgs probe{}; FusedConfig pc{};
         probe.sc = s->dev; probe.cam = s->cam; probe.film = f; probe.rc = make_render_const(*p, f, s->dev.n_ems); probe.nlos_on = s->nlos.on ? 1u : 0u;
-        const bool fits = fused_plan(s->dev, f, n_pixels, spp_chunk, c->n_cu, probe, pc) && pc.scene_lds;
+        const bool fits = fused_plan(s->dev, f, n_pixels, spp_chunk, usable_cus(c, p), probe, pc) && pc.scene_lds;
         mode = fits ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
     }
     *mode_io = mode;
@@ -535,7 +564,7 @@ static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pix
         if (mode == MTR_MODE_FUSED && !f.n_freq) {
             FusedArgs probe{}; FusedConfig pc{};
             probe.sc = s->dev; probe.cam = s->cam; probe.film = f; probe.rc = make_render_const(*p, f, s->dev.n_ems); probe.nlos_on = s->nlos.on ? 1u : 0u;
-            if (fused_plan(s->dev, f, n_pixels, spp_chunk, c->n_cu, probe, pc) && pc.hist_lds) *developed_ok = 1u;
+            if (fused_plan(s->dev, f, n_pixels, spp_chunk, usable_cus(c, p), probe, pc) && pc.hist_lds) *developed_ok = 1u;
         }
     }
     return MTR_OK;
@@ -593,18 +622,18 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
     if (s->log.count) HIP_TRY(c, hipMemsetAsync(s->log.count, 0, sizeof(unsigned long long), c->stream));
     if (times_out) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     uint32_t launches = 0, scatter_launches = 0, wf_trace_n = 0;
-    float scatter_ms = 0.0f, wf_trace_ms = 0.0f;
+    float scatter_ms = 0.0f, wf_trace_ms = 0.0f, wf_shade_ms = 0.0f;
     if (n_pixels && a.spp_chunk) {
         uint32_t mode = p->mode, dev_ok = 0u;
         if (int r = resolve_mode(s, p, n_pixels, a.spp_chunk, &mode, &dev_ok)) return r;
         if ((p->flags & MTR_FLAG_DEVELOPED_ROWS) && !dev_ok)
             return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: MTR_FLAG_DEVELOPED_ROWS needs the fused organisation with time-bin rows in LDS (see mtr_render_plan)");
         if (mode == MTR_MODE_WAVEFRONT) {
-            int r = wf_render(s, p, t4, s4, a.rc, &wf_trace_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr, &wf_trace_n);
+            int r = wf_render(s, p, t4, s4, a.rc, &wf_trace_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr, &wf_trace_n, want_stats, &wf_shade_ms);
             if (r) return r;
         } else {
             FusedConfig cfg{};
-            if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, c->n_cu, a, cfg))
+            if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, usable_cus(c, p), a, cfg))
                 return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
             a.ticket = c->d_ticket + (c->fused_launches++ & 15u);
             HIP_TRY(c, launch_fused(a, cfg, c->stream));
@@ -629,7 +658,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
             times_out->total_ms = ms; times_out->trace_ms = ms - scatter_ms; times_out->scatter_ms = scatter_ms;
             times_out->trace_launches = launches; times_out->scatter_launches = scatter_launches;
-            times_out->wf_trace_ms = wf_trace_ms; times_out->wf_trace_kernel_launches = wf_trace_n;
+            times_out->wf_trace_ms = wf_trace_ms; times_out->wf_trace_kernel_launches = wf_trace_n; times_out->wf_shade_ms = wf_shade_ms;
         }
     }
     return MTR_OK;

@@ -7,6 +7,7 @@
 // splits are chosen in the shape's OBJECT space (where the faces of a rotated cube are flat: coplanar triangles end up in
 // the same leaf) and which the 8-wide collapse turns into one object node with object-space boxes (mtr_core.h, WNodeT).
 #include "mtr_bvh.h"
+#include "mtr_knobs.h"
 
 #include <algorithm>
 #include <cmath>
@@ -259,9 +260,14 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     Builder B(S); B.prims = prims;
     // leaves: two triangles for scenes staged in LDS (k_fused: 1 / 3 / 4 measured worse), four for the large scenes walked in
     // HBM (config 5 at 256 spp, 8-wide tree: 1 / 2 / 3 / 4 triangles per leaf: 335 / 288 / 283 / 275 ms — fewer, fuller leaves)
-    if (n >= 1024) { B.kLeafTarget = 4; B.kBins = 32; }          // (SAH bins 8 / 16 / 32 / 64: 243 / 239 / 233 / 237 ms)
-    if (const char *e = getenv("MTR_BVH_BINS")) { B.kBins = atoi(e); if (B.kBins < 4) B.kBins = 4; if (B.kBins > Builder::kMaxBins) B.kBins = Builder::kMaxBins; }   // experiments
-    if (const char *e = getenv("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
+    // The two cases cannot overlap: a slot costs 120 B of LDS (TriShade + half a TriPair) and the staged scene is limited to 64 KB
+    // (fused_plan / wf_plan), so no scene above 546 triangles is ever walked in LDS — the choice is made on exactly that bound.
+    // (The quantised HBM trees are still built for small scenes — a handful of nodes — because k_nlos_prepare and the
+    // HBM instantiations requested explicitly walk them.)
+    const bool never_in_lds = (size_t)n * (sizeof(TriShade) + sizeof(TriPair) / 2) > 64u * 1024u;
+    if (never_in_lds) { B.kLeafTarget = 4; B.kBins = 32; }          // (SAH bins 8 / 16 / 32 / 64: 243 / 239 / 233 / 237 ms)
+    if (const char *e = mtr::knob("MTR_BVH_BINS")) { B.kBins = atoi(e); if (B.kBins < 4) B.kBins = 4; if (B.kBins > Builder::kMaxBins) B.kBins = Builder::kMaxBins; }   // experiments
+    if (const char *e = mtr::knob("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     S.tmp.reserve(3 * (size_t)n);
     for (uint32_t i = 0; i < n;) {
         const uint8_t kind = prims && prims->kind ? prims->kind[i] : 0;
@@ -281,11 +287,11 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     // the triangle clipped to one cell of a recursive midpoint split.  Intersection is unchanged (a leaf tests the whole
     // triangle, ties go to the original index, duplicates in one leaf are dropped), only culling gets tighter.
     // Large scenes only: the scenes staged in LDS are dominated by rectangles and object nodes.
-    if (n >= 1024 && !getenv("MTR_BVH_NO_SPLITS")) {
+    if (n >= 1024 && !mtr::knob("MTR_BVH_NO_SPLITS")) {
         Box scene; scene.reset();
         for (const Box &b : B.wbox) scene.grow(b);
         double frac = 1e-4;                                           // staircase (config 5 at 256 spp): off 296, 2e-3 287, 5e-4 290, 1e-4 283, 2e-5 290 ms
-        if (const char *e = getenv("MTR_BVH_SPLIT_FRAC")) frac = atof(e);
+        if (const char *e = mtr::knob("MTR_BVH_SPLIT_FRAC")) frac = atof(e);
         const float a_max = scene.area() * (float)frac;
         size_t budget = n / 4;                                        // at most 25 % more references
         struct Piece { uint32_t item; std::vector<double> poly; };
@@ -416,7 +422,7 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
     // an OBJECT subtree with few leaves becomes one node whose boxes live in the object's own space (8-wide tree only)
     const float *xf = nullptr;
     bool is_box = false;
-    const bool objects_on = W == 8 && prims && prims->object_xf && verts && !getenv("MTR_NO_OBJECT_NODES");
+    const bool objects_on = W == 8 && prims && prims->object_xf && verts && !mtr::knob("MTR_NO_OBJECT_NODES");
     if (objects_on) {
         const int32_t obj = bvh.packet_object[packet];
         std::vector<int32_t> leaves;
@@ -432,7 +438,7 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
                 ch.push_back(w);
             }
             // a BOX: the object is an affine cube and its six leaves are its six faces -> children in face order
-            if (leaves.size() == 6 && !getenv("MTR_NO_BOX_NODES")) {
+            if (leaves.size() == 6 && !mtr::knob("MTR_NO_BOX_NODES")) {
                 uint32_t first = 0xffffffffu, faces[12];
                 for (int32_t ref : leaves) {
                     const uint32_t code = ~(uint32_t)ref;
@@ -509,7 +515,7 @@ uint32_t build_wide(const BvhBuild &bvh, const BvhPrims *prims, const float *ver
     wide.clear();
     if (bvh.nodes.empty()) return 0;
     size_t width = kWide;
-    if (const char *e = getenv("MTR_WIDE_WIDTH")) { int w = atoi(e); width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
+    if (const char *e = mtr::knob("MTR_WIDE_WIDTH")) { int w = atoi(e); width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
     uint32_t levels = 0;
     wide_rec<kWide>(bvh, prims, verts, 0, wide, 1, levels, width);
     return levels;

@@ -11,6 +11,7 @@
 // k_splat_*      the stand-alone time-bin scatter-add (add_transient_data + put_ + accum).
 // k_develop_*    TransientHDRFilm.develop.
 #include "mtr_kernels.h"
+#include "mtr_knobs.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -603,7 +604,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     if (cfg.rough && per_cu > 3) per_cu = 3;          // the extended-shading kernels hold 168 registers: three workgroups per CU are resident
-    if (const char *e = getenv("MTR_FUSED_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }     // experiments
+    if (const char *e = mtr::knob("MTR_FUSED_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }     // experiments
     cfg.per_cu = per_cu;
     long grid = (long)n_cu * per_cu;
     uint32_t g_blk = g_want;                       // small renders: rather more workgroups than long pixel queues
@@ -618,7 +619,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const uint32_t c_bal = (uint32_t)((unsigned long long)n_pixels / (8ull * (unsigned long long)grid));
     if (chunk > c_bal) chunk = c_bal;
     if (chunk < 1u) chunk = 1u;
-    if (const char *e = getenv("MTR_FUSED_CHUNK")) { const int v = atoi(e); if (v >= 1) chunk = (uint32_t)v; }     // experiments
+    if (const char *e = mtr::knob("MTR_FUSED_CHUNK")) { const int v = atoi(e); if (v >= 1) chunk = (uint32_t)v; }     // experiments
     if ((unsigned long long)chunk * spp_chunk > 0xffff0000ull) return false;     // the per-chunk sample counter is 32 bits wide
     args.chunk = chunk;
     args.n_chunks = (n_pixels + chunk - 1u) / chunk;

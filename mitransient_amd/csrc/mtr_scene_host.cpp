@@ -1,4 +1,5 @@
 #include "mtr_scene_host.h"
+#include "mtr_knobs.h"
 #include <cstring>
 #include <cmath>
 
@@ -178,7 +179,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     s.wnodes4.clear();
     s.wide4_levels = build_wide4(bvh, s.wnodes4);
     s.wnodes8q.clear(); s.wide8q_levels = 0;
-    if (!getenv("MTR_NO_WIDE8Q")) s.wide8q_levels = build_wide8q(bvh, s.wnodes8q);      // (experiments: without it the HBM walk uses the 4-wide tree)
+    if (!mtr::knob("MTR_NO_WIDE8Q")) s.wide8q_levels = build_wide8q(bvh, s.wnodes8q);      // (experiments: without it the HBM walk uses the 4-wide tree)
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
     s.vnormals.clear(); s.samp_vn.clear();

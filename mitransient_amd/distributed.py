@@ -76,6 +76,18 @@ def all_gather_rows(slab, height: int, group=None):
     return full[:height]
 
 
+def _develop_rows(film, raw_rows, out=None):
+    """develop() of a slab of raw film rows (rows, W, T, 4) -> (rows, W, T, 3), without a steady image"""
+    import torch
+    rows = int(raw_rows.shape[0])
+    dummy_s = torch.zeros((rows, film.size()[0], 4), dtype=torch.float32, device=raw_rows.device)
+    if out is None:
+        return film.develop_slab(raw_rows, dummy_s)[0]
+    dummy_o = torch.empty((rows, film.size()[0], 3), dtype=torch.float32, device=raw_rows.device)
+    film.develop_slab(raw_rows, dummy_s, out=(out, dummy_o))
+    return out
+
+
 class DistributedRenderer:
     """Shards one render over the ranks of a process group.
 
@@ -85,13 +97,27 @@ class DistributedRenderer:
     With partition "spp" the film reduction is PIPELINED against the path kernel: the image is rendered
     in ``bands`` horizontal bands; as soon as a band's kernel has finished (event), its slab of the raw
     film is reduce-scattered on a side stream while the next band renders, then developed and
-    all-gathered straight into its rows of the output.  Only the last band's communication is exposed."""
+    all-gathered straight into its rows of the output.  Only the last band's communication is exposed.
+    Collectives per render: ONE reduce-scatter (+ one all-gather with ``gather``) per band and one all-reduce of the
+    4 MB steady accumulator at the end — 2 * bands + 1 (``last_collectives``); round 3 issued 4 per band.
 
-    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True, bands: int = 8):
+    ``gather=False`` ("the single RCCL reduce"): every rank keeps the developed rows it OWNS.  Through the band pipeline those
+    are not one contiguous slab: band b's rows ``b * H/bands + rank * per ... + per`` with ``per = H / (bands * world)``,
+    stacked in band order — ``owned_rows`` lists the film row of every returned row (the non-pipelined fallback returns the
+    contiguous slab ``row_slab(H, world, rank)`` and leaves ``owned_rows`` = that range).
+
+    ``reserve_cus``: compute units the persistent fused kernel leaves free while ``world > 1`` (mtr_render_params.reserve_cus),
+    so that RCCL's kernels of band b can run WHILE band b + 1 renders instead of waiting for a launch boundary; None keeps the
+    integrator's own ``amd_reserve_cus``."""
+
+    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True, bands: int = 8, reserve_cus=None):
         if partition not in ("spp", "rows"):
             raise ValueError("partition must be 'spp' or 'rows'")
         self.scene, self.partition, self.group, self.gather, self.bands = scene, partition, group, gather, int(bands)
+        self.reserve_cus = reserve_cus
         self.last_path = None            # "single" | "pipelined" | "spp" | "rows": which code path the last render took
+        self.last_collectives = 0        # collectives the last render issued on the data path
+        self.owned_rows = None
 
     def render(self, spp: int, seed: int = 0, sensor: int = 0):
         import torch
@@ -106,7 +132,22 @@ class DistributedRenderer:
         integ.check_transient_(scene, sens)
         if world == 1:
             self.last_path = "single"
+            self.last_collectives = 0
             return integ.render(scene, sens, seed=seed, spp=spp)      # (incl. the single-pass film lifecycle when it applies)
+        if self.reserve_cus is not None:
+            keep = integ.reserve_cus
+            integ.reserve_cus = int(self.reserve_cus)
+            try:
+                return self._render_sharded(integ, sens, film, spp, seed, world, rank)
+            finally:
+                integ.reserve_cus = keep
+        return self._render_sharded(integ, sens, film, spp, seed, world, rank)
+
+    def _render_sharded(self, integ, sens, film, spp, seed, world, rank):
+        import torch
+        import torch.distributed as dist
+        from .tensor import TensorXf
+        scene = self.scene
         W, H = film.size()
         cw, ch = film.crop_size()
         # sample shards through the band pipeline: when the fused kernel can store DEVELOPED rows (MTR_FLAG_DEVELOPED_ROWS), every
@@ -139,6 +180,9 @@ class DistributedRenderer:
             integ.accumulate(scene, sens, passes, total_spp, pixel_range=(r0 * cw, r1 * cw))
         raw_t = film.transient_storage.torch_tensor()
         raw_s = film.steady_accum()
+        lo_, hi_ = row_slab(H, world, rank) if self.partition == "spp" else shard_range(ch, world, rank)
+        self.owned_rows = list(range(lo_, hi_))
+        self.last_collectives = (2 if self.partition == "spp" else 0) + (2 if self.gather else 0)
         if self.partition == "spp":
             slab_t = reduce_scatter_rows(raw_t, self.group)      # THE film reduction
             slab_s = reduce_scatter_rows(raw_s, self.group)
@@ -194,8 +238,8 @@ class DistributedRenderer:
         # b*rows_b + rank*per ... + per), stacked in band order; ``owned_rows`` lists them
         n_out = H if gather else nb * per
         out_t = torch.empty((n_out,) + tuple(film.raw_shape()[1:-1]) + (3,), dtype=torch.float32, device=dev)
-        out_s = torch.empty((n_out, W, 3), dtype=torch.float32, device=dev)
         self.owned_rows = None if gather else [b * rows_b + rank * per + i for b in range(nb) for i in range(per)]
+        self.last_collectives = nb * (2 if gather else 1) + 1
         main = torch.cuda.current_stream(dev)
         side = getattr(self, "_side_stream", None)
         if side is None:
@@ -239,20 +283,28 @@ class DistributedRenderer:
                 side.wait_event(ready)
                 if gloo:
                     side.synchronize()              # gloo collectives are host-driven (CPU test path)
+                # ONE collective per band and direction: the steady accumulator (4 MB for the whole image) is reduced once, below
                 slab_t = reduce_scatter_rows(raw_t[r0:r1], self.group)          # THE film reduction, band b
-                slab_s = reduce_scatter_rows(raw_s[r0:r1], self.group)
                 if dev3:                            # the sum of developed partial rows IS the developed row
-                    d_t, d_s = slab_t, film.develop_slab(None, slab_s)[1]
+                    d_t = slab_t
                     if not gather:
                         out_t[b * per:(b + 1) * per].copy_(d_t)
-                        out_s[b * per:(b + 1) * per].copy_(d_s)
                 elif gather:
-                    d_t, d_s = film.develop_slab(slab_t, slab_s)
+                    d_t = _develop_rows(film, slab_t)
                 else:
-                    film.develop_slab(slab_t, slab_s, out=(out_t[b * per:(b + 1) * per], out_s[b * per:(b + 1) * per]))
+                    _develop_rows(film, slab_t, out=out_t[b * per:(b + 1) * per])
                 if gather:
                     out_t[r0:r1].copy_(all_gather_rows(d_t, rows_b, self.group))
-                    out_s[r0:r1].copy_(all_gather_rows(d_s, rows_b, self.group))
+        # the steady image: every band has rendered -> one all-reduce of the (H, W, 4) sums, developed whole on every rank
+        with torch.cuda.stream(side):
+            for st in set(lanes):
+                side.wait_stream(st)
+            if gloo:
+                side.synchronize()
+            sums = raw_s.contiguous()
+            dist.all_reduce(sums, group=self.group)
+            full_s = film.develop_slab(None, sums)[1]
+            out_s = full_s if gather else full_s[torch.as_tensor(self.owned_rows, device=dev)]
         main.wait_stream(side)
         for st in lanes:
             main.wait_stream(st)

@@ -53,6 +53,8 @@ class TransientHDRFilm:
         # block is rebuilt from it on request (its weight channel is identically 0)
         self.direct_develop = False
         self._developed = None
+        self._developed_written = False   # a render has stored every row of _developed (before that it is torch.empty)
+        self._developed_given = False     # develop() handed _developed to the caller: the next prepare() must not reuse it
 
     # -- mi.Film accessors -------------------------------------------------
     def size(self):
@@ -103,13 +105,20 @@ class TransientHDRFilm:
         if self.direct_develop:
             torch = require_gpu()
             shape = self.raw_shape()[:-1] + (3,)
-            if self._developed is None or tuple(self._developed.shape) != shape or self._developed.device != self._device:
+            # develop() returns this tensor ITSELF (no 3 GiB copy), so once it has been handed out it belongs to the caller — the
+            # reference returns a fresh tensor from every develop() — and the next render gets a new one (the caching allocator
+            # hands back the block of a result the caller has dropped; one the caller still holds stays valid)
+            if (self._developed is None or self._developed_given or tuple(self._developed.shape) != shape
+                    or self._developed.device != self._device):
                 self._developed = None            # (free before allocating: two 3 GiB tensors need not coexist)
                 self._developed = torch.empty(shape, dtype=torch.float32, device=self._device)
+            self._developed_written = False
+            self._developed_given = False
             self.transient_storage = None         # the raw block is not needed (and its 4 GiB are not held)
             self.film_is_zero = False
             return len(self.channels)
         self._developed = None
+        self._developed_written = self._developed_given = False
         self.transient_storage = self.create_block()
         self.film_is_zero = True
         return len(self.channels)
@@ -122,9 +131,15 @@ class TransientHDRFilm:
         """the 4-channel accumulator, rebuilt from a direct-develop render when something needs it (raw output, more
         contributions from Python, a second pass): raw = (developed rgb, weight 0)"""
         if self.transient_storage is None and self._developed is not None:
-            self.transient_storage = self.create_block()
-            self.transient_storage.torch_tensor()[..., :3].copy_(self._developed)
+            self.transient_storage = self.create_block()              # zero-filled
+            if self._developed_written:
+                self.transient_storage.torch_tensor()[..., :3].copy_(self._developed)
+            else:
+                # nothing has been rendered into the direct tensor yet (it is torch.empty): the block starts from zero, as
+                # after prepare() in the ordinary lifecycle, and the first pass may store its rows
+                self.film_is_zero = True
             self._developed = None
+            self._developed_written = self._developed_given = False
             self.direct_develop = False
         return self.transient_storage
 
@@ -151,6 +166,7 @@ class TransientHDRFilm:
             self._steady_accum.zero_()
         if self.transient_storage is None and self._developed is not None:
             self._developed = None
+            self._developed_written = self._developed_given = False
             self.direct_develop = False
             self.transient_storage = self.create_block()
             self.film_is_zero = True
@@ -185,7 +201,7 @@ class TransientHDRFilm:
             ok &= torch.as_tensor(active, dtype=torch.bool, device=dev)
         pixel = torch.where(ok, py * W + px, torch.full_like(px, W * H))   # out-of-range id -> dropped by the kernel
         self._ensure_raw()
-        self.film_is_zero = False
+        self.film_is_zero = False                 # (the block is zero-filled either way; splats add with atomics / RMW)
         laser = None
         if self.exhaustive_scan:            # row position laser_x * Lh + laser_y (transient_image_block.py:136-138)
             lx = torch.as_tensor(laser_x, dtype=torch.int64, device=dev).expand(px.shape)
@@ -235,7 +251,10 @@ class TransientHDRFilm:
             if raw:
                 self._ensure_raw()
             else:
+                if not self._developed_written:
+                    raise RuntimeError("develop() before any render wrote the film")
                 out = self._developed             # written whole by the render: already developed
+                self._developed_given = True      # the caller owns it from here on (prepare_transient_ allocates anew)
                 return TensorXf(out[..., :1].contiguous() if variant.is_monochromatic() else out)
         if not self.transient_storage:
             raise RuntimeError("No transient storage allocated, was prepare_transient_() called first?")

@@ -45,6 +45,9 @@ class TransientADIntegrator:
         # row flush store the developed (H,W,T,3) tensor directly — no cleared 4-channel block, no develop pass.  Same values
         # (the weight channel is 0: develop divides by 1).  False keeps the reference's clear / accumulate / develop steps.
         self.direct_develop = bool(props.get("amd_direct_develop", True))
+        # compute units left WITHOUT a workgroup of the persistent fused kernel (extension; mtr_render_params.reserve_cus): room for
+        # the kernels of other streams — RCCL's film reduction of the previous row band — while a band renders.  0 on one GPU.
+        self.reserve_cus = int(props.get("amd_reserve_cus", 0))
         self.mode = _cabi.MTR_MODE_AUTO            # kernel organisation (extension; not a reference key)
         m = props.get("amd_mode", None)
         if m is not None:
@@ -150,6 +153,7 @@ class TransientADIntegrator:
         p.rr_depth = int(self.rr_depth)
         p.flags = self._flags()
         p.mode = int(self.mode)
+        p.reserve_cus = max(0, int(self.reserve_cus))
         return p
 
     # -- common.py:122-213 ---------------------------------------------------
@@ -236,6 +240,8 @@ class TransientADIntegrator:
                     self.total_counters[k] += self.last_counters[k]
                 for k in self.total_times:
                     self.total_times[k] += self.last_times[k]
+            if direct is not None:
+                film._developed_written = True    # (a band of a banded render counts: its caller covers the other rows)
             if progress_callback:
                 progress_callback((i + 1) / len(samplers_spps))
 

@@ -106,3 +106,17 @@ def test_c_smoke_renders_on_the_gpu():
     exe = _build_abi_smoke()
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "abi_smoke: PASS" in r.stdout, r.stdout
+
+
+def test_release_library_reads_no_experiment_knobs():
+    """the MTR_* environment knobs of the measurement scripts exist only in builds with -DMTR_EXPERIMENTS (mtr_knobs.h): the
+    product must not change its performance or its results with a stray environment variable"""
+    from mitransient_amd import _cabi
+    blob = open(os.path.join(os.path.dirname(_cabi.__file__), "csrc", "libmitransient_amd.so"), "rb").read()
+    for name in (b"MTR_FUSED_PER_CU", b"MTR_FUSED_CHUNK", b"MTR_NO_WIDE8Q", b"MTR_NO_BOX_NODES", b"MTR_WF_SEG", b"MTR_WF_TILE_LOG2",
+                 b"MTR_BVH_LEAF", b"MTR_WIDE_WIDTH"):
+        assert name not in blob, name
+    src = os.path.join(os.path.dirname(_cabi.__file__), "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".cpp", ".h")) and f != "mtr_knobs.h":
+            assert "getenv" not in open(os.path.join(src, f)).read(), f

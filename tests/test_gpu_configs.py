@@ -311,6 +311,43 @@ def test_config4_full_row_length_properties(tmp_path):
     assert float((t2.torch() - keep).double().norm() / keep.double().norm()) <= 1e-6
 
 
+def test_config4_share_at_its_real_load_matches_oracle(tmp_path, oracle):
+    """BASELINE config 4 where the bench runs it: the whole 256 x 256 x 4096-bin film with ONE GPU's share of the samples
+    (512 of 4096 spp) — the 48 KB-row, three-waves-per-SIMD instantiation of the fused kernel at its real load (VERDICT r3:
+    it was held to the oracle at 32 x 32 px x 96 spp only) — and one full image row of 256 pixels against the CPU oracle:
+    relative L2, the set of touched bins, and the counters of that row."""
+    import torch
+    SPP = 512
+    scene = make_nlos_z(tmp_path, sx=256, sy=256, bins=4096, bin_width=2.0 ** -11, start=1.85, capture="confocal", spp=SPP)
+    integ = scene.integrator()
+    integ.collect_stats = True
+    sens = scene.sensors()[0]
+    film = sens.film()
+    s, t = integ.render(scene, seed=0, spp=SPP)
+    torch.cuda.synchronize()
+    assert integ.total_times["scatter_launches"] == 0                       # the fused organisation ran
+    assert tuple(t.torch().shape) == (256, 256, 4096, 3) and integ.last_counters["paths"] == 256 * 256 * SPP
+    keep_t, keep_s = t.torch().clone(), s.torch().clone()
+    del s, t
+    sd = scene.data()
+    for row in (131, 17):
+        p0 = row * 256
+        params = integ.render_params(film, 0, SPP, 0, SPP, p0, p0 + 256)
+        t4, s4, cnt = oracle.render(sd, params, use_bvh=True)
+        fd = type(sd.film).from_buffer_copy(sd.film)
+        fd.width, fd.height, fd.crop_width, fd.crop_height = 256, 1, 256, 1
+        t_ref, s_ref = oracle.develop(fd, np.ascontiguousarray(t4[row]).reshape(1, 256, 4096, 4), np.ascontiguousarray(s4[row]).reshape(1, 256, 4))
+        del t4, s4
+        got_t, got_s = keep_t[row].cpu().numpy(), keep_s[row].cpu().numpy()
+        assert np.count_nonzero(t_ref) > 20000
+        assert rel_l2(got_t, t_ref[0]) <= TOL and rel_l2(got_s, s_ref[0]) <= TOL, (row, rel_l2(got_t, t_ref[0]), rel_l2(got_s, s_ref[0]))
+        assert np.array_equal(got_t != 0, t_ref[0] != 0)
+        passes = integ.prepare(scene, sens, 0, SPP, [])
+        integ.accumulate(scene, sens, passes, SPP, pixel_range=(p0, p0 + 256))
+        for k in COUNTERS:
+            assert integ.total_counters[k] == cnt[k], (row, k)
+
+
 # ------------------------------------------------------------------------------------------------ config 5
 def test_config5_full_size_properties_and_strips(oracle):
     """BASELINE config 5 at its stated size — the staircase's 262,663 triangles, 512 x 512 px, 2048 bins over OPL 0 .. 40,

@@ -46,6 +46,8 @@ def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
             fh.write(str(getattr(r, "last_reduced_channels", 0)))
         with open(os.path.join(tmp, f"info{rank}.txt"), "w") as fh:
             fh.write(f"{r.last_path} {getattr(r, 'last_band_streams', 0)} {' '.join(map(str, getattr(r, 'owned_rows', None) or []))}")
+        with open(os.path.join(tmp, f"coll{rank}.txt"), "w") as fh:
+            fh.write(str(r.last_collectives))
     finally:
         dist.destroy_process_group()
 
@@ -84,6 +86,8 @@ def test_two_rank_pipelined_band_reduction(tmp_path):
         s = np.load(tmp_path / f"s{r}.npy")
         assert t.shape == t_ref.shape == (32, 24, 48, 3)
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+        # one reduce-scatter + one all-gather per band, one all-reduce of the steady sums per render (round 3: four per band)
+        assert int((tmp_path / f"coll{r}.txt").read_text()) == 2 * 8 + 1
 
 
 def test_two_rank_pipelined_with_rough_materials(tmp_path):
@@ -162,6 +166,7 @@ def test_two_rank_reduce_scatter_only(tmp_path):
         info = (tmp_path / f"info{r}.txt").read_text().split()
         rows = np.array([int(x) for x in info[2:]])
         assert info[0] == "pipelined" and t.shape[0] == len(rows) == 16 and not seen[rows].any()
+        assert int((tmp_path / f"coll{r}.txt").read_text()) == 8 + 1         # the film reduction alone: one collective per band + the steady image
         seen[rows] = True
         assert rel_l2(t, t_ref[rows]) <= 1e-6 and rel_l2(s, s_ref[rows]) <= 1e-6
     assert seen.all()
@@ -193,6 +198,33 @@ def test_bench_self_launches_its_ranks():
     assert res["reduce_scatter_only"]["path"] == "pipelined" and res["reduce_scatter_only"]["ms_per_step"] > 0
     assert res["row_sharded"]["path"] == "rows" and res["row_sharded"]["value"] > 0
     assert res["value"] > 0 and res["roofline"]["bound"] in ("hbm", "valu")
+    # the communication alone (no path kernel), the CUs left to it, and how many collectives a step issues
+    assert res["comm_only"]["ms_per_step"] > 0 and res["comm_only"]["collectives_per_step"] == 17
+    assert res["comm_only_reduce_scatter"]["collectives_per_step"] == 9 and res["collectives_per_step"] == 17
+    assert res["reserve_cus"] == 8
+
+
+def test_bench_comm_only_line():
+    """`bench.py --gpus 2 --comm-only`: the line's value is the communication of a step alone"""
+    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0"}, ["--gpus", "2", "--comm-only"] + BENCH_SMALL)
+    assert res["n_gpus"] == 2 and res["unit"] == "ms" and res["higher_is_better"] is False
+    assert res["value"] == res["comm_only"]["ms_per_step"] > 0 and res["comm_only_reduce_scatter"]["ms_per_step"] > 0
+
+
+def test_reserved_compute_units_change_nothing_but_the_grid():
+    """mtr_render_params.reserve_cus (amd_reserve_cus): the persistent kernel leaves CUs to other streams; same samples, same film"""
+    from conftest import make_cornell, rel_l2
+    a = make_cornell(width=64, height=64, bins=64)
+    b = make_cornell(width=64, height=64, bins=64, amd_reserve_cus=16)
+    c = make_cornell(width=64, height=64, bins=64, amd_reserve_cus=100000)          # clamped: at least one CU renders
+    ia = a.integrator(); ia.collect_stats = True
+    sa, ta = ia.render(a, seed=2, spp=32)
+    ref = np.array(ta)
+    for sc in (b, c):
+        integ = sc.integrator(); integ.collect_stats = True
+        s_, t_ = integ.render(sc, seed=2, spp=32)
+        torch.cuda.synchronize()
+        assert rel_l2(np.array(t_), ref) <= 1e-6 and integ.last_counters == ia.last_counters
 
 
 def test_bench_config4_share_two_ranks():

@@ -682,3 +682,70 @@ def test_single_pass_film_lifecycle(oracle, det):
     c = make_cornell(width=40, height=24, bins=100, amd_mode="wavefront")
     gpu_render(c, 4)
     assert not c.sensors()[0].film().direct_develop
+
+
+@pytest.mark.gpu
+def test_results_of_consecutive_renders_stay_valid(oracle):
+    """develop() of the single-pass lifecycle returns the film's own tensor without a copy — so it must give that tensor UP:
+    a result the caller still holds on the device is not overwritten by the next render (the reference returns a fresh tensor
+    from every develop()).  ADVICE round 3: (a + b) / 2 of two renders silently became b."""
+    import torch
+    import mitransient_amd.mi as mi
+    a = make_cornell(width=40, height=24, bins=100, amd_mode="fused")
+    film = a.sensors()[0].film()
+    s0, t0 = mi.render(a, spp=16, seed=0)
+    assert film.direct_develop
+    keep0 = t0.torch().clone()
+    s1, t1 = mi.render(a, spp=16, seed=1)
+    torch.cuda.synchronize()
+    assert t0.torch().data_ptr() != t1.torch().data_ptr()
+    assert torch.equal(t0.torch(), keep0)                     # the first result is what it was
+    assert not torch.equal(t0.torch(), t1.torch())            # ... and the second is another render
+    mean = np.array((t0.torch() + t1.torch()) / 2)
+    r0 = oracle_render(oracle, a, 16, seed=0)[1]
+    r1 = oracle_render(oracle, a, 16, seed=1)[1]
+    assert rel_l2(mean, (r0 + r1) / 2) <= TOL
+    # a result that was dropped gives its memory back: the third render needs no third tensor
+    del t0, keep0
+    s2, t2 = mi.render(a, spp=16, seed=2)
+    torch.cuda.synchronize()
+    assert rel_l2(np.array(t2), oracle_render(oracle, a, 16, seed=2)[1]) <= TOL
+    assert torch.equal(t1.torch(), torch.as_tensor(np.array(t1), device=t1.torch().device))
+
+
+@pytest.mark.gpu
+def test_fallbacks_after_a_direct_prepare_start_from_zero(oracle):
+    """prepare() of the single-pass lifecycle leaves the developed tensor UNINITIALISED (the render stores every row).  Whatever
+    then accumulates in parts instead — sample shards, contributions from Python — must start from a zeroed block, not from a
+    copy of that garbage."""
+    import torch
+    a = make_cornell(width=40, height=24, bins=100, amd_mode="fused")
+    sens = a.sensors()[0]
+    film, integ = sens.film(), a.integrator()
+    t_ref = oracle_render(oracle, a, 16, seed=4)[1]
+    for how in ("shards", "python"):
+        passes = integ.prepare(a, sens, 4, 16, [], _direct_develop=True)
+        assert film.direct_develop and film.transient_storage is None
+        film.developed_storage().fill_(float("nan"))           # what torch.empty may hold
+        if how == "shards":
+            integ.accumulate(a, sens, passes, 16, spp_range=(0, 7))
+            integ.accumulate(a, sens, passes, 16, spp_range=(7, 16))
+            torch.cuda.synchronize()
+            got = np.array(film.develop()[1])
+            assert np.isfinite(got).all() and rel_l2(got, t_ref) <= TOL
+        else:
+            pos = torch.tensor([[3.5, 2.5], [3.5, 2.5], [10.2, 7.9]], device="cuda")
+            dist = torch.tensor([4.0, 4.0, 5.0], device="cuda")
+            spec = torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.5, 0.5], [4.0, 0.0, 1.0]], device="cuda")
+            film.add_transient_data(pos, dist, None, spec)
+            torch.cuda.synchronize()
+            got = np.array(film.develop()[1])
+            want = np.zeros_like(got)
+            b4, b5 = int((4.0 - 3.5) / (6.0 / 100)), int((5.0 - 3.5) / (6.0 / 100))
+            want[2, 3, b4] = [1.5, 2.5, 3.5]
+            want[7, 10, b5] = [4.0, 0.0, 1.0]
+            assert np.isfinite(got).all() and np.allclose(got, want, rtol=1e-6, atol=0)
+    # develop() before any render of a direct film is an error, not garbage
+    integ.prepare(a, sens, 4, 16, [], _direct_develop=True)
+    with pytest.raises(RuntimeError):
+        film.develop()
