@@ -524,7 +524,7 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     bool found = false;
     // Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]: pvec = cross(d, e2); inv_det = 1 / dot(e1, pvec);
     // tvec = o - p0; u = dot(tvec, pvec) * inv_det; qvec = cross(tvec, e1); v = dot(d, qvec) * inv_det;
-    // t = dot(e2, qvec) * inv_det; hit iff 0 <= u <= 1, v >= 0, u + v <= 1, 0 <= t <= tmax  (cross and dot as fma chains).
+    // t = dot(e2, qvec) * inv_det; mitsuba: hit iff 0 <= u <= 1, v >= 0, u + v <= 1, 0 <= t <= tmax  (cross and dot as fma chains).
     // Shared edges are CLOSED (kEdgeEps = 2^-19 of the triangle): the two triangles of an edge evaluate it with different
     // operation orders, so a ray aimed exactly at it can fail both tests by one rounding — which is no measure-zero event
     // when millions of paths connect to ONE point (the laser spot at the centre of a two-triangle relay wall lies on its
@@ -554,9 +554,12 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
         const f2 qx = fma2(tvy, e1z, neg2(mul2(tvz, e1y))), qy = fma2(tvz, e1x, neg2(mul2(tvx, e1z))), qz = fma2(tvx, e1y, neg2(mul2(tvy, e1x)));
         const f2 v = mul2(fma2(qx, d.x, fma2(qy, d.y, mul2(qz, d.z))), inv_det);       // dot(d, qvec) * inv_det
         const f2 t = mul2(fma2(e2x, qx, fma2(e2y, qy, mul2(e2z, qz))), inv_det);       // dot(e2, qvec) * inv_det
-        const f2 uv = add2(u, v);
+        // hit iff u, v, w = 1 - (u + v) >= -kEdgeEps (mitsuba's `u <= 1` follows from the other three) and 0 <= t <= tmax.  ONE
+        // constant: with a second one (1 + eps for `u + v <= 1 + eps`) the scalar registers of k_fused overflowed — 177 more
+        // v_readlane in the persistent loop, 65.3 -> 67.9 ms on config 2; this form has the instruction count of the plain test.
+        const f2 w = rsub2(1.0f, add2(u, v));
         {
-            const bool hit = (u.x >= -kEdgeEps) && (u.x <= 1.0f + kEdgeEps) && (v.x >= -kEdgeEps) && (uv.x <= 1.0f + kEdgeEps) && (t.x >= 0.0f) && (t.x <= tr.tmax);
+            const bool hit = (u.x >= -kEdgeEps) && (v.x >= -kEdgeEps) && (w.x >= -kEdgeEps) && (t.x >= 0.0f) && (t.x <= tr.tmax);
             const bool closer = (t.x < tr.h.t) | ((t.x == tr.h.t) & (orig_a < tr.best_orig));      // bitwise: no branches for three compares
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;
@@ -564,7 +567,7 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
             tr.h.prim = better ? pa : tr.h.prim; tr.best_orig = better ? orig_a : tr.best_orig;
         }
         {
-            const bool hit = two && (u.y >= -kEdgeEps) && (u.y <= 1.0f + kEdgeEps) && (v.y >= -kEdgeEps) && (uv.y <= 1.0f + kEdgeEps) && (t.y >= 0.0f) && (t.y <= tr.tmax);
+            const bool hit = two && (u.y >= -kEdgeEps) && (v.y >= -kEdgeEps) && (w.y >= -kEdgeEps) && (t.y >= 0.0f) && (t.y <= tr.tmax);
             const bool closer = (t.y < tr.h.t) | ((t.y == tr.h.t) & (orig_b < tr.best_orig));
             const bool better = hit && (any_hit ? !found : closer);
             found = found || hit;

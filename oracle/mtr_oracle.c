@@ -434,10 +434,11 @@ static inline int tri_test(const orc_tri *T, const ray3 *r, float *t, float *u, 
     float inv_det = 1.0f / det;
     v3 tvec = vsub(r->o, T->p0);
     float uu = vdot(tvec, pvec) * inv_det;
-    if (!(uu >= -MTR_EDGE_EPS && uu <= 1.0f + MTR_EDGE_EPS)) return 0;
+    if (!(uu >= -MTR_EDGE_EPS)) return 0;
     v3 qvec = vcross(tvec, T->e1);
     float vv = vdot(r->d, qvec) * inv_det;
-    if (!(vv >= -MTR_EDGE_EPS && uu + vv <= 1.0f + MTR_EDGE_EPS)) return 0;
+    float ww = 1.0f - (uu + vv);                  /* the third barycentric coordinate; mitsuba's u <= 1 follows from the three */
+    if (!(vv >= -MTR_EDGE_EPS && ww >= -MTR_EDGE_EPS)) return 0;
     float tt = vdot(T->e2, qvec) * inv_det;
     if (!(tt >= 0.0f && tt <= r->maxt)) return 0;
     *t = tt; *u = uu; *v = vv;

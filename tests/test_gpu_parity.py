@@ -701,7 +701,7 @@ def test_results_of_consecutive_renders_stay_valid(oracle):
     assert t0.torch().data_ptr() != t1.torch().data_ptr()
     assert torch.equal(t0.torch(), keep0)                     # the first result is what it was
     assert not torch.equal(t0.torch(), t1.torch())            # ... and the second is another render
-    mean = np.array((t0.torch() + t1.torch()) / 2)
+    mean = ((t0.torch() + t1.torch()) / 2).cpu().numpy()
     r0 = oracle_render(oracle, a, 16, seed=0)[1]
     r1 = oracle_render(oracle, a, 16, seed=1)[1]
     assert rel_l2(mean, (r0 + r1) / 2) <= TOL

@@ -378,7 +378,9 @@ def check_readme_cornell_box(figures, steady, ncc_min, interior_min, chroma_tol,
         assert c >= least, (ch, c)
         assert max(ft.ncc(a[..., ch], b[:, ::-1, ch]), ft.ncc(a[..., ch], b[::-1, :, ch]), ft.ncc(a[..., ch], b[..., ch].T)) <= c - 0.15, ch
     ci, dy, dx = best_shift(a[..., 0], b[..., 0], reach=3, margin=max(4, n // 16))
-    assert (dy, dx) == (0, 0) and ci >= interior_min, (ci, dy, dx)
+    # (at the figure's own resolution one pixel — 0.3 % of the side — is the precision of cropping its 356 x 359 content out of
+    # the black frame)
+    assert max(abs(dy), abs(dx)) <= (1 if n > 200 else 0) and ci >= interior_min, (ci, dy, dx)
     ratios = {}
     for name, (y0, y1, x0, x1) in CBOX_REGIONS.items():
         sl = (slice(int(y0 * n), int(y1 * n)), slice(int(x0 * n), int(x1 * n)))
