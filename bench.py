@@ -208,7 +208,7 @@ WF_SHADOW_RAY_BYTES = 48.0             # ... + 48 B per shadow ray
 def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
     """Roofline blocks of a render in the wavefront organisation (config 5): the dominant kernel k_wf_trace (VALU issue x active
     lanes: instructions of the committed PMC pass of the SAME workload and sources over its own live HIP-event time), the
-    HBM-bound pair k_wf_shadow_gen + k_wf_shade (SURVEY section 8d's algorithmic bytes over their live time) and the time-bin
+    HBM-bound k_wf_shade (SURVEY section 8d's algorithmic bytes over its live time) and the time-bin
     scatter-add k_wf_scatter (24 B per contribution over its live time).  counters / times: sums over ``n_renders`` renders."""
     out = {}
     trace_ms = times.get("wf_trace_ms", 0.0) / n_renders
@@ -238,13 +238,12 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
         ach = alg / (shade_ms * 1e-3) / 1e9
         traffic = None
         if profile_ok:
-            tr = [pmc_from_profiles(k, "staircase").get("hbm_bytes_per_render") for k in ("k_wf_shade", "k_wf_shadow_gen")]
-            traffic = sum(tr) if all(t is not None for t in tr) else None
-        out["roofline_shade"] = {"kernel": "k_wf_shadow_gen + k_wf_shade", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            traffic = pmc_from_profiles("k_wf_shade", "staircase").get("hbm_bytes_per_render")
+        out["roofline_shade"] = {"kernel": "k_wf_shade", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms_per_render": shade_ms,
                                  "algorithmic_bytes_per_render": alg, "share_of_render": shade_ms / ms_per_render,
                                  "note": "algorithmic bytes = SURVEY section 8d: 216 B per live path and bounce + 48 B per shadow ray; "
-                                         "traffic = 2 x FETCH_SIZE + WRITE_SIZE of both kernels per render (PMC passes)"}
+                                         "traffic = 2 x FETCH_SIZE + WRITE_SIZE of the kernel per render (PMC passes)"}
     if scat_ms > 0:
         alg = SPLAT_BYTES * counters["splats_issued"] / n_renders
         ach = alg / (scat_ms * 1e-3) / 1e9
@@ -606,7 +605,7 @@ def main():
             vline = valu_roofline("k_fused", avg_ms, default_wl, n_launch / args.steps, section="nlos")
         elif not fused and SCENE == "staircase" and MATERIALS == "smooth" and wft_n:
             # config 5: the dominant kernel is k_wf_trace (closest-hit and any-hit runs), timed alone with HIP events; beside it the
-            # HBM-bound pair k_wf_shadow_gen + k_wf_shade and the scatter-add
+            # HBM-bound k_wf_shade and the scatter-add
             blocks = wavefront_rooflines(totals_rank0, {"wf_trace_ms": wft_ms, "wf_trace_kernel_launches": wft_n, "wf_shade_ms": wfs_ms,
                                                         "scatter_ms": wsc_ms, "scatter_launches": wsc_n},
                                          args.steps, ms_per_step, default_wl and profile_is_current("staircase"))

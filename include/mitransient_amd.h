@@ -296,7 +296,7 @@ typedef struct mtr_kernel_times {
     uint32_t scatter_launches;
     float    wf_trace_ms;     /* wavefront (ABI 9): sum of the k_wf_trace launches alone (closest-hit and any-hit runs) */
     uint32_t wf_trace_kernel_launches; /* ... and their number                                   */
-    float    wf_shade_ms;     /* wavefront (ABI 10): sum of the k_wf_shadow_gen + k_wf_shade launches (the HBM-bound pair of scenes in HBM) */
+    float    wf_shade_ms;     /* wavefront (ABI 10): sum of the k_wf_shade launches (HBM-bound for scenes in HBM) */
 } mtr_kernel_times;
 
 typedef struct mtr_ctx   mtr_ctx;

@@ -36,7 +36,7 @@ struct mtr_ctx {
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
-    void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *q_shadow = nullptr, *r_shadow = nullptr, *occ = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr;
+    void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *q_shadow = nullptr, *r_shadow = nullptr, *occ = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr, *q_zombie = nullptr;
     uint32_t n_slots = 0, P = 0, rec_cap = 0, rows = 0;
     uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
 };
@@ -276,7 +276,7 @@ void mtr_scene_destroy(mtr_scene *s)
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count };
+    void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count, s->wf.q_zombie };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
     void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.hg_vn, s->nlos.targets, s->d_freq };
@@ -330,7 +330,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     mtr_ctx *c = s->ctx;
     WfWorkspace &w = s->wf;
     if (w.n_slots >= n_slots && w.P >= P && w.rec_cap == rec_cap && w.rows >= n_seg && w.planes) return MTR_OK;
-    void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.q_shadow, &w.r_shadow, &w.occ, &w.counts, &w.rec, &w.rec_count };
+    void **ptrs[] = { &w.planes, &w.q_live, &w.q_ray, &w.q_mat, &w.q_shadow, &w.r_shadow, &w.occ, &w.counts, &w.rec, &w.rec_count, &w.q_zombie };
     w.n_slots = 0; w.P = 0; w.rec_cap = 0; w.rows = 0;          // sizes are valid only once every buffer below exists
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(c, hipMalloc(&w.planes, wf_planes_bytes(n_slots)));
@@ -338,9 +338,10 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     HIP_TRY(c, hipMalloc(&w.q_ray, (size_t)2 * n_slots * 32));                       // rays of the live lists, in list order
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.q_shadow, (size_t)n_slots * 4));
+    HIP_TRY(c, hipMalloc(&w.q_zombie, (size_t)2 * n_slots * 4));                    // paths that ended with an emitter-sampling term parked, per parity
     HIP_TRY(c, hipMalloc(&w.r_shadow, (size_t)n_slots * 32));
     HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots));
-    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (5 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total + seg_list_n[2] (16 words), seg_list[2][n_seg]
+    HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (7 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total + seg_list_n[2] (16 words), seg_list[2][n_seg], seg_zombie[2][n_seg]
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
     if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
@@ -361,7 +362,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     // tile = P pixels x S samples (2^25 slots); segment = G whole pixels (about 4096 slots: with the persistent
     // k_wf_trace a segment is drained once per launch, so longer segments waste less — staircase 1024: 425 ms,
     // 2048: 390, 4096: 360, 8192: 397)
-    // Tile: as many slots as half of the free device memory holds, at most 2^28 (82 GB of workspace at 305 B per slot).  Every
+    // Tile: as many slots as half of the free device memory holds, at most 2^28 (92 GB of workspace at 341 B per slot).  Every
     // bounce of every tile costs four launches with ~0.1 ms of fixed cost each, and with max_depth 65 most of them run nearly
     // empty: config 5 (2^29 slots) with tiles of 2^25 / 2^26 / 2^27 / 2^28 slots: 2.01 / 1.80 / 1.70 / 1.59 s per render
     // (config 2 in this organisation: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms).
@@ -370,7 +371,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     uint32_t kTileSlots = 1u << 28; uint32_t kSegSlots = cfg.scene_lds ? 4096u : 8192u;
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_slot = 320;                                   // planes 112 + queues 44 + rays 96 + records 64 + occlusion 1, rounded up
+        const size_t per_slot = 344;                                   // planes 128 + queues 52 + rays 96 + records 64 + occlusion 1, rounded up
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // half of what is free now (the workspace this scene already holds counts as free), and never more than a third of
             // the device: the caller's allocator (films, all-gather buffers, a second scene) needs room the driver cannot see
@@ -405,6 +406,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
     a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_ray = (float4 *)w.q_ray; a.q_mat = (uint32_t *)w.q_mat;
     a.q_shadow = (uint32_t *)w.q_shadow; a.r_shadow = (float4 *)w.r_shadow; a.occ = (uint8_t *)w.occ;
+    a.q_zombie = (uint32_t *)w.q_zombie;
     a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;
     a.G = G; a.seg = seg;
@@ -421,7 +423,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     const uint32_t max_depth = p->max_depth < 0 ? 0xffffffffu : (p->max_depth == 0 ? 1u : (uint32_t)p->max_depth + (s->nlos.on ? 2u : 0u));
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev, trace_ev, shade_ev;
     // (timed renders only) events around every k_wf_trace launch — the dominant kernel of scenes in HBM is timed alone — and
-    // around the HBM-bound pair k_wf_shadow_gen + k_wf_shade (their sum: mtr_kernel_times.wf_shade_ms)
+    // around the HBM-bound k_wf_shade (mtr_kernel_times.wf_shade_ms)
     auto launch_timed = [&](int which, int grid_, std::vector<std::pair<hipEvent_t, hipEvent_t>> &bucket) -> hipError_t {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timed) {
@@ -452,6 +454,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             a.live_total = unbounded ? live_total : nullptr;
             a.seg_list_n = live_total + 4;
             a.seg_list = live_total + 16;
+            a.seg_zombie = a.seg_list + (size_t)2 * a.n_seg;
             const int grid = (int)std::min<uint32_t>(a.n_seg, (uint32_t)grid_full);
             const int grid_gen = (int)std::min<uint32_t>((a.n_slots + kBlock - 1) / kBlock, (uint32_t)grid_full);
             HIP_TRY(c, hipMemsetAsync(w.rec_count, 0, (size_t)Pcur * 4, c->stream));
@@ -478,14 +481,15 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                 }
                 a.trace_any = 0u;
                 HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                // closest hit + material lists
-                if (!cfg.scene_lds) {                                                // scene in HBM/L2: shadow rays get their own persistent trace
-                    HIP_TRY(c, launch_timed(4, grid, shade_ev)); a.ticket_cur ^= 1u;         // shadow rays of the emitter samples
-                    a.trace_any = 1u;
-                    HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                   // their occlusion
-                    *n_trace += 2;
-                }
-                HIP_TRY(c, launch_timed(2, grid, shade_ev)); a.ticket_cur ^= 1u;        // shade (+ inline shadow rays when the scene is in LDS) + compaction
+                // shade: commits the emitter-sampling terms the previous bounce parked, runs the loop iteration once, writes the
+                // shadow rays (scene in HBM) or traces them inline (scene in LDS), compacts the survivors
+                HIP_TRY(c, launch_timed(2, grid, shade_ev)); a.ticket_cur ^= 1u;
                 *n_trace += 2;
+                if (!cfg.scene_lds) {                                                // scene in HBM/L2: the shadow rays get their own persistent trace
+                    a.trace_any = 1u;
+                    HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;            // occlusion of this bounce's shadow rays: read by the NEXT shade
+                    *n_trace += 1;
+                }
                 a.parity ^= 1u;
                 ++depth;
                 if (unbounded && (depth & 7u) == 0) {                                // every 8 bounces: anyone left?

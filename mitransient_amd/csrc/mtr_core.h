@@ -87,11 +87,11 @@ MTR_HD void tea4(uint32_t &v0, uint32_t &v1)
         v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
     }
 }
-MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane)
+MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane, bool seq_plus_lane = false)
 {
     uint32_t v0 = seed, v1 = lane;
     tea4(v0, v1);
-    return ((uint64_t)v1 << 1u) | 1u;
+    return (((uint64_t)v1 + (seq_plus_lane ? (uint64_t)lane : 0ull)) << 1u) | 1u;     // == rng_seed(...).inc
 }
 MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane, bool seq_plus_lane = false)
 {

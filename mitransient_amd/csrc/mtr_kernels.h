@@ -103,6 +103,8 @@ struct WfArgs {
     uint32_t *q_shadow;                  // [n_slots] slots whose vertex emits a shadow ray this bounce, same segmentation
     float4 *r_shadow;                    // [n_slots][2] those shadow rays, in list order: (o, tmax) (d, -)
     uint32_t *seg_shadow;                // [n_seg] their counts
+    uint32_t *q_zombie;                  // [2][n_slots] scenes in HBM: paths that ended with an emitter-sampling term parked (Q_PEND), per parity
+    uint32_t *seg_zombie;                // [2][n_seg] their counts
     uint8_t *occ;                        // [n_slots] shadow-ray result per slot: 1 = occluded
     uint32_t trace_any;                  // k_wf_trace: 0 closest hits of the live lists, 1 occlusion of the shadow lists
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths
@@ -122,7 +124,7 @@ struct WfConfig { int stack; bool scene_lds; size_t lds_bytes; };
 size_t wf_planes_bytes(uint32_t n_slots);
 bool wf_plan(const SceneDev &sc, WfConfig &cfg);
 // which: 0 raygen, 1 trace (closest hit + material-sorted queues, or occlusion when a.trace_any), 2 shade,
-// 3 time-bin scatter-add, 4 shadow-ray generation, 5 one whole NLOS bounce (a.nlos_on)
+// 3 time-bin scatter-add, 5 one whole NLOS bounce (a.nlos_on)
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream);
 
 // scratch (variant 1): device buffer of >= 8 * (width * height + 2) bytes for the run table; NULL forces the atomics

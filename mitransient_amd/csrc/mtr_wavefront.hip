@@ -124,18 +124,24 @@ __device__ __forceinline__ uint32_t wf_next_segment(const WfArgs &a, unsigned ch
     return k < a.seg_list_n[a.parity] ? a.seg_list[(size_t)a.parity * a.n_seg + k] : 0xffffffffu;
 }
 // the segment keeps `n` live paths for the next bounce: its length, and its place in the next bounce's list
-__device__ __forceinline__ void wf_segment_survivors(const WfArgs &a, uint32_t sg, uint32_t n)
+// (n_zombie: paths that have ended but whose last emitter-sampling term still waits for its shadow ray — see k_wf_shade)
+__device__ __forceinline__ void wf_segment_survivors(const WfArgs &a, uint32_t sg, uint32_t n, uint32_t n_zombie = 0u)
 {
     const uint32_t nxt = a.parity ^ 1u;
     a.seg_live[(size_t)nxt * a.n_seg + sg] = n;
-    if (n) a.seg_list[(size_t)nxt * a.n_seg + atomicAdd(a.seg_list_n + nxt, 1u)] = sg;
+    a.seg_zombie[(size_t)nxt * a.n_seg + sg] = n_zombie;
+    if (n + n_zombie) a.seg_list[(size_t)nxt * a.n_seg + atomicAdd(a.seg_list_n + nxt, 1u)] = sg;
 }
 
 // ---- SoA-of-quads state: 7 planes of float4 (16 B per lane per access, the coalescing sweet spot;
 // also what keeps the gathers through the slot queues efficient) ----------------------------------
 //   Q_RAY0 (o.xyz, tmax)   Q_RAY1 (d.xyz, eta)      Q_BETA (beta.xyz, dist)   Q_RAD (L.xyz, prev_pdf)
-//   Q_PREV (prev_p.xyz, depth | prev_delta << 31)   Q_RNG (state lo, hi, inc lo, hi)   Q_HIT (t, u, v, prim)
-enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_RNG, Q_HIT, PL_COUNT };
+//   Q_PREV (prev_p.xyz, depth | pending << 30 | prev_delta << 31)   Q_RNG (state lo, hi: 8 B)   Q_HIT (t, u, v, prim)
+//   Q_PEND (Lr.xyz, opl): scenes in HBM — the emitter-sampling term of the LAST bounce, waiting for its shadow ray (deferred commit, below)
+// Q_RNG is the LAST plane and holds 8 bytes per slot: the PCG32 state.  The stream's increment is a function of (seed, lane)
+// (rng_seed) and is recomputed where the state is loaded — 8 bytes less to read and 8 less to write per vertex and bounce
+// in kernels that wait on HBM (round 4; the four TEA rounds are hidden by the loads)
+enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_HIT, Q_PEND, PL16_COUNT, Q_RNG = PL16_COUNT };
 
 // NT: scenes walked in HBM.  Their path state, rays and hits stream through every kernel of a bounce exactly once —
 // NON-TEMPORAL accesses keep them from pushing the scene (BVH nodes, triangles) out of L2: staircase, 720 x 1280 x 64 spp,
@@ -151,6 +157,19 @@ struct PlanesT {
     {
         if (NT) nt_store(base + (size_t)pl * n + slot, v); else base[(size_t)pl * n + slot] = v;
     }
+    // the 8-byte plane behind the 16-byte ones
+    __device__ __forceinline__ uint64_t ld_rng(uint32_t slot) const
+    {
+        const uint32_t *w = (const uint32_t *)(base + (size_t)PL16_COUNT * n) + 2 * (size_t)slot;
+        const uint32_t lo = NT ? __builtin_nontemporal_load(w) : w[0], hi = NT ? __builtin_nontemporal_load(w + 1) : w[1];
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    __device__ __forceinline__ void st_rng(uint32_t slot, uint64_t v) const
+    {
+        uint32_t *w = (uint32_t *)(base + (size_t)PL16_COUNT * n) + 2 * (size_t)slot;
+        if (NT) { __builtin_nontemporal_store((uint32_t)v, w); __builtin_nontemporal_store((uint32_t)(v >> 32), w + 1); }
+        else { w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); }
+    }
 };
 
 template <class Planes>
@@ -163,28 +182,31 @@ __device__ __forceinline__ Ray load_ray(const Planes &P, uint32_t s, float &eta)
 template <class Planes>
 // with_origin: also the (origin, tmax) plane.  Only a kernel that traces from the planes reads it (k_wf_nlos_bounce); the
 // closest-hit kernel takes its rays from the list in list order, shading needs the direction alone
-__device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_origin)
+__device__ __forceinline__ void store_state(const Planes &P, uint32_t s, const Path &p, bool with_origin, uint32_t pend = 0u)
 {
     if (with_origin) P.st(Q_RAY0, s, make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax));
     P.st(Q_RAY1, s, make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta));
     P.st(Q_BETA, s, make_float4(p.beta.x, p.beta.y, p.beta.z, p.dist));
     P.st(Q_RAD, s, make_float4(p.L.x, p.L.y, p.L.z, p.prev_pdf));
-    P.st(Q_PREV, s, make_float4(p.prev_p.x, p.prev_p.y, p.prev_p.z, __uint_as_float(p.depth | (p.prev_delta << 31))));
-    P.st(Q_RNG, s, make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)),
-                                __uint_as_float((uint32_t)p.rng.inc), __uint_as_float((uint32_t)(p.rng.inc >> 32))));
+    P.st(Q_PREV, s, make_float4(p.prev_p.x, p.prev_p.y, p.prev_p.z, __uint_as_float(p.depth | (pend << 30) | (p.prev_delta << 31))));
+    P.st_rng(s, p.rng.state);
 }
 template <class Planes>
-__device__ __forceinline__ void load_state(const Planes &P, uint32_t s, Path &p)
+// with_origin = false: shading needs the ray's direction alone (the hit point comes from the barycentrics, the next ray is
+// written whole) — the (origin, tmax) plane is not read (16 B per vertex that the data flow of shade_finish kept alive)
+__device__ __forceinline__ void load_state(const Planes &P, uint32_t s, Path &p, uint32_t *pend = nullptr, bool with_origin = true)
 {
-    p.ray = load_ray(P, s, p.eta);
-    const float4 b = P.ld(Q_BETA, s), l = P.ld(Q_RAD, s), v = P.ld(Q_PREV, s), g = P.ld(Q_RNG, s);
+    if (with_origin) p.ray = load_ray(P, s, p.eta);
+    else { const float4 b = P.ld(Q_RAY1, s); p.ray.o = mk(0, 0, 0); p.ray.tmax = 0.0f; p.ray.d = mk(b.x, b.y, b.z); p.eta = b.w; }
+    const float4 b = P.ld(Q_BETA, s), l = P.ld(Q_RAD, s), v = P.ld(Q_PREV, s);
+    p.rng.state = P.ld_rng(s);
     p.beta = mk(b.x, b.y, b.z); p.dist = b.w;
     p.L = mk(l.x, l.y, l.z); p.prev_pdf = l.w;
     p.prev_p = mk(v.x, v.y, v.z);
     const uint32_t fl = __float_as_uint(v.w);
-    p.depth = fl & 0x7fffffffu; p.prev_delta = fl >> 31;
-    p.rng.state = (uint64_t)__float_as_uint(g.x) | ((uint64_t)__float_as_uint(g.y) << 32);
-    p.rng.inc = (uint64_t)__float_as_uint(g.z) | ((uint64_t)__float_as_uint(g.w) << 32);
+    p.depth = fl & 0x3fffffffu; p.prev_delta = fl >> 31;
+    if (pend) *pend = (fl >> 30) & 1u;
+    p.rng.inc = 0u;                      // the caller knows the lane: p.rng.inc = rng_inc_of(...)
 }
 
 // slot -> (pixel, sample) of the tile
@@ -302,6 +324,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
     }
     for (uint32_t sg = blockIdx.x * kBlock + tid; sg < a.n_seg; sg += gridDim.x * kBlock) {
         a.seg_live[sg] = min(a.seg, a.n_slots - sg * a.seg);    // every slot of the segment is live
+        a.seg_zombie[sg] = 0u; a.seg_zombie[(size_t)a.n_seg + sg] = 0u;
         a.seg_list[sg] = sg;                                    // ... and every segment is on bounce 0's list (its length: the host)
     }
     if (a.counters) {
@@ -442,79 +465,50 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
 #endif
 }
 
-// shadow rays of this bounce: shade_hit (emitter sampling, transientpath.py:185-218) is re-run on the diffuse list with
-// a null sink, only to learn which vertices emit a shadow ray and which; the rays go, in list order, to the segment's
-// shadow list for k_wf_trace (occlusion), and k_wf_shade re-runs shade_hit for real with the answer in `occ`.
-// (Shadow rays traced inside k_wf_shade, one traverse<true>() per lane, were 83 % of that kernel on the staircase —
-// 169 of 204 ms — for the same reason as closest hits: lanes waiting for the slowest ray of their wave.)
-template <int STACK, bool SCENE_LDS, bool EXT>
-__global__ void __launch_bounds__(kBlock) k_wf_shadow_gen(const WfArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *s_tail = (uint32_t *)smem;
-    const int tid = threadIdx.x;
-    SceneView sv; WStack<STACK> st; uint32_t off;
-    wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
-    const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
-    wf_ticket_begin(a, tid);
-    for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
-        const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + 0];               // only diffuse vertices sample the emitter
-        if (n_k == 0u) { if (tid == 0) a.seg_shadow[sg] = 0u; continue; }       // (an emptied segment)
-        if (tid == 0) *s_tail = 0u;
-        __syncthreads();
-        const uint32_t *q = a.q_mat + (size_t)sg * a.seg;
-        uint32_t *q_out = a.q_shadow + (size_t)sg * a.seg;
-        float4 *r_out = a.r_shadow + 2 * (size_t)sg * a.seg;
-        const uint32_t n_round = (n_k + 63u) & ~63u;
-        for (uint32_t i = tid; i < n_round; i += kBlock) {
-            bool want = false;
-            uint32_t slot = 0;
-            Ray shadow;
-            shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
-            if (i < n_k) {
-                slot = q[i];
-                uint32_t pixel, s, pl;
-                slot_to_lane(a, slot, pixel, s, pl);
-                Path p;
-                load_state(P, slot, p);
-                const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
-                p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
-                Hit h;
-                { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
-                NullSink sink;
-                Pending pd;
-                shade_hit<EXT>(p, h, sv, a.film, a.rc, sink, pd, shadow);
-                want = pd.has_shadow != 0u;
-            }
-            if (__ballot(want) != 0ull) {
-                const uint32_t pos = wave_append(s_tail, want);
-                if (want) {
-                    q_out[pos] = slot;
-                    r_out[2 * (size_t)pos] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.tmax);
-                    r_out[2 * (size_t)pos + 1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) a.seg_shadow[sg] = *s_tail;
-        __syncthreads();
-    }
-}
-
 // shade the material-sorted lists of every segment; survivors form the next live list
 // waves per SIMD the register allocator leaves room for: a scene in HBM/L2 needs the occupancy to hide its latency
 // (4: 425 ms vs 3: 452 ms on the staircase); with the scene in LDS the 168 registers of 3 waves avoid 29 spilled
 // dwords (187 ms vs 215 ms per config-2 render)
 // EXT: the extended shading code (GGX lobes, interpolated normals) — only scenes that need it pay for it
 // (config 2, wavefront organisation: k_wf_shade 1.44 ms per launch without, 1.82 ms with)
+//
+// DEFERRED COMMIT of the emitter-sampling term (scenes walked in HBM; round 4).  The reference's iteration is
+// closest hit -> shade_hit (emission, emitter sample, SHADOW RAY) -> shade_finish (commit the sample if unoccluded, BSDF sample,
+// roulette).  Tracing the shadow ray inside this kernel was 83 % of it (lanes waiting for the slowest ray of their wave), so
+// rounds 1-3 ran shade_hit TWICE: k_wf_shadow_gen (null sink: only the shadow rays) -> k_wf_trace (occlusion) -> k_wf_shade —
+// 160 B per vertex and a second random fetch of the 80-byte shading record just to learn the ray.  Nothing in shade_finish but
+// the commit depends on the shadow ray, so the iteration is now run ONCE: shade_hit writes the shadow ray to the segment's
+// shadow list and parks the term (Lr, optical path length) in the Q_PEND plane, shade_finish runs with the term withheld,
+// the occlusion kernel follows, and the NEXT bounce's k_wf_shade commits the parked term first thing.  The sums are bit for bit
+// the reference's: L = (L + Le) + Lr there, (L + Le) + 0 now and + Lr at the commit — before the next bounce's Le, as there.
+// A path that ENDS with a term parked becomes a "zombie" (its radiance and depth in Q_RAD, the term in Q_PEND, its slot on the
+// segment's zombie list); the next launch commits it and deposits its radiance.  No term can be left at the end of a render:
+// a vertex samples the emitter only if depth + 1 < max_depth, and the host's live count includes the zombies.
+template <class Sink>
+__device__ __forceinline__ void commit_pending(f3 &L, f3 Lr, float opl, uint32_t depth_log, uint32_t px, uint32_t py,
+                                               const Film &film, const RenderConst &rc, Sink &sink)
+{
+    // shade_finish's own commit (transientpath.py:216-218, :230), word for word
+    const uint32_t fx = px - film.crop_x, fy = py - film.crop_y;
+    const float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
+    if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
+        const int32_t bin = film_bin(film, opl);
+        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, opl, depth_log, 1u);
+    }
+    L = mk(L.x + Lr.x, L.y + Lr.y, L.z + Lr.z);
+}
+
 #ifndef MTR_WF_SHADE_WAVES
 #define MTR_WF_SHADE_WAVES 4
 #endif
 template <int STACK, bool SCENE_LDS, bool EXT>
 __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
+    constexpr bool DEFER = !SCENE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_next_p = (uint32_t *)smem;                      // tail of the segment's next live list
+    uint32_t *s_shadow_p = (uint32_t *)smem + 1;                // (DEFER) tail of the segment's shadow-ray list
+    uint32_t *s_zombie_p = (uint32_t *)smem + 2;                // (DEFER) tail of the segment's next zombie list
     const int tid = threadIdx.x;
     SceneView sv; WStack<STACK> st; uint32_t off;
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
@@ -527,24 +521,62 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t pl0 = sg * a.G;                          // first pixel (tile-local) of the segment
         const uint32_t npx = min(a.G, a.P - pl0);
+        const uint32_t n_z = DEFER ? a.seg_zombie[(size_t)par * a.n_seg + sg] : 0u;
         {   // an emptied segment: nothing to shade, nothing survives
-            uint32_t n_all = 0u;
+            uint32_t n_all = n_z;
             for (uint32_t k = 0; k < kWfKeys; ++k) n_all += a.seg_mat[(size_t)sg * kWfKeys + k];
-            if (n_all == 0u) { if (tid == 0) wf_segment_survivors(a, sg, 0u); continue; }
+            if (n_all == 0u) { if (tid == 0) { wf_segment_survivors(a, sg, 0u); if (DEFER) a.seg_shadow[sg] = 0u; } continue; }
         }
         for (uint32_t t = tid; t < npx; t += kBlock) s_rec[t] = a.rec_count[pl0 + t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) s_steady[t] = 0.0f;
-        if (tid == 0) *s_next_p = 0u;
+        if (tid == 0) { *s_next_p = 0u; *s_shadow_p = 0u; *s_zombie_p = 0u; }
         __syncthreads();
         uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
         float4 *r_next = a.q_ray + 2 * ((size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg);
+        uint32_t *qz_next = DEFER ? a.q_zombie + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg : nullptr;
+        uint32_t *q_sh = a.q_shadow + (size_t)sg * a.seg;
+        float4 *r_sh = a.r_shadow + 2 * (size_t)sg * a.seg;
+        auto make_sink = [&](uint32_t pl, uint32_t lane) {
+            RecordSink sink;
+            sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
+            sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
+            sink.n_freq = a.film.n_freq; sink.freq = a.film.freq; sink.start_opl = a.film.start_opl;
+            sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = lane;
+            sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
+            return sink;
+        };
+        auto deposit = [&](uint32_t pl, f3 L) {
+            // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
+            float *sp = s_steady + 4 * (pl - pl0);
+            __hip_atomic_fetch_add(sp, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sp + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sp + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sp + 3, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (DEFER && n_z) {      // zombies of the previous bounce: commit the parked term, deposit the path's radiance
+            const uint32_t *qz = a.q_zombie + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+            for (uint32_t i = tid; i < n_z; i += kBlock) {
+                const uint32_t slot = qz[i];
+                uint32_t pixel, s, pl;
+                slot_to_lane(a, slot, pixel, s, pl);
+                const float4 l = P.ld(Q_RAD, slot), pe = P.ld(Q_PEND, slot);
+                f3 L = mk(l.x, l.y, l.z);
+                if (a.occ[slot] == 0) {
+                    const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                    RecordSink sink = make_sink(pl, pixel * a.rc.spp_total + s);
+                    commit_pending(L, mk(pe.x, pe.y, pe.z), pe.w, __float_as_uint(l.w) - 1u, px + a.film.crop_x, py + a.film.crop_y, a.film, a.rc, sink);
+                    n_splats += sink.n_splats; n_over += sink.n_overflow;
+                }
+                deposit(pl, L);
+            }
+        }
         for (uint32_t k = 0; k < kWfKeys; ++k) {                 // one material type after the other
             const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + k];
             const uint32_t *q = a.q_mat + (size_t)k * a.n_slots + (size_t)sg * a.seg;
             const uint32_t n_round = (n_k + 63u) & ~63u;
             for (uint32_t i = tid; i < n_round; i += kBlock) {
                 const bool on = i < n_k;
-                bool alive = false;
+                bool alive = false, zombie = false;
                 uint32_t slot = 0;
                 f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1); float ray_tmax = 0.0f;
                 if (on) {
@@ -552,18 +584,19 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     uint32_t pixel, s, pl;
                     slot_to_lane(a, slot, pixel, s, pl);
                     Path p;
-                    load_state(P, slot, p);
+                    uint32_t pend = 0u;
+                    load_state(P, slot, p, &pend, false);
                     const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                     p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                    p.rng.inc = rng_inc_of(a.rc.seed, p.lane, (a.rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
                     Hit h;
                     { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                     ++n_closest;
-                    RecordSink sink;
-                    sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
-                    sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
-                    sink.n_freq = a.film.n_freq; sink.freq = a.film.freq; sink.start_opl = a.film.start_opl;
-                    sink.p_local = pl; sink.p_seg = pl - pl0; sink.lane = p.lane;
-                    sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
+                    RecordSink sink = make_sink(pl, p.lane);
+                    if (DEFER && pend && a.occ[slot] == 0) {          // the previous bounce's emitter sample was visible: commit it now
+                        const float4 pe = P.ld(Q_PEND, slot);
+                        commit_pending(p.L, mk(pe.x, pe.y, pe.z), pe.w, p.depth - 1u, p.px, p.py, a.film, a.rc, sink);
+                    }
                     Pending pd; Ray shadow;
                     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
                     if ((a.rc.flags & MTR_FLAG_CAMERA_UNWARP) && p.depth == 0u && h.prim >= 0) p.dist = -h.t;      // camera_unwarp: see k_wf_raygen
@@ -574,21 +607,28 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                         if (SCENE_LDS) {                  // short rays out of LDS: tracing them right here is cheaper (config 2: 168 vs 243 ms)
                             Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
                             occluded = sh.prim >= 0;
-                        } else occluded = a.occ[slot] != 0;   // traced by k_wf_trace from the list k_wf_shadow_gen wrote (staircase: 360 vs 300 ms)
+                        } else {
+                            // the ray goes to the segment's shadow list (k_wf_trace, any-hit, runs next), the term is parked and
+                            // withheld from shade_finish: `occluded` only gates the commit there
+                            const uint32_t pos = wave_append(s_shadow_p, true);
+                            q_sh[pos] = slot;
+                            r_sh[2 * (size_t)pos] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.tmax);
+                            r_sh[2 * (size_t)pos + 1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
+                            P.st(Q_PEND, slot, make_float4(pd.Lr.x, pd.Lr.y, pd.Lr.z, pd.opl));
+                            occluded = true;
+                        }
                     }
                     alive = shade_finish<EXT>(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
-                    if (alive) { ++n_alive; store_state(P, slot, p, false); }      // (a path that ended leaves nothing to read)
-                    else {
-                        // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
-                        float *sp = s_steady + 4 * (pl - pl0);
-                        __hip_atomic_fetch_add(sp, p.L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(sp + 1, p.L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(sp + 2, p.L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(sp + 3, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t pend_now = (DEFER && pd.has_shadow) ? 1u : 0u;
+                    if (alive) { ++n_alive; store_state(P, slot, p, false, pend_now); }      // (a path that ended leaves nothing to read)
+                    else if (pend_now) {                      // ended with a term parked: the next launch commits it and deposits
+                        zombie = true; ++n_alive;             // (the host's live count must keep the loop going for it)
+                        P.st(Q_RAD, slot, make_float4(p.L.x, p.L.y, p.L.z, __uint_as_float(p.depth)));
                     }
+                    else deposit(pl, p.L);
                 }
                 // wave64 stream compaction of the survivors into the segment's next live list
                 if (__ballot(alive) != 0ull) {
@@ -599,10 +639,14 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                         r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, 0.0f);
                     }
                 }
+                if (DEFER && __ballot(zombie) != 0ull) {
+                    const uint32_t pos = wave_append(s_zombie_p, zombie);
+                    if (zombie) qz_next[pos] = slot;
+                }
             }
         }
         __syncthreads();
-        if (tid == 0) wf_segment_survivors(a, sg, *s_next_p);
+        if (tid == 0) { wf_segment_survivors(a, sg, *s_next_p, DEFER ? *s_zombie_p : 0u); if (DEFER) a.seg_shadow[sg] = *s_shadow_p; }
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
             const float v = s_steady[t];
@@ -676,6 +720,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
                 load_state(P, slot, p);
                 const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                 p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                p.rng.inc = rng_inc_of(a.rc.seed, p.lane, (a.rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
                 RecordSink sink;
                 sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
                 sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;
@@ -900,7 +945,6 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
 {
     const bool ext = a.sc.has_rough != 0u;
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
-                            : which == 4 ? (ext ? k_wf_shadow_gen<STACK, SL, true> : k_wf_shadow_gen<STACK, SL, false>)
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
@@ -912,7 +956,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
 
 } // namespace
 
-size_t wf_planes_bytes(uint32_t n_slots) { return (size_t)PL_COUNT * n_slots * 16u; }
+size_t wf_planes_bytes(uint32_t n_slots) { return (size_t)PL16_COUNT * n_slots * 16u + (size_t)n_slots * 8u; }
 
 bool wf_plan(const SceneDev &sc, WfConfig &cfg)
 {
@@ -925,7 +969,7 @@ bool wf_plan(const SceneDev &sc, WfConfig &cfg)
     return true;
 }
 
-// which: 0 raygen, 1 trace, 2 shade, 3 scatter, 4 shadow-ray generation
+// which: 0 raygen, 1 trace, 2 shade, 3 scatter, 5 NLOS bounce
 hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, hipStream_t stream)
 {
     if (which == 3 && a.film.n_freq) {
