@@ -368,10 +368,20 @@ int  mtr_film_develop(mtr_ctx *, const mtr_film_desc *,
 
 /* The time-bin scatter-add alone: add_transient_data + put_ + accum
  * (transient_hdr_film.py:263-276, transient_image_block.py:131-149) over n
- * splats.  variant 0 = global f32 atomics (contract form), 1 = sorted-by-pixel
- * LDS-privatised rows (requires `pixel` non-decreasing). */
+ * splats.  variant 0 = global f32 atomics (the contract form: one atomic per channel wherever the contribution lands).
+ * variant 1 = LDS-privatised rows, one workgroup per pixel: input whose `pixel` is non-decreasing (the order of the
+ * reference's own lanes, pixel * spp + s) is consumed as it is; any other order is first partitioned by pixel on the
+ * device (ABI 10; two scatter passes over 16-byte records — needs 32 bytes of device workspace per contribution for the
+ * duration of the call and synchronises the stream once; films whose pixel index and row position do not fit one 32-bit key
+ * fall back to variant 0 on the device).  OR MTR_SPLAT_FILM_ZERO into `variant` when the film is all-zero on entry: the row
+ * flush then stores whole rows instead of read-modify-write. */
+#define MTR_SPLAT_FILM_ZERO 0x100
 int  mtr_splat_add(mtr_ctx *, const mtr_splat_soa *, const mtr_film_desc *, int variant,
                    float *transient_hwt4 /*device*/, float *elapsed_ms /*host, may be NULL*/);
+
+/* Release the device workspaces the context keeps between calls (ABI 10: the partition workspace of mtr_splat_add on
+ * unsorted input — 32 bytes per contribution of the largest such call).  Synchronises the context's stream. */
+int  mtr_ctx_trim(mtr_ctx *);
 
 /* Debug/test aid: per-lane splat log of one render (records of 8 x u32:
  * lane, depth|kind<<16, pixel, bin, r,g,b bits, opl bits), capacity in records.

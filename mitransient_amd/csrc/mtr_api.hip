@@ -33,6 +33,7 @@ struct mtr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
     void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
+    void *d_part = nullptr; size_t part_cap = 0;         // ... and the partition workspace of unsorted input (kept until mtr_ctx_trim / destroy)
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
@@ -125,6 +126,7 @@ void mtr_ctx_destroy(mtr_ctx *c)
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_freq) (void)hipFree(c->d_freq);
     if (c->d_runs) (void)hipFree(c->d_runs);
+    if (c->d_part) (void)hipFree(c->d_part);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -715,7 +717,9 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
     if (!c || !s || !fd || !t4) return fail(c, MTR_ERR_INVALID, "mtr_splat_add: NULL argument");
     int rc = check_film(c, *fd);
     if (rc) return rc;
-    if (variant != 0 && variant != 1) return fail(c, MTR_ERR_INVALID, "mtr_splat_add: variant must be 0 or 1");
+    const bool film_zero = (variant & MTR_SPLAT_FILM_ZERO) != 0;
+    variant &= ~MTR_SPLAT_FILM_ZERO;
+    if (variant != 0 && variant != 1) return fail(c, MTR_ERR_INVALID, "mtr_splat_add: variant must be 0 or 1 (| MTR_SPLAT_FILM_ZERO)");
     if (s->n && (!s->pixel || !s->opl || !s->r || !s->g || !s->b))
         return fail(c, MTR_ERR_INVALID, "mtr_splat_add: NULL splat array");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -744,12 +748,43 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
         scratch = c->d_runs;
     }
     if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, scratch, c->stream));
+    // variant 1: pixel-sorted input goes through the LDS rows as it is.  Anything else is PARTITIONED BY PIXEL on the device first
+    // (mtr_splat.hip: two scatter passes over 16-byte records, then the same rows) when the film's shape allows it; that path
+    // reads the sortedness flag back — one stream synchronisation — and holds 32 bytes of workspace per contribution for the call
+    const bool can_partition = variant == 1 && scratch && splat_partition_supported(*s, fm);
+    HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, scratch, c->stream, film_zero && variant == 1, !can_partition));
+    if (can_partition && s->n) {
+        uint32_t unsorted = 0;
+        HIP_TRY(c, hipMemcpyAsync(&unsorted, scratch, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (unsorted) {
+            const size_t need = splat_partition_scratch_bytes(*s, fm);
+            hipError_t e = hipSuccess;
+            if (c->part_cap < need) {
+                if (c->d_part) (void)hipFree(c->d_part);
+                c->d_part = nullptr; c->part_cap = 0;
+                e = hipMalloc(&c->d_part, need);
+                if (e == hipSuccess) c->part_cap = need; else { c->d_part = nullptr; (void)hipGetLastError(); }
+            }
+            if (e != hipSuccess) HIP_TRY(c, launch_splat_add(0, *s, fm, t4, nullptr, nullptr, c->stream));     // no room for the workspace: the contract form
+            else HIP_TRY(c, launch_splat_partitioned(*s, fm, t4, film_zero, nullptr, c->d_part, c->n_cu, c->stream));
+        }
+    }
     if (elapsed_ms) {
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
     }
+    return MTR_OK;
+}
+
+int mtr_ctx_trim(mtr_ctx *c)
+{
+    if (!c) return MTR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_part) (void)hipFree(c->d_part);
+    c->d_part = nullptr; c->part_cap = 0;
     return MTR_OK;
 }
 

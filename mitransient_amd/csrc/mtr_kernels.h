@@ -129,7 +129,12 @@ hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, 
 
 // scratch (variant 1): device buffer of >= 8 * (width * height + 2) bytes for the run table; NULL forces the atomics
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
-                            DevCounters *counters, void *scratch, hipStream_t stream);
+                            DevCounters *counters, void *scratch, hipStream_t stream, bool film_zero = false, bool fallback_atomics = true);
+// device-side partition by pixel in front of the row kernel (mtr_splat.hip)
+bool splat_partition_supported(const mtr_splat_soa &s, const Film &film);
+size_t splat_partition_scratch_bytes(const mtr_splat_soa &s, const Film &film);
+hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, float *film_out, bool film_zero, DevCounters *counters,
+                                    void *scratch, int n_cu, hipStream_t stream);
 hipError_t launch_develop(const Film &film, const float *t4, float *t3, const float *s4, float *s3, hipStream_t stream);
 
 } // namespace mtr

@@ -716,23 +716,34 @@ __global__ void __launch_bounds__(kBlock) k_splat_atomic(mtr_splat_soa s, Film f
 // variant 1: contributions sorted by pixel.  k_splat_runs finds where each pixel's run starts (and whether the input is
 // sorted at all); k_splat_rows then works like k_wf_scatter: one workgroup per pixel streams the run into an LDS row —
 // 64-bit fixed point, ds_add_u64 (ds_add_f32 retires at 3 clocks per lane on gfx950) — and adds the touched bins to the
-// film with plain 16-byte read-modify-writes, because the pixel is its own.  Unsorted input falls back to the atomics.
+// film with plain 16-byte read-modify-writes, because the pixel is its own.  Unsorted input is partitioned by pixel first
+// (mtr_splat.hip) or, where that cannot be done, falls back to the atomics.
+//
+// The run table is SPARSE: it is preset to kNoRun, and the record that opens a run (pixel[i - 1] < pixel[i]) writes two
+// entries — the end of the previous pixel's run, starts[pixel[i - 1] + 1], and the start of its own, starts[pixel[i]]; the
+// pixels in between have no contributions and stay kNoRun.  (Rounds 1-3 FILLED the gap: a few entries per record on sorted
+// input — and a hundred thousand per record on unsorted input, where every second record opens a "gap": 52 s for 2^28
+// uniform contributions, found when the partition path first ran this kernel on such input.)
+constexpr unsigned long long kNoRun = ~0ull;
 __global__ void __launch_bounds__(kBlock) k_splat_runs(const uint32_t *pixel, uint64_t n, uint32_t npix,
                                                        unsigned long long *starts, uint32_t *unsorted)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    bool descent = false;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t cur = min(pixel[i], npix);                    // ids >= npix (dropped contributions) sort to the end
         const int64_t prev = i ? (int64_t)min(pixel[i - 1], npix) : -1;
-        if ((int64_t)cur < prev) *unsorted = 1u;
-        for (int64_t q = prev + 1; q <= (int64_t)cur; ++q) starts[q] = i;                   // pixels prev+1 .. cur start here
-        if (i == n - 1) for (uint32_t q = cur + 1; q <= npix; ++q) starts[q] = n;
+        descent = descent || (int64_t)cur < prev;
+        if (!descent && (int64_t)cur > prev) { starts[prev + 1] = i; starts[cur] = i; }       // (after a descent the table is void: no more writes)
+        if (i == n - 1 && cur < npix) starts[cur + 1] = n;
     }
+    // one store per wave that saw a descent (a store per thread — half a million to one address on random input — is slow)
+    if (__ballot(descent) != 0ull && (threadIdx.x & 63u) == 0u) *unsorted = 1u;
 }
 
 template <bool FIXED>
 __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film film, float *out, const unsigned long long *starts,
-                                                       const uint32_t *unsorted, DevCounters *cnt)
+                                                       const uint32_t *unsorted, DevCounters *cnt, uint32_t film_zero)
 {
     if (*unsorted) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -745,7 +756,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
     uint32_t mine = 0;
     for (uint32_t px = blockIdx.x; px < npix; px += gridDim.x) {
         const uint64_t lo = starts[px], hi = starts[px + 1];
-        if (lo == hi) continue;                                      // (uniform across the workgroup)
+        if (lo == kNoRun || lo == hi) continue;                      // no contributions (uniform across the workgroup)
         for (uint64_t i = lo + tid; i < hi; i += kBlock) {
             // (contributions and film rows are touched once: non-temporal accesses, as in k_wf_scatter)
             const int32_t bin = film_row_bin(film, __builtin_nontemporal_load(s.opl + i), s.laser ? s.laser[i] : 0u);
@@ -774,7 +785,9 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
                 nz = r != 0.0f || g != 0.0f || b != 0.0f;
                 if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
             }
-            if (nz) { float4 v = nt_load(dst + t); v.x += r; v.y += g; v.z += b; nt_store(dst + t, v); }
+            // film_zero (MTR_SPLAT_FILM_ZERO): the caller vouches that the film is zero — the row goes out whole, no read
+            if (film_zero) nt_store(dst + t, make_float4(r, g, b, 0.0f));
+            else if (nz) { float4 v = nt_load(dst + t); v.x += r; v.y += g; v.z += b; nt_store(dst + t, v); }
         }
         __syncthreads();
     }
@@ -783,8 +796,10 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
 
 __global__ void k_splat_phasor(mtr_splat_soa s, Film film, float *out, DevCounters *cnt);
 
+// fallback_atomics: variant 1 on unsorted input falls back, on the device, to the f32 atomics (false: the caller partitions the
+// input by pixel instead — launch_splat_partitioned — after reading the flag at scratch[0])
 hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &film, float *film_out,
-                            DevCounters *counters, void *scratch, hipStream_t stream)
+                            DevCounters *counters, void *scratch, hipStream_t stream, bool film_zero, bool fallback_atomics)
 {
     if (s.n == 0) return hipSuccess;
     if (film.n_freq) {
@@ -803,17 +818,20 @@ hipError_t launch_splat_add(int variant, const mtr_splat_soa &s, const Film &fil
         unsigned long long *starts = (unsigned long long *)scratch + 1;
         hipError_t e = hipMemsetAsync(unsorted, 0, 8, stream);
         if (e != hipSuccess) return e;
+        e = hipMemsetAsync(starts, 0xff, 8u * ((size_t)npix + 1u), stream);          // kNoRun
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_splat_runs, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s.pixel, (uint64_t)s.n, npix, starts, unsorted);
         const bool fixed = (size_t)film.bins * 24u <= 72u * 1024u;
         const size_t lds = (size_t)film.bins * (fixed ? 24u : 12u);
         int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
         const unsigned grid = npix < (uint32_t)(256 * per_cu) ? npix : (unsigned)(256 * per_cu);
-        void (*k)(mtr_splat_soa, Film, float *, const unsigned long long *, const uint32_t *, DevCounters *) =
+        void (*k)(mtr_splat_soa, Film, float *, const unsigned long long *, const uint32_t *, DevCounters *, uint32_t) =
             fixed ? k_splat_rows<true> : k_splat_rows<false>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, s, film, film_out, starts, unsorted, counters);
-        hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters, unsorted);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, s, film, film_out, starts, unsorted, counters, film_zero ? 1u : 0u);
+        if (fallback_atomics)
+            hipLaunchKernelGGL(k_splat_atomic, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, film, film_out, counters, unsorted);
     }
     return hipGetLastError();
 }

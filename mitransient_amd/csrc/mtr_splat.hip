@@ -1,0 +1,310 @@
+// mtr_splat.hip — device-side PARTITION BY PIXEL in front of the row kernel of the stand-alone time-bin scatter-add
+// (mtr_splat_add, variant 1, on input that does not come pixel by pixel).
+//
+// The reference adds every contribution with one atomic per channel wherever it lands (transient_image_block.py:79-81,
+// 131-149: dr.scatter_reduce(Add) into the flat (H, W, T, C) tensor).  On gfx950 that form runs at 2 % of the HBM roof: 3 x 2^30
+// f32 atomics into a 4 GiB film are bound by the L2 atomic units (20 G/s), not by bytes.  The fast form needs every
+// contribution of a pixel in ONE workgroup, whose LDS row takes them with 64-bit integer atomics (k_splat_rows*).  For
+// input in arbitrary order that means a sort by pixel; its traffic is what bounds the result:
+//
+//   k_part_hist_hi     read the pixel ids (4 B)                    -> histogram of the HIGH half of the pixel index
+//   k_part_scatter_hi  read 20 B (pixel, opl, r, g, b), write 16 B -> records (pixel | bin << bits, r, g, b) grouped by high half
+//   k_part_hist_lo     read the records (16 B)                     -> histogram of the full pixel index = the run starts
+//   k_part_scatter_lo  read 16 B, write 16 B                       -> records (bin, r, g, b) grouped by pixel
+//   k_splat_rows_rec   read 16 B + the touched film bins           -> LDS row per pixel, one flush per pixel
+//
+// = 88 B per contribution + the film against the 24 algorithmic bytes: at most ~ 25 % of the HBM roof even at full streaming
+// speed.  Two scatter passes because one pass cannot keep 2^18 output streams coalesced: a tile of 4096 records spreads over
+// <= 512 buckets (runs of ~128 B that L2 merges), not over 262144.  The order inside a pixel does not matter (the row sums
+// are order-independent fixed point), so the scatters are UNSTABLE: a tile counts its records per bucket in LDS (the LDS
+// atomic's return value is the record's rank), claims the bucket's next range with one global atomic per (tile, bucket),
+// and writes.
+#include "mtr_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace mtr {
+
+namespace {
+
+constexpr uint32_t kPartPer = 16;                       // records per thread and tile
+constexpr uint32_t kPartTile = kBlock * kPartPer;       // 4096
+constexpr uint32_t kPartMaxDigits = 2048;               // LDS counters per tile (11 bits per half: films up to 2^22 pixels)
+constexpr uint32_t kDropped = 0xffffffffu;
+
+__device__ __forceinline__ unsigned long long splat_fixed(float v)
+{
+    long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42 (see mtr_kernels.hip: splat_to_fixed)
+    if (q == 0 && v != 0.0f) q = v > 0.0f ? 1 : -1;
+    return (unsigned long long)q;
+}
+
+struct PartArgs {
+    mtr_splat_soa s;
+    Film film;
+    uint32_t npix, bits_pix, bits_lo, n_hi, n_lo;
+    uint32_t *hist_hi;      // [n_hi]       counts, then (k_part_scan_hi) the claim cursors of the buckets
+    uint32_t *base_hi;      // [n_hi + 1]   exclusive scan; base_hi[n_hi] = number of records kept
+    uint32_t *starts;       // [npix + 1]   histogram of the pixel index, then its exclusive scan = the run starts
+    uint32_t *cur_lo;       // [npix]       claim cursors of the pixels
+    uint4 *rec_a, *rec_b;
+};
+
+// ---- pass 1: histogram of the high half ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_part_hist_hi(const PartArgs a)
+{
+    __shared__ uint32_t s_cnt[kPartMaxDigits];
+    const int tid = threadIdx.x;
+    for (uint32_t k = tid; k < a.n_hi; k += kBlock) s_cnt[k] = 0u;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < a.s.n; i += stride) {
+        const uint32_t px = __builtin_nontemporal_load(a.s.pixel + i);
+        // (a contribution outside the time window is dropped by the scatter pass, which reads its path length anyway; here it
+        // only makes its bucket's range a little too long)
+        if (px < a.npix) atomicAdd(&s_cnt[px >> a.bits_lo], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < a.n_hi; k += kBlock) if (s_cnt[k]) atomicAdd(a.hist_hi + k, s_cnt[k]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_part_scan_hi(const PartArgs a)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {          // <= 2048 entries
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < a.n_hi; ++k) { const uint32_t c = a.hist_hi[k]; a.base_hi[k] = acc; a.hist_hi[k] = acc; acc += c; }
+        a.base_hi[a.n_hi] = acc;
+    }
+}
+
+// ---- pass 2: scatter by the high half; the record gets its time bin here ----------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_part_scatter_hi(const PartArgs a)
+{
+    __shared__ uint32_t s_cnt[kPartMaxDigits], s_base[kPartMaxDigits];
+    const int tid = threadIdx.x;
+    const uint64_t n_tiles = (a.s.n + kPartTile - 1) / kPartTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (uint32_t k = tid; k < a.n_hi; k += kBlock) s_cnt[k] = 0u;
+        __syncthreads();
+        uint32_t key[kPartPer], rank[kPartPer];
+#pragma unroll
+        for (uint32_t k = 0; k < kPartPer; ++k) {
+            const uint64_t i = tile * kPartTile + (uint64_t)k * kBlock + tid;
+            key[k] = kDropped; rank[k] = 0u;
+            if (i < a.s.n) {
+                const uint32_t px = __builtin_nontemporal_load(a.s.pixel + i);
+                const int32_t bin = film_row_bin(a.film, __builtin_nontemporal_load(a.s.opl + i), a.s.laser ? a.s.laser[i] : 0u);
+                if (px < a.npix && bin >= 0) {
+                    key[k] = px | ((uint32_t)bin << a.bits_pix);
+                    rank[k] = atomicAdd(&s_cnt[px >> a.bits_lo], 1u);        // the LDS atomic's return value: rank inside (tile, bucket)
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < a.n_hi; k += kBlock) { const uint32_t c = s_cnt[k]; if (c) s_base[k] = atomicAdd(a.hist_hi + k, c); }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kPartPer; ++k) {
+            if (key[k] != kDropped) {
+                const uint64_t i = tile * kPartTile + (uint64_t)k * kBlock + tid;
+                const uint32_t px = key[k] & ((1u << a.bits_pix) - 1u);
+                const uint32_t pos = s_base[px >> a.bits_lo] + rank[k];
+                a.rec_a[pos] = make_uint4(key[k], __float_as_uint(__builtin_nontemporal_load(a.s.r + i)),
+                                          __float_as_uint(__builtin_nontemporal_load(a.s.g + i)), __float_as_uint(__builtin_nontemporal_load(a.s.b + i)));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- pass 3: histogram of the full pixel index over the bucket-grouped records ------------------------------------------
+// (a bucket's range was sized with the contributions outside the time window still in it: the unused tail of a range holds
+// no record — the cursors in hist_hi say where each bucket ends)
+__global__ void __launch_bounds__(kBlock) k_part_hist_lo(const PartArgs a)
+{
+    __shared__ uint32_t s_cnt[kPartMaxDigits];
+    const int tid = threadIdx.x;
+    const uint32_t lo_mask = a.n_lo - 1u, pix_mask = (1u << a.bits_pix) - 1u;
+    for (uint32_t hi = blockIdx.y; hi < a.n_hi; hi += gridDim.y) {
+        const uint32_t b0 = a.base_hi[hi], b1 = a.hist_hi[hi];             // [start, end of what was written)
+        for (uint32_t k = tid; k < a.n_lo; k += kBlock) s_cnt[k] = 0u;
+        __syncthreads();
+        for (uint64_t i = (uint64_t)b0 + (uint64_t)blockIdx.x * kBlock + tid; i < b1; i += (uint64_t)gridDim.x * kBlock)
+            atomicAdd(&s_cnt[a.rec_a[i].x & pix_mask & lo_mask], 1u);
+        __syncthreads();
+        for (uint32_t k = tid; k < a.n_lo; k += kBlock) {
+            const uint32_t px = (hi << a.bits_lo) | k;
+            if (s_cnt[k] && px < a.npix) atomicAdd(a.starts + px, s_cnt[k]);
+        }
+        __syncthreads();
+    }
+}
+
+// exclusive scan of starts[0 .. npix] in place (one workgroup: 2^18 entries are 1 MB), cursors = starts
+__global__ void __launch_bounds__(kBlock) k_part_scan_lo(const PartArgs a)
+{
+    __shared__ uint32_t s_sum[kBlock];
+    const int tid = threadIdx.x;
+    const uint32_t n = a.npix + 1u;
+    const uint32_t per = (n + kBlock - 1u) / kBlock;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint32_t acc = 0;
+    for (uint32_t i = lo; i < hi; ++i) acc += a.starts[i];
+    s_sum[tid] = acc;
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (uint32_t t = 0; t < kBlock; ++t) { const uint32_t c = s_sum[t]; s_sum[t] = run; run += c; } }
+    __syncthreads();
+    acc = s_sum[tid];
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = a.starts[i]; a.starts[i] = acc; if (i < a.npix) a.cur_lo[i] = acc; acc += c; }
+}
+
+// ---- pass 4: scatter by the low half inside every bucket ----------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_part_scatter_lo(const PartArgs a)
+{
+    __shared__ uint32_t s_cnt[kPartMaxDigits], s_base[kPartMaxDigits];
+    const int tid = threadIdx.x;
+    const uint32_t lo_mask = a.n_lo - 1u, pix_mask = (1u << a.bits_pix) - 1u;
+    for (uint32_t hi = blockIdx.y; hi < a.n_hi; hi += gridDim.y) {
+        const uint32_t b0 = a.base_hi[hi], b1 = a.hist_hi[hi];
+        const uint32_t n_tiles = (b1 - b0 + kPartTile - 1u) / kPartTile;
+        for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            for (uint32_t k = tid; k < a.n_lo; k += kBlock) s_cnt[k] = 0u;
+            __syncthreads();
+            uint4 rec[kPartPer]; uint32_t rank[kPartPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPartPer; ++k) {
+                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kPartTile + (uint64_t)k * kBlock + tid;
+                rec[k].x = kDropped; rank[k] = 0u;
+                if (i < b1) { rec[k] = nt_load(a.rec_a + i); rank[k] = atomicAdd(&s_cnt[rec[k].x & pix_mask & lo_mask], 1u); }
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < a.n_lo; k += kBlock) { const uint32_t c = s_cnt[k]; if (c) s_base[k] = atomicAdd(a.cur_lo + ((hi << a.bits_lo) | k), c); }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < kPartPer; ++k) {
+                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kPartTile + (uint64_t)k * kBlock + tid;
+                if (i < b1) {
+                    const uint32_t pos = s_base[rec[k].x & pix_mask & lo_mask] + rank[k];
+                    a.rec_b[pos] = make_uint4(rec[k].x >> a.bits_pix, rec[k].y, rec[k].z, rec[k].w);      // (bin, r, g, b)
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- the row kernel on records: one workgroup per pixel, as k_wf_scatter ---------------------------------------------------
+template <bool FIXED>
+__global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, float *out, uint32_t film_zero, DevCounters *cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = (float *)smem;
+    unsigned long long *row64 = (unsigned long long *)smem;
+    const uint32_t T = a.film.bins;
+    const int tid = threadIdx.x;
+    for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t px = blockIdx.x; px < a.npix; px += gridDim.x) {
+        const uint32_t lo = a.starts[px], hi = a.starts[px + 1];
+        if (lo == hi) continue;
+        for (uint32_t i = lo + tid; i < hi; i += kBlock) {
+            const uint4 r = nt_load(a.rec_b + i);
+            if (FIXED) {
+                unsigned long long *p = row64 + r.x;
+                atomicAdd(p, splat_fixed(__uint_as_float(r.y))); atomicAdd(p + T, splat_fixed(__uint_as_float(r.z))); atomicAdd(p + 2 * T, splat_fixed(__uint_as_float(r.w)));
+            } else {
+                float *p = row + r.x;
+                __hip_atomic_fetch_add(p, __uint_as_float(r.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + T, __uint_as_float(r.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ++mine;
+        }
+        __syncthreads();
+        float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
+        for (uint32_t t = tid; t < T; t += kBlock) {
+            float r, g, b; bool nz;
+            if (FIXED) {
+                const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
+                nz = (qr | qg | qb) != 0ull;
+                r = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; g = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;
+                b = __ll2float_rn((long long)qb) * 2.2737367544323206e-13f;
+                if (nz) { row64[t] = 0ull; row64[T + t] = 0ull; row64[2 * T + t] = 0ull; }
+            } else {
+                r = row[t]; g = row[T + t]; b = row[2 * T + t];
+                nz = r != 0.0f || g != 0.0f || b != 0.0f;
+                if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
+            }
+            if (film_zero) nt_store(dst + t, make_float4(r, g, b, 0.0f));          // the caller vouches the film is zero: whole lines, no read
+            else if (nz) { float4 v = nt_load(dst + t); v.x += r; v.y += g; v.z += b; nt_store(dst + t, v); }
+        }
+        __syncthreads();
+    }
+    if (cnt && mine) atomicAdd(&cnt->splats_issued, (unsigned long long)mine);
+}
+
+} // namespace
+
+// Can the partition path take this call?  (record key = pixel | bin << bits_pix in 32 bits; LDS counters for either half)
+bool splat_partition_supported(const mtr_splat_soa &s, const Film &film)
+{
+    const uint64_t npix = (uint64_t)film.width * film.height;
+    if (film.n_freq || s.n == 0 || s.n >= 0xffffffffull || npix < 2 || npix > (1ull << 22)) return false;
+    uint32_t bits_pix = 1; while ((1ull << bits_pix) < npix) ++bits_pix;
+    uint32_t bits_bin = 1; while ((1ull << bits_bin) < film.bins) ++bits_bin;
+    if (bits_pix + bits_bin > 32u) return false;
+    return (size_t)film.bins * 12u <= 150u * 1024u;             // the row must fit LDS
+}
+
+size_t splat_partition_scratch_bytes(const mtr_splat_soa &s, const Film &film)
+{
+    const size_t npix = (size_t)film.width * film.height;
+    return 2 * (size_t)s.n * 16u + (2 * (size_t)kPartMaxDigits + 2 * npix + 64) * 4u;
+}
+
+hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, float *film_out, bool film_zero, DevCounters *counters,
+                                    void *scratch, int n_cu, hipStream_t stream)
+{
+    PartArgs a{};
+    a.s = s; a.film = film;
+    a.npix = film.width * film.height;
+    a.bits_pix = 1; while ((1u << a.bits_pix) < a.npix) ++a.bits_pix;
+    a.bits_lo = a.bits_pix / 2u;
+    a.n_lo = 1u << a.bits_lo;
+    a.n_hi = ((a.npix - 1u) >> a.bits_lo) + 1u;
+    unsigned char *p = (unsigned char *)scratch;
+    a.rec_a = (uint4 *)p; p += (size_t)s.n * 16u;
+    a.rec_b = (uint4 *)p; p += (size_t)s.n * 16u;
+    a.hist_hi = (uint32_t *)p; p += (size_t)kPartMaxDigits * 4u;
+    a.base_hi = (uint32_t *)p; p += ((size_t)kPartMaxDigits + 16u) * 4u;
+    a.starts = (uint32_t *)p; p += ((size_t)a.npix + 16u) * 4u;
+    a.cur_lo = (uint32_t *)p;
+    hipError_t e = hipMemsetAsync(a.hist_hi, 0, (size_t)kPartMaxDigits * 4u, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.starts, 0, ((size_t)a.npix + 16u) * 4u, stream);
+    if (e != hipSuccess) return e;
+    const uint64_t n_tiles = (s.n + kPartTile - 1) / kPartTile;
+    const unsigned g1 = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * 8u);
+    hipLaunchKernelGGL(k_part_hist_hi, dim3(g1), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(k_part_scan_hi, dim3(1), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(k_part_scatter_hi, dim3(g1), dim3(kBlock), 0, stream, a);
+    // per bucket: as many workgroups as an even share of the chip (buckets of uniform input are equally long)
+    const unsigned per_bucket = std::max(1u, (unsigned)((uint64_t)n_cu * 8u / a.n_hi));
+    hipLaunchKernelGGL(k_part_hist_lo, dim3(per_bucket, a.n_hi), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(k_part_scan_lo, dim3(1), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(k_part_scatter_lo, dim3(per_bucket, a.n_hi), dim3(kBlock), 0, stream, a);
+    const bool fixed = (size_t)film.bins * 24u <= 72u * 1024u;
+    const size_t lds = (size_t)film.bins * (fixed ? 24u : 12u);
+    int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    const unsigned grid = a.npix < (uint32_t)(n_cu * per_cu) ? a.npix : (unsigned)(n_cu * per_cu);
+    void (*k)(const PartArgs, float *, uint32_t, DevCounters *) = fixed ? k_splat_rows_rec<true> : k_splat_rows_rec<false>;
+    e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a, film_out, film_zero ? 1u : 0u, counters);
+    return hipGetLastError();
+}
+
+} // namespace mtr

@@ -235,7 +235,7 @@ def _splats(n, npix, T, seed=1234, sorted_by_pixel=False):
     return pixel, opl, r, g, b
 
 
-@pytest.mark.parametrize("variant,sorted_by_pixel", [(0, False), (0, True), (1, True), (1, False)])      # (1, False): unsorted input -> atomics fallback
+@pytest.mark.parametrize("variant,sorted_by_pixel", [(0, False), (0, True), (1, True), (1, False)])      # (1, False): unsorted input -> partitioned by pixel on the device
 def test_splat_add_matches_oracle(oracle, variant, sorted_by_pixel):
     import torch
     scene = make_cornell(width=32, height=16, bins=256)
@@ -253,6 +253,45 @@ def test_splat_add_matches_oracle(oracle, variant, sorted_by_pixel):
     oracle.splat_add(film.desc(), pixel, opl, r, g, b, ref)
     assert np.array_equal(got != 0, ref != 0)
     assert rel_l2(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("case", ["plain", "film_zero", "odd_sizes", "accumulate", "one_pixel"])
+def test_splat_add_partitions_unsorted_input(oracle, case):
+    """mtr_splat_add variant 1 on input in ARBITRARY order: the device-side partition by pixel (mtr_splat.hip: two scatter
+    passes over 16-byte records) in front of the LDS rows — same film as the oracle's scatter-add, ids out of range and path
+    lengths outside the time window dropped, MTR_SPLAT_FILM_ZERO (store-only flush), sizes that are no power of two, a second
+    call accumulating onto the first, every contribution in one pixel."""
+    import torch
+    from mitransient_amd import _cabi
+    W, H, T = (32, 16, 256) if case != "odd_sizes" else (37, 11, 301)
+    scene = make_cornell(width=W, height=H, bins=T)
+    film = scene.sensors()[0].film()
+    film.prepare()
+    n = 300000 if case != "odd_sizes" else 123457
+    pixel, opl, r, g, b = _splats(n, W * H + 3, T, sorted_by_pixel=False)
+    if case == "one_pixel":
+        pixel[:] = 77
+        pixel[::1000] = 5             # (not sorted: 5 after 77)
+    tt = lambda x: torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda()
+    variant = 1 | (_cabi.MTR_SPLAT_FILM_ZERO if case == "film_zero" else 0)
+    film.transient_storage.put_opl(tt(pixel), tt(opl), tt(r), tt(g), tt(b), film.desc(), variant)
+    ref = np.zeros(film.raw_shape(), np.float32)
+    oracle.splat_add(film.desc(), pixel, opl, r, g, b, ref)
+    if case == "accumulate":          # a second batch lands on the first (read-modify-write flush)
+        p2, o2, r2, g2, b2 = _splats(50000, W * H, T, sorted_by_pixel=False)
+        p2, o2 = p2[::-1].copy(), o2[::-1].copy()
+        film.transient_storage.put_opl(tt(p2), tt(o2), tt(r2), tt(g2), tt(b2), film.desc(), 1)
+        oracle.splat_add(film.desc(), p2, o2, r2, g2, b2, ref)
+    torch.cuda.synchronize()
+    got = np.array(film.develop(raw=True)[1])
+    assert np.count_nonzero(ref) > (1000 if case != "one_pixel" else 500)
+    assert np.array_equal(got != 0, ref != 0)
+    assert rel_l2(got, ref) <= TOL
+    assert np.all(got[..., 3] == 0)
+    # the workspace the context kept for the partition can be handed back
+    from mitransient_amd.runtime import get_context
+    ctx = get_context()
+    ctx.check(ctx.lib.mtr_ctx_trim(ctx.handle), "mtr_ctx_trim")
 
 
 def test_film_add_transient_data_api(oracle):

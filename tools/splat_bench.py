@@ -29,13 +29,15 @@ for order in ('uniform', 'pixel-sorted'):
         pix, opl, rgb = pix[idx].contiguous(), opl[idx].contiguous(), rgb[idx].contiguous()
         del idx
     pos = torch.stack(((pix % W).float() + 0.5, (pix // W).float() + 0.5), dim=1)
-    for variant in ((0,) if order == 'uniform' else (0, 1)):
+    for variant in (0, 1, 1 | 0x100):                 # 0x100 = MTR_SPLAT_FILM_ZERO: the film is zero on entry (store-only flush)
         best = 1e30
         for _ in range(3):
             film.clear()
             ms = film.add_transient_data(pos, opl, None, rgb, 1.0, None, variant=variant)
             best = min(best, ms)
         gbs = 24.0 * S / (best * 1e-3) / 1e9
-        print(f'S = 2^{int(np.log2(S))}  {order:12s} variant {variant} ({"f32 atomics to HBM" if variant == 0 else "LDS rows per pixel run"}): '
+        what = {0: "f32 atomics to HBM", 1: "LDS rows per pixel run" if order != 'uniform' else "partition by pixel + LDS rows",
+                0x101: ("LDS rows" if order != 'uniform' else "partition + LDS rows") + ", zero film: store-only flush"}[variant]
+        print(f'S = 2^{int(np.log2(S))}  {order:12s} variant {variant:#x} ({what}): '
               f'{best:9.2f} ms  {S / best / 1e6:8.2f} G contributions/s  {gbs:8.1f} GB/s = {gbs / 8000 * 100:5.1f} % of the HBM peak')
     del pos
