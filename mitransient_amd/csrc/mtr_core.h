@@ -367,6 +367,9 @@ inline FastDiv fastdiv_make(uint32_t d)
 }
 MTR_HD uint32_t fastdiv(uint32_t n, const FastDiv &f)
 {
+#ifdef MTR_FASTDIV_POW2      // experiment: a power of two (m == 1) or one (m == 0) divides by a shift — v_mul_hi_u32 issues at a quarter of the rate
+    if (f.m <= 1u) return n >> (f.s1 + f.s2);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t = __umulhi(f.m, n);
 #else
@@ -1521,9 +1524,13 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
 
 // One whole iteration of the loop of transientpath.py:140-319, run to completion
 // (closest hit -> shade_hit -> shadow ray -> shade_finish).  Returns active_next.
-template <bool ROUGH = true, class Stack, class Sink>
+// `refresh(p, sink)` runs after either traversal: a caller that can recompute parts of the path state (k_fused: film
+// coordinates, lane id and row slot follow from the sample index) does so there instead of holding them in registers across
+// the traversals.
+struct NoRefresh { template <class Sink> MTR_HD void operator()(Path &, Sink &) const {} };
+template <bool ROUGH = true, class Stack, class Sink, class Refresh = NoRefresh>
 MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
-                        Stack &st, Sink &sink, BounceStats &stats)
+                        Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh())
 {
     st.prof_mark(2);
     Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
@@ -1534,6 +1541,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     // (stacks that park path state in LDS: the values come back where they are used, so that they hold no register across
     // the traversals)
     if (Stack::kPark) { p.prev_p = st.unpark_prev_p(); p.prev_pdf = st.unpark_prev_pdf(); p.rng.inc = st.unpark_inc(); }
+    refresh(p, sink);
     shade_hit<ROUGH>(p, h, sc, film, rc, sink, pd, shadow);
     st.prof_mark(1);
     bool occluded = false;
@@ -1544,6 +1552,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     }
     st.prof_mark(0);
     if (Stack::kPark) p.rng.inc = st.unpark_inc();
+    refresh(p, sink);
     const bool an = shade_finish<ROUGH>(p, h, occluded, pd, sc, film, rc, sink);
     if (Stack::kPark) { st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); }
     st.prof_mark(1);

@@ -115,6 +115,7 @@ struct LdsHistSink {
     uint32_t lane;
     uint32_t n_splats;
     SplatLog log;
+    __device__ __forceinline__ void set_row(uint32_t row_off) { row = row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -129,6 +130,7 @@ struct LdsHistSink {
 struct LdsFixedSink {
     unsigned long long *hist; uint32_t plane, row, film_w, lane, n_splats;
     SplatLog log;
+    __device__ __forceinline__ void set_row(uint32_t row_off) { row = row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -143,9 +145,11 @@ struct LdsFixedSink {
 // [G][2F] — and every contribution adds its F terms (phasor_image_block.py:42-67) with LDS float atomics
 struct LdsPhasorSink {
     float *row;                        // the pixel's slot: 2F floats
+    float *rows;                       // slot 0
     const float *freq; uint32_t n_freq; float start_opl;
     uint32_t film_w, lane, n_splats;
     SplatLog log;
+    __device__ __forceinline__ void set_row(uint32_t row_off) { row = rows + row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -166,6 +170,7 @@ struct GlobalAtomicSink {
     uint32_t lane;
     uint32_t n_splats;
     SplatLog log;
+    __device__ __forceinline__ void set_row(uint32_t) {}
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -348,31 +353,57 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         uint32_t did_shadow = 0u, did_splats = 0u;                 // this iteration's per-lane counts (0..1, 0..2)
         if (alive) {
             BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
+            // DERIVED PATH STATE (round 4).  Pixel ordinal, row slot, film coordinates and lane id of a path all follow from
+            // its sample index i — five registers that used to stay live across both traversals of every bounce, in a kernel
+            // that needs ~160 and has 128.  path_bounce calls `refresh` after either traversal (and the end-of-path block below
+            // does the same), so only i survives a traversal; the compiler cannot merge the recomputations because i passes
+            // through an empty asm each time.  ~20 integer instructions per call against 7 fewer spilled dwords: config 2's
+            // scratch 112 -> 84 B per lane, i.e. under what the L2 slices hold for the resident waves — WRITE_SIZE per launch
+            // 23.5 -> 3.8 GB (3.2 GB of it the developed film), L2 requests halved, +1.0 ms.  Keeping the film
+            // coordinates packed in one register and the row offset in another instead (two divisions less per call) was
+            // NOT faster (66.5 against 66.3 ms) and wrote 6.3 GB.
+            auto refresh = [&](Path &pp, auto &sk) {
+                uint32_t ii = i; asm volatile("" : "+v"(ii));
+                const uint32_t qq = fastdiv(ii, a.div_spp);
+                const uint32_t pixel = pix0 + qq;
+                const uint32_t yy = fastdiv(pixel, a.rc.div_crop_w), xx = pixel - a.film.crop_w * yy;
+                pp.px = xx + a.film.crop_x; pp.py = yy + a.film.crop_y;
+                pp.lane = pixel * a.rc.spp_total + (a.spp_begin + (ii - qq * a.spp_chunk));
+                sk.set_row((qq - fastdiv(qq, a.div_G) * K) * T); sk.lane = pp.lane;
+            };
             if (PHASOR) {
-                LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
+                LdsPhasorSink sink; sink.rows = s_hist; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
+                alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
                 did_splats = sink.n_splats;
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
+            if (!NLOS && !alive) {          // (derived path state, above: what the end-of-path block and the row flush read; leaving
+                // them behind from the second `refresh` instead of a third derivation: 96 B of scratch against 84)
+                uint32_t ii = i; asm volatile("" : "+v"(ii));
+                q = fastdiv(ii, a.div_spp); slot = q - fastdiv(q, a.div_G) * K;
+                const uint32_t pixel = pix0 + q;
+                const uint32_t yy = fastdiv(pixel, a.rc.div_crop_w), xx = pixel - a.film.crop_w * yy;
+                p.px = xx + a.film.crop_x; p.py = yy + a.film.crop_y;
+            }
             if (!alive) {
                 // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200).  The lane takes its next sample first:
                 // when that is another sample of the SAME pixel (with 1024 spp a lane runs four in a row), the radiance simply
@@ -632,6 +663,10 @@ template <bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
+#ifdef MTR_ONLY_C2            // tools/regs_c2.sh: compile ONLY the instantiation config 2 runs (register-allocation experiments: one minute instead of four)
+    k = k_fused<true, true, false>;
+    (void)cfg; (void)stream; return k ? hipSuccess : hipErrorInvalidValue;
+#endif
     if (!NLOS && args.film.n_freq) {
         if (!cfg.hist_lds || cfg.rough) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
         k = cfg.scene_lds ? k_fused<true, true, false, MTR_FUSED_MIN_WAVES, true> : k_fused<false, true, false, MTR_FUSED_MIN_WAVES, true>;
@@ -756,7 +791,10 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
     uint32_t mine = 0;
     for (uint32_t px = blockIdx.x; px < npix; px += gridDim.x) {
         const uint64_t lo = starts[px], hi = starts[px + 1];
-        if (lo == kNoRun || lo == hi) continue;                      // no contributions (uniform across the workgroup)
+        // no contributions (uniform across the workgroup).  A pixel WITH a run has both entries set — its start by the record
+        // that opens it, its end by the opener of the next run or by the last record; the pixel right behind a run has only its
+        // first entry set (that run's end), the rest of a gap neither
+        if (lo == kNoRun || hi == kNoRun || lo == hi) continue;
         for (uint64_t i = lo + tid; i < hi; i += kBlock) {
             // (contributions and film rows are touched once: non-temporal accesses, as in k_wf_scatter)
             const int32_t bin = film_row_bin(film, __builtin_nontemporal_load(s.opl + i), s.laser ? s.laser[i] : 0u);

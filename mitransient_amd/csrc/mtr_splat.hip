@@ -29,10 +29,6 @@ namespace mtr {
 
 namespace {
 
-constexpr uint32_t kPartPer = 16;                       // records per thread and tile (low-half scatter: the records live in registers)
-constexpr uint32_t kPartTile = kBlock * kPartPer;       // 4096
-constexpr uint32_t kPartPerHi = 32;                     // high-half scatter: only (key, rank) live in registers -> 8192-record tiles
-constexpr uint32_t kPartTileHi = kBlock * kPartPerHi;
 constexpr uint32_t kPartMaxDigits = 2048;               // LDS counters per tile (11 bits per half: films up to 2^22 pixels)
 constexpr uint32_t kDropped = 0xffffffffu;
 
@@ -81,41 +77,106 @@ __global__ void __launch_bounds__(kBlock) k_part_scan_hi(const PartArgs a)
     }
 }
 
+// ---- the tile step of both scatters ---------------------------------------------------------------------------------------
+// A tile's records are REORDERED BY DIGIT IN LDS before they leave: every thread ranks its records inside (tile, digit) with
+// the return value of an LDS atomic, the digit counters are scanned, each digit's range of the tile is claimed from the
+// digit's global cursor with one atomic, the records are placed at (digit offset + rank) in a 64 KB staging area, and the
+// staging area is written out front to back — consecutive lanes hold consecutive records of one digit, so a digit's 8 records
+// of a 4096-record tile leave as ONE 128-byte run in ONE store instruction.  (Round 4's first version wrote every record from
+// the thread that had loaded it: the 16 records of a run left in 16 different instructions at 16 different times, with two
+// thousand tiles in flight the half-written lines did not survive in the 4 MB L2 slices, and the two scatters ran at a third of
+// the streaming rate: 2^30 uniform contributions 41.6 ms, of which the scatters 31.)
+constexpr uint32_t kStagePer = 16;                       // records per thread and tile
+constexpr uint32_t kStageTile = kBlock * kStagePer;      // 4096 records = 64 KB of staging
+constexpr uint32_t kScanPer = kPartMaxDigits / kBlock;   // digit counters per thread in the scan (8)
+
+struct TileLds {
+    uint4 *stage;            // [kStageTile]
+    uint32_t *cnt, *off, *gbase;     // [n_digits] each
+    uint32_t *wsum;          // [kBlock / 64 + 1]
+};
+__device__ __forceinline__ TileLds tile_lds(unsigned char *smem, uint32_t n_digits)
+{
+    TileLds t;
+    t.stage = (uint4 *)smem;
+    t.cnt = (uint32_t *)(smem + (size_t)kStageTile * 16u);
+    t.off = t.cnt + n_digits; t.gbase = t.off + n_digits; t.wsum = t.gbase + n_digits;
+    return t;
+}
+static size_t tile_lds_bytes(uint32_t n_digits) { return (size_t)kStageTile * 16u + (3u * (size_t)n_digits + 16u) * 4u; }
+
+// exclusive scan of cnt[0 .. n_digits) into off[], one claim per non-empty digit from cursor[] into gbase[]; returns the tile's
+// record count.  Called by the whole workgroup between two barriers of its own.
+__device__ __forceinline__ uint32_t tile_scan_claim(const TileLds &t, uint32_t n_digits, uint32_t *cursor, int tid)
+{
+    __syncthreads();
+    const uint32_t per = (n_digits + kBlock - 1u) / kBlock;          // <= kScanPer
+    uint32_t loc[kScanPer], sum = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < kScanPer; ++e) {
+        const uint32_t idx = tid * per + e;
+        const uint32_t c = (e < per && idx < n_digits) ? t.cnt[idx] : 0u;
+        loc[e] = sum; sum += c;
+    }
+    uint32_t inc = sum;
+    const uint32_t wl = tid & 63u;
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (wl >= o) inc += v; }
+    if (wl == 63u) t.wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64u; ++w) { const uint32_t v = t.wsum[w]; total += v; if (w < (uint32_t)(tid >> 6)) base += v; }
+    const uint32_t excl = base + inc - sum;
+#pragma unroll
+    for (uint32_t e = 0; e < kScanPer; ++e) {
+        const uint32_t idx = tid * per + e;
+        if (e < per && idx < n_digits) {
+            t.off[idx] = excl + loc[e];
+            const uint32_t c = t.cnt[idx];
+            if (c) t.gbase[idx] = atomicAdd(cursor + idx, c);
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
 // ---- pass 2: scatter by the high half; the record gets its time bin here ----------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_part_scatter_hi(const PartArgs a)
 {
-    __shared__ uint32_t s_cnt[kPartMaxDigits], s_base[kPartMaxDigits];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const TileLds t = tile_lds(smem, a.n_hi);
     const int tid = threadIdx.x;
-    const uint64_t n_tiles = (a.s.n + kPartTileHi - 1) / kPartTileHi;
+    const uint32_t pix_mask = (1u << a.bits_pix) - 1u;
+    const uint64_t n_tiles = (a.s.n + kStageTile - 1) / kStageTile;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (uint32_t k = tid; k < a.n_hi; k += kBlock) s_cnt[k] = 0u;
+        for (uint32_t k = tid; k < a.n_hi; k += kBlock) t.cnt[k] = 0u;
         __syncthreads();
-        uint32_t key[kPartPerHi], rank[kPartPerHi];
+        uint32_t key[kStagePer], rank[kStagePer]; float cr[kStagePer], cg[kStagePer], cb[kStagePer];
 #pragma unroll
-        for (uint32_t k = 0; k < kPartPerHi; ++k) {
-            const uint64_t i = tile * kPartTileHi + (uint64_t)k * kBlock + tid;
-            key[k] = kDropped; rank[k] = 0u;
+        for (uint32_t k = 0; k < kStagePer; ++k) {
+            const uint64_t i = tile * kStageTile + (uint64_t)k * kBlock + tid;
+            key[k] = kDropped; rank[k] = 0u; cr[k] = cg[k] = cb[k] = 0.0f;
             if (i < a.s.n) {
                 const uint32_t px = __builtin_nontemporal_load(a.s.pixel + i);
                 const int32_t bin = film_row_bin(a.film, __builtin_nontemporal_load(a.s.opl + i), a.s.laser ? a.s.laser[i] : 0u);
-                if (px < a.npix && bin >= 0) {
-                    key[k] = px | ((uint32_t)bin << a.bits_pix);
-                    rank[k] = atomicAdd(&s_cnt[px >> a.bits_lo], 1u);        // the LDS atomic's return value: rank inside (tile, bucket)
-                }
+                cr[k] = __builtin_nontemporal_load(a.s.r + i); cg[k] = __builtin_nontemporal_load(a.s.g + i); cb[k] = __builtin_nontemporal_load(a.s.b + i);
+                if (px < a.npix && bin >= 0) key[k] = px | ((uint32_t)bin << a.bits_pix);
             }
         }
-        __syncthreads();
-        for (uint32_t k = tid; k < a.n_hi; k += kBlock) { const uint32_t c = s_cnt[k]; if (c) s_base[k] = atomicAdd(a.hist_hi + k, c); }
-        __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < kPartPerHi; ++k) {
-            if (key[k] != kDropped) {
-                const uint64_t i = tile * kPartTileHi + (uint64_t)k * kBlock + tid;
-                const uint32_t px = key[k] & ((1u << a.bits_pix) - 1u);
-                const uint32_t pos = s_base[px >> a.bits_lo] + rank[k];
-                a.rec_a[pos] = make_uint4(key[k], __float_as_uint(__builtin_nontemporal_load(a.s.r + i)),
-                                          __float_as_uint(__builtin_nontemporal_load(a.s.g + i)), __float_as_uint(__builtin_nontemporal_load(a.s.b + i)));
-            }
+        for (uint32_t k = 0; k < kStagePer; ++k)
+            if (key[k] != kDropped) rank[k] = atomicAdd(&t.cnt[(key[k] & pix_mask) >> a.bits_lo], 1u);     // rank inside (tile, bucket)
+        const uint32_t total = tile_scan_claim(t, a.n_hi, a.hist_hi, tid);
+#pragma unroll
+        for (uint32_t k = 0; k < kStagePer; ++k)
+            if (key[k] != kDropped)
+                t.stage[t.off[(key[k] & pix_mask) >> a.bits_lo] + rank[k]] = make_uint4(key[k], __float_as_uint(cr[k]), __float_as_uint(cg[k]), __float_as_uint(cb[k]));
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += kBlock) {
+            const uint4 r = t.stage[j];
+            const uint32_t d = (r.x & pix_mask) >> a.bits_lo;
+            a.rec_a[t.gbase[d] + (j - t.off[d])] = r;
         }
         __syncthreads();
     }
@@ -162,35 +223,42 @@ __global__ void __launch_bounds__(kBlock) k_part_scan_lo(const PartArgs a)
     for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = a.starts[i]; a.starts[i] = acc; if (i < a.npix) a.cur_lo[i] = acc; acc += c; }
 }
 
-// ---- pass 4: scatter by the low half inside every bucket ----------------------------------------------------------------
+// ---- pass 4: scatter by the low half inside every bucket (the same tile step; the digit is the pixel inside the bucket) ------
 __global__ void __launch_bounds__(kBlock) k_part_scatter_lo(const PartArgs a)
 {
-    __shared__ uint32_t s_cnt[kPartMaxDigits], s_base[kPartMaxDigits];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const TileLds t = tile_lds(smem, a.n_lo);
     const int tid = threadIdx.x;
-    const uint32_t lo_mask = a.n_lo - 1u, pix_mask = (1u << a.bits_pix) - 1u;
+    const uint32_t lo_mask = a.n_lo - 1u;
     for (uint32_t hi = blockIdx.y; hi < a.n_hi; hi += gridDim.y) {
         const uint32_t b0 = a.base_hi[hi], b1 = a.hist_hi[hi];
-        const uint32_t n_tiles = (b1 - b0 + kPartTile - 1u) / kPartTile;
+        const uint32_t n_tiles = (b1 - b0 + kStageTile - 1u) / kStageTile;
         for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            for (uint32_t k = tid; k < a.n_lo; k += kBlock) s_cnt[k] = 0u;
+            for (uint32_t k = tid; k < a.n_lo; k += kBlock) t.cnt[k] = 0u;
             __syncthreads();
-            uint4 rec[kPartPer]; uint32_t rank[kPartPer];
+            uint4 rec[kStagePer]; uint32_t rank[kStagePer];
 #pragma unroll
-            for (uint32_t k = 0; k < kPartPer; ++k) {
-                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kPartTile + (uint64_t)k * kBlock + tid;
-                rec[k].x = kDropped; rank[k] = 0u;
-                if (i < b1) { rec[k] = nt_load(a.rec_a + i); rank[k] = atomicAdd(&s_cnt[rec[k].x & pix_mask & lo_mask], 1u); }
+            for (uint32_t k = 0; k < kStagePer; ++k) {
+                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
+                rec[k] = make_uint4(kDropped, 0u, 0u, 0u); rank[k] = 0u;
+                if (i < b1) rec[k] = nt_load(a.rec_a + i);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kStagePer; ++k) {
+                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
+                if (i < b1) rank[k] = atomicAdd(&t.cnt[rec[k].x & lo_mask], 1u);
+            }
+            const uint32_t total = tile_scan_claim(t, a.n_lo, a.cur_lo + ((size_t)hi << a.bits_lo), tid);
+#pragma unroll
+            for (uint32_t k = 0; k < kStagePer; ++k) {
+                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
+                if (i < b1) t.stage[t.off[rec[k].x & lo_mask] + rank[k]] = rec[k];
             }
             __syncthreads();
-            for (uint32_t k = tid; k < a.n_lo; k += kBlock) { const uint32_t c = s_cnt[k]; if (c) s_base[k] = atomicAdd(a.cur_lo + ((hi << a.bits_lo) | k), c); }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t k = 0; k < kPartPer; ++k) {
-                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kPartTile + (uint64_t)k * kBlock + tid;
-                if (i < b1) {
-                    const uint32_t pos = s_base[rec[k].x & pix_mask & lo_mask] + rank[k];
-                    a.rec_b[pos] = make_uint4(rec[k].x >> a.bits_pix, rec[k].y, rec[k].z, rec[k].w);      // (bin, r, g, b)
-                }
+            for (uint32_t j = tid; j < total; j += kBlock) {
+                const uint4 r = t.stage[j];
+                const uint32_t d = r.x & lo_mask;
+                a.rec_b[t.gbase[d] + (j - t.off[d])] = make_uint4(r.x >> a.bits_pix, r.y, r.z, r.w);      // (bin, r, g, b)
             }
             __syncthreads();
         }
@@ -209,39 +277,59 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, flo
     for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
     __syncthreads();
     uint32_t mine = 0;
-    for (uint32_t px = blockIdx.x; px < a.npix; px += gridDim.x) {
-        const uint32_t lo = a.starts[px], hi = a.starts[px + 1];
-        if (lo == hi) continue;
-        for (uint32_t i = lo + tid; i < hi; i += kBlock) {
-            const uint4 r = nt_load(a.rec_b + i);
-            if (FIXED) {
-                unsigned long long *p = row64 + r.x;
-                atomicAdd(p, splat_fixed(__uint_as_float(r.y))); atomicAdd(p + T, splat_fixed(__uint_as_float(r.z))); atomicAdd(p + 2 * T, splat_fixed(__uint_as_float(r.w)));
-            } else {
-                float *p = row + r.x;
-                __hip_atomic_fetch_add(p, __uint_as_float(r.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(p + T, __uint_as_float(r.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            ++mine;
+    // as k_wf_scatter: eight independent 16-byte loads in flight per lane, and the first batch of the NEXT pixel is requested
+    // before this pixel's row is flushed
+    constexpr int kBatch = 8;
+    uint4 r[kBatch];
+    auto fetch = [&](uint32_t lo_, uint32_t hi_) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint32_t i = lo_ + (uint32_t)k * kBlock + tid;
+            r[k] = (i < hi_) ? nt_load(a.rec_b + i) : make_uint4(kDropped, 0u, 0u, 0u);
         }
+    };
+    uint32_t lo_n = 0, hi_n = 0;
+    if (blockIdx.x < a.npix) { lo_n = a.starts[blockIdx.x]; hi_n = a.starts[blockIdx.x + 1]; fetch(lo_n, hi_n); }
+    for (uint32_t px = blockIdx.x; px < a.npix; px += gridDim.x) {
+        const uint32_t lo = lo_n, hi = hi_n;
+        const uint32_t px_next = px + gridDim.x;
+        if (px_next < a.npix) { lo_n = a.starts[px_next]; hi_n = a.starts[px_next + 1]; }
+        for (uint32_t base = lo; base < hi || base == lo; base += kBatch * kBlock) {
+            if (base != lo) fetch(base, hi);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (r[k].x == kDropped) continue;
+                if (FIXED) {
+                    unsigned long long *p = row64 + r[k].x;
+                    atomicAdd(p, splat_fixed(__uint_as_float(r[k].y))); atomicAdd(p + T, splat_fixed(__uint_as_float(r[k].z))); atomicAdd(p + 2 * T, splat_fixed(__uint_as_float(r[k].w)));
+                } else {
+                    float *p = row + r[k].x;
+                    __hip_atomic_fetch_add(p, __uint_as_float(r[k].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p + T, __uint_as_float(r[k].z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(r[k].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ++mine;
+            }
+        }
+        if (px_next < a.npix) fetch(lo_n, hi_n);          // in flight across the flush below
+        if (lo == hi) continue;                           // nothing landed in this row (uniform across the workgroup)
         __syncthreads();
         float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
         for (uint32_t t = tid; t < T; t += kBlock) {
-            float r, g, b; bool nz;
+            float vr, vg, vb; bool nz;
             if (FIXED) {
                 const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
                 nz = (qr | qg | qb) != 0ull;
-                r = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; g = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;
-                b = __ll2float_rn((long long)qb) * 2.2737367544323206e-13f;
+                vr = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; vg = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;
+                vb = __ll2float_rn((long long)qb) * 2.2737367544323206e-13f;
                 if (nz) { row64[t] = 0ull; row64[T + t] = 0ull; row64[2 * T + t] = 0ull; }
             } else {
-                r = row[t]; g = row[T + t]; b = row[2 * T + t];
-                nz = r != 0.0f || g != 0.0f || b != 0.0f;
+                vr = row[t]; vg = row[T + t]; vb = row[2 * T + t];
+                nz = vr != 0.0f || vg != 0.0f || vb != 0.0f;
                 if (nz) { row[t] = 0.0f; row[T + t] = 0.0f; row[2 * T + t] = 0.0f; }
             }
-            if (film_zero) nt_store(dst + t, make_float4(r, g, b, 0.0f));          // the caller vouches the film is zero: whole lines, no read
-            else if (nz) { float4 v = nt_load(dst + t); v.x += r; v.y += g; v.z += b; nt_store(dst + t, v); }
+            if (film_zero) nt_store(dst + t, make_float4(vr, vg, vb, 0.0f));          // the caller vouches the film is zero: whole lines, no read
+            else if (nz) { float4 v = nt_load(dst + t); v.x += vr; v.y += vg; v.z += vb; nt_store(dst + t, v); }
         }
         __syncthreads();
     }
@@ -290,16 +378,25 @@ hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, fl
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.starts, 0, ((size_t)a.npix + 16u) * 4u, stream);
     if (e != hipSuccess) return e;
-    const uint64_t n_tiles = (s.n + kPartTileHi - 1) / kPartTileHi;
-    const unsigned g1 = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * 8u);
-    hipLaunchKernelGGL(k_part_hist_hi, dim3(g1), dim3(kBlock), 0, stream, a);
+    const uint64_t n_tiles = (s.n + kStageTile - 1) / kStageTile;
+    const unsigned g_hist = (unsigned)std::min<uint64_t>((s.n + kBlock * 16ull - 1) / (kBlock * 16ull), (uint64_t)n_cu * 8u);
+    hipLaunchKernelGGL(k_part_hist_hi, dim3(g_hist), dim3(kBlock), 0, stream, a);
     hipLaunchKernelGGL(k_part_scan_hi, dim3(1), dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(k_part_scatter_hi, dim3(g1), dim3(kBlock), 0, stream, a);
+    // the scatters hold a 64 KB staging tile per workgroup: two workgroups per CU, each thread with 16 records in flight
+    const size_t lds_hi = tile_lds_bytes(a.n_hi), lds_lo = tile_lds_bytes(a.n_lo);
+    const unsigned wg_cu_hi = std::max(1u, (unsigned)((160u * 1024u) / (lds_hi + 256u))), wg_cu_lo = std::max(1u, (unsigned)((160u * 1024u) / (lds_lo + 256u)));
+    e = hipFuncSetAttribute((const void *)k_part_scatter_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hi);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_part_scatter_lo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lo);
+    if (e != hipSuccess) return e;
+    const unsigned g_hi = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * wg_cu_hi);
+    hipLaunchKernelGGL(k_part_scatter_hi, dim3(g_hi), dim3(kBlock), lds_hi, stream, a);
     // per bucket: as many workgroups as an even share of the chip (buckets of uniform input are equally long)
-    const unsigned per_bucket = std::max(1u, (unsigned)((uint64_t)n_cu * 8u / a.n_hi));
-    hipLaunchKernelGGL(k_part_hist_lo, dim3(per_bucket, a.n_hi), dim3(kBlock), 0, stream, a);
+    const unsigned per_bucket_h = std::max(1u, (unsigned)((uint64_t)n_cu * 8u / a.n_hi));
+    hipLaunchKernelGGL(k_part_hist_lo, dim3(per_bucket_h, a.n_hi), dim3(kBlock), 0, stream, a);
     hipLaunchKernelGGL(k_part_scan_lo, dim3(1), dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(k_part_scatter_lo, dim3(per_bucket, a.n_hi), dim3(kBlock), 0, stream, a);
+    const unsigned per_bucket_s = std::max(1u, (unsigned)((uint64_t)n_cu * wg_cu_lo / a.n_hi));
+    hipLaunchKernelGGL(k_part_scatter_lo, dim3(per_bucket_s, a.n_hi), dim3(kBlock), lds_lo, stream, a);
     const bool fixed = (size_t)film.bins * 24u <= 72u * 1024u;
     const size_t lds = (size_t)film.bins * (fixed ? 24u : 12u);
     int per_cu = (int)((150u * 1024u) / (lds + 64)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;

@@ -255,6 +255,35 @@ def test_splat_add_matches_oracle(oracle, variant, sorted_by_pixel):
     assert rel_l2(got, ref) <= TOL
 
 
+@pytest.mark.parametrize("film_zero", [False, True])
+def test_splat_add_sorted_input_with_gaps(oracle, film_zero):
+    """mtr_splat_add variant 1 on pixel-sorted input that leaves most pixels EMPTY (the run table is sparse: the pixel behind a
+    run holds that run's end and nothing else; the rest of a gap holds nothing) — a lone pixel, gaps of 1, 2 and many pixels,
+    an empty first pixel, an empty last pixel."""
+    import torch
+    from mitransient_amd import _cabi
+    W, H, T = 32, 16, 256
+    scene = make_cornell(width=W, height=H, bins=T)
+    film = scene.sensors()[0].film()
+    film.prepare()
+    rng = np.random.default_rng(7)
+    used = np.array([3, 4, 6, 9, 10, 11, 200, 201, 460, W * H - 2], np.uint32)          # gaps of 0, 1, 2, many; pixels 0 and W*H-1 empty
+    pixel = np.sort(used[rng.integers(0, len(used), 20000)]).astype(np.uint32)
+    opl = (3.5 + 6.0 * np.clip(rng.normal(400, 120, len(pixel)), -20, T + 20) / T).astype(np.float32)
+    r, g, b = (rng.random(len(pixel), dtype=np.float32) for _ in range(3))
+    tt = lambda x: torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda()
+    variant = 1 | (_cabi.MTR_SPLAT_FILM_ZERO if film_zero else 0)
+    film.transient_storage.put_opl(tt(pixel), tt(opl), tt(r), tt(g), tt(b), film.desc(), variant)
+    film.transient_storage.put_opl(tt(pixel[:1]), tt(opl[:1]), tt(r[:1]), tt(g[:1]), tt(b[:1]), film.desc(), 1)      # one record, one pixel
+    torch.cuda.synchronize()
+    got = np.array(film.develop(raw=True)[1])
+    ref = np.zeros_like(got)
+    oracle.splat_add(film.desc(), pixel, opl, r, g, b, ref)
+    oracle.splat_add(film.desc(), pixel[:1], opl[:1], r[:1], g[:1], b[:1], ref)
+    assert np.array_equal(got != 0, ref != 0)
+    assert rel_l2(got, ref) <= TOL
+
+
 @pytest.mark.parametrize("case", ["plain", "film_zero", "odd_sizes", "accumulate", "one_pixel"])
 def test_splat_add_partitions_unsorted_input(oracle, case):
     """mtr_splat_add variant 1 on input in ARBITRARY order: the device-side partition by pixel (mtr_splat.hip: two scatter

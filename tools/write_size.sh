@@ -3,7 +3,7 @@
 REPO=$(pwd)
 for lib in "$@"; do
   OUT=$REPO/gpurun_out/ws_$(basename $lib .so); rm -rf $OUT; mkdir -p $OUT
-  ( cd /tmp && export TMPDIR=/tmp && MITRANSIENT_AMD_LIB=$REPO/$lib timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scatter-leg > $OUT/log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && MITRANSIENT_AMD_LIB=$REPO/$lib timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scatter-leg --no-extra-configs > $OUT/log 2>&1 )
   python - <<PY
 import csv, glob
 tot={}; n={}
