@@ -86,7 +86,10 @@ __global__ void __launch_bounds__(kBlock) k_part_scan_hi(const PartArgs a)
 // the thread that had loaded it: the 16 records of a run left in 16 different instructions at 16 different times, with two
 // thousand tiles in flight the half-written lines did not survive in the 4 MB L2 slices, and the two scatters ran at a third of
 // the streaming rate: 2^30 uniform contributions 41.6 ms, of which the scatters 31.)
-constexpr uint32_t kStagePer = 16;                       // records per thread and tile
+#ifndef MTR_SPLAT_STAGE_PER
+#define MTR_SPLAT_STAGE_PER 16
+#endif
+constexpr uint32_t kStagePer = MTR_SPLAT_STAGE_PER;      // records per thread and tile
 constexpr uint32_t kStageTile = kBlock * kStagePer;      // 4096 records = 64 KB of staging
 constexpr uint32_t kScanPer = kPartMaxDigits / kBlock;   // digit counters per thread in the scan (8)
 
@@ -105,19 +108,23 @@ __device__ __forceinline__ TileLds tile_lds(unsigned char *smem, uint32_t n_digi
 }
 static size_t tile_lds_bytes(uint32_t n_digits) { return (size_t)kStageTile * 16u + (3u * (size_t)n_digits + 16u) * 4u; }
 
-// exclusive scan of cnt[0 .. n_digits) into off[], one claim per non-empty digit from cursor[] into gbase[]; returns the tile's
-// record count.  Called by the whole workgroup between two barriers of its own.
-__device__ __forceinline__ uint32_t tile_scan_claim(const TileLds &t, uint32_t n_digits, uint32_t *cursor, int tid)
+// exclusive scan of cnt[0 .. n_digits) into off[]; one claim per non-empty digit from cursor[] is ISSUED (the atomics' return
+// values stay in claim[] — the caller stores them to gbase[] with tile_claims_store once it has nothing else to do, so that
+// the round trip to the memory-side atomic unit overlaps the staging of the tile); returns the tile's record count.
+// Called by the whole workgroup; contains two barriers, the first of which also closes the ranking phase.
+__device__ __forceinline__ uint32_t tile_scan_claim(const TileLds &t, uint32_t n_digits, uint32_t *cursor, int tid, uint32_t (&claim)[kScanPer])
 {
     __syncthreads();
     const uint32_t per = (n_digits + kBlock - 1u) / kBlock;          // <= kScanPer
-    uint32_t loc[kScanPer], sum = 0;
+    uint32_t loc[kScanPer], cnt[kScanPer], sum = 0;
 #pragma unroll
     for (uint32_t e = 0; e < kScanPer; ++e) {
         const uint32_t idx = tid * per + e;
-        const uint32_t c = (e < per && idx < n_digits) ? t.cnt[idx] : 0u;
-        loc[e] = sum; sum += c;
+        cnt[e] = (e < per && idx < n_digits) ? t.cnt[idx] : 0u;
+        loc[e] = sum; sum += cnt[e];
     }
+#pragma unroll
+    for (uint32_t e = 0; e < kScanPer; ++e) claim[e] = cnt[e] ? atomicAdd(cursor + (tid * per + e), cnt[e]) : 0u;
     uint32_t inc = sum;
     const uint32_t wl = tid & 63u;
 #pragma unroll
@@ -131,47 +138,69 @@ __device__ __forceinline__ uint32_t tile_scan_claim(const TileLds &t, uint32_t n
 #pragma unroll
     for (uint32_t e = 0; e < kScanPer; ++e) {
         const uint32_t idx = tid * per + e;
-        if (e < per && idx < n_digits) {
-            t.off[idx] = excl + loc[e];
-            const uint32_t c = t.cnt[idx];
-            if (c) t.gbase[idx] = atomicAdd(cursor + idx, c);
-        }
+        if (e < per && idx < n_digits) t.off[idx] = excl + loc[e];
     }
     __syncthreads();
     return total;
 }
+__device__ __forceinline__ void tile_claims_store(const TileLds &t, uint32_t n_digits, int tid, const uint32_t (&claim)[kScanPer])
+{
+    const uint32_t per = (n_digits + kBlock - 1u) / kBlock;
+#pragma unroll
+    for (uint32_t e = 0; e < kScanPer; ++e) {
+        const uint32_t idx = tid * per + e;
+        if (e < per && idx < n_digits) t.gbase[idx] = claim[e];
+    }
+}
 
 // ---- pass 2: scatter by the high half; the record gets its time bin here ----------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_part_scatter_hi(const PartArgs a)
+// SOFTWARE-PIPELINED over tiles: the next tile's 80 loads per thread are issued right after this tile's claims and are in
+// flight while it is staged and written out (two workgroups of four waves per CU: the occupancy hides nothing).
+struct HiIn { uint32_t px[kStagePer], lz[kStagePer]; float opl[kStagePer], r[kStagePer], g[kStagePer], b[kStagePer]; };
+__device__ __forceinline__ void hi_load(const PartArgs &a, uint64_t tile, int tid, HiIn &in)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < kStagePer; ++k) {
+        const uint64_t i = tile * kStageTile + (uint64_t)k * kBlock + tid;
+        in.px[k] = kDropped; in.lz[k] = 0u; in.opl[k] = 0.0f; in.r[k] = in.g[k] = in.b[k] = 0.0f;
+        if (i < a.s.n) {
+            in.px[k] = __builtin_nontemporal_load(a.s.pixel + i); in.opl[k] = __builtin_nontemporal_load(a.s.opl + i);
+            if (a.s.laser) in.lz[k] = __builtin_nontemporal_load(a.s.laser + i);
+            in.r[k] = __builtin_nontemporal_load(a.s.r + i); in.g[k] = __builtin_nontemporal_load(a.s.g + i); in.b[k] = __builtin_nontemporal_load(a.s.b + i);
+        }
+    }
+}
+__global__ void __launch_bounds__(kBlock, 2) k_part_scatter_hi(const PartArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const TileLds t = tile_lds(smem, a.n_hi);
     const int tid = threadIdx.x;
     const uint32_t pix_mask = (1u << a.bits_pix) - 1u;
     const uint64_t n_tiles = (a.s.n + kStageTile - 1) / kStageTile;
+    HiIn cur;
+    hi_load(a, blockIdx.x, tid, cur);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (uint32_t k = tid; k < a.n_hi; k += kBlock) t.cnt[k] = 0u;
         __syncthreads();
-        uint32_t key[kStagePer], rank[kStagePer]; float cr[kStagePer], cg[kStagePer], cb[kStagePer];
+        uint32_t key[kStagePer], rank[kStagePer];
 #pragma unroll
         for (uint32_t k = 0; k < kStagePer; ++k) {
-            const uint64_t i = tile * kStageTile + (uint64_t)k * kBlock + tid;
-            key[k] = kDropped; rank[k] = 0u; cr[k] = cg[k] = cb[k] = 0.0f;
-            if (i < a.s.n) {
-                const uint32_t px = __builtin_nontemporal_load(a.s.pixel + i);
-                const int32_t bin = film_row_bin(a.film, __builtin_nontemporal_load(a.s.opl + i), a.s.laser ? a.s.laser[i] : 0u);
-                cr[k] = __builtin_nontemporal_load(a.s.r + i); cg[k] = __builtin_nontemporal_load(a.s.g + i); cb[k] = __builtin_nontemporal_load(a.s.b + i);
-                if (px < a.npix && bin >= 0) key[k] = px | ((uint32_t)bin << a.bits_pix);
+            key[k] = kDropped; rank[k] = 0u;
+            const int32_t bin = film_row_bin(a.film, cur.opl[k], cur.lz[k]);
+            if (cur.px[k] < a.npix && bin >= 0) {
+                key[k] = cur.px[k] | ((uint32_t)bin << a.bits_pix);
+                rank[k] = atomicAdd(&t.cnt[cur.px[k] >> a.bits_lo], 1u);      // the LDS atomic's return value: rank inside (tile, bucket)
             }
         }
-#pragma unroll
-        for (uint32_t k = 0; k < kStagePer; ++k)
-            if (key[k] != kDropped) rank[k] = atomicAdd(&t.cnt[(key[k] & pix_mask) >> a.bits_lo], 1u);     // rank inside (tile, bucket)
-        const uint32_t total = tile_scan_claim(t, a.n_hi, a.hist_hi, tid);
+        uint32_t claim[kScanPer];
+        const uint32_t total = tile_scan_claim(t, a.n_hi, a.hist_hi, tid, claim);
+        HiIn nxt;
+        hi_load(a, tile + gridDim.x, tid, nxt);           // (past the last tile: every index is out of range, nothing is loaded)
 #pragma unroll
         for (uint32_t k = 0; k < kStagePer; ++k)
             if (key[k] != kDropped)
-                t.stage[t.off[(key[k] & pix_mask) >> a.bits_lo] + rank[k]] = make_uint4(key[k], __float_as_uint(cr[k]), __float_as_uint(cg[k]), __float_as_uint(cb[k]));
+                t.stage[t.off[(key[k] & pix_mask) >> a.bits_lo] + rank[k]] = make_uint4(key[k], __float_as_uint(cur.r[k]), __float_as_uint(cur.g[k]), __float_as_uint(cur.b[k]));
+        tile_claims_store(t, a.n_hi, tid, claim);
         __syncthreads();
         for (uint32_t j = tid; j < total; j += kBlock) {
             const uint4 r = t.stage[j];
@@ -179,6 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_part_scatter_hi(const PartArgs a)
             a.rec_a[t.gbase[d] + (j - t.off[d])] = r;
         }
         __syncthreads();
+        cur = nxt;
     }
 }
 
@@ -205,26 +235,69 @@ __global__ void __launch_bounds__(kBlock) k_part_hist_lo(const PartArgs a)
     }
 }
 
-// exclusive scan of starts[0 .. npix] in place (one workgroup: 2^18 entries are 1 MB), cursors = starts
-__global__ void __launch_bounds__(kBlock) k_part_scan_lo(const PartArgs a)
+// exclusive scan of starts[0 .. npix] in place, cursors = starts.  Two launches of npix / 4096 workgroups: block sums, then every
+// workgroup adds up the sums of the blocks before it (at most 1024 values) and scans its own 4096 entries.  (The first
+// version scanned the 2^18 entries in ONE workgroup: 0.59 ms, as long as the histogram pass over 2^28 records.)
+constexpr uint32_t kScanBlock = kBlock * 16u;
+__global__ void __launch_bounds__(kBlock) k_part_scan_lo_sums(const PartArgs a, uint32_t *block_sums)
 {
-    __shared__ uint32_t s_sum[kBlock];
+    __shared__ uint32_t s_sum[kBlock / 64];
     const int tid = threadIdx.x;
     const uint32_t n = a.npix + 1u;
-    const uint32_t per = (n + kBlock - 1u) / kBlock;
-    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    const uint32_t lo = blockIdx.x * kScanBlock + (uint32_t)tid * 16u;
     uint32_t acc = 0;
-    for (uint32_t i = lo; i < hi; ++i) acc += a.starts[i];
-    s_sum[tid] = acc;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) if (lo + k < n) acc += a.starts[lo + k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) { uint32_t run = 0; for (uint32_t t = 0; t < kBlock; ++t) { const uint32_t c = s_sum[t]; s_sum[t] = run; run += c; } }
+    if (tid == 0) { uint32_t t = 0; for (uint32_t w = 0; w < kBlock / 64; ++w) t += s_sum[w]; block_sums[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(kBlock) k_part_scan_lo(const PartArgs a, const uint32_t *block_sums)
+{
+    __shared__ uint32_t s_sum[kBlock / 64 + 1];
+    const int tid = threadIdx.x;
+    const uint32_t n = a.npix + 1u;
+    // sum of the blocks before this one
+    uint32_t before = 0;
+    for (uint32_t k = tid; k < blockIdx.x; k += kBlock) before += block_sums[k];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = before;
     __syncthreads();
-    acc = s_sum[tid];
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = a.starts[i]; a.starts[i] = acc; if (i < a.npix) a.cur_lo[i] = acc; acc += c; }
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < kBlock / 64; ++w) base += s_sum[w];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * kScanBlock + (uint32_t)tid * 16u;
+    uint32_t c[16], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) { c[k] = (lo + k < n) ? a.starts[lo + k] : 0u; sum += c[k]; }
+    uint32_t inc = sum;
+    const uint32_t wl = tid & 63u;
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (wl >= o) inc += v; }
+    if (wl == 63u) s_sum[tid >> 6] = inc;
+    __syncthreads();
+    for (uint32_t w = 0; w < (uint32_t)(tid >> 6); ++w) base += s_sum[w];
+    uint32_t acc = base + inc - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+        if (lo + k < n) { a.starts[lo + k] = acc; if (lo + k < a.npix) a.cur_lo[lo + k] = acc; }
+        acc += c[k];
+    }
 }
 
 // ---- pass 4: scatter by the low half inside every bucket (the same tile step; the digit is the pixel inside the bucket) ------
-__global__ void __launch_bounds__(kBlock) k_part_scatter_lo(const PartArgs a)
+struct LoIn { uint4 rec[kStagePer]; };
+__device__ __forceinline__ void lo_load(const PartArgs &a, uint32_t b0, uint32_t b1, uint32_t tile, int tid, LoIn &in)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < kStagePer; ++k) {
+        const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
+        in.rec[k] = make_uint4(kDropped, 0u, 0u, 0u);
+        if (i < b1) in.rec[k] = nt_load(a.rec_a + i);
+    }
+}
+__global__ void __launch_bounds__(kBlock, 2) k_part_scatter_lo(const PartArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const TileLds t = tile_lds(smem, a.n_lo);
@@ -233,27 +306,25 @@ __global__ void __launch_bounds__(kBlock) k_part_scatter_lo(const PartArgs a)
     for (uint32_t hi = blockIdx.y; hi < a.n_hi; hi += gridDim.y) {
         const uint32_t b0 = a.base_hi[hi], b1 = a.hist_hi[hi];
         const uint32_t n_tiles = (b1 - b0 + kStageTile - 1u) / kStageTile;
+        LoIn cur;
+        lo_load(a, b0, b1, blockIdx.x, tid, cur);
         for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
             for (uint32_t k = tid; k < a.n_lo; k += kBlock) t.cnt[k] = 0u;
             __syncthreads();
-            uint4 rec[kStagePer]; uint32_t rank[kStagePer];
+            uint32_t rank[kStagePer];
 #pragma unroll
             for (uint32_t k = 0; k < kStagePer; ++k) {
-                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
-                rec[k] = make_uint4(kDropped, 0u, 0u, 0u); rank[k] = 0u;
-                if (i < b1) rec[k] = nt_load(a.rec_a + i);
+                rank[k] = 0u;
+                if (cur.rec[k].x != kDropped) rank[k] = atomicAdd(&t.cnt[cur.rec[k].x & lo_mask], 1u);
             }
+            uint32_t claim[kScanPer];
+            const uint32_t total = tile_scan_claim(t, a.n_lo, a.cur_lo + ((size_t)hi << a.bits_lo), tid, claim);
+            LoIn nxt;
+            lo_load(a, b0, b1, tile + gridDim.x, tid, nxt);
 #pragma unroll
-            for (uint32_t k = 0; k < kStagePer; ++k) {
-                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
-                if (i < b1) rank[k] = atomicAdd(&t.cnt[rec[k].x & lo_mask], 1u);
-            }
-            const uint32_t total = tile_scan_claim(t, a.n_lo, a.cur_lo + ((size_t)hi << a.bits_lo), tid);
-#pragma unroll
-            for (uint32_t k = 0; k < kStagePer; ++k) {
-                const uint64_t i = (uint64_t)b0 + (uint64_t)tile * kStageTile + (uint64_t)k * kBlock + tid;
-                if (i < b1) t.stage[t.off[rec[k].x & lo_mask] + rank[k]] = rec[k];
-            }
+            for (uint32_t k = 0; k < kStagePer; ++k)
+                if (cur.rec[k].x != kDropped) t.stage[t.off[cur.rec[k].x & lo_mask] + rank[k]] = cur.rec[k];
+            tile_claims_store(t, a.n_lo, tid, claim);
             __syncthreads();
             for (uint32_t j = tid; j < total; j += kBlock) {
                 const uint4 r = t.stage[j];
@@ -261,6 +332,7 @@ __global__ void __launch_bounds__(kBlock) k_part_scatter_lo(const PartArgs a)
                 a.rec_b[t.gbase[d] + (j - t.off[d])] = make_uint4(r.x >> a.bits_pix, r.y, r.z, r.w);      // (bin, r, g, b)
             }
             __syncthreads();
+            cur = nxt;
         }
     }
 }
@@ -352,7 +424,7 @@ bool splat_partition_supported(const mtr_splat_soa &s, const Film &film)
 size_t splat_partition_scratch_bytes(const mtr_splat_soa &s, const Film &film)
 {
     const size_t npix = (size_t)film.width * film.height;
-    return 2 * (size_t)s.n * 16u + (2 * (size_t)kPartMaxDigits + 2 * npix + 64) * 4u;
+    return 2 * (size_t)s.n * 16u + (2 * (size_t)kPartMaxDigits + 2 * npix + npix / 4096u + 128) * 4u;
 }
 
 hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, float *film_out, bool film_zero, DevCounters *counters,
@@ -373,7 +445,8 @@ hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, fl
     a.hist_hi = (uint32_t *)p; p += (size_t)kPartMaxDigits * 4u;
     a.base_hi = (uint32_t *)p; p += ((size_t)kPartMaxDigits + 16u) * 4u;
     a.starts = (uint32_t *)p; p += ((size_t)a.npix + 16u) * 4u;
-    a.cur_lo = (uint32_t *)p;
+    a.cur_lo = (uint32_t *)p; p += ((size_t)a.npix + 16u) * 4u;
+    uint32_t *block_sums = (uint32_t *)p;                                           // [npix / 4096 + 1]
     hipError_t e = hipMemsetAsync(a.hist_hi, 0, (size_t)kPartMaxDigits * 4u, stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.starts, 0, ((size_t)a.npix + 16u) * 4u, stream);
@@ -394,7 +467,9 @@ hipError_t launch_splat_partitioned(const mtr_splat_soa &s, const Film &film, fl
     // per bucket: as many workgroups as an even share of the chip (buckets of uniform input are equally long)
     const unsigned per_bucket_h = std::max(1u, (unsigned)((uint64_t)n_cu * 8u / a.n_hi));
     hipLaunchKernelGGL(k_part_hist_lo, dim3(per_bucket_h, a.n_hi), dim3(kBlock), 0, stream, a);
-    hipLaunchKernelGGL(k_part_scan_lo, dim3(1), dim3(kBlock), 0, stream, a);
+    const unsigned n_scan = (a.npix + 1u + kScanBlock - 1u) / kScanBlock;            // <= 1025 (films up to 2^22 pixels)
+    hipLaunchKernelGGL(k_part_scan_lo_sums, dim3(n_scan), dim3(kBlock), 0, stream, a, block_sums);
+    hipLaunchKernelGGL(k_part_scan_lo, dim3(n_scan), dim3(kBlock), 0, stream, a, (const uint32_t *)block_sums);
     const unsigned per_bucket_s = std::max(1u, (unsigned)((uint64_t)n_cu * wg_cu_lo / a.n_hi));
     hipLaunchKernelGGL(k_part_scatter_lo, dim3(per_bucket_s, a.n_hi), dim3(kBlock), lds_lo, stream, a);
     const bool fixed = (size_t)film.bins * 24u <= 72u * 1024u;
