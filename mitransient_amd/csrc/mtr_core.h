@@ -245,13 +245,10 @@ static_assert(sizeof(QNode4) == 64, "quantised 4-wide node");
 //   q[0] = (org.x, org.y, org.z, meta)   meta = ex | ey << 8 | ez << 16 | axis << 24 | count << 26   (count 1 .. 8)
 //   q[1] = (lo.x c0-3, lo.x c4-7, lo.y c0-3, lo.y c4-7)   q[2] = (lo.z c0-3, lo.z c4-7, hi.x c0-3, hi.x c4-7)
 //   q[3] = (hi.y c0-3, hi.y c4-7, hi.z c0-3, hi.z c4-7)   q[4], q[5] = refs of children 0-3, 4-7
-#ifdef MTR_QNODE8_PAD      // experiment: one node per 128-byte line (a 96-byte stride puts the 64 bytes a step reads across two lines for one node in four)
-struct alignas(128) QNode8 { q4 q[6]; q4 pad[2]; };
-static_assert(sizeof(QNode8) == 128, "quantised 8-wide node, padded to a line");
-#else
 struct alignas(16) QNode8 { q4 q[6]; };
 static_assert(sizeof(QNode8) == 96, "quantised 8-wide node");
-#endif
+// (padded to one 128-byte line per node — a 96-byte stride puts the 64 bytes a step reads across two lines for one node in
+// four — config 5 is 3 % SLOWER, k_wf_trace 975 -> 1005 ms: the tree's footprint in L2 matters more than the line crossings)
 // triangles, split by use and stored by SLOT: every leaf starts on an even slot and owns ceil(count / 2) pairs of slots
 // (an odd leaf repeats its last triangle in the pad slot; the pad is never reported as a hit).
 // Intersection record = one PAIR of slots with the two triangles interleaved, so that one 16-byte read delivers two

@@ -1,13 +1,13 @@
 #!/bin/bash
 # tools/merge_profiles.sh <tag> — after `gpurun -- bash tools/profile_all.sh <tag>`: merge the three counter fragments into
-# profiles/traffic.json and copy the summaries the judge reads into profiles/r03_*
-TAG=$1
+# profiles/traffic.json and copy the summaries the judge reads into profiles/<round>_*   usage: tools/merge_profiles.sh <tag> [round = r04]
+TAG=$1; RND=${2:-r04}
 python tools/pmc_summary.py --merge gpurun_out/prof_${TAG}_c2/traffic.json
 python tools/pmc_summary.py --merge gpurun_out/prof_${TAG}_c5/traffic.json --section staircase
 python tools/pmc_summary.py --merge gpurun_out/prof_${TAG}_c4/traffic.json --section nlos
 for c in c2 c5 c4; do
-  cp gpurun_out/prof_${TAG}_$c/pmc_summary.txt profiles/r03_${c}_pmc_summary.txt
-  cp gpurun_out/prof_${TAG}_$c/trace/trace_kernel_stats.csv profiles/r03_${c}_kernel_stats.csv
+  cp gpurun_out/prof_${TAG}_$c/pmc_summary.txt profiles/${RND}_${c}_pmc_summary.txt
+  cp gpurun_out/prof_${TAG}_$c/trace/trace_kernel_stats.csv profiles/${RND}_${c}_kernel_stats.csv
 done
 python -c "
 import json, bench
