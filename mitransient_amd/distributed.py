@@ -45,8 +45,9 @@ def reduce_scatter_rows(t, group=None):
         t = torch.cat([t, pad], dim=0)
     t = t.contiguous()
     out = torch.empty((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    if dist.get_backend(group) == "gloo":
-        # gloo has no reduce_scatter_tensor: all_reduce then slice (CPU test path)
+    if dist.get_backend(group) == "gloo" and t.device.type != "cpu":
+        # gloo reduce-scatters host tensors only (the CPU tests run the same reduce_scatter_tensor call as RCCL, world size 2
+        # and 3); device tensors over gloo — the 2-rank GPU tests on a one-GPU box — go through all_reduce + slice
         tt = t.clone()
         dist.all_reduce(tt, group=group)
         out.copy_(tt[rank * per:(rank + 1) * per])
@@ -67,7 +68,7 @@ def all_gather_rows(slab, height: int, group=None):
         slab = torch.cat([slab, pad], dim=0)
     slab = slab.contiguous()
     full = torch.empty((per * world,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
-    if dist.get_backend(group) == "gloo":
+    if dist.get_backend(group) == "gloo" and slab.device.type != "cpu":      # (as above: host tensors take the call RCCL takes)
         parts = [torch.empty_like(slab) for _ in range(world)]
         dist.all_gather(parts, slab, group=group)
         full = torch.cat(parts, dim=0)
