@@ -415,7 +415,12 @@ def main():
             renderer.render(spp=spp_total, seed=0)
         fence()
         t0 = time.perf_counter()
+        out = None
         for _ in range(args.steps):
+            # the previous step's result is dropped BEFORE the next render allocates its own (a render's result belongs to the
+            # caller since round 4): the caching allocator hands the same 3 GiB block back.  Holding it across the call made the
+            # second timed step hipMalloc a second block — 1 ms on most boxes, 90 ms on one (97 instead of 66.6 ms per step)
+            out = None
             out = renderer.render(spp=spp_total, seed=0)
             # (counters and HIP-event times were read back inside render(): collect_stats)
             for k in totals:

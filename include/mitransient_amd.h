@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 10
+#define MTR_ABI_VERSION 11
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -46,11 +46,13 @@ typedef enum mtr_status {
 /* ---- materials: BSDF subset of the north-star path --------------------- */
 enum { MTR_BSDF_DIFFUSE = 0, MTR_BSDF_CONDUCTOR = 1, MTR_BSDF_DIELECTRIC = 2,
        MTR_BSDF_NULL = 3 /* no BSDF: absorbs */,
-       MTR_BSDF_ROUGHCONDUCTOR = 4, /* GGX microfacet conductor, isotropic alpha, visible-normal sampling (mitsuba `roughconductor`,
-                                       distribution = ggx, sample_visible = true): a smooth lobe, takes part in emitter sampling */
-       MTR_BSDF_ROUGHPLASTIC = 5    /* GGX dielectric coat over a diffuse base (mitsuba `roughplastic`) */ };
+       MTR_BSDF_ROUGHCONDUCTOR = 4, /* microfacet conductor, isotropic alpha, visible-normal sampling (mitsuba `roughconductor`,
+                                       distribution = ggx | beckmann (MTR_MAT_BECKMANN), sample_visible = true): a smooth lobe,
+                                       takes part in emitter sampling */
+       MTR_BSDF_ROUGHPLASTIC = 5    /* microfacet dielectric coat over a diffuse base (mitsuba `roughplastic`) */ };
 enum { MTR_MAT_TWOSIDED = 1u,
-       MTR_MAT_NONLINEAR = 2u /* roughplastic `nonlinear`: diffuse / (1 - diffuse * internal_reflectance) per channel */ };
+       MTR_MAT_NONLINEAR = 2u, /* roughplastic `nonlinear`: diffuse / (1 - diffuse * internal_reflectance) per channel */
+       MTR_MAT_BECKMANN = 4u   /* rough lobes (ABI 11): the Beckmann distribution — mitsuba's default `distribution` — instead of GGX */ };
 #define MTR_ROUGH_TRANSMITTANCE_RES 64
 
 typedef struct mtr_material {

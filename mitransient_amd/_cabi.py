@@ -11,12 +11,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 10
+MTR_ABI_VERSION = 11
 MTR_SPLAT_FILM_ZERO = 0x100      # mtr_splat_add: OR into `variant` when the film is all-zero on entry
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
 MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC = 4, 5
-MTR_MAT_TWOSIDED, MTR_MAT_NONLINEAR = 1, 2
+MTR_MAT_TWOSIDED, MTR_MAT_NONLINEAR, MTR_MAT_BECKMANN = 1, 2, 4
 MTR_ROUGH_TRANSMITTANCE_RES = 64
 MTR_FLAG_CAMERA_UNWARP = 1
 MTR_FLAG_DISCARD_DIRECT_LIGHT = 2

@@ -1085,8 +1085,143 @@ MTR_HD void ggx_sample_visible_11(float cos_theta_i, float u1, float u2, float &
     sx = fmaf(cos_theta_i, py, -(sin_theta_i * z)) * norm;
     sy = px * norm;
 }
+// ---- Beckmann lobes (MTR_MAT_BECKMANN; mitsuba's DEFAULT `distribution`) ----
+// exp / log / erf / erfinv restated with explicit operation order — the SAME sequences in the oracle (mtr_oracle.c) — because
+// libm, ocml and drjit each round these differently and the numerics contract wants oracle and kernels bit for bit:
+//   mtr_expf, mtr_logf: Cephes-style range reduction + polynomial (max. relative error 8e-8 against f64 on [-87, 88] / normal floats);
+//   mtr_erff: Abramowitz & Stegun 7.1.28, 1 - (1 + a1 x + .. + a6 x^6)^-16 (max. absolute error 1.8e-6 in f32; erf(inf) = 1);
+//   mtr_erfinvf: M. Giles, "Approximating the erfinv function" (2010), single precision (max. relative error 2.6e-7).
+// (tests/test_rough_bsdf.py::test_special_functions holds them to scipy.)
+MTR_HD float mtr_expf(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, r * r, r) + 1.0f;
+    return y * bitsf((uint32_t)((int32_t)n + 127) << 23);
+}
+MTR_HD float mtr_logf(float x)          // x: a positive normal float
+{
+    const uint32_t b = fbits(x);
+    int32_t e = (int32_t)(b >> 23) - 127;
+    float m = bitsf((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m *= 0.5f; e += 1; }
+    const float f = m - 1.0f, z = f * f, fe = (float)e;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(fe, 0.693359375f, f + y);
+}
+MTR_HD float mtr_erff(float x)
+{
+    const float a = fabsf(x);
+    float t = 0.0000430638f;
+    t = fmaf(t, a, 0.0002765672f);
+    t = fmaf(t, a, 0.0001520143f);
+    t = fmaf(t, a, 0.0092705272f);
+    t = fmaf(t, a, 0.0422820123f);
+    t = fmaf(t, a, 0.0705230784f);
+    t = fmaf(t, a, 1.0f);
+    t = t * t; t = t * t; t = t * t; t = t * t;
+    const float r = 1.0f - 1.0f / t;
+    return x < 0.0f ? -r : r;
+}
+MTR_HD float mtr_erfinvf(float x)       // |x| < 1
+{
+    float w = -mtr_logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+// [MicrofacetDistribution::eval, Beckmann] D(m) = exp(-((m.x/alpha)^2 + (m.y/alpha)^2) / cos^2) / (pi alpha^2 cos^4), 0 when D cos <= 1e-20
+MTR_HD float beck_eval(f3 m, float alpha)
+{
+    const float mx = m.x / alpha, my = m.y / alpha;
+    const float c2 = m.z * m.z;
+    const float result = mtr_expf(-fmaf(my, my, mx * mx) / c2) / ((kPi * (alpha * alpha)) * (c2 * c2));
+    return (result * m.z > 1e-20f) ? result : 0.0f;
+}
+// [MicrofacetDistribution::smith_g1, Beckmann] the rational approximation of Walter et al. in a = 1 / (alpha tan theta)
+MTR_HD float beck_smith_g1(f3 v, f3 m, float alpha)
+{
+    const float ax = alpha * v.x, ay = alpha * v.y;
+    const float xy_alpha_2 = fmaf(ay, ay, ax * ax);
+    const float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    const float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = a * a;
+    float result = (a >= 1.6f) ? 1.0f : fmaf(2.181f, a_sqr, 3.535f * a) / fmaf(2.577f, a_sqr, fmaf(2.276f, a, 1.0f));
+    if (xy_alpha_2 == 0.0f) result = 1.0f;
+    if (dot(v, m) * v.z <= 0.0f) result = 0.0f;
+    return result;
+}
+// [MicrofacetDistribution::sample_visible_11, Beckmann] numerical inversion of the visible-slope CDF in the erf domain:
+// a closed-form first guess and three Newton iterations, then the slope across from the second number.  (x is kept
+// inside (-1, 1) before every erfinv: a Newton step that overshoots must not produce a NaN slope.)
+MTR_HD void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float &sx, float &sy)
+{
+    const float kInvSqrtPi = 0.56418958354775628695f, kEdge = 0.999999f;
+    const float s0 = fmaf(-cos_theta_i, cos_theta_i, 1.0f);
+    const float tan_theta_i = sqrtf(s0 > 0.0f ? s0 : 0.0f) / cos_theta_i;
+    const float cot_theta_i = 1.0f / tan_theta_i;
+    const float maxval = mtr_erff(cot_theta_i);
+    u1 = fmaxf(fminf(u1, 1.0f - 1e-6f), 1e-6f); u2 = fmaxf(fminf(u2, 1.0f - 1e-6f), 1e-6f);
+    float x = maxval - (maxval + 1.0f) * mtr_erff(sqrtf(-mtr_logf(u1)));
+    const float target = u1 * ((1.0f + maxval) + (kInvSqrtPi * tan_theta_i) * mtr_expf(-(cot_theta_i * cot_theta_i)));
+    for (int it = 0; it < 3; ++it) {
+        x = fmaxf(fminf(x, kEdge), -kEdge);
+        const float slope = mtr_erfinvf(x);
+        const float value = fmaf(kInvSqrtPi * tan_theta_i, mtr_expf(-(slope * slope)), 1.0f + x) - target;
+        const float derivative = 1.0f - slope * tan_theta_i;
+        x -= value / derivative;
+    }
+    x = fmaxf(fminf(x, kEdge), -kEdge);
+    sx = mtr_erfinvf(x);
+    sy = mtr_erfinvf(fmaf(2.0f, u2, -1.0f));
+}
+// the two distributions behind one switch (MTR_MAT_BECKMANN in mtr_material.flags)
+MTR_HD float mf_eval(f3 m, float alpha, bool beck) { return beck ? beck_eval(m, alpha) : ggx_eval(m, alpha); }
+MTR_HD float mf_smith_g1(f3 v, f3 m, float alpha, bool beck) { return beck ? beck_smith_g1(v, m, alpha) : ggx_smith_g1(v, m, alpha); }
+
 // [MicrofacetDistribution::sample, sample_visible] visible normal for wi (cos_theta(wi) > 0) and its density
-MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf)
+MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf, bool beck = false)
 {
     const f3 wi_p = normalize(mk(alpha * wi.x, alpha * wi.y, wi.z));            // 1: stretch
     const float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
@@ -1096,11 +1231,12 @@ MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf)
         sin_phi = fminf(fmaxf(wi_p.y * inv, -1.0f), 1.0f); cos_phi = fminf(fmaxf(wi_p.x * inv, -1.0f), 1.0f);
     }
     float sx, sy;
-    ggx_sample_visible_11(wi_p.z, u1, u2, sx, sy);                               // 2: P22 of the stretched direction
+    if (beck) beck_sample_visible_11(wi_p.z, u1, u2, sx, sy);                    // 2: P22 of the stretched direction
+    else ggx_sample_visible_11(wi_p.z, u1, u2, sx, sy);
     const float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;                 // 3: rotate, unstretch
     const float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
     const f3 m = normalize(mk(-rx, -ry, 1.0f));                                  // 4: normal
-    pdf = ((ggx_eval(m, alpha) * ggx_smith_g1(wi, m, alpha)) * fabsf(dot(wi, m))) / wi.z;
+    pdf = ((mf_eval(m, alpha, beck) * mf_smith_g1(wi, m, alpha, beck)) * fabsf(dot(wi, m))) / wi.z;
     return m;
 }
 // [RoughPlastic: lerp_gather(m_external_transmittance, cos_theta, MI_ROUGH_TRANSMITTANCE_RES)]
@@ -1121,13 +1257,14 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
     const float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
     const f3 H = normalize(mk(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
-    const float D = ggx_eval(H, m.alpha);
-    const float g1i = ggx_smith_g1(wi, H, m.alpha);
+    const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
+    const float D = mf_eval(H, m.alpha, beck);
+    const float g1i = mf_smith_g1(wi, H, m.alpha, beck);
     if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
         const float wih = dot(wi, H);
         if (wih > 0.0f && dot(wo, H) > 0.0f) pdf = (D * g1i) / (4.0f * ci);
         if (D != 0.0f) {
-            const float G = g1i * ggx_smith_g1(wo, H, m.alpha);
+            const float G = g1i * mf_smith_g1(wo, H, m.alpha, beck);
             const float r = (D * G) / (4.0f * ci);
             val = mk((r * fresnel_conductor(wih, m.a[0], m.b[0])) * m.c[0], (r * fresnel_conductor(wih, m.a[1], m.b[1])) * m.c[1],
                      (r * fresnel_conductor(wih, m.a[2], m.b[2])) * m.c[2]);
@@ -1141,7 +1278,7 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
     pdf = fmaf(pdif, kInvPi * co, ((D * g1i) / (4.0f * ci)) * ps);
     float F, ct, eit, eti;
     fresnel_dielectric(dot(wi, H), m.int_ior / m.ext_ior, F, ct, eit, eti);
-    const float G = g1i * ggx_smith_g1(wo, H, m.alpha);
+    const float G = g1i * mf_smith_g1(wo, H, m.alpha, beck);
     const float spec = ((F * D) * G) / (4.0f * ci);
     const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
     const float dscale = (((kInvPi * inv_eta_2) * co) * t_i) * t_o;
@@ -1160,14 +1297,15 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 {
     const float ci = wi.z;
     if (!(ci > 0.0f)) return;
+    const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
     if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
         float pdf;
-        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf);
+        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf, beck);
         const float wim = dot(wi, mm);
         const f3 wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));     // reflect(wi, m)
         bs.wo = wo;
         const bool ok = (pdf != 0.0f) && (wo.z > 0.0f);
-        const float weight = ggx_smith_g1(wo, mm, m.alpha);
+        const float weight = mf_smith_g1(wo, mm, m.alpha, beck);
         bs.pdf = pdf / (4.0f * dot(wo, mm));
         if (ok) bs.w = mk((fresnel_conductor(wim, m.a[0], m.b[0]) * weight) * m.c[0], (fresnel_conductor(wim, m.a[1], m.b[1]) * weight) * m.c[1],
                           (fresnel_conductor(wim, m.a[2], m.b[2]) * weight) * m.c[2]);
@@ -1179,7 +1317,7 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
     f3 wo;
     if (u1 < ps) {
         float pdf_m;
-        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf_m);
+        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf_m, beck);
         const float wim = dot(wi, mm);
         wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
     } else wo = cosine_hemisphere(ua, ub);

@@ -4,7 +4,7 @@ mitsuba computes them when the plugin is built (``RoughPlastic::parameters_chang
 interface for 64 incidence cosines, ``eval_transmittance(distr, wi, eta)``, and the mean reflectance seen from inside,
 ``mean(eval_reflectance(distr, wi, 1 / eta) * wi.z) * 2`` — both Gauss-Legendre quadratures (32 x 32 nodes when
 eta > 1, 128 x 128 otherwise) of the visible-normal sampling estimator over the unit square.  This module restates
-that quadrature in float64 numpy (GGX, isotropic alpha); the library only interpolates the table
+that quadrature in float64 numpy (GGX and Beckmann, isotropic alpha); the library only interpolates the table
 (``mtr_material.external_transmittance``).  [upstream: mitsuba3 src/bsdfs/roughplastic.cpp, include/mitsuba/render/microfacet.h;
 not present under the reference tree — restated from the published source.]
 """
@@ -28,7 +28,29 @@ def _disk(u1, u2):
     return r * np.where(swap, s, c), r * np.where(swap, c, s)
 
 
-def _ggx_sample(wi, alpha, u1, u2):
+def _beckmann_slopes(ct, u1, u2):
+    """MicrofacetDistribution::sample_visible_11 (Beckmann): inversion of the visible-slope CDF in the erf domain, a
+    closed-form first guess + three Newton iterations, as mitsuba does it (float64 here)"""
+    from scipy.special import erf, erfinv
+    inv_sqrt_pi = 1.0 / np.sqrt(np.pi)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        tan_t = np.sqrt(np.maximum(1.0 - ct * ct, 0.0)) / ct
+        cot_t = 1.0 / tan_t
+        maxval = erf(cot_t)
+        u1 = np.clip(u1, 1e-6, 1.0 - 1e-6); u2 = np.clip(u2, 1e-6, 1.0 - 1e-6)
+        x = maxval - (maxval + 1.0) * erf(np.sqrt(-np.log(u1)))
+        tail = np.where(tan_t == 0, 0.0, inv_sqrt_pi * tan_t * np.exp(-cot_t * cot_t))
+        target = u1 * (1.0 + maxval + tail)
+        for _ in range(3):
+            x = np.clip(x, -0.999999, 0.999999)
+            slope = erfinv(x)
+            value = 1.0 + x + inv_sqrt_pi * tan_t * np.exp(-slope * slope) - target
+            x = x - value / (1.0 - slope * tan_t)
+        x = np.clip(x, -0.999999, 0.999999)
+        return erfinv(x), erfinv(2.0 * u2 - 1.0) + 0.0 * x
+
+
+def _ggx_sample(wi, alpha, u1, u2, beckmann=False):
     """MicrofacetDistribution::sample (visible normals); wi (..., 3) with wi.z > 0"""
     wp = np.stack([alpha * wi[..., 0], alpha * wi[..., 1], wi[..., 2]], -1)
     wp = wp / np.linalg.norm(wp, axis=-1, keepdims=True)
@@ -38,26 +60,33 @@ def _ggx_sample(wi, alpha, u1, u2):
     sin_phi = np.where(flat, 0.0, np.clip(wp[..., 1] * inv, -1, 1))
     cos_phi = np.where(flat, 1.0, np.clip(wp[..., 0] * inv, -1, 1))
     ct = wp[..., 2]
-    px, py = _disk(u1, u2)
-    s = 0.5 * (1.0 + ct)
-    a = np.sqrt(np.maximum(1.0 - px * px, 0.0))
-    py = a + (py - a) * s
-    z = np.sqrt(np.maximum(1.0 - px * px - py * py, 0.0))
-    st = np.sqrt(np.maximum(1.0 - ct * ct, 0.0))
-    norm = 1.0 / (st * py + ct * z)
-    sx, sy = (ct * py - st * z) * norm, px * norm
+    if beckmann:
+        sx, sy = _beckmann_slopes(ct, np.broadcast_to(u1, ct.shape), np.broadcast_to(u2, ct.shape))
+    else:
+        px, py = _disk(u1, u2)
+        s = 0.5 * (1.0 + ct)
+        a = np.sqrt(np.maximum(1.0 - px * px, 0.0))
+        py = a + (py - a) * s
+        z = np.sqrt(np.maximum(1.0 - px * px - py * py, 0.0))
+        st = np.sqrt(np.maximum(1.0 - ct * ct, 0.0))
+        norm = 1.0 / (st * py + ct * z)
+        sx, sy = (ct * py - st * z) * norm, px * norm
     rx = (cos_phi * sx - sin_phi * sy) * alpha
     ry = (sin_phi * sx + cos_phi * sy) * alpha
     m = np.stack([-rx, -ry, np.ones_like(rx)], -1)
     return m / np.linalg.norm(m, axis=-1, keepdims=True)
 
 
-def _g1(v, m, alpha):
+def _g1(v, m, alpha, beckmann=False):
     """MicrofacetDistribution::smith_g1"""
     xy = (alpha * v[..., 0]) ** 2 + (alpha * v[..., 1]) ** 2
     with np.errstate(divide="ignore", invalid="ignore"):
         t = xy / v[..., 2] ** 2
-        r = 2.0 / (1.0 + np.sqrt(1.0 + t))
+        if beckmann:
+            a = 1.0 / np.sqrt(t)
+            r = np.where(a >= 1.6, 1.0, (3.535 * a + 2.181 * a * a) / (1.0 + 2.276 * a + 2.577 * a * a))
+        else:
+            r = 2.0 / (1.0 + np.sqrt(1.0 + t))
     r = np.where(xy == 0, 1.0, r)
     return np.where(np.sum(v * m, -1) * v[..., 2] <= 0, 0.0, r)
 
@@ -89,30 +118,30 @@ def _quadrature(eta):
     return u1, u2, w
 
 
-def eval_reflectance(alpha, mu, eta):
+def eval_reflectance(alpha, mu, eta, beckmann=False):
     """eval_reflectance(distr, wi = (sqrt(1 - mu^2), 0, mu), eta), one value per mu"""
     u1, u2, w = _quadrature(eta)
     mu = np.asarray(mu, np.float64)
     wi = np.stack([np.sqrt(1.0 - mu * mu), np.zeros_like(mu), mu], -1)[:, None, None, :]
-    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None])
+    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None], beckmann)
     d = np.sum(wi * m, -1)
     wo = 2.0 * d[..., None] * m - wi
     f = _fresnel(d, eta)[0]
-    smith = _g1(wo, m, alpha) * f
+    smith = _g1(wo, m, alpha, beckmann) * f
     smith = np.where((wo[..., 2] <= 0) | (f <= 0), 0.0, smith)
     return np.sum(smith * w[None], axis=(1, 2)) * 0.25
 
 
-def eval_transmittance(alpha, mu, eta):
+def eval_transmittance(alpha, mu, eta, beckmann=False):
     """eval_transmittance(distr, wi, eta)"""
     u1, u2, w = _quadrature(eta)
     mu = np.asarray(mu, np.float64)
     wi = np.stack([np.sqrt(1.0 - mu * mu), np.zeros_like(mu), mu], -1)[:, None, None, :]
-    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None])
+    m = _ggx_sample(np.broadcast_to(wi, (len(mu),) + u1.shape + (3,)), alpha, u1[None], u2[None], beckmann)
     d = np.sum(wi * m, -1)
     f, cos_t, eta_it, eta_ti = _fresnel(d, eta)
     wo = m * (d * eta_ti + cos_t)[..., None] - wi * eta_ti[..., None]          # refract(wi, m, cos_theta_t, eta_ti)
-    smith = _g1(wo, m, alpha) * (1.0 - f)
+    smith = _g1(wo, m, alpha, beckmann) * (1.0 - f)
     smith = np.where((wo[..., 2] >= 0) | (f >= 1), 0.0, smith)
     return np.sum(smith * w[None], axis=(1, 2)) * 0.25
 
@@ -120,13 +149,14 @@ def eval_transmittance(alpha, mu, eta):
 _cache = {}
 
 
-def rough_plastic_tables(alpha: float, eta: float):
+def rough_plastic_tables(alpha: float, eta: float, distribution: str = "ggx"):
     """(external_transmittance float32[64], internal_reflectance float32) of RoughPlastic::parameters_changed"""
-    key = (float(np.float32(alpha)), float(np.float32(eta)))
+    key = (float(np.float32(alpha)), float(np.float32(eta)), distribution)
     if key not in _cache:
-        a, e = key
+        a, e, _ = key
+        beck = distribution == "beckmann"
         mu = np.maximum(1e-6, np.linspace(0.0, 1.0, RES))
-        ext = eval_transmittance(a, mu, e)
-        internal = float(np.mean(eval_reflectance(a, mu, 1.0 / e) * mu) * 2.0)
+        ext = eval_transmittance(a, mu, e, beck)
+        internal = float(np.mean(eval_reflectance(a, mu, 1.0 / e, beck) * mu) * 2.0)
         _cache[key] = (ext.astype(np.float32), np.float32(internal))
     return _cache[key]

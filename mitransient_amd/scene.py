@@ -252,9 +252,13 @@ class _SceneBuilder:
             for k in range(3):
                 m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
         elif t in ("roughconductor", "roughplastic"):
-            # GGX lobes [mitsuba3: src/bsdfs/roughconductor.cpp, roughplastic.cpp]: isotropic alpha, visible-normal sampling
-            if str(bd.get("distribution", "beckmann")) != "ggx":
-                raise ValueError(f"{t}: only distribution = \"ggx\" is available (mitsuba's default is beckmann: say so explicitly)")
+            # microfacet lobes [mitsuba3: src/bsdfs/roughconductor.cpp, roughplastic.cpp]: isotropic alpha, visible-normal sampling,
+            # distribution = beckmann (mitsuba's default) | ggx
+            distribution = str(bd.get("distribution", "beckmann"))
+            if distribution not in ("ggx", "beckmann"):
+                raise ValueError(f"{t}: distribution must be \"beckmann\" or \"ggx\", not \"{distribution}\"")
+            if distribution == "beckmann":
+                m.flags |= _cabi.MTR_MAT_BECKMANN
             if "alpha_u" in bd or "alpha_v" in bd:
                 raise ValueError(f"{t}: anisotropic roughness (alpha_u / alpha_v) is not available")
             if not bd.get("sample_visible", True):
@@ -283,7 +287,7 @@ class _SceneBuilder:
                 if bd.get("nonlinear", False):
                     m.flags |= _cabi.MTR_MAT_NONLINEAR
                 eta = float(np.float32(m.int_ior) / np.float32(m.ext_ior))
-                ext, internal = rough_plastic_tables(float(m.alpha), eta)
+                ext, internal = rough_plastic_tables(float(m.alpha), eta, distribution)
                 for k in range(_cabi.MTR_ROUGH_TRANSMITTANCE_RES):
                     m.external_transmittance[k] = ext[k]
                 m.internal_reflectance = internal

@@ -705,8 +705,146 @@ static void ggx_sample_visible_11(float cos_theta_i, float u1, float u2, float *
     *sx = fmaf(cos_theta_i, py, -(sin_theta_i * z)) * norm;
     *sy = px * norm;
 }
+/* ---- Beckmann lobes (MTR_MAT_BECKMANN; mitsuba's default `distribution`), restated from the published MicrofacetDistribution.
+ * exp / log / erf / erfinv are restated with explicit operation order, the same sequences as the product's mtr_core.h (libm, ocml
+ * and drjit each round them differently): Cephes-style expf / logf, Abramowitz & Stegun 7.1.28 for erf, M. Giles' single-precision
+ * erfinv.  tests/test_rough_bsdf.py::test_special_functions holds them to scipy. */
+static float orc_bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t orc_fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float orc_expf(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, r * r, r) + 1.0f;
+    return y * orc_bitsf((uint32_t)((int32_t)n + 127) << 23);
+}
+static float orc_logf(float x)
+{
+    uint32_t b = orc_fbits(x);
+    int32_t e = (int32_t)(b >> 23) - 127;
+    float m = orc_bitsf((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m *= 0.5f; e += 1; }
+    float f = m - 1.0f, z = f * f, fe = (float)e;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(fe, 0.693359375f, f + y);
+}
+static float orc_erff(float x)
+{
+    float a = fabsf(x);
+    float t = 0.0000430638f;
+    t = fmaf(t, a, 0.0002765672f);
+    t = fmaf(t, a, 0.0001520143f);
+    t = fmaf(t, a, 0.0092705272f);
+    t = fmaf(t, a, 0.0422820123f);
+    t = fmaf(t, a, 0.0705230784f);
+    t = fmaf(t, a, 1.0f);
+    t = t * t; t = t * t; t = t * t; t = t * t;
+    float r = 1.0f - 1.0f / t;
+    return x < 0.0f ? -r : r;
+}
+static float orc_erfinvf(float x)
+{
+    float w = -orc_logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+/* test hook: which = 0 exp, 1 log, 2 erf, 3 erfinv */
+void orc_special(int which, uint64_t n, const float *x, float *y)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        y[i] = which == 0 ? orc_expf(x[i]) : which == 1 ? orc_logf(x[i]) : which == 2 ? orc_erff(x[i]) : orc_erfinvf(x[i]);
+}
+/* [MicrofacetDistribution::eval] (Beckmann): exp(-(sqr(m.x/alpha_u) + sqr(m.y/alpha_v)) / cos^2) / (pi alpha_u alpha_v cos^4) */
+static float beck_eval(v3 m, float alpha)
+{
+    float mx = m.x / alpha, my = m.y / alpha;
+    float c2 = m.z * m.z;
+    float result = orc_expf(-fmaf(my, my, mx * mx) / c2) / ((ORC_PI * (alpha * alpha)) * (c2 * c2));
+    return (result * m.z > 1e-20f) ? result : 0.0f;
+}
+/* [MicrofacetDistribution::smith_g1] (Beckmann): a = rsqrt(tan_theta_alpha_2); 1 for a >= 1.6, else the rational approximation */
+static float beck_smith_g1(v3 v, v3 m, float alpha)
+{
+    float ax = alpha * v.x, ay = alpha * v.y;
+    float xy_alpha_2 = fmaf(ay, ay, ax * ax);
+    float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+    float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = a * a;
+    float result = (a >= 1.6f) ? 1.0f : fmaf(2.181f, a_sqr, 3.535f * a) / fmaf(2.577f, a_sqr, fmaf(2.276f, a, 1.0f));
+    if (xy_alpha_2 == 0.0f) result = 1.0f;
+    if (vdot(v, m) * v.z <= 0.0f) result = 0.0f;
+    return result;
+}
+/* [MicrofacetDistribution::sample_visible_11] (Beckmann): numerical inversion in the erf domain — first guess, three Newton
+ * iterations; x is clamped inside (-1, 1) before every erfinv (an overshooting step must not yield a NaN slope) */
+static void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float *sx, float *sy)
+{
+    const float kInvSqrtPi = 0.56418958354775628695f, kEdge = 0.999999f;
+    float s0 = fmaf(-cos_theta_i, cos_theta_i, 1.0f);
+    float tan_theta_i = sqrtf(s0 > 0.0f ? s0 : 0.0f) / cos_theta_i;
+    float cot_theta_i = 1.0f / tan_theta_i;
+    float maxval = orc_erff(cot_theta_i);
+    u1 = fmaxf(fminf(u1, 1.0f - 1e-6f), 1e-6f); u2 = fmaxf(fminf(u2, 1.0f - 1e-6f), 1e-6f);
+    float x = maxval - (maxval + 1.0f) * orc_erff(sqrtf(-orc_logf(u1)));
+    float target = u1 * ((1.0f + maxval) + (kInvSqrtPi * tan_theta_i) * orc_expf(-(cot_theta_i * cot_theta_i)));
+    for (int it = 0; it < 3; ++it) {
+        x = fmaxf(fminf(x, kEdge), -kEdge);
+        float slope = orc_erfinvf(x);
+        float value = fmaf(kInvSqrtPi * tan_theta_i, orc_expf(-(slope * slope)), 1.0f + x) - target;
+        float derivative = 1.0f - slope * tan_theta_i;
+        x -= value / derivative;
+    }
+    x = fmaxf(fminf(x, kEdge), -kEdge);
+    *sx = orc_erfinvf(x);
+    *sy = orc_erfinvf(fmaf(2.0f, u2, -1.0f));
+}
+static float mf_eval(v3 m, float alpha, int beck) { return beck ? beck_eval(m, alpha) : ggx_eval(m, alpha); }
+static float mf_smith_g1(v3 v, v3 m, float alpha, int beck) { return beck ? beck_smith_g1(v, m, alpha) : ggx_smith_g1(v, m, alpha); }
+
 /* [MicrofacetDistribution::sample], visible normals: stretch, sample the slope, rotate + unstretch, normal and density */
-static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf)
+static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf, int beck)
 {
     v3 wi_p = vnormalize(V(alpha * wi.x, alpha * wi.y, wi.z));
     float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
@@ -716,11 +854,12 @@ static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf)
         sin_phi = fminf(fmaxf(wi_p.y * inv, -1.0f), 1.0f); cos_phi = fminf(fmaxf(wi_p.x * inv, -1.0f), 1.0f);
     }
     float sx, sy;
-    ggx_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
+    if (beck) beck_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
+    else ggx_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
     float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;
     float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
     v3 m = vnormalize(V(-rx, -ry, 1.0f));
-    *pdf = ((ggx_eval(m, alpha) * ggx_smith_g1(wi, m, alpha)) * fabsf(vdot(wi, m))) / wi.z;
+    *pdf = ((mf_eval(m, alpha, beck) * mf_smith_g1(wi, m, alpha, beck)) * fabsf(vdot(wi, m))) / wi.z;
     return m;
 }
 /* [RoughPlastic: dr::lerp_gather over m_external_transmittance, MI_ROUGH_TRANSMITTANCE_RES = 64] */
@@ -742,13 +881,14 @@ static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], fl
     float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
     v3 H = vnormalize(V(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
-    float D = ggx_eval(H, m->alpha);
-    float g1i = ggx_smith_g1(wi, H, m->alpha);
+    int beck = (m->flags & MTR_MAT_BECKMANN) != 0u;
+    float D = mf_eval(H, m->alpha, beck);
+    float g1i = mf_smith_g1(wi, H, m->alpha, beck);
     if (m->type == MTR_BSDF_ROUGHCONDUCTOR) {
         float wih = vdot(wi, H);
         if (wih > 0.0f && vdot(wo, H) > 0.0f) *pdf = (D * g1i) / (4.0f * ci);
         if (D != 0.0f) {
-            float G = g1i * ggx_smith_g1(wo, H, m->alpha);
+            float G = g1i * mf_smith_g1(wo, H, m->alpha, beck);
             float r = (D * G) / (4.0f * ci);
             for (int k = 0; k < 3; ++k) val[k] = (r * fresnel_conductor(wih, m->a[k], m->b[k])) * m->c[k];
         }
@@ -760,7 +900,7 @@ static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], fl
     *pdf = fmaf(pdif, ORC_INV_PI * co, ((D * g1i) / (4.0f * ci)) * ps);
     float F, ct, eit, eti;
     fresnel_dielectric(vdot(wi, H), m->int_ior / m->ext_ior, &F, &ct, &eit, &eti);
-    float G = g1i * ggx_smith_g1(wo, H, m->alpha);
+    float G = g1i * mf_smith_g1(wo, H, m->alpha, beck);
     float spec = ((F * D) * G) / (4.0f * ci);
     float eta = m->int_ior / m->ext_ior, inv_eta_2 = 1.0f / (eta * eta);
     float dscale = (((ORC_INV_PI * inv_eta_2) * co) * t_i) * t_o;
@@ -812,12 +952,12 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
     case MTR_BSDF_ROUGHCONDUCTOR: {          /* [RoughConductor::sample] */
         if (!(ci > 0.0f)) break;
         float pdf;
-        v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf);
+        v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf, (m->flags & MTR_MAT_BECKMANN) != 0u);
         float wim = vdot(wi, mm);
         v3 wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));   /* reflect(wi, m) */
         bs->wo = wo;
         int ok = (pdf != 0.0f) && (wo.z > 0.0f);
-        float weight = ggx_smith_g1(wo, mm, m->alpha);        /* sample_visible: weight = G1(wo) */
+        float weight = mf_smith_g1(wo, mm, m->alpha, (m->flags & MTR_MAT_BECKMANN) != 0u);        /* sample_visible: weight = G1(wo) */
         bs->pdf = pdf / (4.0f * vdot(wo, mm));                /* Jacobian of the half-direction mapping */
         if (ok) for (int k = 0; k < 3; ++k) bs->w[k] = (fresnel_conductor(wim, m->a[k], m->b[k]) * weight) * m->c[k];
         break; }
@@ -829,7 +969,7 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
         v3 wo;
         if (u1 < ps) {
             float pdf_m;
-            v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf_m);
+            v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf_m, (m->flags & MTR_MAT_BECKMANN) != 0u);
             float wim = vdot(wi, mm);
             wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
         } else wo = square_to_cos_hemi(ua, ub);

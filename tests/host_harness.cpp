@@ -189,6 +189,13 @@ extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3
     return 0;
 }
 
+// the product's restatements of exp / log / erf / erfinv (Beckmann lobes): which = 0 exp, 1 log, 2 erf, 3 erfinv
+extern "C" void hh_special(int which, uint64_t n, const float *x, float *y)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        y[i] = which == 0 ? mtr_expf(x[i]) : which == 1 ? mtr_logf(x[i]) : which == 2 ? mtr_erff(x[i]) : mtr_erfinvf(x[i]);
+}
+
 // the product's BSDF arithmetic on arrays of local directions (tests/test_rough_bsdf.py)
 extern "C" void hh_bsdf_eval_pdf(const mtr_material *m, uint32_t n, const float *wi3, const float *wo3, float *val3, float *pdf)
 {

@@ -1,4 +1,4 @@
-"""GPU parity of the GGX lobes (MTR_BSDF_ROUGHCONDUCTOR / MTR_BSDF_ROUGHPLASTIC) against the CPU oracle, through the C-ABI:
+"""GPU parity of the microfacet lobes (MTR_BSDF_ROUGHCONDUCTOR / MTR_BSDF_ROUGHPLASTIC, GGX and Beckmann) against the CPU oracle, through the C-ABI:
 both kernel organisations, a scene staged in LDS and a scene walked in HBM (material-sorted lists: the rough lobes share
 the list of the smooth BSDFs, whose vertices sample the emitter)."""
 import numpy as np
@@ -11,10 +11,11 @@ from test_rough_bsdf import _rough_cornell
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("distribution", ["ggx", None], ids=["ggx", "beckmann-by-default"])
 @pytest.mark.parametrize("mode", MODES)
-def test_rough_cornell_matches_oracle(oracle, mode):
+def test_rough_cornell_matches_oracle(oracle, mode, distribution):
     import mitransient_amd.mi as mi
-    d = _rough_cornell(width=48, height=40)
+    d = _rough_cornell(distribution, width=48, height=40)
     d["integrator"].update(max_depth=8, rr_depth=3, amd_mode=mode)
     scene = mi.load_dict(d)
     s_gpu, t_gpu, s_raw, t_raw = gpu_render(scene, 24, seed=5, raw=True)
@@ -54,7 +55,7 @@ def test_rough_materials_unsupported_combinations_fail_loudly():
     AUTO picks the wavefront pipeline for them"""
     import mitransient_amd.mi as mi
     from mitransient_amd._cabi import MitransientAMDError
-    d = _rough_cornell(width=16, height=16)
+    d = _rough_cornell("ggx", width=16, height=16)
     d["integrator"].update(amd_mode="fused", amd_deterministic=True)
     scene = mi.load_dict(d)
     with pytest.raises(MitransientAMDError, match="wavefront"):

@@ -76,9 +76,12 @@ def test_plugin_defaults_and_errors():
     d["floor"]["bsdf"] = {"type": "roughdielectric"}
     with pytest.raises(ValueError, match="unknown plugin"):
         mi.load_dict(d).data()
-    d["floor"]["bsdf"] = {"type": "roughplastic"}              # mitsuba's default distribution (beckmann) is not built
-    with pytest.raises(ValueError, match="ggx"):
+    d["floor"]["bsdf"] = {"type": "roughplastic", "distribution": "phong"}      # beckmann (mitsuba's default) and ggx are built
+    with pytest.raises(ValueError, match="beckmann"):
         mi.load_dict(d).data()
+    from mitransient_amd import _cabi
+    d["floor"]["bsdf"] = {"type": "roughplastic"}
+    assert any(m.flags & _cabi.MTR_MAT_BECKMANN for m in mi.load_dict(d).data().materials)
     d = mitr.cornell_box()
     d["sensor"]["film"]["crop_width"] = 9999
     with pytest.raises(ValueError):
