@@ -52,7 +52,9 @@ enum { MTR_BSDF_DIFFUSE = 0, MTR_BSDF_CONDUCTOR = 1, MTR_BSDF_DIELECTRIC = 2,
        MTR_BSDF_ROUGHPLASTIC = 5    /* microfacet dielectric coat over a diffuse base (mitsuba `roughplastic`) */ };
 enum { MTR_MAT_TWOSIDED = 1u,
        MTR_MAT_NONLINEAR = 2u, /* roughplastic `nonlinear`: diffuse / (1 - diffuse * internal_reflectance) per channel */
-       MTR_MAT_BECKMANN = 4u   /* rough lobes (ABI 11): the Beckmann distribution — mitsuba's default `distribution` — instead of GGX */ };
+       MTR_MAT_BECKMANN = 4u,  /* rough lobes (ABI 11): the Beckmann distribution — mitsuba's default `distribution` — instead of GGX */
+       MTR_MAT_ANISOTROPIC = 8u /* roughconductor (ABI 11): `alpha` is alpha_u (along the shading frame's tangent, dp/du) and c2[0]
+                                   holds alpha_v (a field conductors do not use otherwise)                                    */ };
 #define MTR_ROUGH_TRANSMITTANCE_RES 64
 
 typedef struct mtr_material {
@@ -63,9 +65,9 @@ typedef struct mtr_material {
     float    c[3];        /* conductor/dielectric/rough*: specular_reflectance rgb */
     float    int_ior;     /* dielectric, roughplastic                            */
     float    ext_ior;     /* dielectric, roughplastic                            */
-    float    c2[3];       /* dielectric: specular_transmittance rgb              */
+    float    c2[3];       /* dielectric: specular_transmittance rgb | roughconductor with MTR_MAT_ANISOTROPIC: c2[0] = alpha_v */
     /* rough lobes (ABI 8) */
-    float    alpha;       /* GGX roughness (alpha_u = alpha_v)                   */
+    float    alpha;       /* roughness of the lobe (alpha_u = alpha_v unless MTR_MAT_ANISOTROPIC) */
     float    internal_reflectance;   /* roughplastic: mean rough reflectance of the coat seen from inside          */
     float    specular_sampling_weight; /* roughplastic: s_mean / (d_mean + s_mean)                                 */
     uint32_t albedo_texture;  /* 1 + index into mtr_scene_desc.textures of a bitmap that replaces `a` (diffuse reflectance,

@@ -1050,17 +1050,17 @@ MTR_HD void fresnel_dielectric(float ci, float eta, float &r, float &cos_t, floa
 // Restated from mitsuba 3's MicrofacetDistribution (isotropic alpha, sample_visible = true), RoughConductor and
 // RoughPlastic; operation order is the numerics contract shared with the test oracle (fma only where written).
 // [mitsuba3: MicrofacetDistribution::eval] D(m) = 1 / (pi alpha^2 ((m.x/alpha)^2 + (m.y/alpha)^2 + m.z^2)^2), 0 when D cos <= 1e-20
-MTR_HD float ggx_eval(f3 m, float alpha)
+MTR_HD float ggx_eval(f3 m, float au, float av)
 {
-    const float mx = m.x / alpha, my = m.y / alpha;
+    const float mx = m.x / au, my = m.y / av;
     const float t = fmaf(m.z, m.z, fmaf(my, my, mx * mx));
-    const float result = 1.0f / (((kPi * (alpha * alpha)) * t) * t);
+    const float result = 1.0f / (((kPi * (au * av)) * t) * t);
     return (result * m.z > 1e-20f) ? result : 0.0f;
 }
 // [MicrofacetDistribution::smith_g1] 2 / (1 + sqrt(1 + alpha^2 tan^2)); 1 at perpendicular incidence; 0 when v sees the back of m
-MTR_HD float ggx_smith_g1(f3 v, f3 m, float alpha)
+MTR_HD float ggx_smith_g1(f3 v, f3 m, float au, float av)
 {
-    const float ax = alpha * v.x, ay = alpha * v.y;
+    const float ax = au * v.x, ay = av * v.y;
     const float xy_alpha_2 = fmaf(ay, ay, ax * ax);
     const float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
     float result = 2.0f / (1.0f + sqrtf(1.0f + tan_theta_alpha_2));
@@ -1173,17 +1173,17 @@ MTR_HD float mtr_erfinvf(float x)       // |x| < 1
     return p * x;
 }
 // [MicrofacetDistribution::eval, Beckmann] D(m) = exp(-((m.x/alpha)^2 + (m.y/alpha)^2) / cos^2) / (pi alpha^2 cos^4), 0 when D cos <= 1e-20
-MTR_HD float beck_eval(f3 m, float alpha)
+MTR_HD float beck_eval(f3 m, float au, float av)
 {
-    const float mx = m.x / alpha, my = m.y / alpha;
+    const float mx = m.x / au, my = m.y / av;
     const float c2 = m.z * m.z;
-    const float result = mtr_expf(-fmaf(my, my, mx * mx) / c2) / ((kPi * (alpha * alpha)) * (c2 * c2));
+    const float result = mtr_expf(-fmaf(my, my, mx * mx) / c2) / ((kPi * (au * av)) * (c2 * c2));
     return (result * m.z > 1e-20f) ? result : 0.0f;
 }
 // [MicrofacetDistribution::smith_g1, Beckmann] the rational approximation of Walter et al. in a = 1 / (alpha tan theta)
-MTR_HD float beck_smith_g1(f3 v, f3 m, float alpha)
+MTR_HD float beck_smith_g1(f3 v, f3 m, float au, float av)
 {
-    const float ax = alpha * v.x, ay = alpha * v.y;
+    const float ax = au * v.x, ay = av * v.y;
     const float xy_alpha_2 = fmaf(ay, ay, ax * ax);
     const float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
     const float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = a * a;
@@ -1217,13 +1217,16 @@ MTR_HD void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float 
     sy = mtr_erfinvf(fmaf(2.0f, u2, -1.0f));
 }
 // the two distributions behind one switch (MTR_MAT_BECKMANN in mtr_material.flags)
-MTR_HD float mf_eval(f3 m, float alpha, bool beck) { return beck ? beck_eval(m, alpha) : ggx_eval(m, alpha); }
-MTR_HD float mf_smith_g1(f3 v, f3 m, float alpha, bool beck) { return beck ? beck_smith_g1(v, m, alpha) : ggx_smith_g1(v, m, alpha); }
+// (au, av: roughness along the tangent / the bitangent of the shading frame; equal unless MTR_MAT_ANISOTROPIC)
+MTR_HD float mf_eval(f3 m, float au, float av, bool beck) { return beck ? beck_eval(m, au, av) : ggx_eval(m, au, av); }
+MTR_HD float mf_smith_g1(f3 v, f3 m, float au, float av, bool beck) { return beck ? beck_smith_g1(v, m, au, av) : ggx_smith_g1(v, m, au, av); }
+// [RoughConductor: alpha_u, alpha_v] the second roughness of an anisotropic roughconductor travels in c2[0] (a field conductors do not use)
+MTR_HD float rough_alpha_v(const mtr_material &m) { return (m.flags & MTR_MAT_ANISOTROPIC) ? m.c2[0] : m.alpha; }
 
 // [MicrofacetDistribution::sample, sample_visible] visible normal for wi (cos_theta(wi) > 0) and its density
-MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf, bool beck = false)
+MTR_HD f3 ggx_sample(f3 wi, float au, float av, float u1, float u2, float &pdf, bool beck = false)
 {
-    const f3 wi_p = normalize(mk(alpha * wi.x, alpha * wi.y, wi.z));            // 1: stretch
+    const f3 wi_p = normalize(mk(au * wi.x, av * wi.y, wi.z));                  // 1: stretch
     const float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
     float sin_phi = 0.0f, cos_phi = 1.0f;                                        // Frame3f::sincos_phi
     if (fabsf(sin_theta_2) > 4.0f * 5.9604644775390625e-8f) {
@@ -1233,10 +1236,10 @@ MTR_HD f3 ggx_sample(f3 wi, float alpha, float u1, float u2, float &pdf, bool be
     float sx, sy;
     if (beck) beck_sample_visible_11(wi_p.z, u1, u2, sx, sy);                    // 2: P22 of the stretched direction
     else ggx_sample_visible_11(wi_p.z, u1, u2, sx, sy);
-    const float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;                 // 3: rotate, unstretch
-    const float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
+    const float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * au;                    // 3: rotate, unstretch
+    const float ry = fmaf(sin_phi, sx, cos_phi * sy) * av;
     const f3 m = normalize(mk(-rx, -ry, 1.0f));                                  // 4: normal
-    pdf = ((mf_eval(m, alpha, beck) * mf_smith_g1(wi, m, alpha, beck)) * fabsf(dot(wi, m))) / wi.z;
+    pdf = ((mf_eval(m, au, av, beck) * mf_smith_g1(wi, m, au, av, beck)) * fabsf(dot(wi, m))) / wi.z;
     return m;
 }
 // [RoughPlastic: lerp_gather(m_external_transmittance, cos_theta, MI_ROUGH_TRANSMITTANCE_RES)]
@@ -1258,13 +1261,14 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
     if (!(ci > 0.0f && co > 0.0f)) return;
     const f3 H = normalize(mk(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
     const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
-    const float D = mf_eval(H, m.alpha, beck);
-    const float g1i = mf_smith_g1(wi, H, m.alpha, beck);
+    const float au = m.alpha, av = rough_alpha_v(m);
+    const float D = mf_eval(H, au, av, beck);
+    const float g1i = mf_smith_g1(wi, H, au, av, beck);
     if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
         const float wih = dot(wi, H);
         if (wih > 0.0f && dot(wo, H) > 0.0f) pdf = (D * g1i) / (4.0f * ci);
         if (D != 0.0f) {
-            const float G = g1i * mf_smith_g1(wo, H, m.alpha, beck);
+            const float G = g1i * mf_smith_g1(wo, H, au, av, beck);
             const float r = (D * G) / (4.0f * ci);
             val = mk((r * fresnel_conductor(wih, m.a[0], m.b[0])) * m.c[0], (r * fresnel_conductor(wih, m.a[1], m.b[1])) * m.c[1],
                      (r * fresnel_conductor(wih, m.a[2], m.b[2])) * m.c[2]);
@@ -1278,7 +1282,7 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
     pdf = fmaf(pdif, kInvPi * co, ((D * g1i) / (4.0f * ci)) * ps);
     float F, ct, eit, eti;
     fresnel_dielectric(dot(wi, H), m.int_ior / m.ext_ior, F, ct, eit, eti);
-    const float G = g1i * mf_smith_g1(wo, H, m.alpha, beck);
+    const float G = g1i * mf_smith_g1(wo, H, au, av, beck);
     const float spec = ((F * D) * G) / (4.0f * ci);
     const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
     const float dscale = (((kInvPi * inv_eta_2) * co) * t_i) * t_o;
@@ -1300,12 +1304,12 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
     const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
     if (m.type == MTR_BSDF_ROUGHCONDUCTOR) {
         float pdf;
-        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf, beck);
+        const f3 mm = ggx_sample(wi, m.alpha, rough_alpha_v(m), ua, ub, pdf, beck);
         const float wim = dot(wi, mm);
         const f3 wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));     // reflect(wi, m)
         bs.wo = wo;
         const bool ok = (pdf != 0.0f) && (wo.z > 0.0f);
-        const float weight = mf_smith_g1(wo, mm, m.alpha, beck);
+        const float weight = mf_smith_g1(wo, mm, m.alpha, rough_alpha_v(m), beck);
         bs.pdf = pdf / (4.0f * dot(wo, mm));
         if (ok) bs.w = mk((fresnel_conductor(wim, m.a[0], m.b[0]) * weight) * m.c[0], (fresnel_conductor(wim, m.a[1], m.b[1]) * weight) * m.c[1],
                           (fresnel_conductor(wim, m.a[2], m.b[2]) * weight) * m.c[2]);
@@ -1317,7 +1321,7 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
     f3 wo;
     if (u1 < ps) {
         float pdf_m;
-        const f3 mm = ggx_sample(wi, m.alpha, ua, ub, pdf_m, beck);
+        const f3 mm = ggx_sample(wi, m.alpha, m.alpha, ua, ub, pdf_m, beck);
         const float wim = dot(wi, mm);
         wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
     } else wo = cosine_hemisphere(ua, ub);

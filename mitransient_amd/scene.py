@@ -259,11 +259,21 @@ class _SceneBuilder:
                 raise ValueError(f"{t}: distribution must be \"beckmann\" or \"ggx\", not \"{distribution}\"")
             if distribution == "beckmann":
                 m.flags |= _cabi.MTR_MAT_BECKMANN
-            if "alpha_u" in bd or "alpha_v" in bd:
-                raise ValueError(f"{t}: anisotropic roughness (alpha_u / alpha_v) is not available")
             if not bd.get("sample_visible", True):
                 raise ValueError(f"{t}: sample_visible = false is not available")
             alpha = bd.get("alpha", 0.1)
+            if "alpha_u" in bd or "alpha_v" in bd:
+                # [roughconductor.cpp] either `alpha` or BOTH `alpha_u` and `alpha_v`; roughplastic has a single alpha
+                if t != "roughconductor":
+                    raise ValueError(f"{t}: alpha_u / alpha_v are parameters of roughconductor; roughplastic takes `alpha`")
+                if "alpha" in bd or not ("alpha_u" in bd and "alpha_v" in bd):
+                    raise ValueError("roughconductor: specify either alpha or alpha_u and alpha_v")
+                alpha = bd["alpha_u"]
+                if isinstance(bd["alpha_v"], dict):
+                    raise ValueError(f"{t}: textured alpha is not available")
+                if np.float32(bd["alpha_v"]) != np.float32(alpha) if not isinstance(alpha, dict) else False:
+                    m.flags |= _cabi.MTR_MAT_ANISOTROPIC
+                    m.c2[0] = np.float32(bd["alpha_v"])
             if isinstance(alpha, dict):
                 raise ValueError(f"{t}: textured alpha is not available")
             m.alpha = np.float32(alpha)

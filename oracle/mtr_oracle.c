@@ -670,17 +670,17 @@ static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, f
 /* ---- GGX microfacet lobes: mitsuba 3's MicrofacetDistribution (isotropic alpha, sample_visible = true), RoughConductor and
  * RoughPlastic, restated from the published source (upstream not present under /root/reference: unverified here).
  * [MicrofacetDistribution::eval]: 1 / (pi alpha_u alpha_v (sqr(m.x/alpha_u) + sqr(m.y/alpha_v) + sqr(m.z))^2), 0 when D cos <= 1e-20 */
-static float ggx_eval(v3 m, float alpha)
+static float ggx_eval(v3 m, float au, float av)
 {
-    float mx = m.x / alpha, my = m.y / alpha;
+    float mx = m.x / au, my = m.y / av;
     float t = fmaf(m.z, m.z, fmaf(my, my, mx * mx));
-    float result = 1.0f / (((ORC_PI * (alpha * alpha)) * t) * t);
+    float result = 1.0f / (((ORC_PI * (au * av)) * t) * t);
     return (result * m.z > 1e-20f) ? result : 0.0f;
 }
 /* [MicrofacetDistribution::smith_g1] */
-static float ggx_smith_g1(v3 v, v3 m, float alpha)
+static float ggx_smith_g1(v3 v, v3 m, float au, float av)
 {
-    float ax = alpha * v.x, ay = alpha * v.y;
+    float ax = au * v.x, ay = av * v.y;
     float xy_alpha_2 = fmaf(ay, ay, ax * ax);
     float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
     float result = 2.0f / (1.0f + sqrtf(1.0f + tan_theta_alpha_2));
@@ -798,17 +798,17 @@ void orc_special(int which, uint64_t n, const float *x, float *y)
         y[i] = which == 0 ? orc_expf(x[i]) : which == 1 ? orc_logf(x[i]) : which == 2 ? orc_erff(x[i]) : orc_erfinvf(x[i]);
 }
 /* [MicrofacetDistribution::eval] (Beckmann): exp(-(sqr(m.x/alpha_u) + sqr(m.y/alpha_v)) / cos^2) / (pi alpha_u alpha_v cos^4) */
-static float beck_eval(v3 m, float alpha)
+static float beck_eval(v3 m, float au, float av)
 {
-    float mx = m.x / alpha, my = m.y / alpha;
+    float mx = m.x / au, my = m.y / av;
     float c2 = m.z * m.z;
-    float result = orc_expf(-fmaf(my, my, mx * mx) / c2) / ((ORC_PI * (alpha * alpha)) * (c2 * c2));
+    float result = orc_expf(-fmaf(my, my, mx * mx) / c2) / ((ORC_PI * (au * av)) * (c2 * c2));
     return (result * m.z > 1e-20f) ? result : 0.0f;
 }
 /* [MicrofacetDistribution::smith_g1] (Beckmann): a = rsqrt(tan_theta_alpha_2); 1 for a >= 1.6, else the rational approximation */
-static float beck_smith_g1(v3 v, v3 m, float alpha)
+static float beck_smith_g1(v3 v, v3 m, float au, float av)
 {
-    float ax = alpha * v.x, ay = alpha * v.y;
+    float ax = au * v.x, ay = av * v.y;
     float xy_alpha_2 = fmaf(ay, ay, ax * ax);
     float tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
     float a = 1.0f / sqrtf(tan_theta_alpha_2), a_sqr = a * a;
@@ -840,13 +840,15 @@ static void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float 
     *sx = orc_erfinvf(x);
     *sy = orc_erfinvf(fmaf(2.0f, u2, -1.0f));
 }
-static float mf_eval(v3 m, float alpha, int beck) { return beck ? beck_eval(m, alpha) : ggx_eval(m, alpha); }
-static float mf_smith_g1(v3 v, v3 m, float alpha, int beck) { return beck ? beck_smith_g1(v, m, alpha) : ggx_smith_g1(v, m, alpha); }
+static float mf_eval(v3 m, float au, float av, int beck) { return beck ? beck_eval(m, au, av) : ggx_eval(m, au, av); }
+static float mf_smith_g1(v3 v, v3 m, float au, float av, int beck) { return beck ? beck_smith_g1(v, m, au, av) : ggx_smith_g1(v, m, au, av); }
+/* [RoughConductor: alpha_u, alpha_v] MTR_MAT_ANISOTROPIC: the roughness along the bitangent travels in c2[0] */
+static float rough_alpha_v(const mtr_material *m) { return (m->flags & MTR_MAT_ANISOTROPIC) ? m->c2[0] : m->alpha; }
 
 /* [MicrofacetDistribution::sample], visible normals: stretch, sample the slope, rotate + unstretch, normal and density */
-static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf, int beck)
+static v3 ggx_sample(v3 wi, float au, float av, float u1, float u2, float *pdf, int beck)
 {
-    v3 wi_p = vnormalize(V(alpha * wi.x, alpha * wi.y, wi.z));
+    v3 wi_p = vnormalize(V(au * wi.x, av * wi.y, wi.z));
     float sin_theta_2 = fmaf(-wi_p.z, wi_p.z, 1.0f);
     float sin_phi = 0.0f, cos_phi = 1.0f;                  /* [Frame3f::sincos_phi] */
     if (fabsf(sin_theta_2) > 4.0f * 5.9604644775390625e-8f) {
@@ -856,10 +858,10 @@ static v3 ggx_sample(v3 wi, float alpha, float u1, float u2, float *pdf, int bec
     float sx, sy;
     if (beck) beck_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
     else ggx_sample_visible_11(wi_p.z, u1, u2, &sx, &sy);
-    float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * alpha;
-    float ry = fmaf(sin_phi, sx, cos_phi * sy) * alpha;
+    float rx = fmaf(cos_phi, sx, -(sin_phi * sy)) * au;
+    float ry = fmaf(sin_phi, sx, cos_phi * sy) * av;
     v3 m = vnormalize(V(-rx, -ry, 1.0f));
-    *pdf = ((mf_eval(m, alpha, beck) * mf_smith_g1(wi, m, alpha, beck)) * fabsf(vdot(wi, m))) / wi.z;
+    *pdf = ((mf_eval(m, au, av, beck) * mf_smith_g1(wi, m, au, av, beck)) * fabsf(vdot(wi, m))) / wi.z;
     return m;
 }
 /* [RoughPlastic: dr::lerp_gather over m_external_transmittance, MI_ROUGH_TRANSMITTANCE_RES = 64] */
@@ -882,13 +884,14 @@ static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], fl
     if (!(ci > 0.0f && co > 0.0f)) return;
     v3 H = vnormalize(V(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));
     int beck = (m->flags & MTR_MAT_BECKMANN) != 0u;
-    float D = mf_eval(H, m->alpha, beck);
-    float g1i = mf_smith_g1(wi, H, m->alpha, beck);
+    float au = m->alpha, av = rough_alpha_v(m);
+    float D = mf_eval(H, au, av, beck);
+    float g1i = mf_smith_g1(wi, H, au, av, beck);
     if (m->type == MTR_BSDF_ROUGHCONDUCTOR) {
         float wih = vdot(wi, H);
         if (wih > 0.0f && vdot(wo, H) > 0.0f) *pdf = (D * g1i) / (4.0f * ci);
         if (D != 0.0f) {
-            float G = g1i * mf_smith_g1(wo, H, m->alpha, beck);
+            float G = g1i * mf_smith_g1(wo, H, au, av, beck);
             float r = (D * G) / (4.0f * ci);
             for (int k = 0; k < 3; ++k) val[k] = (r * fresnel_conductor(wih, m->a[k], m->b[k])) * m->c[k];
         }
@@ -900,7 +903,7 @@ static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], fl
     *pdf = fmaf(pdif, ORC_INV_PI * co, ((D * g1i) / (4.0f * ci)) * ps);
     float F, ct, eit, eti;
     fresnel_dielectric(vdot(wi, H), m->int_ior / m->ext_ior, &F, &ct, &eit, &eti);
-    float G = g1i * mf_smith_g1(wo, H, m->alpha, beck);
+    float G = g1i * mf_smith_g1(wo, H, au, av, beck);
     float spec = ((F * D) * G) / (4.0f * ci);
     float eta = m->int_ior / m->ext_ior, inv_eta_2 = 1.0f / (eta * eta);
     float dscale = (((ORC_INV_PI * inv_eta_2) * co) * t_i) * t_o;
@@ -952,12 +955,12 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
     case MTR_BSDF_ROUGHCONDUCTOR: {          /* [RoughConductor::sample] */
         if (!(ci > 0.0f)) break;
         float pdf;
-        v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf, (m->flags & MTR_MAT_BECKMANN) != 0u);
+        v3 mm = ggx_sample(wi, m->alpha, rough_alpha_v(m), ua, ub, &pdf, (m->flags & MTR_MAT_BECKMANN) != 0u);
         float wim = vdot(wi, mm);
         v3 wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));   /* reflect(wi, m) */
         bs->wo = wo;
         int ok = (pdf != 0.0f) && (wo.z > 0.0f);
-        float weight = mf_smith_g1(wo, mm, m->alpha, (m->flags & MTR_MAT_BECKMANN) != 0u);        /* sample_visible: weight = G1(wo) */
+        float weight = mf_smith_g1(wo, mm, m->alpha, rough_alpha_v(m), (m->flags & MTR_MAT_BECKMANN) != 0u);        /* sample_visible: weight = G1(wo) */
         bs->pdf = pdf / (4.0f * vdot(wo, mm));                /* Jacobian of the half-direction mapping */
         if (ok) for (int k = 0; k < 3; ++k) bs->w[k] = (fresnel_conductor(wim, m->a[k], m->b[k]) * weight) * m->c[k];
         break; }
@@ -969,7 +972,7 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
         v3 wo;
         if (u1 < ps) {
             float pdf_m;
-            v3 mm = ggx_sample(wi, m->alpha, ua, ub, &pdf_m, (m->flags & MTR_MAT_BECKMANN) != 0u);
+            v3 mm = ggx_sample(wi, m->alpha, m->alpha, ua, ub, &pdf_m, (m->flags & MTR_MAT_BECKMANN) != 0u);
             float wim = vdot(wi, mm);
             wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
         } else wo = square_to_cos_hemi(ua, ub);

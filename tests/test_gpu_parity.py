@@ -323,6 +323,49 @@ def test_splat_add_partitions_unsorted_input(oracle, case):
     ctx.check(ctx.lib.mtr_ctx_trim(ctx.handle), "mtr_ctx_trim")
 
 
+@pytest.mark.parametrize("case", ["exhaustive_lasers", "two_pixels", "long_rows", "tile_plus_one", "all_dropped_but_one"])
+def test_splat_add_partition_edge_cases(oracle, case):
+    """the partition path of mtr_splat_add at its edges: an exhaustive_scan film (row = [laser][t], laser ids out of range
+    dropped), a film of two pixels (one bucket, one digit bit per half), rows too long for the fixed-point LDS form (T = 4096:
+    the f32 rows), one record more than a staging tile, and input of which a single record survives the time window."""
+    import torch
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import Properties
+    mi.set_variant("llvm_ad_rgb")
+    W, H, T, n = {"exhaustive_lasers": (6, 5, 64, 60000), "two_pixels": (2, 1, 8, 5000), "long_rows": (8, 4, 4096, 100000),
+                  "tile_plus_one": (32, 16, 256, 4097), "all_dropped_but_one": (16, 16, 64, 20000)}[case]
+    props = {"width": W, "height": H, "temporal_bins": T, "start_opl": 3.5, "bin_width_opl": 6.0 / T, "rfilter": {"type": "box"}}
+    if case == "exhaustive_lasers":
+        props.update(exhaustive_scan=True, laser_scan_width=3, laser_scan_height=2)
+    film = mitr.TransientHDRFilm(Properties("transient_hdr_film", props))
+    film.prepare([])
+    rng = np.random.default_rng(11)
+    pixel = rng.integers(0, W * H + (2 if case != "two_pixels" else 0), n).astype(np.uint32)
+    opl = (3.5 + 6.0 * np.clip(rng.normal(0.4 * T, 0.12 * T, n), -0.05 * T, 1.05 * T) / T).astype(np.float32)
+    if case == "all_dropped_but_one":
+        opl[:] = 1.0                      # before the window
+        opl[n // 2] = 4.0
+    r, g, b = (rng.random(n, dtype=np.float32) for _ in range(3))
+    tt = lambda x: torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda()
+    lx = ly = laser = None
+    if case == "exhaustive_lasers":
+        lx = rng.integers(0, 4, n).astype(np.uint32)          # 3 = out of range
+        ly = rng.integers(0, 2, n).astype(np.uint32)
+        laser = np.where(lx < 3, lx * 2 + ly, 6).astype(np.uint32)
+    assert np.any(np.diff(pixel.astype(np.int64)) < 0)        # unsorted: the partition runs
+    film.transient_storage.put_opl(tt(pixel), tt(opl), tt(r), tt(g), tt(b), film.desc(), 1, laser=tt(laser) if laser is not None else None)
+    torch.cuda.synchronize()
+    got = film.transient_storage.torch_tensor().cpu().numpy()
+    ref = np.zeros(film.raw_shape(), np.float32)
+    oracle.splat_add(film.desc(), pixel, opl, r, g, b, ref, lx, ly)
+    assert np.count_nonzero(ref) > 0
+    assert np.array_equal(got != 0, ref != 0)
+    assert rel_l2(got, ref) <= TOL
+    if case == "all_dropped_but_one":
+        assert np.count_nonzero(ref[..., 0]) == 1
+
+
 def test_film_add_transient_data_api(oracle):
     """TransientHDRFilm.add_transient_data with (pos, distance, spec) arrays, incl. the f32 bin-edge KATs."""
     import torch

@@ -15,13 +15,16 @@ FP = C.POINTER(C.c_float)
 
 
 def _mat(kind, alpha=0.1, twosided=False, nonlinear=True, diffuse=(0.5, 0.3, 0.2)):
-    """kind: "roughconductor" | "roughplastic", GGX; with the suffix "-beckmann" mitsuba's default distribution (no key at all)"""
+    """kind: "roughconductor" | "roughplastic", GGX; with "-beckmann" mitsuba's default distribution (no key at all); with
+    "-aniso" (roughconductor) alpha_u != alpha_v"""
     import mitransient_amd.mi as mi
     from mitransient_amd.scene import _SceneBuilder
     mi.set_variant("llvm_ad_rgb")
-    dist = {} if kind.endswith("-beckmann") else {"distribution": "ggx"}
+    dist = {} if "-beckmann" in kind else {"distribution": "ggx"}
     if kind.startswith("roughconductor"):
-        bd = {"type": "roughconductor", **dist, "alpha": alpha, "eta": [1.657, 0.880, 0.521],
+        # "-aniso": alpha_u = alpha, alpha_v = 3 alpha (the lobe is three times wider along the bitangent)
+        rough = {"alpha_u": alpha, "alpha_v": 3.0 * alpha} if kind.endswith("-aniso") else {"alpha": alpha}
+        bd = {"type": "roughconductor", **dist, **rough, "eta": [1.657, 0.880, 0.521],
               "k": [9.224, 6.270, 4.837], "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.7]}}
     else:
         bd = {"type": "roughplastic", **dist, "alpha": alpha, "int_ior": 1.5, "ext_ior": 1.0,
@@ -54,7 +57,8 @@ def _sample(lib, prefix, m, wi, u1, ua, ub):
     return wo, pdf, w
 
 
-KINDS = ["roughconductor", "roughplastic", "roughconductor-beckmann", "roughplastic-beckmann"]
+KINDS = ["roughconductor", "roughplastic", "roughconductor-beckmann", "roughplastic-beckmann", "roughconductor-aniso",
+         "roughconductor-beckmann-aniso"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -71,7 +75,7 @@ def test_product_arithmetic_equals_oracle(oracle, host_harness, kind, alpha):
         v0, p0 = _eval(oracle.lib(), "orc_", m, wi, wo)
         v1, p1 = _eval(host_harness, "hh_", m, wi, wo)
         assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
-        assert (p0 > 0).mean() > (0.3 if not kind.endswith("beckmann") else 0.02)      # (Beckmann's tails underflow: D = 0 a few alpha off the peak)
+        assert (p0 > 0).mean() > (0.3 if "beckmann" not in kind else 0.02)      # (Beckmann's tails underflow: D = 0 a few alpha off the peak)
         u = rng.random((3, n)).astype(np.float32)
         a = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
         b = _sample(host_harness, "hh_", m, wi, u[0], u[1], u[2])
@@ -130,6 +134,33 @@ def test_beckmann_is_the_default_distribution_and_differs_from_ggx(oracle):
         assert lo <= vb[0, 0] / vg[0, 0] <= hi, (tilt, vb, vg)
 
 
+@pytest.mark.parametrize("kind", ["roughconductor-aniso", "roughconductor-beckmann-aniso"])
+def test_anisotropic_lobe_is_wider_along_the_bitangent(oracle, kind):
+    """alpha_u = 0.1 along the tangent (x), alpha_v = 0.3 along the bitangent (y): the sampled normals spread three times as
+    far in y as in x; with alpha_u = alpha_v the flag is not even set and the material is the isotropic one"""
+    from mitransient_amd import _cabi
+    from mitransient_amd.scene import _SceneBuilder
+    m = _mat(kind, 0.1)
+    assert m.flags & _cabi.MTR_MAT_ANISOTROPIC and abs(m.c2[0] - 0.3) < 1e-6 and abs(m.alpha - 0.1) < 1e-7
+    iso = _SceneBuilder({}, ".")._make_material({"type": "roughconductor", "distribution": "ggx", "alpha_u": 0.2, "alpha_v": 0.2})
+    assert not (iso.flags & _cabi.MTR_MAT_ANISOTROPIC) and abs(iso.alpha - 0.2) < 1e-7
+    for bad in ({"alpha": 0.1, "alpha_u": 0.1, "alpha_v": 0.2}, {"alpha_u": 0.1}):
+        with pytest.raises(ValueError):
+            _SceneBuilder({}, ".")._make_material({"type": "roughconductor", **bad})
+    with pytest.raises(ValueError):
+        _SceneBuilder({}, ".")._make_material({"type": "roughplastic", "alpha_u": 0.1, "alpha_v": 0.2})
+    rng = np.random.default_rng(2)
+    n = 200000
+    wi = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (n, 1))
+    u = rng.random((3, n)).astype(np.float32)
+    wo, pdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+    ok = pdf > 0
+    h = wo[ok] + wi[ok]
+    h /= np.linalg.norm(h, axis=1, keepdims=True)
+    sx, sy = np.median(np.abs(h[:, 0] / h[:, 2])), np.median(np.abs(h[:, 1] / h[:, 2]))
+    assert 2.7 < sy / sx < 3.3, (sx, sy)
+
+
 def _hemisphere_grid(n_t=512, n_p=1024):
     """midpoint rule in (cos theta, phi): directions and solid-angle weights"""
     ct = (np.arange(n_t) + 0.5) / n_t
@@ -157,7 +188,7 @@ def test_density_integrates_to_one_and_energy_is_bounded(oracle, kind, alpha):
         swo, spdf, sw = _sample(oracle.lib(), "orc_", m, np.ascontiguousarray(wi[:ns]), u[0], u[1], u[2])
         usable = ((swo[:, 2] > 0) & (spdf > 0)).mean()
         assert abs(total - usable) < 0.01 and 0.5 < total <= 1.001, (kind, alpha, mu, total, usable)
-        if mu > 0.9 and alpha <= 0.1:
+        if mu > 0.9 and alpha <= 0.1 and not kind.endswith("-aniso"):       # (alpha_v = 3 alpha loses more of the lobe below the horizon)
             assert total > 0.98
         albedo = val.astype(np.float64).sum(0) * dw
         assert np.all(albedo <= 1.0 + 1e-3) and np.all(albedo > 0.05)
@@ -173,7 +204,7 @@ def test_samples_follow_the_density_and_weights_are_value_over_pdf(oracle, kind)
     u = rng.random((3, n)).astype(np.float32)
     wo, pdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
     ok = (pdf > 0) & (w.max(1) > 0)
-    assert ok.mean() > 0.9
+    assert ok.mean() > (0.9 if not kind.endswith("-aniso") else 0.7)          # (alpha_v = 0.75: a quarter of the visible normals reflect below the horizon)
     val, pdf2 = _eval(oracle.lib(), "orc_", m, wi[ok], wo[ok])
     # the density reported with the sample is the density of that direction, and weight * pdf is the value
     assert np.allclose(pdf[ok], pdf2, rtol=2e-4, atol=1e-6)
@@ -221,7 +252,8 @@ def _rough_cornell(distribution="ggx", **film):
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
-    dk = {} if distribution is None else {"distribution": distribution}
+    aniso = distribution == "aniso"            # Beckmann by default + anisotropic roughconductors (one of them GGX)
+    dk = {} if distribution is None or aniso else {"distribution": distribution}
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
     d["sensor"]["film"].update(film)
@@ -233,10 +265,13 @@ def _rough_cornell(distribution="ggx", **film):
                                                       "diffuse_reflectance": {"type": "rgb", "value": [0.2, 0.5, 0.7]}}}
     d["small-box"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "roughconductor", **dk, "alpha": 0.05,
                                                            "eta": 0.2, "k": 3.9}}
+    if aniso:
+        d["large-box"]["bsdf"].pop("alpha"); d["large-box"]["bsdf"].update(alpha_u=0.1, alpha_v=0.3)
+        d["small-box"]["bsdf"]["bsdf"].pop("alpha"); d["small-box"]["bsdf"]["bsdf"].update(alpha_u=0.15, alpha_v=0.05, distribution="ggx")
     return d
 
 
-@pytest.mark.parametrize("distribution", ["ggx", None], ids=["ggx", "beckmann-by-default"])
+@pytest.mark.parametrize("distribution", ["ggx", None, "aniso"], ids=["ggx", "beckmann-by-default", "anisotropic"])
 @pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-8"])
 def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide, distribution):
     import mitransient_amd.mi as mi
