@@ -232,7 +232,18 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
         else:
             blk.update({"achieved": None, "frac": None, "roofline_stale": True,
                         "note": "instruction counts need the PMC pass of THESE sources (tools/profile.sh ... --scene staircase); the live kernel time stands"})
-        out["roofline"] = blk
+        out["roofline_valu"] = blk
+        # the contract form for the same kernel: the bytes a trace launch must move (a 32-byte ray read and a 16-byte
+        # hit written per closest-hit ray, 32 + 1 per shadow ray) over its live time; `traffic` = L2-miss bytes of the PMC pass
+        alg = (48.0 * counters["rays_closest"] + 33.0 * counters["rays_shadow"]) / n_renders
+        ach_h = alg / (trace_ms * 1e-3) / 1e9
+        out["roofline"] = {"kernel": "k_wf_trace", "bound": "hbm", "achieved": ach_h, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach_h / HBM_PEAK_GBS, "traffic": c5.get("hbm_bytes_per_render") if profile_ok else None,
+                           "kernel_ms_per_render": trace_ms, "algorithmic_bytes_per_render": alg,
+                           "launches_per_render": times.get("wf_trace_kernel_launches", 0) / n_renders,
+                           "note": "rays and hits stream through once; the kernel is bound by instructions per ray at ~37 of 64 lanes and by "
+                                   "L2 misses on the scene (traffic >> algorithmic bytes: the 10 MB of triangle pairs do not fit an L2 slice), "
+                                   "see roofline_valu"}
     if shade_ms > 0:
         alg = WF_STATE_BYTES_PER_BOUNCE * counters["bounces"] / n_renders + WF_SHADOW_RAY_BYTES * counters["rays_shadow"] / n_renders
         ach = alg / (shade_ms * 1e-3) / 1e9
@@ -298,10 +309,10 @@ def extra_config_legs(spp4, spp5):
         hbm = {"kernel": "k_fused<NLOS>", "bound": "hbm", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": avg, "algorithmic_bytes_per_launch": alg,
                "traffic": traffic_from_profiles("k_fused", "nlos") if spp4 == 512 else None}
+        r4["roofline"] = hbm
         if v is not None:
-            r4["roofline"], r4["roofline_hbm"] = v, hbm
+            r4["roofline_valu"] = v
         else:
-            r4["roofline"] = hbm
             r4["roofline_stale"] = not profile_is_current("nlos")
     out["config4_share"] = r4
     del sc4
@@ -614,17 +625,26 @@ def main():
             blocks = wavefront_rooflines(totals_rank0, {"wf_trace_ms": wft_ms, "wf_trace_kernel_launches": wft_n, "wf_shade_ms": wfs_ms,
                                                         "scatter_ms": wsc_ms, "scatter_launches": wsc_n},
                                          args.steps, ms_per_step, default_wl and profile_is_current("staircase"))
-            if blocks.get("roofline", {}).get("frac") is not None:
-                vline = blocks["roofline"]
+            if blocks.get("roofline_valu", {}).get("frac") is not None:
+                vline = blocks["roofline_valu"]
+            if "roofline" in blocks:
+                hbm_line["kernel"] = "k_wf_trace+k_wf_shade+k_wf_scatter (whole render: 24 B x contributions)"
+                res["roofline_render"] = dict(hbm_line)
+                hbm_line = blocks["roofline"]
             for k in ("roofline_shade", "scatter_add"):
                 if k in blocks:
                     res[k] = blocks[k]
+        # `roofline` is the CONTRACT form: algorithmic bytes of the scatter-add per launch of the dominant kernel over
+        # its live launch time against the HBM peak, `traffic` = the PMC passes' HBM bytes.  The fused kernel keeps the scatter-add in
+        # LDS, so that fraction is small by construction; what bounds the kernel is VALU issue at ~30 of 64 active lanes, which
+        # `roofline_valu` states beside it (a utilisation figure, rounds 2-3 printed it as `roofline`)
+        hbm_line["note"] = ("algorithmic bytes = 24 B x time-bin contributions (SURVEY 8d); the scatter-add itself lives in LDS rows "
+                            "(k_fused) / in k_wf_scatter (`scatter_add`): the dominant kernel is instruction-bound, see roofline_valu")
+        res["roofline"] = hbm_line
         if vline is not None:
             vline["launches_per_step"] = n_launch / args.steps
-            res["roofline"] = vline
-            res["roofline_hbm"] = hbm_line
+            res["roofline_valu"] = vline
         else:
-            res["roofline"] = hbm_line
             if (SCENE == "cornell" and fused and default_wl and not profile_is_current()) or \
                (SCENE == "nlos" and fused and default_wl and not profile_is_current("nlos")) or \
                (SCENE == "staircase" and default_wl and not profile_is_current("staircase")):

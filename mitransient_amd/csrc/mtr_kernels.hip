@@ -789,25 +789,53 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
     for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
     __syncthreads();
     uint32_t mine = 0;
-    for (uint32_t px = blockIdx.x; px < npix; px += gridDim.x) {
-        const uint64_t lo = starts[px], hi = starts[px + 1];
-        // no contributions (uniform across the workgroup).  A pixel WITH a run has both entries set — its start by the record
-        // that opens it, its end by the opener of the next run or by the last record; the pixel right behind a run has only its
-        // first entry set (that run's end), the rest of a gap neither
-        if (lo == kNoRun || hi == kNoRun || lo == hi) continue;
-        for (uint64_t i = lo + tid; i < hi; i += kBlock) {
-            // (contributions and film rows are touched once: non-temporal accesses, as in k_wf_scatter)
-            const int32_t bin = film_row_bin(film, __builtin_nontemporal_load(s.opl + i), s.laser ? s.laser[i] : 0u);
-            if (bin < 0) continue;
-            const float vr = __builtin_nontemporal_load(s.r + i), vg = __builtin_nontemporal_load(s.g + i), vb = __builtin_nontemporal_load(s.b + i);
-            if (FIXED) {
-                unsigned long long *p = row64 + bin;
-                atomicAdd(p, splat_to_fixed(vr)); atomicAdd(p + T, splat_to_fixed(vg)); atomicAdd(p + 2 * T, splat_to_fixed(vb));
-            } else {
-                lds_add(row + bin, vr); lds_add(row + T + bin, vg); lds_add(row + 2 * T + bin, vb);
+    // as k_wf_scatter: a batch of independent loads in flight per lane (4 records x 4 arrays), and the first batch of the NEXT
+    // pixel's run is requested before this pixel's row is flushed (contributions and film rows are touched once: non-temporal)
+    constexpr int kBatch = 4;
+    float bo[kBatch], br[kBatch], bg[kBatch], bb[kBatch]; uint32_t bl[kBatch]; bool bv[kBatch];
+    auto fetch = [&](uint64_t lo_, uint64_t hi_) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint64_t i = lo_ + (uint64_t)k * kBlock + tid;
+            bv[k] = i < hi_; bo[k] = 0.0f; br[k] = bg[k] = bb[k] = 0.0f; bl[k] = 0u;
+            if (bv[k]) {
+                bo[k] = __builtin_nontemporal_load(s.opl + i); br[k] = __builtin_nontemporal_load(s.r + i);
+                bg[k] = __builtin_nontemporal_load(s.g + i); bb[k] = __builtin_nontemporal_load(s.b + i);
+                if (s.laser) bl[k] = s.laser[i];
             }
-            ++mine;
         }
+    };
+    // a pixel WITH a run has both table entries set — its start by the record that opens it, its end by the opener of the next
+    // run or by the last record; the pixel right behind a run has only its first entry set (that run's end), the rest of a gap
+    // neither: those are empty
+    auto run_of = [&](uint32_t px_, uint64_t &lo_, uint64_t &hi_) {
+        lo_ = starts[px_]; hi_ = starts[px_ + 1];
+        if (lo_ == kNoRun || hi_ == kNoRun) { lo_ = 0; hi_ = 0; }
+    };
+    uint64_t lo_n = 0, hi_n = 0;
+    if (blockIdx.x < npix) { run_of(blockIdx.x, lo_n, hi_n); fetch(lo_n, hi_n); }
+    for (uint32_t px = blockIdx.x; px < npix; px += gridDim.x) {
+        const uint64_t lo = lo_n, hi = hi_n;
+        const uint32_t px_next = px + gridDim.x;
+        if (px_next < npix) run_of(px_next, lo_n, hi_n);
+        for (uint64_t base = lo; base < hi || base == lo; base += (uint64_t)kBatch * kBlock) {
+            if (base != lo) fetch(base, hi);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (!bv[k]) continue;
+                const int32_t bin = film_row_bin(film, bo[k], bl[k]);
+                if (bin < 0) continue;
+                if (FIXED) {
+                    unsigned long long *p = row64 + bin;
+                    atomicAdd(p, splat_to_fixed(br[k])); atomicAdd(p + T, splat_to_fixed(bg[k])); atomicAdd(p + 2 * T, splat_to_fixed(bb[k]));
+                } else {
+                    lds_add(row + bin, br[k]); lds_add(row + T + bin, bg[k]); lds_add(row + 2 * T + bin, bb[k]);
+                }
+                ++mine;
+            }
+        }
+        if (px_next < npix) fetch(lo_n, hi_n);            // in flight across the flush below
+        if (lo == hi) continue;                           // no contributions (uniform across the workgroup)
         __syncthreads();
         float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
         for (uint32_t t = tid; t < T; t += kBlock) {
