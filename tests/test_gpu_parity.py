@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): relative L2 <= 1e-5 on the (H,W,T,3) tensor; int
 outputs (counters, (pixel,bin) sets) exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from conftest import make_cornell, rel_l2
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5   # relative L2, stated by BASELINE.json north_star
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def gpu_render(scene, spp, seed=0, raw=False, **kw):
@@ -364,6 +366,14 @@ def test_splat_add_partition_edge_cases(oracle, case):
     assert rel_l2(got, ref) <= TOL
     if case == "all_dropped_but_one":
         assert np.count_nonzero(ref[..., 0]) == 1
+
+
+def test_splat_add_soak_against_the_contract_form():
+    """tools/soak_splat.py, shortened: random film shapes, sizes across tile multiples, orders, zero / non-zero films, the
+    workspace reused and trimmed in between — variant 1 (LDS rows, partition) against variant 0 (f32 atomics)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_splat.py"), "3", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "12 calls OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_film_add_transient_data_api(oracle):
