@@ -49,7 +49,10 @@ enum { MTR_BSDF_DIFFUSE = 0, MTR_BSDF_CONDUCTOR = 1, MTR_BSDF_DIELECTRIC = 2,
        MTR_BSDF_ROUGHCONDUCTOR = 4, /* microfacet conductor, isotropic alpha, visible-normal sampling (mitsuba `roughconductor`,
                                        distribution = ggx | beckmann (MTR_MAT_BECKMANN), sample_visible = true): a smooth lobe,
                                        takes part in emitter sampling */
-       MTR_BSDF_ROUGHPLASTIC = 5    /* microfacet dielectric coat over a diffuse base (mitsuba `roughplastic`) */ };
+       MTR_BSDF_ROUGHPLASTIC = 5,   /* microfacet dielectric coat over a diffuse base (mitsuba `roughplastic`) */
+       MTR_BSDF_ROUGHDIELECTRIC = 6 /* rough refractive interface (mitsuba `roughdielectric`, ABI 11): int_ior / ext_ior, c = specular
+                                       reflectance, c2 = specular transmittance, alpha (MTR_MAT_ANISOTROPIC: alpha_v in b[0]);
+                                       transmissive, never under MTR_MAT_TWOSIDED */ };
 enum { MTR_MAT_TWOSIDED = 1u,
        MTR_MAT_NONLINEAR = 2u, /* roughplastic `nonlinear`: diffuse / (1 - diffuse * internal_reflectance) per channel */
        MTR_MAT_BECKMANN = 4u,  /* rough lobes (ABI 11): the Beckmann distribution — mitsuba's default `distribution` — instead of GGX */
@@ -61,7 +64,7 @@ typedef struct mtr_material {
     uint32_t type;        /* MTR_BSDF_*                                          */
     uint32_t flags;       /* MTR_MAT_*                                           */
     float    a[3];        /* diffuse: reflectance rgb | (rough)conductor: eta rgb | roughplastic: diffuse_reflectance rgb */
-    float    b[3];        /* (rough)conductor: k rgb                             */
+    float    b[3];        /* (rough)conductor: k rgb | roughdielectric with MTR_MAT_ANISOTROPIC: b[0] = alpha_v */
     float    c[3];        /* conductor/dielectric/rough*: specular_reflectance rgb */
     float    int_ior;     /* dielectric, roughplastic                            */
     float    ext_ior;     /* dielectric, roughplastic                            */

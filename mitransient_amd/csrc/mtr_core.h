@@ -1221,7 +1221,11 @@ MTR_HD void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float 
 MTR_HD float mf_eval(f3 m, float au, float av, bool beck) { return beck ? beck_eval(m, au, av) : ggx_eval(m, au, av); }
 MTR_HD float mf_smith_g1(f3 v, f3 m, float au, float av, bool beck) { return beck ? beck_smith_g1(v, m, au, av) : ggx_smith_g1(v, m, au, av); }
 // [RoughConductor: alpha_u, alpha_v] the second roughness of an anisotropic roughconductor travels in c2[0] (a field conductors do not use)
-MTR_HD float rough_alpha_v(const mtr_material &m) { return (m.flags & MTR_MAT_ANISOTROPIC) ? m.c2[0] : m.alpha; }
+// (roughdielectric: in b[0] — its c2 is the specular transmittance)
+MTR_HD float rough_alpha_v(const mtr_material &m)
+{
+    return (m.flags & MTR_MAT_ANISOTROPIC) ? (m.type == MTR_BSDF_ROUGHDIELECTRIC ? m.b[0] : m.c2[0]) : m.alpha;
+}
 
 // [MicrofacetDistribution::sample, sample_visible] visible normal for wi (cos_theta(wi) > 0) and its density
 MTR_HD f3 ggx_sample(f3 wi, float au, float av, float u1, float u2, float &pdf, bool beck = false)
@@ -1251,11 +1255,54 @@ MTR_HD float rough_transmittance(const mtr_material &m, float cos_theta)
     const float w1 = x - (float)i, w0 = 1.0f - w1;
     return fmaf(w0, m.external_transmittance[i], w1 * m.external_transmittance[i + 1u]);
 }
-MTR_HD bool bsdf_is_rough(uint32_t type) { return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC; }
+MTR_HD bool bsdf_is_rough(uint32_t type) { return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC || type == MTR_BSDF_ROUGHDIELECTRIC; }
+
+// ---- rough dielectric interface (MTR_BSDF_ROUGHDIELECTRIC; round 4) ----
+// [mitsuba3: src/bsdfs/roughdielectric.cpp, sample_visible = true, TransportMode::Radiance] Walter et al.'s microfacet model of a
+// refractive interface: reflection and transmission lobes around the half-vector / the generalised half-vector
+// m = normalize(wi + wo * eta).  wi may come from either side (no two-sided wrapper: the plugin is transmissive).
+MTR_HD f3 mulsign3(f3 v, float s) { return sign_neg(s) ? mk(-v.x, -v.y, -v.z) : v; }
+MTR_HD void rough_dielectric_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &val, float &pdf)
+{
+    val = mk(0, 0, 0); pdf = 0.0f;
+    const float ci = wi.z, co = wo.z;
+    if (ci == 0.0f) return;
+    const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
+    const float au = m.alpha, av = rough_alpha_v(m);
+    const bool reflect = ci * co > 0.0f;
+    const float eta_m = m.int_ior / m.ext_ior, inv_eta_m = m.ext_ior / m.int_ior;
+    const float eta = ci > 0.0f ? eta_m : inv_eta_m, inv_eta = ci > 0.0f ? inv_eta_m : eta_m;
+    const float sc = reflect ? 1.0f : eta;
+    f3 h = normalize(mk(fmaf(wo.x, sc, wi.x), fmaf(wo.y, sc, wi.y), fmaf(wo.z, sc, wi.z)));
+    h = mulsign3(h, h.z);                                             // into the hemisphere of the macro normal
+    const float D = mf_eval(h, au, av, beck);
+    const float wih = dot(wi, h), woh = dot(wo, h);
+    float F, ct, eit, eti;
+    fresnel_dielectric(wih, eta_m, F, ct, eit, eti);
+    const float g1i = mf_smith_g1(wi, h, au, av, beck);
+    const float G = g1i * mf_smith_g1(wo, h, au, av, beck);
+    const float t = fmaf(eta, woh, wih);
+    if (reflect) {
+        const float v = ((F * D) * G) / (4.0f * fabsf(ci));
+        val = mk(m.c[0] * v, m.c[1] * v, m.c[2] * v);
+    } else {
+        // radiance is scaled by the solid-angle compression across the interface (1 / eta^2)
+        const float scale = inv_eta * inv_eta;
+        const float v = fabsf(((((((scale * (1.0f - F)) * D) * G) * eta) * eta) * wih) * woh / (ci * (t * t)));
+        val = mk(m.c2[0] * v, m.c2[1] * v, m.c2[2] * v);
+    }
+    // the sides micro- and macro-surface must agree on (what smith_g1 enforces in eval and sample)
+    if (!(wih * ci > 0.0f && woh * co > 0.0f)) return;
+    const float dwh_dwo = reflect ? 1.0f / (4.0f * woh) : ((eta * eta) * woh) / (t * t);
+    const f3 wu = mulsign3(wi, ci);
+    const float pm = ((D * mf_smith_g1(wu, h, au, av, beck)) * fabsf(dot(wu, h))) / wu.z;       // MicrofacetDistribution::pdf, visible normals
+    pdf = fabsf((pm * dwh_dwo) * (reflect ? F : 1.0f - F));
+}
 // value (cosine included) and density of a rough lobe for local directions; wi, wo already on the two-sided side
 // [RoughConductor::eval / ::pdf, RoughPlastic::eval / ::pdf]
 MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &val, float &pdf)
 {
+    if (m.type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_eval_pdf(m, wi, wo, val, pdf); return; }
     val = mk(0, 0, 0); pdf = 0.0f;
     const float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
@@ -1297,8 +1344,45 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
 
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
 // [RoughConductor::sample, RoughPlastic::sample]; wi on the two-sided side
+// [RoughDielectric::sample]: a visible normal for wi flipped to the upper side, reflection with probability F, else refraction
+MTR_HD void rough_dielectric_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
+{
+    const float ci = wi.z;
+    if (ci == 0.0f) return;
+    const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
+    const float au = m.alpha, av = rough_alpha_v(m);
+    float pdf_m;
+    const f3 mm = ggx_sample(mulsign3(wi, ci), au, av, ua, ub, pdf_m, beck);
+    if (pdf_m == 0.0f) return;
+    const float wim = dot(wi, mm);
+    float F, ct, eit, eti;
+    fresnel_dielectric(wim, m.int_ior / m.ext_ior, F, ct, eit, eti);
+    const bool refl = u1 <= F;
+    float pdf = pdf_m * (refl ? F : 1.0f - F);
+    f3 wo, w; float dwh_dwo;
+    if (refl) {
+        wo = mk(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));     // reflect(wi, m)
+        bs.eta = 1.0f;
+        w = mk(m.c[0], m.c[1], m.c[2]);
+        dwh_dwo = 1.0f / (4.0f * dot(wo, mm));
+    } else {
+        const float k = fmaf(wim, eti, ct);                                                                        // refract(wi, m, cos_theta_t, eta_ti)
+        wo = mk(fmaf(mm.x, k, -(wi.x * eti)), fmaf(mm.y, k, -(wi.y * eti)), fmaf(mm.z, k, -(wi.z * eti)));
+        bs.eta = eit;
+        const float f2 = eti * eti;                                                                                // radiance: solid-angle compression
+        w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
+        const float wom = dot(wo, mm), t = fmaf(eit, wom, wim);
+        dwh_dwo = ((eit * eit) * wom) / (t * t);
+    }
+    const float g1 = mf_smith_g1(wo, mm, au, av, beck);
+    bs.wo = wo;
+    bs.pdf = pdf * fabsf(dwh_dwo);
+    bs.w = mk(w.x * g1, w.y * g1, w.z * g1);
+}
+
 MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
 {
+    if (m.type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_sample(m, wi, u1, ua, ub, bs); return; }
     const float ci = wi.z;
     if (!(ci > 0.0f)) return;
     const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;

@@ -217,7 +217,7 @@ class _SceneBuilder:
                 bd = dict(bd, type="conductor"); t = "conductor"
             elif t == "plastic" or (t == "roughplastic" and self.approx == "smooth"):
                 bd = {"type": "diffuse", "reflectance": bd.get("diffuse_reflectance", 0.5)}; t = "diffuse"
-            elif t in ("roughdielectric", "thindielectric"):
+            elif t == "thindielectric" or (t == "roughdielectric" and self.approx == "smooth"):
                 bd = dict(bd, type="dielectric"); t = "dielectric"
         if t == "twosided":
             inner = [v for k, v in bd.items() if isinstance(v, dict) and k != "type"]
@@ -225,7 +225,7 @@ class _SceneBuilder:
                 raise ValueError("twosided: exactly one nested BSDF is supported")
             inner_d, _ = self._resolve(inner[0])
             m = self._make_material(inner_d)
-            if m.type == _cabi.MTR_BSDF_DIELECTRIC:
+            if m.type in (_cabi.MTR_BSDF_DIELECTRIC, _cabi.MTR_BSDF_ROUGHDIELECTRIC):
                 raise ValueError("twosided: only materials without a transmission component can be nested")
             m.flags |= _cabi.MTR_MAT_TWOSIDED
             return m
@@ -249,6 +249,38 @@ class _SceneBuilder:
             m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
             sr = _color3(bd.get("specular_reflectance", 1.0), "dielectric.specular_reflectance")
             st = _color3(bd.get("specular_transmittance", 1.0), "dielectric.specular_transmittance")
+            for k in range(3):
+                m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
+        elif t == "roughdielectric":
+            # [mitsuba3: src/bsdfs/roughdielectric.cpp] rough refractive interface: distribution (beckmann by default), alpha or
+            # alpha_u + alpha_v, int_ior / ext_ior, specular_reflectance / specular_transmittance; visible-normal sampling
+            m.type = _cabi.MTR_BSDF_ROUGHDIELECTRIC
+            distribution = str(bd.get("distribution", "beckmann"))
+            if distribution not in ("ggx", "beckmann"):
+                raise ValueError(f"roughdielectric: distribution must be \"beckmann\" or \"ggx\", not \"{distribution}\"")
+            if distribution == "beckmann":
+                m.flags |= _cabi.MTR_MAT_BECKMANN
+            if not bd.get("sample_visible", True):
+                raise ValueError("roughdielectric: sample_visible = false is not available")
+            alpha = bd.get("alpha", 0.1)
+            if "alpha_u" in bd or "alpha_v" in bd:
+                if "alpha" in bd or not ("alpha_u" in bd and "alpha_v" in bd):
+                    raise ValueError("roughdielectric: specify either alpha or alpha_u and alpha_v")
+                alpha = bd["alpha_u"]
+                if isinstance(bd["alpha_v"], dict):
+                    raise ValueError("roughdielectric: textured alpha is not available")
+                if not isinstance(alpha, dict) and np.float32(bd["alpha_v"]) != np.float32(alpha):
+                    m.flags |= _cabi.MTR_MAT_ANISOTROPIC
+                    m.b[0] = np.float32(bd["alpha_v"])           # (c2 is the transmittance: alpha_v travels in b[0])
+            if isinstance(alpha, dict):
+                raise ValueError("roughdielectric: textured alpha is not available")
+            m.alpha = np.float32(alpha)
+            m.int_ior = np.float32(_ior(bd.get("int_ior"), "bk7"))
+            m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
+            if m.int_ior == m.ext_ior:
+                raise ValueError("roughdielectric: the interior and exterior indices of refraction must differ")
+            sr = _color3(bd.get("specular_reflectance", 1.0), "roughdielectric.specular_reflectance")
+            st = _color3(bd.get("specular_transmittance", 1.0), "roughdielectric.specular_transmittance")
             for k in range(3):
                 m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
         elif t in ("roughconductor", "roughplastic"):
@@ -304,7 +336,7 @@ class _SceneBuilder:
                 d_mean = float(np.mean([np.float32(x) for x in diff])); s_mean = float(np.mean([np.float32(x) for x in sr]))
                 m.specular_sampling_weight = np.float32(s_mean / (d_mean + s_mean))
         else:
-            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, roughconductor, roughplastic, twosided)")
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, roughconductor, roughplastic, roughdielectric, twosided)")
         return m
 
     # -- shapes ------------------------------------------------------------
@@ -823,9 +855,14 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
             mats, ems = [], []
             for m in b.materials:
                 m = type(m).from_buffer_copy(m)
+                aniso = bool(m.flags & _cabi.MTR_MAT_ANISOTROPIC)            # alpha_v travels in c2[0] (roughconductor) / b[0] (roughdielectric)
+                keep = ("b" if m.type == _cabi.MTR_BSDF_ROUGHDIELECTRIC else "c2") if aniso else None
+                alpha_v = getattr(m, keep)[0] if keep else None
                 for fld in ("a", "b", "c", "c2"):
                     arr = getattr(m, fld)
                     arr[0] = arr[1] = arr[2] = lum3(arr)
+                if keep:
+                    getattr(m, keep)[0] = alpha_v
                 if m.type == _cabi.MTR_BSDF_ROUGHPLASTIC and (m.a[0] + m.c[0]) > 0:
                     m.specular_sampling_weight = np.float32(m.c[0] / (m.a[0] + m.c[0]))
                 mats.append(m)

@@ -843,7 +843,10 @@ static void beck_sample_visible_11(float cos_theta_i, float u1, float u2, float 
 static float mf_eval(v3 m, float au, float av, int beck) { return beck ? beck_eval(m, au, av) : ggx_eval(m, au, av); }
 static float mf_smith_g1(v3 v, v3 m, float au, float av, int beck) { return beck ? beck_smith_g1(v, m, au, av) : ggx_smith_g1(v, m, au, av); }
 /* [RoughConductor: alpha_u, alpha_v] MTR_MAT_ANISOTROPIC: the roughness along the bitangent travels in c2[0] */
-static float rough_alpha_v(const mtr_material *m) { return (m->flags & MTR_MAT_ANISOTROPIC) ? m->c2[0] : m->alpha; }
+static float rough_alpha_v(const mtr_material *m)
+{
+    return (m->flags & MTR_MAT_ANISOTROPIC) ? (m->type == MTR_BSDF_ROUGHDIELECTRIC ? m->b[0] : m->c2[0]) : m->alpha;
+}
 
 /* [MicrofacetDistribution::sample], visible normals: stretch, sample the slope, rotate + unstretch, normal and density */
 static v3 ggx_sample(v3 wi, float au, float av, float u1, float u2, float *pdf, int beck)
@@ -873,12 +876,55 @@ static float rough_transmittance(const mtr_material *m, float cos_theta)
     float w1 = x - (float)i, w0 = 1.0f - w1;
     return fmaf(w0, m->external_transmittance[i], w1 * m->external_transmittance[i + 1u]);
 }
-static int bsdf_is_rough(const mtr_material *m) { return m->type == MTR_BSDF_ROUGHCONDUCTOR || m->type == MTR_BSDF_ROUGHPLASTIC; }
+static int bsdf_is_rough(const mtr_material *m)
+{
+    return m->type == MTR_BSDF_ROUGHCONDUCTOR || m->type == MTR_BSDF_ROUGHPLASTIC || m->type == MTR_BSDF_ROUGHDIELECTRIC;
+}
 static float fresnel_conductor(float cos_i, float eta_r, float eta_i);
 static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, float *eta_it, float *eta_ti);
 /* [RoughConductor::eval / ::pdf], [RoughPlastic::eval / ::pdf]; wi, wo local, already on the two-sided side */
+/* [mitsuba3: src/bsdfs/roughdielectric.cpp — RoughDielectric::eval / ::pdf, sample_visible = true, TransportMode::Radiance; restated
+ * from the published source, unverified here].  reflect = cos_theta_i cos_theta_o > 0; m = normalize(wi + wo * (reflect ? 1 : eta)),
+ * flipped into the macro normal's hemisphere; F D G / (4 |cos_i|) or |scale (1 - F) D G eta^2 (wi.m)(wo.m) / (cos_i (wi.m + eta wo.m)^2)|,
+ * scale = 1 / eta^2; pdf = distr.pdf(mulsign(wi, cos_i), m) |dwh_dwo| (F | 1 - F) where micro- and macro-surface agree on the sides */
+static v3 mulsign3(v3 v, float s) { return (s < 0.0f || (s == 0.0f && signbit(s))) ? V(-v.x, -v.y, -v.z) : v; }
+static void rough_dielectric_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
+{
+    val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
+    float ci = wi.z, co = wo.z;
+    if (ci == 0.0f) return;
+    int beck = (m->flags & MTR_MAT_BECKMANN) != 0u;
+    float au = m->alpha, av = rough_alpha_v(m);
+    int reflect = ci * co > 0.0f;
+    float eta_m = m->int_ior / m->ext_ior, inv_eta_m = m->ext_ior / m->int_ior;
+    float eta = ci > 0.0f ? eta_m : inv_eta_m, inv_eta = ci > 0.0f ? inv_eta_m : eta_m;
+    float sc = reflect ? 1.0f : eta;
+    v3 h = vnormalize(V(fmaf(wo.x, sc, wi.x), fmaf(wo.y, sc, wi.y), fmaf(wo.z, sc, wi.z)));
+    h = mulsign3(h, h.z);
+    float D = mf_eval(h, au, av, beck);
+    float wih = vdot(wi, h), woh = vdot(wo, h);
+    float F, ct, eit, eti;
+    fresnel_dielectric(wih, eta_m, &F, &ct, &eit, &eti);
+    float g1i = mf_smith_g1(wi, h, au, av, beck);
+    float G = g1i * mf_smith_g1(wo, h, au, av, beck);
+    float t = fmaf(eta, woh, wih);
+    if (reflect) {
+        float v = ((F * D) * G) / (4.0f * fabsf(ci));
+        for (int k = 0; k < 3; ++k) val[k] = m->c[k] * v;
+    } else {
+        float scale = inv_eta * inv_eta;
+        float v = fabsf(((((((scale * (1.0f - F)) * D) * G) * eta) * eta) * wih) * woh / (ci * (t * t)));
+        for (int k = 0; k < 3; ++k) val[k] = m->c2[k] * v;
+    }
+    if (!(wih * ci > 0.0f && woh * co > 0.0f)) return;
+    float dwh_dwo = reflect ? 1.0f / (4.0f * woh) : ((eta * eta) * woh) / (t * t);
+    v3 wu = mulsign3(wi, ci);
+    float pm = ((D * mf_smith_g1(wu, h, au, av, beck)) * fabsf(vdot(wu, h))) / wu.z;
+    *pdf = fabsf((pm * dwh_dwo) * (reflect ? F : 1.0f - F));
+}
 static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
 {
+    if (m->type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_eval_pdf(m, wi, wo, val, pdf); return; }
     val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
     float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
@@ -981,6 +1027,38 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
         rough_eval_pdf(m, wi, wo, val, &pdf);
         bs->pdf = pdf;
         if (pdf > 0.0f) { float ip = 1.0f / pdf; for (int k = 0; k < 3; ++k) bs->w[k] = val[k] * ip; }
+        break; }
+    case MTR_BSDF_ROUGHDIELECTRIC: {         /* [RoughDielectric::sample]: visible normal for wi flipped up; reflect with probability F */
+        if (ci == 0.0f) break;
+        int beck = (m->flags & MTR_MAT_BECKMANN) != 0u;
+        float au = m->alpha, av = rough_alpha_v(m);
+        float pdf_m;
+        v3 mm = ggx_sample(mulsign3(wi, ci), au, av, ua, ub, &pdf_m, beck);
+        if (pdf_m == 0.0f) break;
+        float wim = vdot(wi, mm);
+        float F, ct, eit, eti;
+        fresnel_dielectric(wim, m->int_ior / m->ext_ior, &F, &ct, &eit, &eti);
+        int refl = u1 <= F;
+        float pdf = pdf_m * (refl ? F : 1.0f - F);
+        v3 wo; float w[3], dwh_dwo;
+        if (refl) {
+            wo = V(fmaf(mm.x, 2.0f * wim, -wi.x), fmaf(mm.y, 2.0f * wim, -wi.y), fmaf(mm.z, 2.0f * wim, -wi.z));
+            bs->eta = 1.0f;
+            for (int k = 0; k < 3; ++k) w[k] = m->c[k];
+            dwh_dwo = 1.0f / (4.0f * vdot(wo, mm));
+        } else {
+            float kk = fmaf(wim, eti, ct);                    /* refract(wi, m, cos_theta_t, eta_ti) */
+            wo = V(fmaf(mm.x, kk, -(wi.x * eti)), fmaf(mm.y, kk, -(wi.y * eti)), fmaf(mm.z, kk, -(wi.z * eti)));
+            bs->eta = eit;
+            float f2 = eti * eti;
+            for (int k = 0; k < 3; ++k) w[k] = m->c2[k] * f2;
+            float wom = vdot(wo, mm), t = fmaf(eit, wom, wim);
+            dwh_dwo = ((eit * eit) * wom) / (t * t);
+        }
+        float g1 = mf_smith_g1(wo, mm, au, av, beck);
+        bs->wo = wo;
+        bs->pdf = pdf * fabsf(dwh_dwo);
+        for (int k = 0; k < 3; ++k) bs->w[k] = w[k] * g1;
         break; }
     default: break;
     }

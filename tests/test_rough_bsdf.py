@@ -29,6 +29,11 @@ def _mat(kind, alpha=0.1, twosided=False, nonlinear=True, diffuse=(0.5, 0.3, 0.2
     else:
         bd = {"type": "roughplastic", **dist, "alpha": alpha, "int_ior": 1.5, "ext_ior": 1.0,
               "nonlinear": nonlinear, "diffuse_reflectance": {"type": "rgb", "value": list(diffuse)}}
+    if kind.startswith("roughdielectric"):
+        rough = {"alpha_u": alpha, "alpha_v": 3.0 * alpha} if kind.endswith("-aniso") else {"alpha": alpha}
+        bd = {"type": "roughdielectric", **dist, **rough, "int_ior": 1.5, "ext_ior": 1.0,
+              "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.7]},
+              "specular_transmittance": {"type": "rgb", "value": [0.7, 0.9, 0.8]}}
     if twosided:
         bd = {"type": "twosided", "bsdf": bd}
     return _SceneBuilder({}, ".")._make_material(bd)
@@ -247,13 +252,130 @@ def test_rough_plastic_tables():
     assert np.all(np.diff(ext[8:]) > -1e-3) and 0.9 < ext[-1] < 0.97 and 0.3 < ext[0] < 0.8
 
 
+# ---- roughdielectric: a transmissive lobe — directions on the whole sphere, wi from either side ---------------------------
+DKINDS = ["roughdielectric", "roughdielectric-beckmann", "roughdielectric-aniso"]
+
+
+def _sphere_grid(n_t=512, n_p=1024):
+    ct = (np.arange(n_t) + 0.5) / n_t * 2 - 1
+    ph = (np.arange(n_p) + 0.5) / n_p * 2 * np.pi
+    CT, PH = np.meshgrid(ct, ph, indexing="ij")
+    st = np.sqrt(1 - CT * CT)
+    d = np.stack([st * np.cos(PH), st * np.sin(PH), CT], -1).reshape(-1, 3).astype(np.float32)
+    return np.ascontiguousarray(d), 4 * np.pi / (n_t * n_p)
+
+
+@pytest.mark.parametrize("kind", DKINDS)
+@pytest.mark.parametrize("alpha", [0.05, 0.3])
+def test_rough_dielectric_product_equals_oracle(oracle, host_harness, kind, alpha):
+    """every bit of eval / pdf / sample for directions on the whole sphere (wi inside and outside, grazing, perpendicular)"""
+    rng = np.random.default_rng(4)
+    m = _mat(kind, alpha)
+    n = 200000
+    wi, wo = _dirs(n, rng, upper=False), _dirs(n, rng, upper=False)
+    wi[:1000, 2] *= 1e-3; wo[1000:2000, 2] *= 1e-3
+    wi[2000:2050] = [0, 0, 1]; wi[2050:2100] = [0, 0, -1]
+    v0, p0 = _eval(oracle.lib(), "orc_", m, wi, wo)
+    v1, p1 = _eval(host_harness, "hh_", m, wi, wo)
+    assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+    assert (p0 > 0).mean() > 0.02 and np.isfinite(v0).all() and np.isfinite(p0).all()
+    u = rng.random((3, n)).astype(np.float32)
+    a = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+    b = _sample(host_harness, "hh_", m, wi, u[0], u[1], u[2])
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all() and np.isfinite(a[2]).all()
+
+
+@pytest.mark.parametrize("kind", DKINDS)
+@pytest.mark.parametrize("side", [1.0, -1.0], ids=["from-outside", "from-inside"])
+def test_rough_dielectric_density_samples_and_weights(oracle, kind, side):
+    """the density integrates over the SPHERE to the usable-sample fraction; the density reported with a sample is the density
+    of that direction; weight x pdf = value; the sampled directions follow the density (both lobes, either side); reflected
+    plus transmitted energy stays below one"""
+    m = _mat(kind, 0.25)
+    g, dw = _sphere_grid(1536, 3072)             # (fine: a Beckmann lobe falls off fast across a histogram cell)
+    rng = np.random.default_rng(6)
+    for mu in (0.9, 0.5):
+        wi1 = np.array([[np.sqrt(1 - mu * mu), 0, side * mu]], np.float32)
+        val, pdf = _eval(oracle.lib(), "orc_", m, np.tile(wi1, (len(g), 1)), g)
+        total = pdf.astype(np.float64).sum() * dw
+        n = 400000
+        wi = np.tile(wi1, (n, 1))
+        u = rng.random((3, n)).astype(np.float32)
+        wo, spdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+        ok = (spdf > 0) & (w.max(1) > 0)
+        assert abs(total - ok.mean()) < 0.015 and 0.5 < total <= 1.002, (kind, side, mu, total, ok.mean())
+        sval, spdf2 = _eval(oracle.lib(), "orc_", m, np.ascontiguousarray(wi[ok]), np.ascontiguousarray(wo[ok]))
+        assert np.allclose(spdf[ok], spdf2, rtol=5e-4, atol=1e-6)
+        assert np.allclose(w[ok] * spdf[ok, None], sval, rtol=3e-3, atol=1e-6)
+        # both lobes are taken, in the proportion the densities of the two hemispheres integrate to
+        up = g[:, 2] * side > 0
+        frac_r = pdf[up].astype(np.float64).sum() * dw / total
+        assert abs((wo[ok, 2] * side > 0).mean() - frac_r) < 0.01 and 0.01 < frac_r < 0.995          # (from inside at 60 degrees nearly everything is reflected: past the critical angle)
+        # histogram on the sphere
+        n_t, n_p = 24, 16
+        cell = lambda d: np.minimum(((d[:, 2] + 1) / 2 * n_t).astype(int), n_t - 1) * n_p + \
+            np.minimum(((np.arctan2(d[:, 1], d[:, 0]) / (2 * np.pi)) % 1.0 * n_p).astype(int), n_p - 1)
+        hist = np.bincount(cell(wo[ok]), minlength=n_t * n_p).astype(np.float64) / n
+        expect = np.bincount(cell(g), weights=pdf.astype(np.float64) * dw, minlength=n_t * n_p)
+        big = expect > 5e-4
+        assert big.sum() > 5                         # (Beckmann's lobes are narrow: a handful of cells hold them)
+        assert np.all(np.abs(hist[big] - expect[big]) < 6 * np.sqrt(expect[big] / n) + 0.03 * expect[big])
+        # energy: reflectance + transmittance (radiance leaving into a medium of index n carries n^2: undo the 1 / eta^2 scale)
+        eta = 1.5 if side > 0 else 1 / 1.5
+        refl = val[up].astype(np.float64).sum(0) * dw
+        tran = val[~up].astype(np.float64).sum(0) * dw * eta * eta
+        assert np.all(refl / np.array([0.9, 0.8, 0.7]) + tran / np.array([0.7, 0.9, 0.8]) <= 1.0 + 5e-3)
+        assert np.all(refl + tran > 0.3)
+
+
+def test_rough_dielectric_plugin_rules():
+    from mitransient_amd import _cabi
+    from mitransient_amd.scene import _SceneBuilder
+    mk = lambda bd: _SceneBuilder({}, ".")._make_material(bd)
+    m = mk({"type": "roughdielectric"})                                   # mitsuba's defaults: beckmann, alpha 0.1, bk7 in air
+    assert m.type == _cabi.MTR_BSDF_ROUGHDIELECTRIC and m.flags & _cabi.MTR_MAT_BECKMANN and abs(m.alpha - 0.1) < 1e-7
+    assert abs(m.int_ior - 1.5046) < 1e-4 and abs(m.ext_ior - 1.000277) < 1e-5
+    m = mk({"type": "roughdielectric", "distribution": "ggx", "alpha_u": 0.1, "alpha_v": 0.2})
+    assert m.flags & _cabi.MTR_MAT_ANISOTROPIC and abs(m.b[0] - 0.2) < 1e-7 and m.c2[0] == 1.0
+    with pytest.raises(ValueError):
+        mk({"type": "twosided", "bsdf": {"type": "roughdielectric"}})     # transmissive: not under twosided
+    with pytest.raises(ValueError):
+        mk({"type": "roughdielectric", "int_ior": 1.3, "ext_ior": 1.3})
+
+
+def test_rough_dielectric_tends_to_the_smooth_dielectric(oracle):
+    """alpha -> 0: a glass box with a barely rough interface renders (steady image, mean over the frame) like the `dielectric`
+    one — reflection, refraction, the eta bookkeeping of paths inside and the radiance scaling all enter"""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    means = {}
+    for name, bsdf in (("rough", {"type": "roughdielectric", "distribution": "ggx", "alpha": 0.002, "int_ior": 1.5, "ext_ior": 1.0}),
+                       ("smooth", {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0})):
+        d = mitr.cornell_box()
+        d["sensor"]["film"].update(width=16, height=16, temporal_bins=8, start_opl=0.0, bin_width_opl=4.0)
+        d["integrator"].update(max_depth=12, rr_depth=20)
+        d["small-box"]["bsdf"] = bsdf
+        d["large-box"]["bsdf"] = bsdf
+        scene = mi.load_dict(d)
+        p = scene.integrator().render_params(scene.sensors()[0].film(), 0, 256)
+        t4, s4, cnt = oracle.render(scene.data(), p)
+        img = s4[..., :3] / s4[..., 3:4]
+        means[name] = (img.mean(), img.std() / np.sqrt(img.size), cnt["rays_closest"])
+    (a, sa, ra), (b, sb, rb) = means["rough"], means["smooth"]
+    assert abs(a - b) < 0.03 * b + 6 * (sa + sb), (means)
+    assert abs(ra - rb) < 0.02 * rb                       # paths are as long: the same number of rays
+
+
 def _rough_cornell(distribution="ggx", **film):
     """distribution: "ggx", "beckmann", or None = no key at all (mitsuba's default: Beckmann)"""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
     aniso = distribution == "aniso"            # Beckmann by default + anisotropic roughconductors (one of them GGX)
-    dk = {} if distribution is None or aniso else {"distribution": distribution}
+    dk = {} if distribution in (None, "glass") or aniso else {"distribution": distribution}
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
     d["sensor"]["film"].update(film)
@@ -265,13 +387,17 @@ def _rough_cornell(distribution="ggx", **film):
                                                       "diffuse_reflectance": {"type": "rgb", "value": [0.2, 0.5, 0.7]}}}
     d["small-box"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "roughconductor", **dk, "alpha": 0.05,
                                                            "eta": 0.2, "k": 3.9}}
+    if distribution == "glass":                # rough refractive boxes: paths go through them (eta changes, both lobes, both sides)
+        d["small-box"]["bsdf"] = {"type": "roughdielectric", "distribution": "ggx", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
+        d["large-box"]["bsdf"] = {"type": "roughdielectric", "alpha_u": 0.05, "alpha_v": 0.2, "int_ior": "water",
+                                  "specular_transmittance": {"type": "rgb", "value": [0.8, 0.95, 0.9]}}
     if aniso:
         d["large-box"]["bsdf"].pop("alpha"); d["large-box"]["bsdf"].update(alpha_u=0.1, alpha_v=0.3)
         d["small-box"]["bsdf"]["bsdf"].pop("alpha"); d["small-box"]["bsdf"]["bsdf"].update(alpha_u=0.15, alpha_v=0.05, distribution="ggx")
     return d
 
 
-@pytest.mark.parametrize("distribution", ["ggx", None, "aniso"], ids=["ggx", "beckmann-by-default", "anisotropic"])
+@pytest.mark.parametrize("distribution", ["ggx", None, "aniso", "glass"], ids=["ggx", "beckmann-by-default", "anisotropic", "roughdielectric"])
 @pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-8"])
 def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide, distribution):
     import mitransient_amd.mi as mi
@@ -292,7 +418,7 @@ def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide, distri
     assert np.count_nonzero(t4) > 3000 and np.isfinite(t4).all()
 
 
-@pytest.mark.parametrize("distribution", ["ggx", "beckmann"])
+@pytest.mark.parametrize("distribution", ["ggx", "beckmann", "glass"])
 def test_energy_identity_with_rough_materials(oracle, distribution):
     """transient.sum(time) == steady when the window holds every path (1-simple-nlos-scenes.ipynb md cell 8)"""
     import mitransient_amd.mi as mi

@@ -73,7 +73,7 @@ def test_plugin_defaults_and_errors():
     with pytest.raises(ValueError, match="unknown plugin"):
         mi.load_dict(d)
     d = mitr.cornell_box()
-    d["floor"]["bsdf"] = {"type": "roughdielectric"}
+    d["floor"]["bsdf"] = {"type": "hair"}
     with pytest.raises(ValueError, match="unknown plugin"):
         mi.load_dict(d).data()
     d["floor"]["bsdf"] = {"type": "roughplastic", "distribution": "phong"}      # beckmann (mitsuba's default) and ggx are built
