@@ -50,9 +50,14 @@ enum { MTR_BSDF_DIFFUSE = 0, MTR_BSDF_CONDUCTOR = 1, MTR_BSDF_DIELECTRIC = 2,
                                        distribution = ggx | beckmann (MTR_MAT_BECKMANN), sample_visible = true): a smooth lobe,
                                        takes part in emitter sampling */
        MTR_BSDF_ROUGHPLASTIC = 5,   /* microfacet dielectric coat over a diffuse base (mitsuba `roughplastic`) */
-       MTR_BSDF_ROUGHDIELECTRIC = 6 /* rough refractive interface (mitsuba `roughdielectric`, ABI 11): int_ior / ext_ior, c = specular
+       MTR_BSDF_ROUGHDIELECTRIC = 6, /* rough refractive interface (mitsuba `roughdielectric`, ABI 11): int_ior / ext_ior, c = specular
                                        reflectance, c2 = specular transmittance, alpha (MTR_MAT_ANISOTROPIC: alpha_v in b[0]);
-                                       transmissive, never under MTR_MAT_TWOSIDED */ };
+                                       transmissive, never under MTR_MAT_TWOSIDED */
+       MTR_BSDF_THINDIELECTRIC = 7, /* thin dielectric slab (mitsuba `thindielectric`, ABI 11): two delta lobes, no refraction, eta stays 1;
+                                       int_ior / ext_ior, c / c2 = specular reflectance / transmittance */
+       MTR_BSDF_PLASTIC = 8         /* smooth dielectric coat over a diffuse base (mitsuba `plastic`, ABI 11): a = diffuse_reflectance,
+                                       c = specular_reflectance, int_ior / ext_ior, MTR_MAT_NONLINEAR, internal_reflectance =
+                                       fresnel_diffuse_reflectance(1 / eta), specular_sampling_weight                              */ };
 enum { MTR_MAT_TWOSIDED = 1u,
        MTR_MAT_NONLINEAR = 2u, /* roughplastic `nonlinear`: diffuse / (1 - diffuse * internal_reflectance) per channel */
        MTR_MAT_BECKMANN = 4u,  /* rough lobes (ABI 11): the Beckmann distribution — mitsuba's default `distribution` — instead of GGX */

@@ -15,7 +15,7 @@ MTR_ABI_VERSION = 11
 MTR_SPLAT_FILM_ZERO = 0x100      # mtr_splat_add: OR into `variant` when the film is all-zero on entry
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
-MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC, MTR_BSDF_ROUGHDIELECTRIC = 4, 5, 6
+MTR_BSDF_ROUGHCONDUCTOR, MTR_BSDF_ROUGHPLASTIC, MTR_BSDF_ROUGHDIELECTRIC, MTR_BSDF_THINDIELECTRIC, MTR_BSDF_PLASTIC = 4, 5, 6, 7, 8
 MTR_MAT_TWOSIDED, MTR_MAT_NONLINEAR, MTR_MAT_BECKMANN, MTR_MAT_ANISOTROPIC = 1, 2, 4, 8
 MTR_ROUGH_TRANSMITTANCE_RES = 64
 MTR_FLAG_CAMERA_UNWARP = 1

@@ -212,7 +212,8 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.n_nodes = (uint32_t)hs.nodes.size(); s->dev.n_slots = (uint32_t)hs.tshade.size();
     s->dev.n_mats = d->n_materials; s->dev.n_ems = d->n_emitters;
     s->dev.has_rough = 0u;
-    for (uint32_t i = 0; i < d->n_materials; ++i) if (bsdf_is_rough(d->materials[i].type)) s->dev.has_rough = 1u;
+    for (uint32_t i = 0; i < d->n_materials; ++i)
+        if (bsdf_is_rough(d->materials[i].type) || d->materials[i].type == MTR_BSDF_THINDIELECTRIC) s->dev.has_rough = 1u;
     if (!hs.vnormals.empty() || !hs.texels.empty()) s->dev.has_rough = 1u;      // smooth-shaded triangles, bitmap textures: the extended shading code as well
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;

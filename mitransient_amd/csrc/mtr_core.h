@@ -1255,7 +1255,40 @@ MTR_HD float rough_transmittance(const mtr_material &m, float cos_theta)
     const float w1 = x - (float)i, w0 = 1.0f - w1;
     return fmaf(w0, m.external_transmittance[i], w1 * m.external_transmittance[i + 1u]);
 }
-MTR_HD bool bsdf_is_rough(uint32_t type) { return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC || type == MTR_BSDF_ROUGHDIELECTRIC; }
+// the SMOOTH lobes of the extended shading code (emitter sampling + MIS apply; eval / pdf / sample through rough_eval_pdf and
+// rough_sample): the microfacet lobes and — round 4 — `plastic`, whose diffuse base is smooth and whose coat is a delta lobe
+MTR_HD bool bsdf_is_rough(uint32_t type)
+{
+    return type == MTR_BSDF_ROUGHCONDUCTOR || type == MTR_BSDF_ROUGHPLASTIC || type == MTR_BSDF_ROUGHDIELECTRIC || type == MTR_BSDF_PLASTIC;
+}
+// ---- plastic (MTR_BSDF_PLASTIC; round 4) [mitsuba3: src/bsdfs/plastic.cpp] ----
+// a smooth dielectric coat over a diffuse base with internal scattering: eval / pdf see the diffuse lobe only (the coat is a
+// delta lobe), internal_reflectance = fresnel_diffuse_reflectance(1 / eta) (computed by the caller, as mitsuba does at build time)
+MTR_HD void plastic_probs(const mtr_material &m, float f_i, float &ps, float &pdif)
+{
+    ps = f_i * m.specular_sampling_weight; pdif = (1.0f - f_i) * (1.0f - m.specular_sampling_weight);
+    ps = ps / (ps + pdif); pdif = 1.0f - ps;
+}
+MTR_HD void plastic_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &val, float &pdf)
+{
+    val = mk(0, 0, 0); pdf = 0.0f;
+    const float ci = wi.z, co = wo.z;
+    if (!(ci > 0.0f && co > 0.0f)) return;
+    const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+    float f_i, f_o, ct, eit, eti;
+    fresnel_dielectric(ci, eta, f_i, ct, eit, eti);
+    fresnel_dielectric(co, eta, f_o, ct, eit, eti);
+    float ps, pdif;
+    plastic_probs(m, f_i, ps, pdif);
+    const float cpdf = kInvPi * co;
+    pdf = cpdf * pdif;
+    const float scale = ((cpdf * inv_eta_2) * (1.0f - f_i)) * (1.0f - f_o);
+    const float a[3] = { albedo.x, albedo.y, albedo.z };
+    float o[3];
+    for (int k = 0; k < 3; ++k)
+        o[k] = (a[k] / (1.0f - ((m.flags & MTR_MAT_NONLINEAR) ? a[k] * m.internal_reflectance : m.internal_reflectance))) * scale;
+    val = mk(o[0], o[1], o[2]);
+}
 
 // ---- rough dielectric interface (MTR_BSDF_ROUGHDIELECTRIC; round 4) ----
 // [mitsuba3: src/bsdfs/roughdielectric.cpp, sample_visible = true, TransportMode::Radiance] Walter et al.'s microfacet model of a
@@ -1303,6 +1336,7 @@ MTR_HD void rough_dielectric_eval_pdf(const mtr_material &m, f3 wi, f3 wo, f3 &v
 MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &val, float &pdf)
 {
     if (m.type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_eval_pdf(m, wi, wo, val, pdf); return; }
+    if (m.type == MTR_BSDF_PLASTIC) { plastic_eval_pdf(m, albedo, wi, wo, val, pdf); return; }
     val = mk(0, 0, 0); pdf = 0.0f;
     const float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
@@ -1343,6 +1377,45 @@ MTR_HD void rough_eval_pdf(const mtr_material &m, f3 albedo, f3 wi, f3 wo, f3 &v
 }
 
 struct BsdfSample { f3 wo; float pdf, eta; bool delta; f3 w; };
+// [Plastic::sample]: the coat's mirror direction with probability ps (a delta lobe), else a cosine-weighted direction of the base
+MTR_HD void plastic_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
+{
+    const float ci = wi.z;
+    if (!(ci > 0.0f)) return;
+    const float eta = m.int_ior / m.ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+    float f_i, ct, eit, eti;
+    fresnel_dielectric(ci, eta, f_i, ct, eit, eti);
+    float ps, pdif;
+    plastic_probs(m, f_i, ps, pdif);
+    if (u1 < ps) {
+        bs.wo = mk(-wi.x, -wi.y, wi.z); bs.pdf = ps; bs.delta = true;
+        const float s = f_i / ps;
+        bs.w = mk(m.c[0] * s, m.c[1] * s, m.c[2] * s);
+    } else {
+        const f3 wo = cosine_hemisphere(ua, ub);
+        float f_o;
+        fresnel_dielectric(wo.z, eta, f_o, ct, eit, eti);
+        bs.wo = wo; bs.pdf = pdif * (kInvPi * wo.z);
+        const float scale = ((inv_eta_2 * (1.0f - f_i)) * (1.0f - f_o)) / pdif;
+        const float a[3] = { albedo.x, albedo.y, albedo.z };
+        float o[3];
+        for (int k = 0; k < 3; ++k)
+            o[k] = (a[k] / (1.0f - ((m.flags & MTR_MAT_NONLINEAR) ? a[k] * m.internal_reflectance : m.internal_reflectance))) * scale;
+        if (bs.pdf > 0.0f) bs.w = mk(o[0], o[1], o[2]);
+    }
+}
+// [ThinDielectric::sample] a thin slab: no refraction, the internal reflections folded into r' = 2 r / (1 + r); two delta lobes
+MTR_HD void thin_dielectric_sample(const mtr_material &m, f3 wi, float u1, BsdfSample &bs)
+{
+    float r, ct, eit, eti;
+    fresnel_dielectric(fabsf(wi.z), m.int_ior / m.ext_ior, r, ct, eit, eti);
+    if (r < 1.0f) r *= 2.0f / (1.0f + r);
+    const bool refl = u1 <= r;
+    bs.delta = true; bs.eta = 1.0f;
+    bs.pdf = refl ? r : 1.0f - r;
+    if (refl) { bs.wo = mk(-wi.x, -wi.y, wi.z); bs.w = mk(m.c[0], m.c[1], m.c[2]); }
+    else { bs.wo = mk(-wi.x, -wi.y, -wi.z); bs.w = mk(m.c2[0], m.c2[1], m.c2[2]); }
+}
 // [RoughConductor::sample, RoughPlastic::sample]; wi on the two-sided side
 // [RoughDielectric::sample]: a visible normal for wi flipped to the upper side, reflection with probability F, else refraction
 MTR_HD void rough_dielectric_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
@@ -1383,6 +1456,7 @@ MTR_HD void rough_dielectric_sample(const mtr_material &m, f3 wi, float u1, floa
 MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, float ua, float ub, BsdfSample &bs)
 {
     if (m.type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_sample(m, wi, u1, ua, ub, bs); return; }
+    if (m.type == MTR_BSDF_PLASTIC) { plastic_sample(m, albedo, wi, u1, ua, ub, bs); return; }
     const float ci = wi.z;
     if (!(ci > 0.0f)) return;
     const bool beck = (m.flags & MTR_MAT_BECKMANN) != 0u;
@@ -1447,6 +1521,7 @@ MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, 
             bs.w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
         }
     } else if (ROUGH && bsdf_is_rough(m.type)) rough_sample(m, albedo, wi, u1, ua, ub, bs);
+    else if (ROUGH && m.type == MTR_BSDF_THINDIELECTRIC) thin_dielectric_sample(m, wi, u1, bs);
     if (flip) bs.wo.z = -bs.wo.z;
     return bs;
 }

@@ -127,9 +127,9 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         if (d.tri_emitter[i] >= (int32_t)d.n_emitters) return "triangle references an unknown emitter";
     }
     for (uint32_t i = 0; i < d.n_materials; ++i)
-        if (d.materials[i].type > MTR_BSDF_ROUGHDIELECTRIC) return "unknown BSDF type";
+        if (d.materials[i].type > MTR_BSDF_PLASTIC) return "unknown BSDF type";
     for (uint32_t i = 0; i < d.n_materials; ++i)
-        if (bsdf_is_rough(d.materials[i].type) && !(d.materials[i].alpha > 0.0f)) return "rough BSDF: alpha must be positive";
+        if (bsdf_is_rough(d.materials[i].type) && d.materials[i].type != MTR_BSDF_PLASTIC && !(d.materials[i].alpha > 0.0f)) return "rough BSDF: alpha must be positive";
 
     s.film = film_from_desc(d.film);
     memcpy(s.cam.s2c, d.camera.sample_to_camera, sizeof s.cam.s2c);

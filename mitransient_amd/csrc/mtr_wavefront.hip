@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
                         uint32_t key = 4u;                      // miss
                         if (tr.h.prim >= 0) {
                             key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
-                            if (bsdf_is_rough(key)) key = 0u;       // the GGX lobes share the list of the smooth BSDFs (emitter sampling)
+                            if (bsdf_is_rough(key)) key = 0u;       // the extended smooth lobes share the list of the smooth BSDFs (emitter sampling)
+                            else if (key == MTR_BSDF_THINDIELECTRIC) key = MTR_BSDF_DIELECTRIC;      // two delta lobes: the dielectrics' list
                         }
                         s_key[pos] = (uint8_t)key;
                     }

@@ -139,6 +139,19 @@ def _ior(v, default):
 _EMITTER_TYPES = ("area", "angulararea", "point", "spot", "projector", "constant", "envmap", "directional")
 
 
+def fresnel_diffuse_reflectance(eta):
+    """[mitsuba3: fresnel_diffuse_reflectance] the diffuse Fresnel reflectance of a dielectric boundary, by the two published
+    fits mitsuba cherry-picks from: Egan & Hilgeman (1973) for eta < 1, d'Eon & Irving (2011) otherwise (float32 arithmetic)"""
+    f = np.float32
+    eta = f(eta); inv = f(1.0) / eta
+    if eta < f(1.0):
+        return f(f(0.0636) * inv + (eta * (eta * f(-1.4399) + f(0.7099)) + f(0.6681)))
+    acc = f(-1.36881)
+    for c in (4.98554, -7.80989, 6.75335, -3.4793, 0.919317):
+        acc = f(acc * inv + f(c))
+    return acc
+
+
 class _SceneBuilder:
     def __init__(self, d: Dict[str, Any], base_dir: str = ".", approximate_materials: bool = False):
         self.d = d
@@ -215,9 +228,9 @@ class _SceneBuilder:
                 return self._make_material(self._resolve(inner[0])[0])
             if t == "roughconductor" and self.approx == "smooth":
                 bd = dict(bd, type="conductor"); t = "conductor"
-            elif t == "plastic" or (t == "roughplastic" and self.approx == "smooth"):
+            elif t in ("plastic", "roughplastic") and self.approx == "smooth":
                 bd = {"type": "diffuse", "reflectance": bd.get("diffuse_reflectance", 0.5)}; t = "diffuse"
-            elif t == "thindielectric" or (t == "roughdielectric" and self.approx == "smooth"):
+            elif t == "roughdielectric" and self.approx == "smooth":
                 bd = dict(bd, type="dielectric"); t = "dielectric"
         if t == "twosided":
             inner = [v for k, v in bd.items() if isinstance(v, dict) and k != "type"]
@@ -225,7 +238,7 @@ class _SceneBuilder:
                 raise ValueError("twosided: exactly one nested BSDF is supported")
             inner_d, _ = self._resolve(inner[0])
             m = self._make_material(inner_d)
-            if m.type in (_cabi.MTR_BSDF_DIELECTRIC, _cabi.MTR_BSDF_ROUGHDIELECTRIC):
+            if m.type in (_cabi.MTR_BSDF_DIELECTRIC, _cabi.MTR_BSDF_ROUGHDIELECTRIC, _cabi.MTR_BSDF_THINDIELECTRIC):
                 raise ValueError("twosided: only materials without a transmission component can be nested")
             m.flags |= _cabi.MTR_MAT_TWOSIDED
             return m
@@ -251,6 +264,30 @@ class _SceneBuilder:
             st = _color3(bd.get("specular_transmittance", 1.0), "dielectric.specular_transmittance")
             for k in range(3):
                 m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
+        elif t == "thindielectric":
+            # [mitsuba3: src/bsdfs/thindielectric.cpp] a thin slab: reflection and straight-through transmission, both delta lobes
+            m.type = _cabi.MTR_BSDF_THINDIELECTRIC
+            m.int_ior = np.float32(_ior(bd.get("int_ior"), "bk7"))
+            m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
+            sr = _color3(bd.get("specular_reflectance", 1.0), "thindielectric.specular_reflectance")
+            st = _color3(bd.get("specular_transmittance", 1.0), "thindielectric.specular_transmittance")
+            for k in range(3):
+                m.c[k], m.c2[k] = np.float32(sr[k]), np.float32(st[k])
+        elif t == "plastic":
+            # [mitsuba3: src/bsdfs/plastic.cpp] smooth dielectric coat over a diffuse base with internal scattering
+            m.type = _cabi.MTR_BSDF_PLASTIC
+            m.int_ior = np.float32(_ior(bd.get("int_ior"), "polypropylene"))
+            m.ext_ior = np.float32(_ior(bd.get("ext_ior"), "air"))
+            diff = self._albedo(m, bd.get("diffuse_reflectance", 0.5), "plastic.diffuse_reflectance", ab)
+            sr = _color3(bd.get("specular_reflectance", 1.0), "plastic.specular_reflectance", ab)
+            for k in range(3):
+                m.a[k], m.c[k] = np.float32(diff[k]), np.float32(sr[k])
+            if bd.get("nonlinear", False):
+                m.flags |= _cabi.MTR_MAT_NONLINEAR
+            eta = np.float32(m.int_ior) / np.float32(m.ext_ior)
+            m.internal_reflectance = fresnel_diffuse_reflectance(np.float32(1.0) / eta)        # m_fdr_int
+            d_mean = float(np.mean([np.float32(x) for x in diff])); s_mean = float(np.mean([np.float32(x) for x in sr]))
+            m.specular_sampling_weight = np.float32(s_mean / (d_mean + s_mean))
         elif t == "roughdielectric":
             # [mitsuba3: src/bsdfs/roughdielectric.cpp] rough refractive interface: distribution (beckmann by default), alpha or
             # alpha_u + alpha_v, int_ior / ext_ior, specular_reflectance / specular_transmittance; visible-normal sampling
@@ -336,7 +373,7 @@ class _SceneBuilder:
                 d_mean = float(np.mean([np.float32(x) for x in diff])); s_mean = float(np.mean([np.float32(x) for x in sr]))
                 m.specular_sampling_weight = np.float32(s_mean / (d_mean + s_mean))
         else:
-            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, roughconductor, roughplastic, roughdielectric, twosided)")
+            raise ValueError(f"failed to instantiate unknown plugin of type \"{t}\" (supported BSDFs: diffuse, conductor, dielectric, thindielectric, plastic, roughconductor, roughplastic, roughdielectric, twosided)")
         return m
 
     # -- shapes ------------------------------------------------------------
@@ -863,7 +900,7 @@ def flatten_scene(d: Dict[str, Any], film, sensor_dict: Dict[str, Any], base_dir
                     arr[0] = arr[1] = arr[2] = lum3(arr)
                 if keep:
                     getattr(m, keep)[0] = alpha_v
-                if m.type == _cabi.MTR_BSDF_ROUGHPLASTIC and (m.a[0] + m.c[0]) > 0:
+                if m.type in (_cabi.MTR_BSDF_ROUGHPLASTIC, _cabi.MTR_BSDF_PLASTIC) and (m.a[0] + m.c[0]) > 0:
                     m.specular_sampling_weight = np.float32(m.c[0] / (m.a[0] + m.c[0]))
                 mats.append(m)
             for e in b.emitters:

@@ -876,9 +876,34 @@ static float rough_transmittance(const mtr_material *m, float cos_theta)
     float w1 = x - (float)i, w0 = 1.0f - w1;
     return fmaf(w0, m->external_transmittance[i], w1 * m->external_transmittance[i + 1u]);
 }
-static int bsdf_is_rough(const mtr_material *m)
+static int bsdf_is_rough(const mtr_material *m)          /* the smooth lobes beyond `diffuse`: microfacet lobes and plastic's base */
 {
-    return m->type == MTR_BSDF_ROUGHCONDUCTOR || m->type == MTR_BSDF_ROUGHPLASTIC || m->type == MTR_BSDF_ROUGHDIELECTRIC;
+    return m->type == MTR_BSDF_ROUGHCONDUCTOR || m->type == MTR_BSDF_ROUGHPLASTIC || m->type == MTR_BSDF_ROUGHDIELECTRIC || m->type == MTR_BSDF_PLASTIC;
+}
+/* [mitsuba3: src/bsdfs/plastic.cpp — Plastic::eval / ::pdf; restated from the published source].  The coat is a delta lobe: eval and
+ * pdf see the diffuse base only — diff / (1 - (nonlinear ? diff fdr_int : fdr_int)) * cos/pi * 1/eta^2 * (1 - F_i)(1 - F_o); the lobe
+ * probabilities are F_i ssw and (1 - F_i)(1 - ssw), normalised.  internal_reflectance = m_fdr_int, computed by the caller. */
+static void plastic_probs(const mtr_material *m, float f_i, float *ps, float *pdif)
+{
+    *ps = f_i * m->specular_sampling_weight; *pdif = (1.0f - f_i) * (1.0f - m->specular_sampling_weight);
+    *ps = *ps / (*ps + *pdif); *pdif = 1.0f - *ps;
+}
+static void plastic_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
+{
+    val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
+    float ci = wi.z, co = wo.z;
+    if (!(ci > 0.0f && co > 0.0f)) return;
+    float eta = m->int_ior / m->ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+    float f_i, f_o, ct, eit, eti;
+    fresnel_dielectric(ci, eta, &f_i, &ct, &eit, &eti);
+    fresnel_dielectric(co, eta, &f_o, &ct, &eit, &eti);
+    float ps, pdif;
+    plastic_probs(m, f_i, &ps, &pdif);
+    float cpdf = ORC_INV_PI * co;
+    *pdf = cpdf * pdif;
+    float scale = ((cpdf * inv_eta_2) * (1.0f - f_i)) * (1.0f - f_o);
+    for (int k = 0; k < 3; ++k)
+        val[k] = (m->a[k] / (1.0f - ((m->flags & MTR_MAT_NONLINEAR) ? m->a[k] * m->internal_reflectance : m->internal_reflectance))) * scale;
 }
 static float fresnel_conductor(float cos_i, float eta_r, float eta_i);
 static void fresnel_dielectric(float cos_i, float eta, float *r, float *cos_t, float *eta_it, float *eta_ti);
@@ -925,6 +950,7 @@ static void rough_dielectric_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float
 static void rough_eval_pdf(const mtr_material *m, v3 wi, v3 wo, float val[3], float *pdf)
 {
     if (m->type == MTR_BSDF_ROUGHDIELECTRIC) { rough_dielectric_eval_pdf(m, wi, wo, val, pdf); return; }
+    if (m->type == MTR_BSDF_PLASTIC) { plastic_eval_pdf(m, wi, wo, val, pdf); return; }
     val[0] = val[1] = val[2] = 0.0f; *pdf = 0.0f;
     float ci = wi.z, co = wo.z;
     if (!(ci > 0.0f && co > 0.0f)) return;
@@ -1059,6 +1085,38 @@ static void bsdf_sample(const mtr_material *m, v3 wi, float u1, float ua, float 
         bs->wo = wo;
         bs->pdf = pdf * fabsf(dwh_dwo);
         for (int k = 0; k < 3; ++k) bs->w[k] = w[k] * g1;
+        break; }
+    case MTR_BSDF_PLASTIC: {                 /* [Plastic::sample] */
+        if (!(ci > 0.0f)) break;
+        float eta = m->int_ior / m->ext_ior, inv_eta_2 = 1.0f / (eta * eta);
+        float f_i, ct, eit, eti;
+        fresnel_dielectric(ci, eta, &f_i, &ct, &eit, &eti);
+        float ps, pdif;
+        plastic_probs(m, f_i, &ps, &pdif);
+        if (u1 < ps) {
+            bs->wo = V(-wi.x, -wi.y, wi.z); bs->pdf = ps; bs->delta = 1;
+            float s = f_i / ps;
+            for (int k = 0; k < 3; ++k) bs->w[k] = m->c[k] * s;
+        } else {
+            v3 wo = square_to_cos_hemi(ua, ub);
+            float f_o;
+            fresnel_dielectric(wo.z, eta, &f_o, &ct, &eit, &eti);
+            bs->wo = wo; bs->pdf = pdif * (ORC_INV_PI * wo.z);
+            float scale = ((inv_eta_2 * (1.0f - f_i)) * (1.0f - f_o)) / pdif;
+            if (bs->pdf > 0.0f)
+                for (int k = 0; k < 3; ++k)
+                    bs->w[k] = (m->a[k] / (1.0f - ((m->flags & MTR_MAT_NONLINEAR) ? m->a[k] * m->internal_reflectance : m->internal_reflectance))) * scale;
+        }
+        break; }
+    case MTR_BSDF_THINDIELECTRIC: {          /* [ThinDielectric::sample]: r' = 2 r / (1 + r), straight-through transmission, eta = 1 */
+        float r, ct, eit, eti;
+        fresnel_dielectric(fabsf(wi.z), m->int_ior / m->ext_ior, &r, &ct, &eit, &eti);
+        if (r < 1.0f) r *= 2.0f / (1.0f + r);
+        int refl = u1 <= r;
+        bs->delta = 1; bs->eta = 1.0f;
+        bs->pdf = refl ? r : 1.0f - r;
+        if (refl) { bs->wo = V(-wi.x, -wi.y, wi.z); for (int k = 0; k < 3; ++k) bs->w[k] = m->c[k]; }
+        else { bs->wo = V(-wi.x, -wi.y, -wi.z); for (int k = 0; k < 3; ++k) bs->w[k] = m->c2[k]; }
         break; }
     default: break;
     }

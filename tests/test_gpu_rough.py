@@ -11,7 +11,8 @@ from test_rough_bsdf import _rough_cornell
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("distribution", ["ggx", None, "aniso", "glass"], ids=["ggx", "beckmann-by-default", "anisotropic", "roughdielectric"])
+@pytest.mark.parametrize("distribution", ["ggx", None, "aniso", "glass", "plastic"],
+                         ids=["ggx", "beckmann-by-default", "anisotropic", "roughdielectric", "plastic-thindielectric"])
 @pytest.mark.parametrize("mode", MODES)
 def test_rough_cornell_matches_oracle(oracle, mode, distribution):
     import mitransient_amd.mi as mi

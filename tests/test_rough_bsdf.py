@@ -34,6 +34,12 @@ def _mat(kind, alpha=0.1, twosided=False, nonlinear=True, diffuse=(0.5, 0.3, 0.2
         bd = {"type": "roughdielectric", **dist, **rough, "int_ior": 1.5, "ext_ior": 1.0,
               "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.7]},
               "specular_transmittance": {"type": "rgb", "value": [0.7, 0.9, 0.8]}}
+    if kind == "plastic":
+        bd = {"type": "plastic", "int_ior": 1.5, "ext_ior": 1.0, "nonlinear": nonlinear,
+              "diffuse_reflectance": {"type": "rgb", "value": list(diffuse)}, "specular_reflectance": {"type": "rgb", "value": [0.9, 1.0, 0.8]}}
+    if kind == "thindielectric":
+        bd = {"type": "thindielectric", "int_ior": 1.5, "ext_ior": 1.0, "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.7]},
+              "specular_transmittance": {"type": "rgb", "value": [0.7, 0.9, 0.8]}}
     if twosided:
         bd = {"type": "twosided", "bsdf": bd}
     return _SceneBuilder({}, ".")._make_material(bd)
@@ -330,6 +336,60 @@ def test_rough_dielectric_density_samples_and_weights(oracle, kind, side):
         assert np.all(refl + tran > 0.3)
 
 
+def test_plastic_and_thindielectric(oracle, host_harness):
+    """`plastic` (a delta coat over a diffuse base: eval / pdf see the base, the lobes are chosen by F_i and the sampling weight)
+    and `thindielectric` (two delta lobes, r' = 2r / (1 + r), straight through): product = oracle bit for bit, densities, weights
+    and energy as the plugins define them"""
+    rng = np.random.default_rng(8)
+    n = 200000
+    for kind, twosided in (("plastic", False), ("plastic", True), ("thindielectric", False)):
+        m = _mat(kind, twosided=twosided)
+        wi, wo = _dirs(n, rng, upper=(kind == "plastic" and not twosided)), _dirs(n, rng, upper=False)
+        wi[:500, 2] *= 1e-3
+        v0, p0 = _eval(oracle.lib(), "orc_", m, wi, wo)
+        v1, p1 = _eval(host_harness, "hh_", m, wi, wo)
+        assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+        u = rng.random((3, n)).astype(np.float32)
+        a = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+        b = _sample(host_harness, "hh_", m, wi, u[0], u[1], u[2])
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    # plastic at one incidence: the base's density integrates to the probability of taking the base
+    m = _mat("plastic")
+    g, dw = _hemisphere_grid()
+    mu = 0.6
+    wi1 = np.array([[np.sqrt(1 - mu * mu), 0, mu]], np.float32)
+    val, pdf = _eval(oracle.lib(), "orc_", m, np.tile(wi1, (len(g), 1)), g)
+    p_base = pdf.astype(np.float64).sum() * dw
+    n = 300000
+    wi = np.tile(wi1, (n, 1))
+    u = rng.random((3, n)).astype(np.float32)
+    wo, spdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+    mirror = np.all(np.abs(wo - wi * np.array([-1, -1, 1], np.float32)) < 1e-6, axis=1)
+    assert abs(mirror.mean() - (1 - p_base)) < 0.005 and 0.02 < mirror.mean() < 0.5
+    sval, spdf2 = _eval(oracle.lib(), "orc_", m, np.ascontiguousarray(wi[~mirror]), np.ascontiguousarray(wo[~mirror]))
+    assert np.allclose(spdf[~mirror], spdf2, rtol=2e-4) and np.allclose(w[~mirror] * spdf[~mirror, None], sval, rtol=2e-3, atol=1e-7)
+    # the coat: weight x probability = specular_reflectance x F(cos 0.6, 1.5); Fresnel by the formula
+    ci, eta = mu, 1.5
+    ct = np.sqrt(1 - (1 - ci * ci) / eta ** 2)
+    F = 0.5 * (((ci - eta * ct) / (ci + eta * ct)) ** 2 + ((ct - eta * ci) / (ct + eta * ci)) ** 2)
+    assert np.allclose(w[mirror][0] * spdf[mirror][0], np.array([0.9, 1.0, 0.8]) * F, rtol=1e-4)
+    albedo = val.astype(np.float64).sum(0) * dw + np.array([0.9, 1.0, 0.8]) * F
+    assert np.all(albedo <= 1.0) and np.all(albedo > 0.1)
+    # thin slab: reflect with r' = 2r / (1 + r), else straight through; from either side; eta stays 1
+    m = _mat("thindielectric")
+    wi = np.tile(np.array([[0.6, 0.0, -0.8]], np.float32), (n, 1))
+    wo, spdf, w = _sample(oracle.lib(), "orc_", m, wi, u[0], u[1], u[2])
+    ci = 0.8; ct = np.sqrt(1 - (1 - ci * ci) / eta ** 2)
+    r = 0.5 * (((ci - eta * ct) / (ci + eta * ct)) ** 2 + ((ct - eta * ci) / (ct + eta * ci)) ** 2)
+    r2 = 2 * r / (1 + r)
+    refl = wo[:, 2] < 0
+    assert abs(refl.mean() - r2) < 0.004
+    assert np.allclose(wo[refl], [-0.6, 0.0, -0.8]) and np.allclose(wo[~refl], [-0.6, 0.0, 0.8])
+    assert np.allclose(w[refl], [0.9, 0.8, 0.7]) and np.allclose(w[~refl], [0.7, 0.9, 0.8])
+    assert np.allclose(spdf[refl], r2, rtol=1e-5) and np.allclose(spdf[~refl], 1 - r2, rtol=1e-5)
+
+
 def test_rough_dielectric_plugin_rules():
     from mitransient_amd import _cabi
     from mitransient_amd.scene import _SceneBuilder
@@ -375,7 +435,7 @@ def _rough_cornell(distribution="ggx", **film):
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
     aniso = distribution == "aniso"            # Beckmann by default + anisotropic roughconductors (one of them GGX)
-    dk = {} if distribution in (None, "glass") or aniso else {"distribution": distribution}
+    dk = {} if distribution in (None, "glass", "plastic") or aniso else {"distribution": distribution}
     d = mitr.cornell_box()
     d["sensor"]["film"].update(width=24, height=24, temporal_bins=64, start_opl=3.5, bin_width_opl=6.0 / 64)
     d["sensor"]["film"].update(film)
@@ -391,13 +451,19 @@ def _rough_cornell(distribution="ggx", **film):
         d["small-box"]["bsdf"] = {"type": "roughdielectric", "distribution": "ggx", "alpha": 0.1, "int_ior": 1.5, "ext_ior": 1.0}
         d["large-box"]["bsdf"] = {"type": "roughdielectric", "alpha_u": 0.05, "alpha_v": 0.2, "int_ior": "water",
                                   "specular_transmittance": {"type": "rgb", "value": [0.8, 0.95, 0.9]}}
+    if distribution == "plastic":              # a plastic floor (nonlinear), a thin glass pane as the small box, a two-sided plastic back wall
+        d["floor"]["bsdf"] = {"type": "plastic", "int_ior": 1.5, "nonlinear": True, "diffuse_reflectance": {"type": "rgb", "value": [0.58, 0.42, 0.3]}}
+        d["back"]["bsdf"] = {"type": "twosided", "bsdf": {"type": "plastic", "diffuse_reflectance": {"type": "rgb", "value": [0.2, 0.5, 0.7]},
+                                                          "specular_reflectance": {"type": "rgb", "value": [0.8, 0.8, 0.8]}}}
+        d["small-box"]["bsdf"] = {"type": "thindielectric", "specular_transmittance": {"type": "rgb", "value": [0.9, 0.95, 0.85]}}
     if aniso:
         d["large-box"]["bsdf"].pop("alpha"); d["large-box"]["bsdf"].update(alpha_u=0.1, alpha_v=0.3)
         d["small-box"]["bsdf"]["bsdf"].pop("alpha"); d["small-box"]["bsdf"]["bsdf"].update(alpha_u=0.15, alpha_v=0.05, distribution="ggx")
     return d
 
 
-@pytest.mark.parametrize("distribution", ["ggx", None, "aniso", "glass"], ids=["ggx", "beckmann-by-default", "anisotropic", "roughdielectric"])
+@pytest.mark.parametrize("distribution", ["ggx", None, "aniso", "glass", "plastic"],
+                         ids=["ggx", "beckmann-by-default", "anisotropic", "roughdielectric", "plastic-thindielectric"])
 @pytest.mark.parametrize("wide", [0, 1], ids=["bvh2", "wide-8"])
 def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide, distribution):
     import mitransient_amd.mi as mi
@@ -418,7 +484,7 @@ def test_host_harness_rough_scene_bit_for_bit(oracle, host_harness, wide, distri
     assert np.count_nonzero(t4) > 3000 and np.isfinite(t4).all()
 
 
-@pytest.mark.parametrize("distribution", ["ggx", "beckmann", "glass"])
+@pytest.mark.parametrize("distribution", ["ggx", "beckmann", "glass", "plastic"])
 def test_energy_identity_with_rough_materials(oracle, distribution):
     """transient.sum(time) == steady when the window holds every path (1-simple-nlos-scenes.ipynb md cell 8)"""
     import mitransient_amd.mi as mi
