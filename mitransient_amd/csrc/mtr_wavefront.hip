@@ -348,11 +348,16 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 #ifndef MTR_WF_REFILL_MIN
 #define MTR_WF_REFILL_MIN 16
 #endif
+#ifndef MTR_WF_TRACE_WAVES_ANY
+#define MTR_WF_TRACE_WAVES_ANY 6      // the occlusion instantiation (80 registers, none spilled)
+#endif
 #ifndef MTR_WF_TRACE_WAVES
 #define MTR_WF_TRACE_WAVES 6          // scenes in HBM: the walk waits on loads, 6 waves per SIMD (80 registers, 6 spilled) beat 5 and 8 (measured)
 #endif
-template <int STACK, bool SCENE_LDS>
-__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_wf_trace(const WfArgs a)
+// ANY: the occlusion pass of a bounce's shadow rays (a.trace_any) as its own instantiation — no hit record to keep, nothing to sort
+// into material lists: the compiler drops the closest-hit bookkeeping from the walk instead of carrying both behind a flag
+template <int STACK, bool SCENE_LDS, bool ANY>
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WAVES_ANY : MTR_WF_TRACE_WAVES)) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_cnt = (uint32_t *)smem;                         // [kWfKeys] list tails of the segment
@@ -367,7 +372,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : MTR_WF_TRACE_WAVES) k_
 #ifdef MTR_PROFILE_SIMT
     unsigned long long prof[4] = { 0, 0, 0, 0 };      // node iterations, lanes in them, leaf iterations, lanes in them
 #endif
-    const bool any_hit = a.trace_any != 0u;         // occlusion of this bounce's shadow rays instead of closest hits
+    constexpr bool any_hit = ANY;                   // occlusion of this bounce's shadow rays instead of closest hits
     wf_ticket_begin(a, tid);
     for (uint32_t sg = wf_next_segment(a, smem, tid, true); sg < a.n_seg; sg = wf_next_segment(a, smem, tid, false)) {
         const uint32_t n_live = any_hit ? a.seg_shadow[sg] : a.seg_live[(size_t)par * a.n_seg + sg];
@@ -945,7 +950,7 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     const bool ext = a.sc.has_rough != 0u;
-    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? k_wf_trace<STACK, SL>
+    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? (a.trace_any ? k_wf_trace<STACK, SL, true> : k_wf_trace<STACK, SL, false>)
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
