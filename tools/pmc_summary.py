@@ -41,9 +41,25 @@ def summarise(out, tag, renders):
                 fh.write(f"   {c:28s} total {val:.6g}  dispatches {n}  per-dispatch {val / n:.6g}\n")
     print(open(out + "/pmc_summary.txt").read())
     traffic = {"source_hash": source_hash(), "profile": tag}
+    # instantiations of one kernel are summed under its name (k_wf_trace<..., false> = closest hits and <..., true> = occlusion since
+    # round 4); the occlusion instantiation is also listed on its own as k_wf_trace_any
+    by_name = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt2 = collections.Counter()
     for k, v in agg.items():
         m = re.search(r"k_(fused|wf_[a-z_]+|develop_[a-z]+)", k)
-        if not m or "FETCH_SIZE" not in v:
+        if not m:
+            continue
+        names = [m.group(0)]
+        if m.group(0) == "k_wf_trace" and re.search(r"k_wf_trace<[^>]*true>", k):
+            names.append("k_wf_trace_any")
+        for nm in names:
+            for c, val in v.items():
+                by_name[nm][c] += val
+                cnt2[(nm, c)] += cnt[(k, c)]
+    cnt = cnt2
+    for k, v in by_name.items():
+        m = re.match(r"k_[a-z_]+", k)
+        if "FETCH_SIZE" not in v:
             continue
         nf = cnt[(k, "FETCH_SIZE")]
         nw = cnt.get((k, "WRITE_SIZE"), 1)
