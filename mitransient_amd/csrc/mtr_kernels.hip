@@ -115,7 +115,6 @@ struct LdsHistSink {
     uint32_t lane;
     uint32_t n_splats;
     SplatLog log;
-    __device__ __forceinline__ void set_row(uint32_t row_off) { row = row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -130,7 +129,6 @@ struct LdsHistSink {
 struct LdsFixedSink {
     unsigned long long *hist; uint32_t plane, row, film_w, lane, n_splats;
     SplatLog log;
-    __device__ __forceinline__ void set_row(uint32_t row_off) { row = row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -145,11 +143,9 @@ struct LdsFixedSink {
 // [G][2F] — and every contribution adds its F terms (phasor_image_block.py:42-67) with LDS float atomics
 struct LdsPhasorSink {
     float *row;                        // the pixel's slot: 2F floats
-    float *rows;                       // slot 0
     const float *freq; uint32_t n_freq; float start_opl;
     uint32_t film_w, lane, n_splats;
     SplatLog log;
-    __device__ __forceinline__ void set_row(uint32_t row_off) { row = rows + row_off; }
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -170,7 +166,6 @@ struct GlobalAtomicSink {
     uint32_t lane;
     uint32_t n_splats;
     SplatLog log;
-    __device__ __forceinline__ void set_row(uint32_t) {}
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
@@ -229,6 +224,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         copy16(ee, a.sc.ems, align16(a.sc.n_ems * sizeof(Emitter)), tid);
         sv.nodes = nullptr; sv.wnodes = n; sv.wnodes4 = nullptr; sv.wnodes8q = nullptr; sv.tpairs = tg; sv.tshade = ts; sv.mats = mm; sv.ems = ee;
         sv.node_pairs = true;
+        __builtin_assume(sv.wnodes != nullptr);          // (an LDS address: the compiler does not know it cannot be null, and would keep the other walkers of traverse())
     } else {
         sv.nodes = a.sc.nodes; sv.tpairs = a.sc.tpairs; sv.tshade = a.sc.tshade; sv.mats = a.sc.mats; sv.ems = a.sc.ems;
         sv.wnodes = nullptr; sv.wnodes4 = a.sc.wnodes4; sv.wnodes8q = a.sc.wnodes8q;
@@ -312,6 +308,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     Path p;
     p.L = mk(0, 0, 0);
     uint32_t q = 0, slot = 0;
+    uint32_t xy = 0;                     // (packed film coordinates, below) px | py << 16 of the lane's path
     bool carry = false;                  // the path that just ended leaves its radiance in p.L: this lane's next path is in the same pixel
     for (;;) {
         st.prof_mark(4);                 // (experiment builds) sections: 0 traversal, 1 shading, 2 path start, 3 end-of-path bookkeeping, 4 row flush, 5 idle
@@ -331,6 +328,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                         if (h0.prim >= 0) p.dist = -h0.t;
                     }
                     p.L = L_carried; carry = false;
+                    xy = p.px | (p.py << 16);
                     alive = true; waiting = false; started = true;
                 }
             }
@@ -353,26 +351,21 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         uint32_t did_shadow = 0u, did_splats = 0u;                 // this iteration's per-lane counts (0..1, 0..2)
         if (alive) {
             BounceStats bstat; bstat.closest = 0; bstat.shadow = 0;
-            // DERIVED PATH STATE (round 4).  Pixel ordinal, row slot, film coordinates and lane id of a path all follow from
-            // its sample index i — five registers that used to stay live across both traversals of every bounce, in a kernel
-            // that needs ~160 and has 128.  path_bounce calls `refresh` after either traversal (and the end-of-path block below
-            // does the same), so only i survives a traversal; the compiler cannot merge the recomputations because i passes
-            // through an empty asm each time.  ~20 integer instructions per call against 7 fewer spilled dwords: config 2's
-            // scratch 112 -> 84 B per lane, i.e. under what the L2 slices hold for the resident waves — WRITE_SIZE per launch
-            // 23.5 -> 3.8 GB (3.2 GB of it the developed film), L2 requests halved, +1.0 ms.  Keeping the film
-            // coordinates packed in one register and the row offset in another instead (two divisions less per call) was
-            // NOT faster (66.5 against 66.3 ms) and wrote 6.3 GB.
-            auto refresh = [&](Path &pp, auto &sk) {
-                uint32_t ii = i; asm volatile("" : "+v"(ii));
-                const uint32_t qq = fastdiv(ii, a.div_spp);
-                const uint32_t pixel = pix0 + qq;
-                const uint32_t yy = fastdiv(pixel, a.rc.div_crop_w), xx = pixel - a.film.crop_w * yy;
-                pp.px = xx + a.film.crop_x; pp.py = yy + a.film.crop_y;
-                pp.lane = pixel * a.rc.spp_total + (a.spp_begin + (ii - qq * a.spp_chunk));
-                sk.set_row((qq - fastdiv(qq, a.div_G) * K) * T); sk.lane = pp.lane;
+            // PACKED FILM COORDINATES (round 4).  A path's film coordinates px, py are read after either traversal (the in-film test
+            // of its contributions) and at its end, and nowhere inside a traversal: they ride in ONE register (xy), which
+            // path_bounce's `refresh` hook unpacks after either traversal — the compiler cannot keep the unpacked pair alive
+            // instead, because xy passes through an empty asm each time.  Together with the unused tree walkers folded out of
+            // traverse() (the assume on sv.wnodes above) this takes config 2's scratch from 112 to 84 B per lane — under what the L2
+            // slices hold for the resident waves: WRITE_SIZE per launch 23.5 -> 5.8 GB (3.2 GB of it the film) — at 65.0 ms.
+            // (Measured beside it, same box: everything recomputed from the sample index — pixel ordinal, row slot, coordinates,
+            // lane id: 68 B, 3.5 GB, but 66.1 ms; nothing packed: 96 B, 64.3 ms, 14.7 GB; xy + the row slot from q: 76 B, 65.3 ms,
+            // 4.0 GB.  DESIGN.md section 6.)
+            auto refresh = [&](Path &pp, auto &) {
+                uint32_t w = xy; asm volatile("" : "+v"(w));
+                pp.px = w & 0xffffu; pp.py = w >> 16;
             };
             if (PHASOR) {
-                LdsPhasorSink sink; sink.rows = s_hist; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
+                LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
                 did_splats = sink.n_splats;
@@ -396,14 +389,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
-            if (!NLOS && !alive) {          // (derived path state, above: what the end-of-path block and the row flush read; leaving
-                // them behind from the second `refresh` instead of a third derivation: 96 B of scratch against 84)
-                uint32_t ii = i; asm volatile("" : "+v"(ii));
-                q = fastdiv(ii, a.div_spp); slot = q - fastdiv(q, a.div_G) * K;
-                const uint32_t pixel = pix0 + q;
-                const uint32_t yy = fastdiv(pixel, a.rc.div_crop_w), xx = pixel - a.film.crop_w * yy;
-                p.px = xx + a.film.crop_x; p.py = yy + a.film.crop_y;
-            }
+            if (!NLOS && !alive) { uint32_t w = xy; asm volatile("" : "+v"(w)); p.px = w & 0xffffu; p.py = w >> 16; }      // (packed film coordinates, above)
             if (!alive) {
                 // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200).  The lane takes its next sample first:
                 // when that is another sample of the SAME pixel (with 1024 spp a lane runs four in a row), the radiance simply
@@ -600,6 +586,8 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     const uint32_t kLdsMax = 160u * 1024u;
     int stack = sc.bvh_depth <= 8 ? 8 : sc.bvh_depth <= 16 ? 16 : sc.bvh_depth <= 32 ? 32 : 64;
     if (sc.bvh_depth > 64) return false;
+    // (k_fused keeps a path's film coordinates packed in one register, 16 bits each)
+    if ((uint64_t)film.crop_x + film.crop_w > 65536ull || (uint64_t)film.crop_y + film.crop_h > 65536ull) return false;
     uint32_t scene_b = scene_lds_bytes(sc);
     cfg.scene_lds = sc.wnodes != nullptr && scene_b <= 64u * 1024u;
     // the kernel walks a WIDE tree (8-wide in LDS, quantised 4-wide in HBM): one stacked group per level (+ the row the

@@ -434,13 +434,22 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
                 if (n_node >= n_leaf) { if (at_node) wide_node_step<kWide, true>(tr, sv.wnodes, st); }
                 else { if (at_leaf) wide_leaf_step<kWide>(tr, sv, sv.wnodes, st, any_hit); }
             } else {
+                // (release builds always hold the quantised 8-wide tree of a scene walked in HBM — mtr_scene_host.cpp — so the
+                // 4-wide walker is compiled only where a knob can switch the tree off: half the code, no spills in either instantiation)
+#ifdef MTR_EXPERIMENTS
                 if (sv.wnodes8q) {
+#else
+                {
+#endif
                     if (n_node >= n_leaf) { if (at_node) q8_node_step(tr, sv.wnodes8q, st); }
                     else { if (at_leaf) q8_leaf_step(tr, sv, st, any_hit); }
-                } else {
+                }
+#ifdef MTR_EXPERIMENTS
+                else {
                     if (n_node >= n_leaf) { if (at_node) qwide_node_step(tr, sv.wnodes4, st); }
                     else { if (at_leaf) qwide_leaf_step(tr, sv, st, any_hit); }
                 }
+#endif
             }
         }
         __syncthreads();
