@@ -1828,9 +1828,12 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
 // coordinates, lane id and row slot follow from the sample index) does so there instead of holding them in registers across
 // the traversals.
 struct NoRefresh { template <class Sink> MTR_HD void operator()(Path &, Sink &) const {} };
+// unwarp_here: camera_unwarp (transientpath.py:133-138) without its own traversal — the hit whose distance the unwarp subtracts IS
+// bounce 0's closest hit, so distance = -t is set here at depth 0 (bit-identical: -t + t * eta with eta = 1), as k_wf_shade does;
+// callers that pass false trace the camera ray themselves before the first bounce
 template <bool ROUGH = true, class Stack, class Sink, class Refresh = NoRefresh>
 MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
-                        Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh())
+                        Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh(), bool unwarp_here = false)
 {
     st.prof_mark(2);
     Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
@@ -1842,6 +1845,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     // the traversals)
     if (Stack::kPark) { p.prev_p = st.unpark_prev_p(); p.prev_pdf = st.unpark_prev_pdf(); p.rng.inc = st.unpark_inc(); }
     refresh(p, sink);
+    if (unwarp_here && p.depth == 0u && h.prim >= 0) p.dist = -h.t;
     shade_hit<ROUGH>(p, h, sc, film, rc, sink, pd, shadow);
     st.prof_mark(1);
     bool occluded = false;

@@ -323,10 +323,6 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     const f3 L_carried = carry ? p.L : mk(0, 0, 0);
                     if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
                     else { path_begin(p, a.cam, a.film, a.rc, pixel, s); if (LdsStack::kPark) { st.park_inc(p.rng.inc); st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); } }
-                    if (!NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) {          // transientpath.py:133-138
-                        Hit h0 = traverse<false>(sv, p.ray.o, p.ray.d, p.ray.tmax, st);
-                        if (h0.prim >= 0) p.dist = -h0.t;
-                    }
                     p.L = L_carried; carry = false;
                     xy = p.px | (p.py << 16);
                     alive = true; waiting = false; started = true;
@@ -360,6 +356,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             // (Measured beside it, same box: everything recomputed from the sample index — pixel ordinal, row slot, coordinates,
             // lane id: 68 B, 3.5 GB, but 66.1 ms; nothing packed: 96 B, 64.3 ms, 14.7 GB; xy + the row slot from q: 76 B, 65.3 ms,
             // 4.0 GB.  DESIGN.md section 6.)
+            // camera_unwarp: no traversal of its own (a third inlined copy of the walk in every instantiation) — bounce 0's closest
+            // hit is the camera ray's; the extra ray the reference traces is still COUNTED (w_closest, at path start)
+            const bool unwarp = !NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) != 0u;
             auto refresh = [&](Path &pp, auto &) {
                 uint32_t w = xy; asm volatile("" : "+v"(w));
                 pp.px = w & 0xffffu; pp.py = w >> 16;
@@ -367,25 +366,25 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             if (PHASOR) {
                 LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
+                alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 did_splats = sink.n_splats;
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh);
+                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
