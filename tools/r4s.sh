@@ -2,8 +2,8 @@
 # round-4 batch S2 (final sources): the three profile passes, the counters merged on the box, the three bench lines, the splat bench, the 1-rank RCCL path
 O=gpurun_out/r4s; mkdir -p $O
 (timeout 1800 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; echo "pytest rc=$?" >> $O/gputests.log); tail -3 $O/gputests.log
-bash tools/profile_all.sh r04h
-bash tools/merge_profiles.sh r04h > $O/merge.log 2>&1; tail -2 $O/merge.log
+bash tools/profile_all.sh r04i
+bash tools/merge_profiles.sh r04i > $O/merge.log 2>&1; tail -2 $O/merge.log
 cp profiles/traffic.json $O/traffic.json
 timeout 600 python bench.py > $O/config2_bench.json 2> $O/bench.err
 timeout 300 python bench.py --scene staircase --steps 3 --warmup 1 > $O/staircase_bench.json 2> $O/staircase.err
