@@ -215,6 +215,15 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     for (uint32_t i = 0; i < d->n_materials; ++i)
         if (bsdf_is_rough(d->materials[i].type) || d->materials[i].type == MTR_BSDF_THINDIELECTRIC) s->dev.has_rough = 1u;
     if (!hs.vnormals.empty() || !hs.texels.empty()) s->dev.has_rough = 1u;      // smooth-shaded triangles, bitmap textures: the extended shading code as well
+    // scene traits (mtr_core.h): facts about the tables that let the kernels drop shading code no hit can reach
+    s->dev.traits = 0u;
+    if (!s->dev.has_rough) {
+        bool diffuse_only = d->n_materials > 0;
+        for (uint32_t i = 0; i < d->n_materials; ++i)
+            if (d->materials[i].type != MTR_BSDF_DIFFUSE || (d->materials[i].flags & MTR_MAT_TWOSIDED)) diffuse_only = false;
+        if (diffuse_only) s->dev.traits |= kTrDiffuse;
+        if (d->n_emitters == 1 && !hs.ems[0].is_mesh) s->dev.traits |= kTrOneRectEmitter;
+    }
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);

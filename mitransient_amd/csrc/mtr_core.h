@@ -1490,11 +1490,30 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
     if (pdf > 0.0f) { const float ip = 1.0f / pdf; bs.w = mk(val.x * ip, val.y * ip, val.z * ip); }
 }
 
-template <bool ROUGH = true>
+// SCENE TRAITS (round 5): what the host knows about the scene's material / emitter tables, as compile-time bits of the shading
+// code — the specialisation Dr.Jit's tracing gives the reference for free (its megakernel only holds the vcall targets the
+// scene has).  A trait only REMOVES code whose result is known: every value that is still computed is computed by the same
+// operations in the same order, and the folds are exact (x * 1.0f == x), so a specialised kernel returns the bits of the
+// general one (tests/test_gpu_parity.py runs both on the same scenes).
+//   kTrDiffuse: every material is MTR_BSDF_DIFFUSE without MTR_MAT_TWOSIDED (transientpath.py:157 `si.bsdf(ray)` has ONE
+//     target): no delta lobe, so prev_bsdf_delta (:240) is true exactly at depth 0; bs.eta == 1, so eta (:232) stays 1 and
+//     `distance += t * eta` (:154), `rr_prob = min(beta_max * eta^2, .95)` (:248) lose their factors; no Fresnel code at all.
+//   kTrOneRectEmitter: exactly one emitter, an analytic rectangle (:192 `sample_emitter_direction` has one target): no
+//     emitter pick and its sample reuse, no mesh tables, no 1 / n_emitters factors.
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u;
+constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter;      // what the kernels are instantiated for besides 0
+
+template <bool ROUGH = true, uint32_t TR = 0u>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)
 {
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
+    if (TR & kTrDiffuse) {
+        bs.wo = cosine_hemisphere(ua, ub);
+        bs.pdf = kInvPi * bs.wo.z;
+        if (wi.z > 0.0f && bs.pdf > 0.0f) bs.w = mk(m.a[0], m.a[1], m.a[2]);
+        return bs;
+    }
     bool flip = (m.flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f;
     if (flip) wi.z = -wi.z;
     float ci = wi.z;
@@ -1659,12 +1678,16 @@ struct Pending {
 
 // Part A of one loop iteration (transientpath.py:148-218): consumes the closest hit, splats the
 // emission term, samples the emitter and emits the shadow ray.  RNG: next_2d (:193).
-template <bool ROUGH = true, class Sink>
+template <bool ROUGH = true, uint32_t TR = 0u, class Sink>
 MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &film, const RenderConst &rc,
                       Sink &sink, Pending &pd, Ray &shadow)
 {
+    constexpr bool kDiff = (TR & kTrDiffuse) != 0u, kOneRect = (TR & kTrOneRectEmitter) != 0u;
     const bool valid = h.prim >= 0;
-    p.dist += h.t * p.eta;                                           // :154 (inf on a miss)
+    const float eta = kDiff ? 1.0f : p.eta;
+    const bool prev_delta = kDiff ? (p.depth == 0u) : (p.prev_delta != 0u);
+    const uint32_t n_emitters = kOneRect ? 1u : sc.n_emitters;
+    p.dist += kDiff ? h.t : h.t * eta;                               // :154 (inf on a miss)
     pd.active_next = (((p.depth + 1u) < rc.max_depth) & valid) ? 1u : 0u;   // :185
     pd.Le = mk(0, 0, 0); pd.Lr = mk(0, 0, 0); pd.opl = 0.0f; pd.has_shadow = 0u;
     const uint32_t fx = p.px - film.crop_x, fy = p.py - film.crop_y;       // transient_image_block.py:132
@@ -1676,17 +1699,17 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
 
     // direct emission (:166-176)
     if (c.em_plus1 != 0u && !(rc.flags & MTR_FLAG_DISCARD_DIRECT_LIGHT)) {
-        const Emitter &E = sc.ems[c.em_plus1 - 1u];
+        const Emitter &E = sc.ems[kOneRect ? 0u : c.em_plus1 - 1u];
         f3 rel = c.sp - p.prev_p;
         float dist = sqrtf(dot(rel, rel));
         f3 dd = rel / dist;
         float em_pdf = 0.0f;
-        if (!p.prev_delta) {
+        if (!prev_delta) {
             float dp = dot(dd, c.sn);                  // DirectionSample(scene, si, ref): ds.n = si.sh_frame.n
             if (dp < 0.0f) {
                 float adp = fabsf(dp);
                 em_pdf = E.inv_area * (adp != 0.0f ? (dist * dist) / adp : 0.0f);
-                if (sc.n_emitters > 1) em_pdf *= rc.inv_n_emitters;
+                if (n_emitters > 1) em_pdf *= rc.inv_n_emitters;
             }
         }
         float mis = mis_weight(p.prev_pdf, em_pdf);
@@ -1702,17 +1725,17 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
     }
 
     // emitter sampling (:188-213); only smooth BSDFs (diffuse, the rough lobes) take part
-    if (pd.active_next && (mat.type == MTR_BSDF_DIFFUSE || (ROUGH && bsdf_is_rough(mat.type))) && sc.n_emitters > 0 ) {
+    if (pd.active_next && (kDiff || mat.type == MTR_BSDF_DIFFUSE || (ROUGH && bsdf_is_rough(mat.type))) && n_emitters > 0 ) {
         uint32_t ei = 0;
-        if (sc.n_emitters > 1) {
+        if (n_emitters > 1) {
             float su = u1 * rc.n_emitters_f;
             uint32_t i = (uint32_t)su;
-            if (i > sc.n_emitters - 1) i = sc.n_emitters - 1;
+            if (i > n_emitters - 1) i = n_emitters - 1;
             ei = i; u1 = su - (float)i;
         }
         const Emitter &E = sc.ems[ei];
         f3 ep, en;
-        if (E.is_mesh) {
+        if (!kOneRect && E.is_mesh) {
             mesh_sample_position(sc.samp_tris, sc.face_cdf, sc.face_pmf, E.first_tri, E.n_tris, u1, u2, ep, en, ROUGH ? sc.samp_vn : nullptr);
         } else {
             float a = fmaf(u1, 2.0f, -1.0f), b = fmaf(u2, 2.0f, -1.0f);
@@ -1730,12 +1753,12 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
         if ((dp < 0.0f) & (pdf_dir != 0.0f)) {
             f3 emw = ld3(E.radiance) / pdf_dir;
             float pdf = pdf_dir;
-            if (sc.n_emitters > 1) { pdf = pdf_dir * rc.inv_n_emitters; emw = emw * rc.n_emitters_f; }
+            if (n_emitters > 1) { pdf = pdf_dir * rc.inv_n_emitters; emw = emw * rc.n_emitters_f; }
             if (pdf != 0.0f) {
                 // BSDF value * cos and MIS (:207-213), evaluated before the visibility test
                 f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
                 f3 wi_e = c.wi;
-                if ((mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
+                if (!kDiff && (mat.flags & MTR_MAT_TWOSIDED) && wi_e.z < 0.0f) { wi_e.z = -wi_e.z; wo.z = -wo.z; }
                 // shadow ray: spawn_ray_to(ds.p) + ray_test
                 f3 so = offset_point(c.sp, c.gn, ep - c.sp);
                 f3 sd = ep - so;
@@ -1748,7 +1771,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                     float mis_em = mis_weight(pdf, bpdf);
                     pd.Lr = mk(((p.beta.x * mis_em) * bval.x) * emw.x, ((p.beta.y * mis_em) * bval.y) * emw.y,
                                ((p.beta.z * mis_em) * bval.z) * emw.z);
-                    pd.opl = p.dist + dist * p.eta;
+                    pd.opl = p.dist + dist * eta;
                 } else
                 if (wi_e.z > 0.0f && wo.z > 0.0f) {
                     float bpdf = kInvPi * wo.z;
@@ -1757,7 +1780,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                     pd.Lr = mk(((p.beta.x * mis_em) * ((alb.x * kInvPi) * wo.z)) * emw.x,
                                ((p.beta.y * mis_em) * ((alb.y * kInvPi) * wo.z)) * emw.y,
                                ((p.beta.z * mis_em) * ((alb.z * kInvPi) * wo.z)) * emw.z);
-                    pd.opl = p.dist + dist * p.eta;                  // :217
+                    pd.opl = p.dist + (kDiff ? dist : dist * eta);   // :217
                 }
             }
         }
@@ -1767,10 +1790,11 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
 // Part B (transientpath.py:216-257, :318): commits the emitter-sampling term given the shadow-ray
 // answer, samples the BSDF, updates the loop state and applies Russian roulette.
 // RNG: next_1d, next_2d (:223-224), next_1d (:256).  Returns active_next.
-template <bool ROUGH = true, class Sink>
+template <bool ROUGH = true, uint32_t TR = 0u, class Sink>
 MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd, const SceneView &sc,
                          const Film &film, const RenderConst &rc, Sink &sink)
 {
+    constexpr bool kDiff = (TR & kTrDiffuse) != 0u;
     const bool valid = h.prim >= 0;
     bool active_next = pd.active_next != 0u;
     f3 Lr = mk(0, 0, 0);
@@ -1794,7 +1818,7 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
         const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
         sp = c.sp;
         if (active_next) {
-            bs = bsdf_sample<ROUGH>(sc.mats[c.mat], c.wi, s1, s2a, s2b, material_albedo<ROUGH>(sc, sc.mats[c.mat], h));     // :222-227
+            bs = bsdf_sample<ROUGH, TR>(sc.mats[c.mat], c.wi, s1, s2a, s2b, material_albedo<ROUGH>(sc, sc.mats[c.mat], h));     // :222-227
             f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                          fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                          fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));
@@ -1803,14 +1827,15 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
             p.ray.tmax = kInf;
         }
     }
-    p.eta *= bs.eta;                                                                             // :232
+    if (!kDiff) p.eta *= bs.eta;                                                                 // :232
     p.beta = mk(p.beta.x * bs.w.x, p.beta.y * bs.w.y, p.beta.z * bs.w.z);                        // :233
-    p.prev_p = sp; p.prev_pdf = bs.pdf; p.prev_delta = bs.delta ? 1u : 0u;                      // :237-240
+    p.prev_p = sp; p.prev_pdf = bs.pdf;                                                          // :237-240
+    if (!kDiff) p.prev_delta = bs.delta ? 1u : 0u;
 
     // stopping criterion (:245-257)
     float bmax = max3(p.beta.x, p.beta.y, p.beta.z);
     active_next &= (bmax != 0.0f);
-    float rr_prob = fminf(bmax * (p.eta * p.eta), 0.95f);
+    float rr_prob = fminf(kDiff ? bmax : bmax * (p.eta * p.eta), 0.95f);
     active_next &= rr_prob > 0.0f;
     bool rr_active = p.depth >= rc.rr_depth;
     if (rr_active) {
@@ -1831,7 +1856,7 @@ struct NoRefresh { template <class Sink> MTR_HD void operator()(Path &, Sink &) 
 // unwarp_here: camera_unwarp (transientpath.py:133-138) without its own traversal — the hit whose distance the unwarp subtracts IS
 // bounce 0's closest hit, so distance = -t is set here at depth 0 (bit-identical: -t + t * eta with eta = 1), as k_wf_shade does;
 // callers that pass false trace the camera ray themselves before the first bounce
-template <bool ROUGH = true, class Stack, class Sink, class Refresh = NoRefresh>
+template <bool ROUGH = true, uint32_t TR = 0u, class Stack, class Sink, class Refresh = NoRefresh>
 MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const RenderConst &rc,
                         Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh(), bool unwarp_here = false)
 {
@@ -1846,7 +1871,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     if (Stack::kPark) { p.prev_p = st.unpark_prev_p(); p.prev_pdf = st.unpark_prev_pdf(); p.rng.inc = st.unpark_inc(); }
     refresh(p, sink);
     if (unwarp_here && p.depth == 0u && h.prim >= 0) p.dist = -h.t;
-    shade_hit<ROUGH>(p, h, sc, film, rc, sink, pd, shadow);
+    shade_hit<ROUGH, TR>(p, h, sc, film, rc, sink, pd, shadow);
     st.prof_mark(1);
     bool occluded = false;
     if (pd.has_shadow) {
@@ -1857,7 +1882,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     st.prof_mark(0);
     if (Stack::kPark) p.rng.inc = st.unpark_inc();
     refresh(p, sink);
-    const bool an = shade_finish<ROUGH>(p, h, occluded, pd, sc, film, rc, sink);
+    const bool an = shade_finish<ROUGH, TR>(p, h, occluded, pd, sc, film, rc, sink);
     if (Stack::kPark) { st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); }
     st.prof_mark(1);
     return an;

@@ -27,6 +27,7 @@ struct SceneDev {
     uint32_t bvh_depth;
     uint32_t wide_levels, wide4_levels, wide8q_levels;   // levels of wnodes / wnodes4 / wnodes8q: a wide walk stacks at most one group per level
     uint32_t lds_bytes;              // bytes needed to stage the whole scene in LDS
+    uint32_t traits;                 // kTr* bits (mtr_core.h) that hold for the material / emitter tables: kernels specialised on them are chosen
     uint32_t has_rough;              // the scene needs the EXTENDED shading code (kernels instantiated with ROUGH = true): a material
                                      // is a GGX lobe (MTR_BSDF_ROUGH*), or a triangle is smooth-shaded (vnormals)
 };
@@ -70,7 +71,7 @@ struct FusedArgs {
     NlosConst nlos;
 };
 
-struct FusedConfig { int stack; bool scene_lds; bool hist_lds; bool fixed; bool rough; size_t lds_bytes; int grid; int per_cu; };
+struct FusedConfig { int stack; bool scene_lds; bool hist_lds; bool fixed; bool rough; size_t lds_bytes; int grid; int per_cu; uint32_t traits; };
 
 // chooses G, LDS carve-up and grid for a render; returns false if nothing fits
 bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_t spp_chunk, int n_cu,

@@ -191,7 +191,8 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 // 48 KB histogram per workgroup: three per CU) get the 168-register budget of 3 waves per SIMD instead of spilling.
 // PHASOR: phasor_hdr_film (HIST_LDS form only): the ring rows hold (Re, Im) per frequency, the flush adds 2F floats per pixel
 // FIXED: MTR_FLAG_DETERMINISTIC (HIST_LDS form only): rows and steady sums in 64-bit fixed point
-template <bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES, bool PHASOR = false, bool FIXED = false, bool ROUGH = false>
+// TR: scene traits (mtr_core.h: kTrDiffuse | kTrOneRectEmitter) — shading code the scene's tables cannot reach is not compiled in
+template <bool SCENE_LDS, bool HIST_LDS, bool NLOS, int MINW = MTR_FUSED_MIN_WAVES, bool PHASOR = false, bool FIXED = false, bool ROUGH = false, uint32_t TR = 0u>
 __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -366,25 +367,25 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             if (PHASOR) {
                 LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                alive = path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 did_splats = sink.n_splats;
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
@@ -610,6 +611,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     else { G = g_want; cfg.hist_lds = false; }                          // row > LDS: f32 atomics to HBM
     cfg.fixed = det && cfg.hist_lds;
     cfg.rough = sc.has_rough != 0u;
+    cfg.traits = cfg.rough ? 0u : sc.traits;
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
@@ -651,7 +653,7 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
 {
     void (*k)(const FusedArgs) = nullptr;
 #ifdef MTR_ONLY_C2            // tools/regs_c2.sh: compile ONLY the instantiation config 2 runs (register-allocation experiments: one minute instead of four)
-    k = k_fused<true, true, false>;
+    k = k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
     (void)cfg; (void)stream; return k ? hipSuccess : hipErrorInvalidValue;
 #endif
     if (!NLOS && args.film.n_freq) {
@@ -664,6 +666,8 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
                           : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
     }
     else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornell)          // diffuse materials, one rectangle emitter: the specialised shading code
+        k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornell> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
     else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<false, true, NLOS>;
