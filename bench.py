@@ -327,8 +327,75 @@ def extra_config_legs(spp4, spp5):
     out["config5" if spp5 == 2048 else "config5_reduced"] = r5
     del sc5
     torch.cuda.empty_cache()
+    # ... and the scene AS ITS FILE DESCRIBES IT — what a user of the reference's scene.xml gets: GGX lobes (6 roughplastic, 2
+    # roughconductor), interpolated vertex normals, the nine bitmap textures (256-px fixtures) — instead of the section-8d mapping
+    sc5r = staircase(width=512, height=512, temporal_bins=2048, max_depth=65, materials="rough", vertex_normals=True, textures=True)
+    film = sc5r.sensors()[0].film()
+    film.start_opl, film.bin_width_opl = 0.0, 40.0 / 2048
+    r5r, c5r, t5r = run(sc5r, spp5, 2)
+    r5r["workload"] = (f"staircase scene.xml as written (262,663 triangles, GGX roughplastic / roughconductor lobes, vertex normals, bitmap "
+                       f"textures), 512x512 px, 2048 time bins (start_opl 0, width 40/2048), {spp5} of 2048 spp, max_depth 65, camera_unwarp")
+    r5r.update(wavefront_rooflines(c5r, t5r, 2, r5r["ms"], False))       # (live times and algorithmic bytes; the PMC passes are of the smooth workload)
+    out["config5_rough" if spp5 == 2048 else "config5_rough_reduced"] = r5r
+    del sc5r
+    torch.cuda.empty_cache()
     out["wall_s"] = time.perf_counter() - t0
     return out
+
+
+def splat_microbench(log2_s=30):
+    """SURVEY section 8d's micro-benchmark of the scatter-add ALONE, as stated: S = 2^30 synthetic contributions into a
+    512 x 512 x 1024-bin film through the film's own `add_transient_data` (-> mtr_splat_add, variant 1), pixel ~ U[0, 2^18)
+    either pixel-major sorted (the order the reference's own call produces: lanes are pixel-major) or in arbitrary order,
+    bin ~ clipped Normal(400, 120), rgb ~ U(0, 1), seed 1234.  frac = 24 B x S / time / 8 TB/s, time = the kernels' HIP events
+    (best of 3).  Falls back to 2^28 when 2^30 does not fit beside what the process already holds."""
+    import torch
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.scene import Properties
+    mi.set_variant("llvm_ad_rgb")
+    W = H = 512
+    T = 1024
+
+    def run(log2):
+        S = 1 << log2
+        film = mitr.TransientHDRFilm(Properties("transient_hdr_film", {"width": W, "height": H, "temporal_bins": T, "start_opl": 3.5,
+                                                                       "bin_width_opl": 6.0 / T, "rfilter": {"type": "box"}}))
+        film.prepare([])
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234)
+        pix = torch.randint(0, W * H, (S,), device="cuda", generator=g, dtype=torch.int32)
+        bins = torch.clamp(torch.normal(400.0, 120.0, (S,), device="cuda", generator=g), 0, T - 1).floor_()
+        opl = bins.add_(0.5).mul_(6.0 / T).add_(3.5)
+        del bins
+        rgb = torch.rand((S, 3), device="cuda", generator=g)
+        out = {"contributions": S, "film": f"{W}x{H}x{T}", "algorithmic_bytes": SPLAT_BYTES * S, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+
+        def leg(name, pixels, variant, what):
+            pos = torch.stack(((pixels % W).float() + 0.5, (pixels // W).float() + 0.5), dim=1)
+            best = None
+            for _ in range(3):
+                film.clear()
+                ms = film.add_transient_data(pos, opl, None, rgb, 1.0, None, variant=variant)
+                best = ms if best is None else min(best, ms)
+            gbs = SPLAT_BYTES * S / (best * 1e-3) / 1e9
+            out[name] = {"ms": best, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "what": what}
+        leg("uniform", pix, 1, "arbitrary order: device-side partition by pixel (two scatter passes over 16-byte records) + LDS rows")
+        # (opl and rgb are i.i.d. and independent of the pixel: sorting the pixel column alone gives the sorted benchmark's distribution)
+        pix = torch.sort(pix)[0]
+        leg("sorted", pix, 1, "pixel-major sorted (the order of the reference's own call): LDS row per pixel run, 16-byte read-modify-write of the touched bins")
+        leg("sorted_zero_film", pix, 1 | 0x100, "the same onto a film the caller vouches is zero (MTR_SPLAT_FILM_ZERO): whole-row stores")
+        film.clear()
+        return out
+    for log2 in (log2_s, 28):
+        try:
+            r = run(log2)
+            torch.cuda.empty_cache()
+            return r
+        except (RuntimeError, torch.OutOfMemoryError, Exception) as e:      # noqa: BLE001 — a side leg must never take the line down
+            err = f"{type(e).__name__}: {e}"[:200]
+            torch.cuda.empty_cache()
+    return {"error": err}
 
 
 def main():
@@ -351,6 +418,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scatter-leg", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config-4 / config-5 side legs")
+    ap.add_argument("--no-splat-microbench", action="store_true", help="skip SURVEY 8d's stand-alone scatter-add micro-benchmark (2^30 contributions)")
+    ap.add_argument("--splat-log2", type=int, default=30, help="log2 of the micro-benchmark's contribution count")
     ap.add_argument("--reduced-config5", action="store_true", help="config-5 side leg at 128 of its 2048 spp (quick runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--reserve-cus", type=int, default=None,
@@ -562,6 +631,15 @@ def main():
         torch.cuda.empty_cache()
         extra = extra_config_legs(512, 2048 if not args.reduced_config5 else 128)
 
+    splat_mb = None
+    if rank == 0 and world == 1 and SCENE == "cornell" and not args.no_splat_microbench and not args.no_extra_configs:
+        try:
+            del renderer, scene
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        splat_mb = splat_microbench(args.splat_log2)
+
     if rank == 0:
         rays = totals["rays_closest"] + totals["rays_shadow"]
         ms_per_step = elapsed / args.steps * 1e3
@@ -665,6 +743,8 @@ def main():
             res["scatter_add"] = scatter
         if extra:
             res["extra_configs"] = extra
+        if splat_mb:
+            res["splat_microbench"] = splat_mb
         if cpu_res is not None:
             res["cpu_baseline"] = cpu_res
             res["gpu_over_cpu"] = res["value"] / cpu_res["value"]

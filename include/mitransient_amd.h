@@ -247,7 +247,11 @@ enum { MTR_FLAG_CAMERA_UNWARP = 1u,        /* common.py:25, transientpath.py:133
                                               mitsuba's independent sampler passes size = 1 after the TEA scramble in the
                                               versions we know [upstream-unverified, SURVEY A.9].  Kept so that ONE real
                                               reference render decides the question without a code change
-                                              (tests/test_reference_golden.py).                                */ };
+                                              (tests/test_reference_golden.py).                                */,
+       MTR_FLAG_PCG_TEA64 = 128u           /* a third reading of the same call site (round 5; a new flag bit, no ABI change): m_rng.seed(1, sample_tea_64(seed, idx),
+                                              sample_tea_64(idx, seed)) — 64-bit state and stream words, each the two TEA
+                                              outputs glued together (v0 + (v1 << 32)) — instead of the two halves of one
+                                              sample_tea_32(seed, idx) [upstream-unverified].  Wins over PLUS_LANE if both are set. */ };
 
 /* which kernel organisation executes the path */
 enum { MTR_MODE_AUTO = 0,
@@ -392,7 +396,8 @@ int  mtr_splat_add(mtr_ctx *, const mtr_splat_soa *, const mtr_film_desc *, int 
                    float *transient_hwt4 /*device*/, float *elapsed_ms /*host, may be NULL*/);
 
 /* Release the device workspaces the context keeps between calls (ABI 10: the partition workspace of mtr_splat_add on
- * unsorted input — 32 bytes per contribution of the largest such call).  Synchronises the context's stream. */
+ * unsorted input — 32 bytes per contribution; a workspace above 256 MiB is released by the call itself, a smaller one
+ * stays with the context).  Synchronises the context's stream. */
 int  mtr_ctx_trim(mtr_ctx *);
 
 /* Debug/test aid: per-lane splat log of one render (records of 8 x u32:

@@ -22,6 +22,7 @@ MTR_FLAG_CAMERA_UNWARP = 1
 MTR_FLAG_DISCARD_DIRECT_LIGHT = 2
 MTR_FLAG_FILM_ZERO = 4
 MTR_FLAG_PCG_INITSEQ_PLUS_LANE = 8
+MTR_FLAG_PCG_TEA64 = 128
 MTR_FLAG_KEEP_COUNTERS = 16
 MTR_FLAG_DETERMINISTIC = 32
 MTR_FLAG_DEVELOPED_ROWS = 64

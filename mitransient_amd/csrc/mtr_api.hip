@@ -31,15 +31,17 @@ struct mtr_ctx {
                                            // row bands may overlap on two streams: each needs its own), [16, 18) wavefront segments
     uint32_t fused_launches = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;               // mtr_splat_add: the partitioned passes, timed apart from the first pass (the workspace allocation in between is host time)
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
     void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
-    void *d_part = nullptr; size_t part_cap = 0;         // ... and the partition workspace of unsorted input (kept until mtr_ctx_trim / destroy)
+    void *d_part = nullptr; size_t part_cap = 0;         // ... and the partition workspace of unsorted input (at most 256 MiB of it kept between calls, until mtr_ctx_trim / destroy)
 };
 
 struct WfWorkspace {            // MTR_MODE_WAVEFRONT buffers, sized for one tile, reused across renders
     void *planes = nullptr, *q_live = nullptr, *q_ray = nullptr, *q_mat = nullptr, *q_shadow = nullptr, *r_shadow = nullptr, *occ = nullptr, *counts = nullptr, *rec = nullptr, *rec_count = nullptr, *q_zombie = nullptr;
     uint32_t n_slots = 0, P = 0, rec_cap = 0, rows = 0;
-    uint32_t *host_count = nullptr;       // pinned: live count read back between bounce chunks
+    uint32_t *host_count = nullptr;       // pinned: live counts read back between bounce chunks (two words, alternating)
+    hipEvent_t poll_ev[2] = { nullptr, nullptr };     // ... and the events that say a word has landed
 };
 
 struct NlosDev {                // NLOS tier: device tables + constants (mtr_scene_set_nlos)
@@ -114,6 +116,8 @@ int mtr_ctx_create(int device_ordinal, mtr_ctx **out)
     HIP_TRY(nullptr, hipMalloc((void **)&c->d_ticket, 32 * sizeof(uint32_t)));
     HIP_TRY(nullptr, hipEventCreate(&c->ev0));
     HIP_TRY(nullptr, hipEventCreate(&c->ev1));
+    HIP_TRY(nullptr, hipEventCreate(&c->ev2));
+    HIP_TRY(nullptr, hipEventCreate(&c->ev3));
     *out = c;
     return MTR_OK;
 }
@@ -129,6 +133,8 @@ void mtr_ctx_destroy(mtr_ctx *c)
     if (c->d_part) (void)hipFree(c->d_part);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     delete c;
 }
 
@@ -291,6 +297,7 @@ void mtr_scene_destroy(mtr_scene *s)
     void *w[] = { s->wf.planes, s->wf.q_live, s->wf.q_ray, s->wf.q_mat, s->wf.q_shadow, s->wf.r_shadow, s->wf.occ, s->wf.counts, s->wf.rec, s->wf.rec_count, s->wf.q_zombie };
     for (void *p : w) if (p) (void)hipFree(p);
     if (s->wf.host_count) (void)hipHostFree(s->wf.host_count);
+    for (hipEvent_t e : s->wf.poll_ev) if (e) (void)hipEventDestroy(e);
     void *nl[] = { s->nlos.shapes, s->nlos.tables, s->nlos.hg_tris, s->nlos.hg_vn, s->nlos.targets, s->d_freq };
     for (void *p : nl) if (p) (void)hipFree(p);
     delete s;
@@ -357,6 +364,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
     if (!w.host_count) HIP_TRY(c, hipHostMalloc((void **)&w.host_count, 64));
+    for (hipEvent_t &e : w.poll_ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     w.n_slots = n_slots; w.P = P; w.rec_cap = rec_cap; w.rows = n_seg;
     return MTR_OK;
 }
@@ -476,6 +484,23 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             HIP_TRY(c, launch_wf(a, cfg, 0, grid_gen, c->stream));                   // raygen (writes live list 0)
             HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)a.seg_list_n, (int)a.n_seg, 1, c->stream));     // bounce 0 walks every segment
             uint32_t depth = 0;
+            // "Anyone left?" WITHOUT draining the stream (round 5).  Every 8 bounces the live count is copied to a pinned word and an
+            // event is recorded behind the copy; the host then waits for the PREVIOUS poll's event — the count of 8 bounces ago —
+            // while the chunk it has just enqueued keeps the GPU busy.  The loop therefore runs at most 8 bounces past the last
+            // live path (launches over an empty segment list: 4 us each) and the stream never idles while the host decides; rounds
+            // 1-4 synchronised the stream here, a bubble per chunk and a stall for a caller overlapping bands with collectives.
+            uint32_t n_polls = 0;
+            auto poll_live = [&](bool &done) -> int {
+                const uint32_t cur = n_polls & 1u;
+                HIP_TRY(c, hipMemcpyAsync(w.host_count + cur, live_total, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipEventRecord(w.poll_ev[cur], c->stream));
+                if (n_polls) {
+                    HIP_TRY(c, hipEventSynchronize(w.poll_ev[cur ^ 1u]));
+                    if (w.host_count[cur ^ 1u] == 0u) done = true;
+                }
+                ++n_polls;
+                return MTR_OK;
+            };
             while (depth < max_depth) {
                 if (unbounded) HIP_TRY(c, hipMemsetAsync(live_total, 0, 4, c->stream));
                 HIP_TRY(c, hipMemsetAsync(a.seg_list_n + (a.parity ^ 1u), 0, 4, c->stream));     // the list this bounce's survivors build
@@ -484,11 +509,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                     *n_trace += 1;
                     a.parity ^= 1u;
                     ++depth;
-                    if (unbounded && (depth & 7u) == 0) {
-                        HIP_TRY(c, hipMemcpyAsync(w.host_count, live_total, 4, hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(c, hipStreamSynchronize(c->stream));
-                        if (*w.host_count == 0) break;
-                    }
+                    if (unbounded && (depth & 7u) == 0) { bool done = false; if (int r = poll_live(done)) return r; if (done) break; }
                     continue;
                 }
                 a.trace_any = 0u;
@@ -504,11 +525,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                 }
                 a.parity ^= 1u;
                 ++depth;
-                if (unbounded && (depth & 7u) == 0) {                                // every 8 bounces: anyone left?
-                    HIP_TRY(c, hipMemcpyAsync(w.host_count, live_total, 4, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    if (*w.host_count == 0) break;
-                }
+                if (unbounded && (depth & 7u) == 0) { bool done = false; if (int r = poll_live(done)) return r; if (done) break; }      // every 8 bounces: anyone left?
             }
             hipEvent_t a0 = nullptr, a1 = nullptr;
             if (timed) {
@@ -763,11 +780,17 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
     // reads the sortedness flag back — one stream synchronisation — and holds 32 bytes of workspace per contribution for the call
     const bool can_partition = variant == 1 && scratch && splat_partition_supported(*s, fm);
     HIP_TRY(c, launch_splat_add(variant, *s, fm, t4, nullptr, scratch, c->stream, film_zero && variant == 1, !can_partition));
+    bool second_leg = false;
     if (can_partition && s->n) {
         uint32_t unsorted = 0;
+        if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipMemcpyAsync(&unsorted, scratch, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (unsorted) {
+            // The workspace (32 B per contribution: 32 GiB for 2^30 of them) is raw device memory that torch's caching allocator
+            // cannot see.  At most kPartRetain of it stays with the context between calls; a larger one is released before the
+            // call returns (one more stream synchronisation — the call has blocked once already to read the flag).
+            constexpr size_t kPartRetain = (size_t)256 << 20;
             const size_t need = splat_partition_scratch_bytes(*s, fm);
             hipError_t e = hipSuccess;
             if (c->part_cap < need) {
@@ -776,14 +799,26 @@ int mtr_splat_add(mtr_ctx *c, const mtr_splat_soa *s, const mtr_film_desc *fd, i
                 e = hipMalloc(&c->d_part, need);
                 if (e == hipSuccess) c->part_cap = need; else { c->d_part = nullptr; (void)hipGetLastError(); }
             }
+            // (timed calls: the passes below get their own pair of events — the allocation above is host time, not kernel time)
+            if (elapsed_ms) { HIP_TRY(c, hipEventRecord(c->ev2, c->stream)); second_leg = true; }
             if (e != hipSuccess) HIP_TRY(c, launch_splat_add(0, *s, fm, t4, nullptr, nullptr, c->stream));     // no room for the workspace: the contract form
             else HIP_TRY(c, launch_splat_partitioned(*s, fm, t4, film_zero, nullptr, c->d_part, c->n_cu, c->stream));
+            if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev3, c->stream));
+            if (c->part_cap > kPartRetain) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                (void)hipFree(c->d_part);
+                c->d_part = nullptr; c->part_cap = 0;
+            }
         }
-    }
+    } else if (elapsed_ms) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (elapsed_ms) {
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+        if (second_leg) {
+            float ms2 = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev2, c->ev3));
+            *elapsed_ms += ms2;
+        }
     }
     return MTR_OK;
 }

@@ -87,21 +87,39 @@ MTR_HD void tea4(uint32_t &v0, uint32_t &v1)
         v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
     }
 }
-MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane, bool seq_plus_lane = false)
+// The (initstate, initseq) pair mitsuba's independent sampler hands to PCG32::seed for (seed, lane) — three readings of one
+// upstream call site, selected by render flags (include/mitransient_amd.h) until a real reference render decides:
+//   default                         sample_tea_32(seed, lane) -> (v0, v1)
+//   MTR_FLAG_PCG_INITSEQ_PLUS_LANE  ... with lane added to the stream word (drjit's PCG32::seed adds arange(size))
+//   MTR_FLAG_PCG_TEA64              (sample_tea_64(seed, lane), sample_tea_64(lane, seed)), sample_tea_64 = v0 + (v1 << 32)
+MTR_HD void rng_seed_words(uint32_t seed, uint32_t lane, uint32_t flags, uint64_t &initstate, uint64_t &initseq)
 {
     uint32_t v0 = seed, v1 = lane;
     tea4(v0, v1);
-    return (((uint64_t)v1 + (seq_plus_lane ? (uint64_t)lane : 0ull)) << 1u) | 1u;     // == rng_seed(...).inc
+    if (flags & MTR_FLAG_PCG_TEA64) {
+        uint32_t w0 = lane, w1 = seed;
+        tea4(w0, w1);
+        initstate = (uint64_t)v0 + ((uint64_t)v1 << 32); initseq = (uint64_t)w0 + ((uint64_t)w1 << 32);
+    } else {
+        initstate = (uint64_t)v0;
+        initseq = (uint64_t)v1 + ((flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) ? (uint64_t)lane : 0ull);
+    }
 }
-MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane, bool seq_plus_lane = false)
+MTR_HD uint64_t rng_inc_of(uint32_t seed, uint32_t lane, uint32_t flags = 0u)
 {
-    uint32_t v0 = seed, v1 = lane;
-    tea4(v0, v1);
+    uint64_t st, sq;
+    rng_seed_words(seed, lane, flags, st, sq);
+    return (sq << 1u) | 1u;                                  // == rng_seed(...).inc
+}
+MTR_HD Rng rng_seed(uint32_t seed, uint32_t lane, uint32_t flags = 0u)
+{
+    uint64_t st, sq;
+    rng_seed_words(seed, lane, flags, st, sq);
     Rng r;
-    r.inc = (((uint64_t)v1 + (seq_plus_lane ? (uint64_t)lane : 0ull)) << 1u) | 1u;      // MTR_FLAG_PCG_INITSEQ_PLUS_LANE
+    r.inc = (sq << 1u) | 1u;
     r.state = 0u;
     rng_u32(r);
-    r.state += (uint64_t)v0;
+    r.state += st;
     rng_u32(r);
     return r;
 }
@@ -1573,7 +1591,7 @@ MTR_HD void path_begin(Path &p, const Camera &cam, const Film &f, const RenderCo
     uint32_t lane = pixel * rc.spp_total + s;
     uint32_t py = fastdiv(pixel, rc.div_crop_w), px = pixel - f.crop_w * py;
     p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
-    p.rng = rng_seed(rc.seed, lane, (rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
+    p.rng = rng_seed(rc.seed, lane, rc.flags);
     float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
     p.ray = camera_ray(cam, rc, p.px, p.py, j1, j2);
     p.beta = mk(1, 1, 1); p.L = mk(0, 0, 0); p.prev_p = mk(0, 0, 0);

@@ -132,7 +132,7 @@ MTR_HD void nlos_begin(Path &p, const NlosConst &nc, const Film &f, const Render
     const uint32_t lane = pixel * rc.spp_total + s;
     const uint32_t py = pixel / f.crop_w, px = pixel - f.crop_w * py;
     p.px = px + f.crop_x; p.py = py + f.crop_y; p.lane = lane;
-    p.rng = rng_seed(rc.seed, lane, (rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
+    p.rng = rng_seed(rc.seed, lane, rc.flags);
     const float j1 = rng_f32(p.rng), j2 = rng_f32(p.rng);
     const float sx = fmaf((float)p.px + j1, rc.inv_crop_w, rc.off_x), sy = fmaf((float)p.py + j2, rc.inv_crop_h, rc.off_y);
     p.ray = nc.camera_sensor ? camera_ray(nc.cam, rc, p.px, p.py, j1, j2) : nlos_sensor_ray(nc, sx, sy);

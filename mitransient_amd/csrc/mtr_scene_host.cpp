@@ -128,8 +128,15 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
     }
     for (uint32_t i = 0; i < d.n_materials; ++i)
         if (d.materials[i].type > MTR_BSDF_PLASTIC) return "unknown BSDF type";
-    for (uint32_t i = 0; i < d.n_materials; ++i)
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
         if (bsdf_is_rough(d.materials[i].type) && d.materials[i].type != MTR_BSDF_PLASTIC && !(d.materials[i].alpha > 0.0f)) return "rough BSDF: alpha must be positive";
+        // the second roughness of an anisotropic lobe (c2[0]; roughdielectric: b[0]) divides in ggx_eval / beck_eval just like alpha
+        if (bsdf_is_rough(d.materials[i].type) && d.materials[i].type != MTR_BSDF_PLASTIC && (d.materials[i].flags & MTR_MAT_ANISOTROPIC) &&
+            !(rough_alpha_v(d.materials[i]) > 0.0f)) return "rough BSDF: alpha_v of an anisotropic lobe must be positive";
+        // the two-sided adapter is defined for materials without a transmission component only (the header's contract; scene.py enforces it too)
+        if ((d.materials[i].flags & MTR_MAT_TWOSIDED) && (d.materials[i].type == MTR_BSDF_DIELECTRIC || d.materials[i].type == MTR_BSDF_ROUGHDIELECTRIC ||
+                                                           d.materials[i].type == MTR_BSDF_THINDIELECTRIC)) return "MTR_MAT_TWOSIDED on a transmissive BSDF";
+    }
 
     s.film = film_from_desc(d.film);
     memcpy(s.cam.s2c, d.camera.sample_to_camera, sizeof s.cam.s2c);

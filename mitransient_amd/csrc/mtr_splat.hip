@@ -418,6 +418,9 @@ bool splat_partition_supported(const mtr_splat_soa &s, const Film &film)
     uint32_t bits_pix = 1; while ((1ull << bits_pix) < npix) ++bits_pix;
     uint32_t bits_bin = 1; while ((1ull << bits_bin) < film.bins) ++bits_bin;
     if (bits_pix + bits_bin > 32u) return false;
+    // the record key pixel | bin << bits_pix shares its value space with the sentinel kDropped = 0xffffffff: when both counts are
+    // exact powers of two that fill the 32 bits, the last pixel's last bin WOULD be that key and its contribution would vanish
+    if (bits_pix + bits_bin == 32u && (((uint64_t)(film.bins - 1u) << bits_pix) | (npix - 1u)) == 0xffffffffull) return false;
     return (size_t)film.bins * 12u <= 150u * 1024u;             // the row must fit LDS
 }
 

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     load_state(P, slot, p, &pend, false);
                     const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                     p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
-                    p.rng.inc = rng_inc_of(a.rc.seed, p.lane, (a.rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
+                    p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
                     Hit h;
                     { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                     ++n_closest;
@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
                 load_state(P, slot, p);
                 const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                 p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
-                p.rng.inc = rng_inc_of(a.rc.seed, p.lane, (a.rc.flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0u);
+                p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
                 RecordSink sink;
                 sink.rec = a.rec; sink.s_rec_count = s_rec; sink.rec_cap = a.rec_cap;
                 sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = a.film.bins;

@@ -52,7 +52,14 @@ def reduce_scatter_rows(t, group=None):
         dist.all_reduce(tt, group=group)
         out.copy_(tt[rank * per:(rank + 1) * per])
     else:
-        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+        try:
+            dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+        except (RuntimeError, NotImplementedError):
+            if dist.get_backend(group) != "gloo":
+                raise
+            tt = t.clone()                   # older torch: gloo has no reduce_scatter_tensor — the same sum through all_reduce + slice
+            dist.all_reduce(tt, group=group)
+            out.copy_(tt[rank * per:(rank + 1) * per])
     lo, hi = row_slab(H, world, rank)
     return out[:hi - lo]
 
@@ -73,7 +80,14 @@ def all_gather_rows(slab, height: int, group=None):
         dist.all_gather(parts, slab, group=group)
         full = torch.cat(parts, dim=0)
     else:
-        dist.all_gather_into_tensor(full, slab, group=group)
+        try:
+            dist.all_gather_into_tensor(full, slab, group=group)
+        except (RuntimeError, NotImplementedError):
+            if dist.get_backend(group) != "gloo":
+                raise
+            parts = [torch.empty_like(slab) for _ in range(dist.get_world_size(group))]      # older torch over gloo
+            dist.all_gather(parts, slab, group=group)
+            full = torch.cat(parts, dim=0)
     return full[:height]
 
 
@@ -302,10 +316,15 @@ class DistributedRenderer:
                 side.wait_stream(st)
             if gloo:
                 side.synchronize()
-            sums = raw_s.contiguous()
+            # a COPY: raw_s is the film's own steady accumulator and must keep this rank's partial sums, like transient_storage
+            sums = raw_s.clone()
             dist.all_reduce(sums, group=self.group)
             full_s = film.develop_slab(None, sums)[1]
             out_s = full_s if gather else full_s[torch.as_tensor(self.owned_rows, device=dev)]
+            # allocated under the side stream, read on the main one: the caching allocator must not hand the block to later
+            # side-stream work while main still reads it
+            if dev.type == "cuda":
+                out_s.record_stream(main)
         main.wait_stream(side)
         for st in lanes:
             main.wait_stream(st)

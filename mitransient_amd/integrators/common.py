@@ -28,8 +28,10 @@ class TransientADIntegrator:
         self.rr_depth = int(props.get("rr_depth", 5))
         if self.rr_depth <= 0:
             raise Exception("\"rr_depth\" must be set to a value greater than zero!")
-        # hide_emitters only affects environment / directly visible emitters in the camera's alpha [mitsuba3: ADIntegrator];
-        # transientpath.py never reads it and the subset has no environment emitter: parsed, kept, without effect
+        # hide_emitters: transientpath.py reads it in its "Hide the environment emitter" block after si.bsdf(ray) — a camera ray
+        # (depth 0) that MISSES the scene stops being active when the flag is set, which only changes what an ENVIRONMENT emitter
+        # would have contributed.  The subset has no environment emitter (a miss contributes nothing either way): parsed, kept,
+        # without effect here
         self.hide_emitters = bool(props.get("hide_emitters", False))
         # common.py:25-30
         self.camera_unwarp = bool(props.get("camera_unwarp", False))
@@ -39,6 +41,8 @@ class TransientADIntegrator:
         _ = props.get("block_size", 0)
         # sampler seeding variant (extension; see MTR_FLAG_PCG_INITSEQ_PLUS_LANE in the header): False = TEA(seed, lane) only
         self.pcg_initseq_plus_lane = bool(props.get("amd_pcg_initseq_plus_lane", False))
+        # ... and the 64-bit reading of the same call site (MTR_FLAG_PCG_TEA64)
+        self.pcg_tea64 = bool(props.get("amd_pcg_tea64", False))
         # order-independent (fixed-point) accumulation in the fused kernel: bit-reproducible renders (extension)
         self.deterministic = bool(props.get("amd_deterministic", False))
         # single-pass film lifecycle (extension): when one pass of the fused kernel renders all samples of all pixels, let its
@@ -134,6 +138,8 @@ class TransientADIntegrator:
             f |= _cabi.MTR_FLAG_DISCARD_DIRECT_LIGHT
         if self.pcg_initseq_plus_lane:
             f |= _cabi.MTR_FLAG_PCG_INITSEQ_PLUS_LANE
+        if self.pcg_tea64:
+            f |= _cabi.MTR_FLAG_PCG_TEA64
         if self.deterministic:
             f |= _cabi.MTR_FLAG_DETERMINISTIC
         return f

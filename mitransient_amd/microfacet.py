@@ -28,10 +28,41 @@ def _disk(u1, u2):
     return r * np.where(swap, s, c), r * np.where(swap, c, s)
 
 
+def _erf_pair():
+    """erf / erfinv in float64: scipy's when it is installed, else numpy restatements (math.erf element-wise; erfinv by
+    M. Giles' single-precision polynomial as the first guess and three Newton steps on erf) — scipy is NOT a dependency
+    of loading a default (Beckmann) `roughplastic` scene"""
+    try:
+        from scipy.special import erf, erfinv
+        return erf, erfinv
+    except ImportError:
+        pass
+    import math
+    erf = np.vectorize(math.erf, otypes=[np.float64])
+
+    def erfinv(x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            w = -np.log((1.0 - x) * (1.0 + x))
+            w1 = w - 2.5
+            p1 = 2.81022636e-08
+            for c in (3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087, -0.00125372503, -0.00417768164, 0.246640727, 1.50140941):
+                p1 = p1 * w1 + c
+            w2 = np.sqrt(np.maximum(w, 5.0)) - 3.0
+            p2 = -0.000200214257
+            for c in (0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773, -0.0076224613, 0.00943887047, 1.00167406, 2.83297682):
+                p2 = p2 * w2 + c
+            y = np.where(w < 5.0, p1, p2) * x
+            for _ in range(3):
+                y = y - (erf(y) - x) * (0.5 * np.sqrt(np.pi)) * np.exp(y * y)
+        return np.where(np.abs(x) >= 1.0, np.copysign(np.inf, x), y)
+    return erf, erfinv
+
+
 def _beckmann_slopes(ct, u1, u2):
     """MicrofacetDistribution::sample_visible_11 (Beckmann): inversion of the visible-slope CDF in the erf domain, a
     closed-form first guess + three Newton iterations, as mitsuba does it (float64 here)"""
-    from scipy.special import erf, erfinv
+    erf, erfinv = _erf_pair()
     inv_sqrt_pi = 1.0 / np.sqrt(np.pi)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         tan_t = np.sqrt(np.maximum(1.0 - ct * ct, 0.0)) / ct

@@ -107,10 +107,19 @@ static float pcg32_next_f32(pcg32 *r)
     return x.f - 1.0f;
 }
 /* sampler.seed(seed, wavefront_size): per-lane stream from TEA(seed, lane) */
-static void sampler_seed_v(pcg32 *r, uint32_t seed_value, uint32_t lane, int seq_plus_lane)
+static void sampler_seed_v(pcg32 *r, uint32_t seed_value, uint32_t lane, uint32_t flags)
 {
+    const int seq_plus_lane = (flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0;
     uint32_t v0 = seed_value, v1 = lane;
     tea32(&v0, &v1, 4);
+    if (flags & MTR_FLAG_PCG_TEA64) {
+        /* third reading [upstream-unverified]: m_rng.seed(1, sample_tea_64(seed, idx), sample_tea_64(idx, seed)) with
+         * sample_tea_64(a, b) = v0 + (v1 << 32) of sample_tea_32(a, b): 64-bit state and stream words */
+        uint32_t w0 = lane, w1 = seed_value;
+        tea32(&w0, &w1, 4);
+        pcg32_seed(r, (uint64_t)v0 + ((uint64_t)v1 << 32), (uint64_t)w0 + ((uint64_t)w1 << 32));
+        return;
+    }
     /* [drjit: PCG32::seed(size, initstate, initseq)] inc = ((initseq + arange(size)) << 1) | 1; mitsuba's sampler seeds with
      * size = 1 after the scramble (seq_plus_lane = 0); the other reading is kept switchable (MTR_FLAG_PCG_INITSEQ_PLUS_LANE) */
     pcg32_seed(r, (uint64_t)v0, (uint64_t)v1 + (seq_plus_lane ? (uint64_t)lane : 0u));
@@ -1289,7 +1298,7 @@ static void trace_lane(const orc_scene *sc, const mtr_render_params *P, film_t *
     uint32_t py = idx / f->crop_width, px = idx - f->crop_width * py;
     px += f->crop_offset_x; py += f->crop_offset_y;
 
-    pcg32 rng; sampler_seed_v(&rng, P->seed, lane, (P->flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0);   /* common.py:52 */
+    pcg32 rng; sampler_seed_v(&rng, P->seed, lane, P->flags);   /* common.py:52 */
     float j1 = pcg32_next_f32(&rng), j2 = pcg32_next_f32(&rng);
     ray3 ray = sample_ray(d, px, py, j1, j2);
 
@@ -1783,7 +1792,7 @@ static void trace_lane_nlos(const orc_scene *sc, const nlos_scene *N, const mtr_
     uint32_t idx = lane / spp;
     uint32_t py = idx / f->crop_width, px = idx - f->crop_width * py;
     px += f->crop_offset_x; py += f->crop_offset_y;
-    pcg32 rng; sampler_seed_v(&rng, P->seed, lane, (P->flags & MTR_FLAG_PCG_INITSEQ_PLUS_LANE) != 0);
+    pcg32 rng; sampler_seed_v(&rng, P->seed, lane, P->flags);
     float j1 = pcg32_next_f32(&rng), j2 = pcg32_next_f32(&rng);
     /* sample_rays: pos_adjusted = (pos + jitter) * (1/crop) + offset, then the sensor snaps it to the pixel centre */
     float scx = 1.0f / (float)f->crop_width, scy = 1.0f / (float)f->crop_height;

@@ -4,8 +4,8 @@
 it is absent so far (PARITY UNPINNED), so the two reference tests skip.  The decision procedure itself is exercised on
 synthetic files made from the oracle (test_pin_procedure_on_synthetic_goldens), so that the day a real file is dropped in
 it answers, without a code change:
-  1. which PCG32 seeding Mitsuba's independent sampler uses (TEA only / TEA + lane offset on initseq — SURVEY A.9):
-     the variant whose 16-spp render reproduces the file's exact cells;
+  1. which PCG32 seeding Mitsuba's independent sampler uses (TEA only / TEA + lane offset on initseq — SURVEY A.9 — / the
+     64-bit sample_tea_64 words, MTR_FLAG_PCG_TEA64): the variant whose 16-spp render reproduces the file's exact cells;
   2. whether per-sample arithmetic lines up (rel-L2 <= 1e-5 = the north star's bar) or only the estimators agree:
      per-time-bin and per-pixel totals of a 1024-spp render within k sigma of the file's, sigma from batch means.
 """
@@ -33,7 +33,12 @@ def make_rough_cornell():
     return mi.load_dict(rough_cornell(mitr.cornell_box()))
 
 K_SIGMA = 5.0
-SEEDINGS = {"tea": False, "tea+lane": True}
+SEEDINGS = {"tea": "tea", "tea+lane": "tea+lane", "tea64": "tea64"}      # name -> what `render` is asked for
+
+
+def set_seeding(integ, which):
+    integ.pcg_initseq_plus_lane = which == "tea+lane"
+    integ.pcg_tea64 = which == "tea64"
 
 
 def classify(g, render):
@@ -53,7 +58,7 @@ def classify(g, render):
     nb = 16
     step = spp // nb
     bins, pix = [], []
-    flag = SEEDINGS[out["exact_seeding"]] if out["exact_seeding"] else False
+    flag = SEEDINGS[out["exact_seeding"]] if out["exact_seeding"] else "tea"
     for b in range(nb):
         s3, t3 = render(spp, seed, flag, (b * step, (b + 1) * step))          # batch b alone, scaled by 1/spp
         bins.append(t3.sum(axis=(0, 1)).astype(np.float64).sum(axis=-1) * nb)
@@ -78,7 +83,7 @@ def _oracle_render(oracle, scene):
     integ, film = scene.integrator(), scene.sensors()[0].film()
 
     def render(spp, seed, seq_plus_lane, spp_range):
-        integ.pcg_initseq_plus_lane = seq_plus_lane
+        set_seeding(integ, seq_plus_lane)
         s0, s1 = (0, spp) if spp_range is None else spp_range
         t4, s4, _ = oracle.render(sd, integ.render_params(film, seed, spp, s0, s1), use_bvh=True)
         t3, s3 = oracle.develop(sd.film, t4, s4)
@@ -103,11 +108,12 @@ def test_pin_procedure_on_synthetic_goldens(oracle, tmp_path):
     for name, flag in SEEDINGS.items():
         v = classify(synth(flag), render)
         assert v["exact_seeding"] == name and v["statistical"], v
-        other = [k for k in SEEDINGS if k != name][0]
-        assert v["exact_rel"][other] > 1e-2, v                      # the two seedings really are different streams
-    v = classify(synth(False, seed_shift=77), render)               # same estimator, unrelated samples
+        for other in SEEDINGS:
+            if other != name:
+                assert v["exact_rel"][other] > 1e-2, v              # the seedings really are different streams
+    v = classify(synth("tea", seed_shift=77), render)               # same estimator, unrelated samples
     assert v["exact_seeding"] is None and v["statistical"], v
-    v = classify(synth(False, seed_shift=77, scale=1.1), render)    # a 10 % bias must not pass
+    v = classify(synth("tea", seed_shift=77, scale=1.1), render)    # a 10 % bias must not pass
     assert v["exact_seeding"] is None and not v["statistical"], v
 
 
@@ -130,7 +136,7 @@ def test_rough_pin_scene_loads_and_self_classifies(oracle):
     render = _oracle_render(oracle, scene)
     g = {}
     for prefix, spp, seed in (("lo", 16, 0), ("hi", 128, 1)):
-        s3, t3 = render(spp, seed, False, None)
+        s3, t3 = render(spp, seed, "tea", None)
         g.update(pack_render(prefix, s3, t3))
         g[f"{prefix}_spp_seed"] = np.asarray([spp, seed])
     v = classify(g, render)
@@ -153,7 +159,7 @@ def test_hip_path_against_reference_render():
     integ, sens = scene.integrator(), scene.sensors()[0]
 
     def render(spp, seed, seq_plus_lane, spp_range):
-        integ.pcg_initseq_plus_lane = seq_plus_lane
+        set_seeding(integ, seq_plus_lane)
         passes = integ.prepare(scene, sens, seed, spp, [])
         integ.accumulate(scene, sens, passes, spp, spp_range=spp_range)
         s, t = sens.film().develop()

@@ -392,3 +392,38 @@ def test_multi_pass_prepare_host_logic(oracle, host_harness, monkeypatch):
     p1 = integ.render_params(film, passes[2][0].seed_value(), 3)                 # the same lanes scaled by 1/3 instead of 1/11
     t1, _, _ = oracle.render(sd, p1, n_threads=1)
     assert np.allclose(t4 * np.float32(11.0 / 3.0), t1, rtol=2e-6, atol=0)
+
+
+def test_c_abi_rejects_bad_materials(host_harness):
+    """derive_scene (the C-ABI's own validation, not only the Python loader's): a non-positive second roughness of an
+    anisotropic lobe and MTR_MAT_TWOSIDED on a transmissive BSDF are refused (ggx_eval / beck_eval divide by alpha_v; the
+    two-sided adapter is defined for materials without a transmission component)"""
+    import copy
+    from mitransient_amd import _cabi
+    base = make_cornell().data()
+    nn, dd, ll = C.c_uint32(), C.c_uint32(), C.c_uint32()
+
+    def accepted(edit):
+        sd = copy.copy(base)
+        mats = (_cabi.mtr_material * base.n_materials)()
+        for i in range(base.n_materials):
+            C.memmove(C.byref(mats[i]), C.byref(base.materials[i]), C.sizeof(_cabi.mtr_material))
+        edit(mats[0])
+        sd.materials = mats
+        desc = sd.desc()
+        return host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dd), C.byref(ll)) == 0
+
+    def aniso(av):
+        def edit(m):
+            m.type = 4; m.flags = _cabi.MTR_MAT_ANISOTROPIC; m.alpha = 0.2; m.c2[0] = av      # roughconductor: alpha_v in c2[0]
+        return edit
+
+    def twosided(t):
+        def edit(m):
+            m.type = t; m.flags = _cabi.MTR_MAT_TWOSIDED; m.alpha = 0.2; m.int_ior = 1.5; m.ext_ior = 1.0
+        return edit
+    assert accepted(lambda m: None)
+    assert accepted(aniso(0.3)) and not accepted(aniso(0.0)) and not accepted(aniso(-0.1))
+    assert accepted(twosided(0)) and accepted(twosided(4))
+    for t in (2, 6, 7):                      # dielectric, roughdielectric, thindielectric
+        assert not accepted(twosided(t)), t
