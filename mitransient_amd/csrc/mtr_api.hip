@@ -229,6 +229,13 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
             if (d->materials[i].type != MTR_BSDF_DIFFUSE || (d->materials[i].flags & MTR_MAT_TWOSIDED)) diffuse_only = false;
         if (diffuse_only) s->dev.traits |= kTrDiffuse;
         if (d->n_emitters == 1 && !hs.ems[0].is_mesh) s->dev.traits |= kTrOneRectEmitter;
+        bool leaf_pairs = hs.has_wide;
+        for (const WNode &n : hs.wnodes)
+            for (uint32_t k = 0; k < n.count; ++k) {
+                const uint32_t code = ~(uint32_t)n.ref[k];
+                if (n.ref[k] < 0 && !(code & kLeafQuadBit) && (code & 3u) + 1u > 2u) leaf_pairs = false;
+            }
+        if (leaf_pairs) s->dev.traits |= kTrLeafPair;
     }
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;

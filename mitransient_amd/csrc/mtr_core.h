@@ -411,6 +411,7 @@ MTR_HD f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- intersection
 struct Hit { float t, u, v; int32_t prim; };
+struct Ray { f3 o, d; float tmax; };
 
 // reciprocal direction of the slab tests.  It only feeds CULLING (conservative: padded boxes, hits are decided by the
 // primitive tests alone), so the device takes the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction
@@ -535,12 +536,14 @@ MTR_HD bool trav_quad_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     return hit;
 }
 
-template <class Stack>
+// ONE_PAIR: the caller knows that no triangle leaf of the tree holds more than two triangles (scene trait kTrLeafPair): one
+// pass, no loop around it
+template <bool ONE_PAIR = false, class Stack>
 MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
 {
     const uint32_t code = ~(uint32_t)tr.cur;
     if (code & kLeafQuadBit) return trav_quad_test(tr, sc, st, any_hit);
-    const uint32_t first = code >> 2, cnt = (code & 3u) + 1u;
+    const uint32_t first = code >> 2, cnt = ONE_PAIR ? (code & 1u) + 1u : (code & 3u) + 1u;
     bool found = false;
     // Moller-Trumbore [mitsuba3: Mesh::ray_intersect_triangle]: pvec = cross(d, e2); inv_det = 1 / dot(e1, pvec);
     // tvec = o - p0; u = dot(tvec, pvec) * inv_det; qvec = cross(tvec, e1); v = dot(d, qvec) * inv_det;
@@ -553,7 +556,7 @@ MTR_HD bool trav_leaf_test(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
     // Two triangles of the leaf per pass, one in each half of a register pair (v_pk_mul/add/fma_f32): either half is bit
     // for bit what a scalar evaluation gives; a leaf with an odd count has its last triangle repeated in the pad slot,
     // whose result is ignored.
-    for (uint32_t i = 0; i < cnt; i += 2u) {
+    for (uint32_t i = 0; i < (ONE_PAIR ? 1u : cnt); i += 2u) {
         st.count(1);
         const bool two = (i + 1u) < cnt;
         const int32_t pa = (int32_t)(first + i), pb = pa + 1;
@@ -676,8 +679,10 @@ MTR_HD void wide_advance(Trav &tr, const void *nodes, Stack &st, uint32_t g)
 }
 // one wide-node step: packed pairs of slab tests -> mask of the children the ray enters.
 // OFFS: entry / exit planes fetched at sign-dependent byte offsets (LDS) instead of whole quads + selects (HBM).
+// (wide_node_test: the step without the advance to the next child — returns the group word to advance from; callers that
+// share ONE advance between their node and primitive steps use it directly: wide_walk_device)
 template <uint32_t W, bool OFFS, class Stack>
-MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
+MTR_HD uint32_t wide_node_test(Trav &tr, const void *nodes, Stack &st)
 {
     typedef WNodeT<W> N;
     st.count(0);
@@ -737,12 +742,18 @@ MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
         else neg = axis == 0u ? sx : (axis == 1u ? sy : sz);
         g = ((uint32_t)tr.cur << N::kNodeShift) | (n_quads << N::kQuadShift) | (neg ? N::kRevBit : 0u) | m;
     }
+    return g;
+}
+template <uint32_t W, bool OFFS, class Stack>
+MTR_HD void wide_node_step(Trav &tr, const void *nodes, Stack &st)
+{
+    const uint32_t g = wide_node_test<W, OFFS>(tr, nodes, st);
     wide_advance<W>(tr, nodes, st, g);
 }
-template <uint32_t W, class Stack>
+template <uint32_t W, bool ONE_PAIR = false, class Stack>
 MTR_HD void wide_leaf_step(Trav &tr, const SceneView &sc, const void *nodes, Stack &st, bool any_hit)
 {
-    const bool found = trav_leaf_test(tr, sc, st, any_hit);
+    const bool found = trav_leaf_test<ONE_PAIR>(tr, sc, st, any_hit);
     if (any_hit & found) tr.cur = kTravDone;
     else wide_advance<W>(tr, nodes, st, tr.grp);
 }
@@ -886,7 +897,7 @@ MTR_HD void q8_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hit)
 // to a lane that was already done (ray over ds_bpermute, pairing through the empty LDS stack rows, results merged by the
 // (t, original index) rule; all parity tests green): 70.7 ms for closest-hit rays only against 68.2, and 92 ms with the
 // shadow rays included (the state alive across the shadow traversal left no registers: 30 -> 118 spilled).
-template <bool ANY_HIT, class Stack>
+template <bool ANY_HIT, bool ONE_PAIR = false, class Stack>
 __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, Stack &st)
 {
 #ifndef MTR_WALK_LANE_EXIT
@@ -898,20 +909,24 @@ __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, 
         const bool act = tr.cur != kTravDone;
         if (__ballot(act) == 0ull) break;
         const bool at_prim = act && tr.cur < 0;
+        // ONE advance per wave iteration (round 5): the rectangle test, the triangle-leaf test and the node step only say where to
+        // advance from; rounds 2-4 carried three inlined copies of wide_advance, two of which ran one after the other whenever an
+        // iteration held rectangle lanes AND triangle-leaf lanes
+        uint32_t g = tr.grp;
+        bool adv = false;
         if (__ballot(at_prim) != 0ull) {
             if (at_prim) {
-                if (is_quad_leaf(tr.cur)) {
-                    const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
-                    if (ANY_HIT & found) tr.cur = kTravDone;
-                    else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
-                } else wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+                const bool found = is_quad_leaf(tr.cur) ? trav_quad_test(tr, sc, st, ANY_HIT) : trav_leaf_test<ONE_PAIR>(tr, sc, st, ANY_HIT);
+                if (ANY_HIT & found) tr.cur = kTravDone;
+                else adv = true;
             }
-            continue;
-        }
+        } else {
 #ifdef MTR_PROFILE_CYCLES      // experiment build: section 0 = the walk up to the wave's second node step, 5 = the rest of it
-        if (++n_phase_ == 2u) st.prof_mark(0);
+            if (++n_phase_ == 2u) st.prof_mark(0);
 #endif
-        if (tr.cur >= 0) wide_node_step<kWide, true>(tr, sc.wnodes, st);
+            if (tr.cur >= 0) { g = wide_node_test<kWide, true>(tr, sc.wnodes, st); adv = true; }
+        }
+        if (adv) wide_advance<kWide>(tr, sc.wnodes, st, g);
     }
 #ifdef MTR_PROFILE_CYCLES
     st.prof_mark(n_phase_ >= 2u ? 5 : 0);
@@ -924,7 +939,7 @@ __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, 
                 const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
                 if (ANY_HIT & found) tr.cur = kTravDone;
                 else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
-            } else if (at_prim) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+            } else if (at_prim) wide_leaf_step<kWide, ONE_PAIR>(tr, sc, sc.wnodes, st, ANY_HIT);
         } else {
             wide_node_step<kWide, true>(tr, sc.wnodes, st);
         }
@@ -935,7 +950,7 @@ __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, 
 
 // run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
 // intersects leaves together)
-template <bool ANY_HIT, class Stack>
+template <bool ANY_HIT, bool ONE_PAIR = false, class Stack>
 MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
     Trav tr;
@@ -947,7 +962,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
         // three kinds of steps, each run by the whole wave at once: inner nodes until no lane holds one, then one
         // rectangle test for the lanes holding a rectangle, else one triangle-leaf pass
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MTR_NODES_FIRST)
-        wide_walk_device<ANY_HIT>(tr, sc, st);
+        wide_walk_device<ANY_HIT, ONE_PAIR>(tr, sc, st);
 #else
         while (tr.cur != kTravDone) {
             while (tr.cur >= 0) {
@@ -960,7 +975,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
                 const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
                 if (ANY_HIT & found) tr.cur = kTravDone;
                 else wide_advance<kWide>(tr, sc.wnodes, st, tr.grp);
-            } else if (tr.cur != kTravDone) wide_leaf_step<kWide>(tr, sc, sc.wnodes, st, ANY_HIT);
+            } else if (tr.cur != kTravDone) wide_leaf_step<kWide, ONE_PAIR>(tr, sc, sc.wnodes, st, ANY_HIT);
         }
 #endif
     } else if (sc.wnodes8q) {
@@ -990,8 +1005,6 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 }
 
 // ---------------------------------------------------------------- sensor
-struct Ray { f3 o, d; float tmax; };
-
 MTR_HD Ray camera_ray(const Camera &c, const RenderConst &rc, uint32_t px, uint32_t py, float j1, float j2)
 {
     float sx = fmaf((float)px + j1, rc.inv_crop_w, rc.off_x);
@@ -1518,8 +1531,10 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 //     `distance += t * eta` (:154), `rr_prob = min(beta_max * eta^2, .95)` (:248) lose their factors; no Fresnel code at all.
 //   kTrOneRectEmitter: exactly one emitter, an analytic rectangle (:192 `sample_emitter_direction` has one target): no
 //     emitter pick and its sample reuse, no mesh tables, no 1 / n_emitters factors.
-constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u;
-constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter;      // what the kernels are instantiated for besides 0
+//   kTrLeafPair: no triangle leaf of the 8-wide tree holds more than two triangles (the builder's target size; object-space
+//     leaves never do): the leaf test is one packed pass without a loop around it.
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u;
+constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0
 
 template <bool ROUGH = true, uint32_t TR = 0u>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)
@@ -1879,7 +1894,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
                         Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh(), bool unwarp_here = false)
 {
     st.prof_mark(2);
-    Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
+    Hit h = traverse<false, (TR & kTrLeafPair) != 0u>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
     st.prof_mark(0);
     stats.closest++;
     Pending pd; Ray shadow;
@@ -1894,7 +1909,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     bool occluded = false;
     if (pd.has_shadow) {
         stats.shadow++;
-        Hit sh = traverse<true>(sc, shadow.o, shadow.d, shadow.tmax, st);
+        Hit sh = traverse<true, (TR & kTrLeafPair) != 0u>(sc, shadow.o, shadow.d, shadow.tmax, st);
         occluded = sh.prim >= 0;
     }
     st.prof_mark(0);
@@ -1904,6 +1919,25 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     if (Stack::kPark) { st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); }
     st.prof_mark(1);
     return an;
+}
+
+// ---- the DEFERRED COMMIT of an emitter-sampling term (k_wf_shade on scenes walked in HBM, round 4): the shadow ray is traced after
+// the iteration that sampled it and the term is committed first thing in the path's next iteration.  The sums are the reference's
+// bit for bit: L = (L + Le) + Lr there; (L + Le) + 0 and + Lr at the commit, before the next vertex's Le.
+// (Round 5 tried the same in k_fused, walking a lane's shadow ray and its next closest-hit ray in ONE loop: node wave-steps
+// unchanged, primitive wave-steps +72 %, 62.6 -> 87.1 ms — profiles/r05_deferred_walk_experiment.txt.)
+// shade_finish's own commit (transientpath.py:216-218, :230), word for word:
+template <class Sink>
+MTR_HD void commit_pending(f3 &L, f3 Lr, float opl, uint32_t depth_log, uint32_t px, uint32_t py,
+                           const Film &film, const RenderConst &rc, Sink &sink)
+{
+    const uint32_t fx = px - film.crop_x, fy = py - film.crop_y;
+    const float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
+    if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
+        const int32_t bin = film_bin(film, opl);
+        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, opl, depth_log, 1u);
+    }
+    L = mk(L.x + Lr.x, L.y + Lr.y, L.z + Lr.z);
 }
 
 } // namespace mtr

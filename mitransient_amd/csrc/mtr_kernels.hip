@@ -652,10 +652,11 @@ template <bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
-#ifdef MTR_ONLY_C2            // tools/regs_c2.sh: compile ONLY the instantiation config 2 runs (register-allocation experiments: one minute instead of four)
+#ifdef MTR_ONLY_C2            // tools/regs_c2.sh, tools/build_variant.sh -DMTR_ONLY_C2: compile ONLY the instantiation config 2 runs (experiments: one
+                              // minute per variant instead of four); such a library renders config 2 and refuses everything else
+    if (NLOS || args.film.n_freq || cfg.rough || cfg.fixed || !cfg.scene_lds || !cfg.hist_lds || cfg.traits != kTrCornell || cfg.per_cu <= 3) return hipErrorInvalidValue;
     k = k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
-    (void)cfg; (void)stream; return k ? hipSuccess : hipErrorInvalidValue;
-#endif
+#else
     if (!NLOS && args.film.n_freq) {
         if (!cfg.hist_lds || cfg.rough) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
         k = cfg.scene_lds ? k_fused<true, true, false, MTR_FUSED_MIN_WAVES, true> : k_fused<false, true, false, MTR_FUSED_MIN_WAVES, true>;
@@ -672,6 +673,7 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<false, true, NLOS>;
     else k = k_fused<false, false, NLOS>;
+#endif
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(args.ticket, 0, sizeof(uint32_t), stream);

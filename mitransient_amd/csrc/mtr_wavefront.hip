@@ -499,19 +499,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
 // A path that ENDS with a term parked becomes a "zombie" (its radiance and depth in Q_RAD, the term in Q_PEND, its slot on the
 // segment's zombie list); the next launch commits it and deposits its radiance.  No term can be left at the end of a render:
 // a vertex samples the emitter only if depth + 1 < max_depth, and the host's live count includes the zombies.
-template <class Sink>
-__device__ __forceinline__ void commit_pending(f3 &L, f3 Lr, float opl, uint32_t depth_log, uint32_t px, uint32_t py,
-                                               const Film &film, const RenderConst &rc, Sink &sink)
-{
-    // shade_finish's own commit (transientpath.py:216-218, :230), word for word
-    const uint32_t fx = px - film.crop_x, fy = py - film.crop_y;
-    const float vr = Lr.x * rc.sample_scale, vg = Lr.y * rc.sample_scale, vb = Lr.z * rc.sample_scale;
-    if ((fx < film.width) & (fy < film.height) && (vr != 0.0f || vg != 0.0f || vb != 0.0f)) {
-        const int32_t bin = film_bin(film, opl);
-        if (bin >= 0) sink.splat(fx, fy, (uint32_t)bin, vr, vg, vb, opl, depth_log, 1u);
-    }
-    L = mk(L.x + Lr.x, L.y + Lr.y, L.z + Lr.z);
-}
+// (commit_pending: mtr_core.h — shade_finish's own commit, shared with k_fused's deferred organisation)
 
 #ifndef MTR_WF_SHADE_WAVES
 #define MTR_WF_SHADE_WAVES 4
