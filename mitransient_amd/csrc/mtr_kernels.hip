@@ -77,6 +77,23 @@ struct LdsStack {
 #endif
 };
 
+// A field of the kernel's (single, by-value) argument read from the kernarg segment with scalar loads AT THE POINT OF USE: the
+// empty asm makes the address opaque, so the loads can neither be hoisted out of the persistent loop nor merged with the
+// compiler's own copy of the argument.  (Taking the address of the argument itself sends the whole struct through scratch.)
+template <class T>
+__device__ __forceinline__ T kernarg_copy(size_t offset)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized fields");
+    typedef const uint32_t __attribute__((address_space(4))) *WordPtr;
+    WordPtr w = (WordPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+    asm volatile("" : "+s"(w));
+    T out;
+    uint32_t *o = (uint32_t *)&out;
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) o[k] = w[k];
+    return out;
+}
+
 __device__ __forceinline__ void lds_add(float *p, float v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -184,6 +201,12 @@ __device__ __forceinline__ void copy16(void *dst, const void *src, uint32_t byte
 __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // ------------------------------------------------------------------ fused kernel
+// the run of FusedArgs that the path start and the end-of-path bookkeeping read (kernarg_copy)
+struct LoopArgs { uint32_t spp_begin, spp_chunk, G; FastDiv div_spp, div_G; };
+static_assert(offsetof(FusedArgs, spp_chunk) - offsetof(FusedArgs, spp_begin) == offsetof(LoopArgs, spp_chunk) &&
+              offsetof(FusedArgs, G) - offsetof(FusedArgs, spp_begin) == offsetof(LoopArgs, G) &&
+              offsetof(FusedArgs, div_spp) - offsetof(FusedArgs, spp_begin) == offsetof(LoopArgs, div_spp) &&
+              offsetof(FusedArgs, div_G) - offsetof(FusedArgs, spp_begin) == offsetof(LoopArgs, div_G), "LoopArgs mirrors FusedArgs");
 #ifndef MTR_FUSED_MIN_WAVES
 #define MTR_FUSED_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
@@ -315,15 +338,27 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         st.prof_mark(4);                 // (experiment builds) sections: 0 traversal, 1 shading, 2 path start, 3 end-of-path bookkeeping, 4 row flush, 5 idle
         if (__ballot(waiting) != 0ull) {
             bool started = false;
+            // (the arguments a path start needs: read from the kernarg segment here, see kernarg_copy)
+            const LoopArgs la = kernarg_copy<LoopArgs>(offsetof(FusedArgs, spp_begin));
             if (waiting) {
-                q = fastdiv(i, a.div_spp);
-                slot = q - fastdiv(q, a.div_G) * K;
+                q = fastdiv(i, la.div_spp);
+                slot = q - fastdiv(q, la.div_G) * la.G;
                 if (__hip_atomic_load(s_owner + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == q) {
-                    const uint32_t s = a.spp_begin + (i - q * a.spp_chunk);
+                    const uint32_t s = la.spp_begin + (i - q * la.spp_chunk);
                     const uint32_t pixel = pixel_of(q);
                     const f3 L_carried = carry ? p.L : mk(0, 0, 0);
                     if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
-                    else { path_begin(p, a.cam, a.film, a.rc, pixel, s); if (LdsStack::kPark) { st.park_inc(p.rng.inc); st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); } }
+                    else {
+                        // COLD KERNEL ARGUMENTS FROM THE KERNARG SEGMENT (round 5).  The camera (34 dwords) is read only here; as a by-value
+                        // argument it lived in scalar registers across the whole persistent loop, i.e. in v_readlane'd spill slots
+                        // (the loop holds more than 100 uniform values).  Scalar loads from the kernarg segment where a path starts
+                        // instead: 111 -> 82 spilled SGPRs, config 2 61.1 -> 60.4 ms (same box)
+                        const Camera cam_l = kernarg_copy<Camera>(offsetof(FusedArgs, cam));
+                        const Film film_s = kernarg_copy<Film>(offsetof(FusedArgs, film));
+                        const RenderConst rc_s = kernarg_copy<RenderConst>(offsetof(FusedArgs, rc));
+                        path_begin(p, cam_l, film_s, rc_s, pixel, s);
+                        if (LdsStack::kPark) { st.park_inc(p.rng.inc); st.park_prev_p(p.prev_p); st.park_prev_pdf(p.prev_pdf); }
+                    }
                     p.L = L_carried; carry = false;
                     xy = p.px | (p.py << 16);
                     alive = true; waiting = false; started = true;
@@ -360,32 +395,38 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             // camera_unwarp: no traversal of its own (a third inlined copy of the walk in every instantiation) — bounce 0's closest
             // hit is the camera ray's; the extra ray the reference traces is still COUNTED (w_closest, at path start)
             const bool unwarp = !NLOS && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) != 0u;
+            // ... and the film / render constants (29 dwords) come from the kernarg segment after either traversal, where the
+            // shading reads them, instead of staying in scalar registers (spill slots) through the walks (kernarg_copy, above)
+            Film film_l = a.film; RenderConst rc_l = a.rc;
+            // (NOT the splat log and NOT the arguments of the end-of-path bookkeeping: re-read where they are used as well, 37 instead
+            // of 65 spilled SGPRs but 59.0 -> 59.9 / 59.6 ms — short sections wait for their scalar loads)
             auto refresh = [&](Path &pp, auto &) {
                 uint32_t w = xy; asm volatile("" : "+v"(w));
                 pp.px = w & 0xffffu; pp.py = w >> 16;
+                if (!NLOS) { film_l = kernarg_copy<Film>(offsetof(FusedArgs, film)); rc_l = kernarg_copy<RenderConst>(offsetof(FusedArgs, rc)); }
             };
             if (PHASOR) {
                 LdsPhasorSink sink; sink.row = s_hist + slot * T; sink.freq = a.film.freq; sink.n_freq = a.film.n_freq;
                 sink.start_opl = a.film.start_opl; sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                alive = path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 did_splats = sink.n_splats;
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
-                             : path_bounce<ROUGH, TR>(p, sv, a.film, a.rc, st, sink, bstat, refresh, unwarp);
+                             : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
             if (NLOS) { n_closest += bstat.closest; n_shadow += bstat.shadow; } else did_shadow = bstat.shadow;
