@@ -504,7 +504,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
 #ifndef MTR_WF_SHADE_WAVES
 #define MTR_WF_SHADE_WAVES 4
 #endif
-template <int STACK, bool SCENE_LDS, bool EXT>
+// TR: scene traits (mtr_core.h kTr*; scenes staged in LDS only): shading code the scene's tables cannot reach is not compiled in
+template <int STACK, bool SCENE_LDS, bool EXT, uint32_t TR = 0u>
 __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
     constexpr bool DEFER = !SCENE_LDS;
@@ -603,12 +604,12 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     Pending pd; Ray shadow;
                     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
                     if ((a.rc.flags & MTR_FLAG_CAMERA_UNWARP) && p.depth == 0u && h.prim >= 0) p.dist = -h.t;      // camera_unwarp: see k_wf_raygen
-                    shade_hit<EXT>(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                    shade_hit<EXT, TR>(p, h, sv, a.film, a.rc, sink, pd, shadow);
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
                         if (SCENE_LDS) {                  // short rays out of LDS: tracing them right here is cheaper (config 2: 168 vs 243 ms)
-                            Hit sh = traverse<true>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                            Hit sh = traverse<true, (TR & kTrLeafPair) != 0u>(sv, shadow.o, shadow.d, shadow.tmax, st);
                             occluded = sh.prim >= 0;
                         } else {
                             // the ray goes to the segment's shadow list (k_wf_trace, any-hit, runs next), the term is parked and
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                             occluded = true;
                         }
                     }
-                    alive = shade_finish<EXT>(p, h, occluded, pd, sv, a.film, a.rc, sink);
+                    alive = shade_finish<EXT, TR>(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
@@ -947,6 +948,16 @@ template <int STACK, bool SL>
 hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStream_t stream)
 {
     const bool ext = a.sc.has_rough != 0u;
+    if constexpr (SL) {          // scenes staged in LDS whose tables allow it: the specialised shading code (as k_fused)
+        if (which == 2 && !ext && a.sc.traits == kTrCornell) {
+            void (*ks)(const WfArgs) = k_wf_shade<STACK, true, false, kTrCornell>;
+            lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);
+            hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(ks, dim3(grid), dim3(kBlock), lds, stream, a);
+            return hipGetLastError();
+        }
+    }
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? (a.trace_any ? k_wf_trace<STACK, SL, true> : k_wf_trace<STACK, SL, false>)
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
