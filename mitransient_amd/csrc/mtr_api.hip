@@ -596,7 +596,12 @@ static int resolve_mode(mtr_scene *s, const mtr_render_params *p, uint32_t n_pix
         FusedArgs probe{}; FusedConfig pc{};
         probe.sc = s->dev; probe.cam = s->cam; probe.film = f; probe.rc = make_render_const(*p, f, s->dev.n_ems); probe.nlos_on = s->nlos.on ? 1u : 0u;
         const bool fits = fused_plan(s->dev, f, n_pixels, spp_chunk, usable_cus(c, p), probe, pc) && pc.scene_lds;
-        mode = fits ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
+        // ... and only a SHALLOW tree (a room of rectangles and a few objects: root + object nodes).  k_fused walks in lock-step — every
+        // traversal costs its wave the longest walk of 64 lanes — which a deeper tree punishes at once: the Cornell box with its boxes
+        // tessellated 2 x 2 per face (108 triangles, 3 levels) renders in 204 ms fused against 125 ms in the wavefront organisation,
+        // whose trace kernel refills finished lanes (36 triangles, 2 levels: 58.7 against 97.5 ms; profiles/r05_size_sweep.txt)
+        const bool shallow = s->dev.wide_levels <= 2u;
+        mode = (fits && shallow) ? MTR_MODE_FUSED : MTR_MODE_WAVEFRONT;
     }
     *mode_io = mode;
     if (developed_ok) {          // MTR_FLAG_DEVELOPED_ROWS: the fused kernel's row flush, rows in LDS, time bins (not a phasor film)

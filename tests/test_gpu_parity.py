@@ -870,3 +870,69 @@ def test_fallbacks_after_a_direct_prepare_start_from_zero(oracle):
     integ.prepare(a, sens, 4, 16, [], _direct_develop=True)
     with pytest.raises(RuntimeError):
         film.develop()
+
+
+@pytest.mark.parametrize("seeding", ["tea", "tea+lane", "tea64"])
+def test_sampler_seeding_variants(oracle, seeding):
+    """the three readings of mitsuba's PCG32Sampler::seed (MTR_FLAG_PCG_INITSEQ_PLUS_LANE, MTR_FLAG_PCG_TEA64): kernels and oracle
+    draw the same streams under each, and the streams differ from one another (tests/test_reference_golden.py decides between
+    them the day a real reference render exists)"""
+    outs = {}
+    for mode in MODES:
+        scene = make_cornell(width=32, height=32, bins=64, amd_mode=mode)
+        integ = scene.integrator()
+        integ.pcg_initseq_plus_lane = seeding == "tea+lane"
+        integ.pcg_tea64 = seeding == "tea64"
+        s_gpu, t_gpu = gpu_render(scene, 8)
+        s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 8)
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+        got = integ.last_counters
+        for k in ("paths", "rays_closest", "rays_shadow", "splats_issued"):
+            assert got[k] == cnt[k], k
+        outs[mode] = t_gpu
+    plain = make_cornell(width=32, height=32, bins=64)
+    _, t_plain = gpu_render(plain, 8)
+    assert (seeding == "tea") == (rel_l2(outs["fused"], t_plain) <= TOL)
+
+
+def test_auto_mode_follows_the_depth_of_the_tree(oracle, tmp_path, monkeypatch):
+    """MTR_MODE_AUTO (mtr_render_plan): the fused kernel for a scene staged in LDS whose 8-wide tree is shallow (the Cornell box: root +
+    object nodes), the wavefront organisation as soon as the tree is deeper (the same box with its two boxes as 2 x 2-tessellated
+    meshes, 108 triangles: 204 ms fused against 125 ms at config 2's size — profiles/r05_size_sweep.txt); both agree with the oracle"""
+    import sys
+    import mitransient_amd.mi as mi
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import size_sweep
+    monkeypatch.setattr(size_sweep, "TMP", str(tmp_path))
+    picked = {}
+    for n in (1, 2):
+        scene = mi.load_dict(size_sweep.cornell(n, 48, 48, 96))
+        s_gpu, t_gpu = gpu_render(scene, 8)
+        s_ref, t_ref, *_ = oracle_render(oracle, scene, 8)
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+        picked[n] = "wavefront" if scene.integrator().last_times["scatter_launches"] else "fused"
+    assert picked == {1: "fused", 2: "wavefront"}, picked
+
+
+def test_specialised_kernels_return_the_bits_of_the_general_ones(oracle):
+    """scene traits (mtr_core.h kTr*): the Cornell box runs the kernels specialised on 'diffuse materials, one rectangle emitter,
+    leaves of one pair'; the same box with a SECOND, black rectangle emitter far outside runs the general ones.  A black emitter adds
+    nothing to any sum but halves every emitter-sampling pdf, so radiance cannot be compared — the traversal can: the time-bin
+    cells touched by direct emission (max_depth 1: no emitter sampling at all) must be identical, bit for bit."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    outs = []
+    for extra in (False, True):
+        d = mitr.cornell_box()
+        d["sensor"]["film"].update(width=48, height=48, temporal_bins=96, start_opl=3.5, bin_width_opl=6.0 / 96)
+        d["integrator"]["max_depth"] = 1
+        d["integrator"]["amd_mode"] = "fused"
+        if extra:
+            d["far-light"] = {"type": "rectangle", "to_world": T().translate([50.0, 50.0, 50.0]).scale([0.01, 0.01, 0.01]),
+                              "bsdf": {"type": "ref", "id": "white"},
+                              "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [0.0, 0.0, 0.0]}}}
+        scene = mi.load_dict(d)
+        outs.append(gpu_render(scene, 16)[1])
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
