@@ -5,9 +5,9 @@ tag=${1:-rXX}
 out=gpurun_out/${tag}_fused_simt_sections.txt
 mkdir -p gpurun_out
 {
-echo "# $tag build: in-kernel SIMT counters (-DMTR_PROFILE_SIMT, tools/simt.py 64), wave-clock sections (-DMTR_PROFILE_CYCLES, tools/cycles.py), wave occupancy (-DMTR_PROFILE_OCC, tools/occ.py); config 2"
+echo "# $tag build: in-kernel SIMT counters (-DMTR_PROFILE_SIMT, tools/simt.py 1024), wave-clock sections (-DMTR_PROFILE_CYCLES, tools/cycles.py), wave occupancy (-DMTR_PROFILE_OCC, tools/occ.py); config 2"
 echo "== SIMT"
-MITRANSIENT_AMD_LIB=$(pwd)/ab/libs/lib_prof_SIMT.so timeout 300 python tools/simt.py 64 2>&1 | tail -4
+MITRANSIENT_AMD_LIB=$(pwd)/ab/libs/lib_prof_SIMT.so timeout 300 python tools/simt.py 1024 2>&1 | tail -4
 echo "== sections"
 MITRANSIENT_AMD_LIB=$(pwd)/ab/libs/lib_prof_CYCLES.so timeout 300 python tools/cycles.py 2>&1 | tail -8
 echo "== occupancy"
