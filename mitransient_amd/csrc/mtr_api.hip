@@ -520,6 +520,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
                     continue;
                 }
                 a.trace_any = 0u;
+                a.first_bounce = depth == 0u ? 1u : 0u;
                 HIP_TRY(c, trace_timed(1, grid)); a.ticket_cur ^= 1u;                // closest hit + material lists
                 // shade: commits the emitter-sampling terms the previous bounce parked, runs the loop iteration once, writes the
                 // shadow rays (scene in HBM) or traces them inline (scene in LDS), compacts the survivors

@@ -108,6 +108,7 @@ struct WfArgs {
     uint32_t *seg_zombie;                // [2][n_seg] their counts
     uint8_t *occ;                        // [n_slots] shadow-ray result per slot: 1 = occluded
     uint32_t trace_any;                  // k_wf_trace: 0 closest hits of the live lists, 1 occlusion of the shadow lists
+    uint32_t first_bounce;               // k_wf_shade: this launch shades bounce 0 — the path state is rebuilt from (pixel, sample), not loaded
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths
     uint32_t *live_total;                // optional: number of survivors of this bounce (unbounded-depth renders)
     uint4 *rec;                          // [P][rec_cap] time-bin records (bin, r, g, b)

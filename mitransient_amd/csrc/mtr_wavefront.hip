@@ -317,7 +317,10 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
         // bounce 0, which k_wf_trace is about to find for this very ray — k_wf_shade takes it from there (depth 0) instead of
         // tracing every camera ray twice (config 5: k_wf_raygen 31 -> 6 ms per tile); the ray is still counted
         if (!a.nlos_on && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) ++n_closest;
-        store_state(P, slot, p, a.nlos_on != 0u);
+        // The path state of bounce 0 is a function of (pixel, sample) alone: k_wf_shade REBUILDS it in its first launch (a.first_bounce)
+        // instead of reading back what this kernel would have written — 72 B written here and 72 B read there per slot, 38 GB of
+        // config 2's 2^28 slots (round 5; the NLOS bounce kernel reads the planes, so that tier still stores them)
+        if (a.nlos_on) store_state(P, slot, p, true);
         a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
         a.q_ray[2 * (size_t)slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax);
         a.q_ray[2 * (size_t)slot + 1] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta);
@@ -505,7 +508,9 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
 #define MTR_WF_SHADE_WAVES 4
 #endif
 // TR: scene traits (mtr_core.h kTr*; scenes staged in LDS only): shading code the scene's tables cannot reach is not compiled in
-template <int STACK, bool SCENE_LDS, bool EXT, uint32_t TR = 0u>
+// FIRST: the launch that shades bounce 0 — the path state is rebuilt from (pixel, sample) instead of loaded (k_wf_raygen); its own
+// instantiation, so that the camera and path_begin's code stay out of the kernel every other bounce runs
+template <int STACK, bool SCENE_LDS, bool EXT, uint32_t TR = 0u, bool FIRST = false>
 __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
     constexpr bool DEFER = !SCENE_LDS;
@@ -589,10 +594,13 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     slot_to_lane(a, slot, pixel, s, pl);
                     Path p;
                     uint32_t pend = 0u;
-                    load_state(P, slot, p, &pend, false);
-                    const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
-                    p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
-                    p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
+                    if (FIRST) path_begin(p, a.cam, a.film, a.rc, pixel, s);      // (see k_wf_raygen: bounce 0's state is recomputed, not read)
+                    else {
+                        load_state(P, slot, p, &pend, false);
+                        const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                        p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
+                        p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
+                    }
                     Hit h;
                     { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                     ++n_closest;
@@ -950,7 +958,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
     const bool ext = a.sc.has_rough != 0u;
     if constexpr (SL) {          // scenes staged in LDS whose tables allow it: the specialised shading code (as k_fused)
         if (which == 2 && !ext && a.sc.traits == kTrCornell) {
-            void (*ks)(const WfArgs) = k_wf_shade<STACK, true, false, kTrCornell>;
+            void (*ks)(const WfArgs) = a.first_bounce ? k_wf_shade<STACK, true, false, kTrCornell, true> : k_wf_shade<STACK, true, false, kTrCornell>;
             lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);
             hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -960,6 +968,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
     }
     void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? (a.trace_any ? k_wf_trace<STACK, SL, true> : k_wf_trace<STACK, SL, false>)
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
+                            : a.first_bounce ? (ext ? k_wf_shade<STACK, SL, true, 0u, true> : k_wf_shade<STACK, SL, false, 0u, true>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
     lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1010,15 +1019,10 @@ hipError_t launch_wf(const WfArgs &a, const WfConfig &cfg, int which, int grid, 
         hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);
         return hipGetLastError();
     }
-#define WF_CASE(S)                                                                             \
-    case S: return cfg.scene_lds ? launch_set<S, true>(a, which, grid, cfg.lds_bytes, stream) \
-                                 : launch_set<S, false>(a, which, grid, cfg.lds_bytes, stream);
-    switch (cfg.stack) {
-        WF_CASE(8) WF_CASE(16) WF_CASE(32)
-    default: return cfg.scene_lds ? launch_set<64, true>(a, which, grid, cfg.lds_bytes, stream)
-                                  : launch_set<64, false>(a, which, grid, cfg.lds_bytes, stream);
-    }
-#undef WF_CASE
+    // (the traversal stack is sized by the levels of the tree that is walked — wf_stack_rows — not by a compile-time class: ONE
+    // instantiation of every kernel; rounds 1-4 compiled four identical copies, for stack classes 8 / 16 / 32 / 64)
+    return cfg.scene_lds ? launch_set<64, true>(a, which, grid, cfg.lds_bytes, stream)
+                         : launch_set<64, false>(a, which, grid, cfg.lds_bytes, stream);
 }
 
 } // namespace mtr
