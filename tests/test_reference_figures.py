@@ -364,7 +364,7 @@ def check_readme_cornell_box(figures, steady, ncc_min, interior_min, chroma_tol,
     the surfaces behind the luminaire's front edge (`level_tol`) and an achromatic 1.08 ... 1.21 on the parts of walls, floor
     and ceiling in front of it (z < 238 of 559), which the reference's own notebook render of the same file
     (4-rainbow_visualization.ipynb, `cbox_sparse_fusion`: no such ring against this render) does not show: an exposure
-    gradient of that one image, recorded in DESIGN.md section 2 and bounded here.  A render of mitransient.cornell_box() fails
+    gradient of that one image, recorded in HISTORY.md (part 2, section 2) and bounded here.  A render of mitransient.cornell_box() fails
     this check (asserted by the callers)."""
     fig = figures[0]["readme_cornell_box"]
     ref = figure_content(figure_content(fig, bright_margin=True), bright_margin=False)      # white margin, then the black frame
