@@ -207,6 +207,9 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         }
         s.uvs.assign(2 * (size_t)n_slots, q4{ 0, 0, 0, 0 });
     }
+    if (d.n_tris >= (1u << 29)) return "too many triangles (the tie-break word holds 29 bits of triangle index)";
+    // the tie-break word of an intersection record: (original index << 3) | list key of the triangle's material (mtr_core.h hit_list_key)
+    auto tie_word = [&](uint32_t orig) { return (orig << 3) | hit_list_key(d.materials[d.tri_material[orig]].type); };
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
         const uint32_t o = bvh.order[slot] != kPadSlot ? bvh.order[slot] : bvh.order[slot - 1];   // pad: repeat the leaf's last triangle
         s.slot_orig[slot] = o;
@@ -226,7 +229,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
             rect_to_object(R->center, R->du, R->dv, rx, ry, rz);
             TriPair &tp = s.tpairs[slot >> 1];
             tp.g[0] = q4{ rz[0], rz[1], rz[2], rz[3] }; tp.g[1] = q4{ rx[0], rx[1], rx[2], rx[3] }; tp.g[2] = q4{ ry[0], ry[1], ry[2], ry[3] };
-            tp.g[3] = q4{ 0, 0, 0, 0 }; tp.g[4] = q4{ 0, 0, bitsf(prim), bitsf(kQuadMark) };
+            tp.g[3] = q4{ 0, 0, 0, 0 }; tp.g[4] = q4{ 0, 0, bitsf(tie_word(prim)), bitsf(kQuadMark) };
             h.h[0] = q4{ n.x, n.y, n.z, sdir.x };
             h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
             h.h[2] = q4{ t.z, du.x, du.y, du.z };
@@ -277,7 +280,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         const float comp[9] = { p0.x, p0.y, p0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z };
         const uint32_t half = slot & 1u;
         for (int k = 0; k < 9; ++k) g[2 * k + half] = comp[k];
-        g[18 + half] = bitsf(o);
+        g[18 + half] = bitsf(tie_word(o));
         h.h[0] = q4{ n.x, n.y, n.z, sdir.x };
         h.h[1] = q4{ sdir.y, sdir.z, t.x, t.y };
         h.h[2] = q4{ t.z, v[3], v[4], v[5] };

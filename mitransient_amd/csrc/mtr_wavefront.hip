@@ -405,12 +405,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
                     if (any_hit) a.occ[slot] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
                     else {
                         P.st(Q_HIT, slot, make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim)));
-                        uint32_t key = 4u;                      // miss
-                        if (tr.h.prim >= 0) {
-                            key = sv.mats[fbits(sv.tshade[tr.h.prim].h[4].z) & 0xffffu].type;
-                            if (bsdf_is_rough(key)) key = 0u;       // the extended smooth lobes share the list of the smooth BSDFs (emitter sampling)
-                            else if (key == MTR_BSDF_THINDIELECTRIC) key = MTR_BSDF_DIELECTRIC;      // two delta lobes: the dielectrics' list
-                        }
+                        // hit: the list key rides in the low bits of the tie-break word of the best hit (TriPair, mtr_core.h)
+                        const uint32_t key = tr.h.prim >= 0 ? (tr.best_orig & 7u) : 4u;
                         s_key[pos] = (uint8_t)key;
                     }
                     pending = false;
