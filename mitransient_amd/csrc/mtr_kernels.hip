@@ -347,7 +347,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                     const uint32_t s = la.spp_begin + (i - q * la.spp_chunk);
                     const uint32_t pixel = pixel_of(q);
                     const f3 L_carried = carry ? p.L : mk(0, 0, 0);
-                    if (NLOS) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
+                    if (NLOS) {
+                        const NlosConst nc_s = kernarg_copy<NlosConst>(offsetof(FusedArgs, nlos));
+                        const Film film_s = kernarg_copy<Film>(offsetof(FusedArgs, film));
+                        const RenderConst rc_s = kernarg_copy<RenderConst>(offsetof(FusedArgs, rc));
+                        nlos_begin(p, nc_s, film_s, rc_s, pixel, s);
+                    }
                     else {
                         // COLD KERNEL ARGUMENTS FROM THE KERNARG SEGMENT (round 5).  The camera (34 dwords) is read only here; as a by-value
                         // argument it lived in scalar registers across the whole persistent loop, i.e. in v_readlane'd spill slots
@@ -398,6 +403,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             // ... and the film / render constants (29 dwords) come from the kernarg segment after either traversal, where the
             // shading reads them, instead of staying in scalar registers (spill slots) through the walks (kernarg_copy, above)
             Film film_l = a.film; RenderConst rc_l = a.rc;
+            // the NLOS loop (four walks per bounce, ~110 dwords of projector / wall / table constants): the same, after every walk
+            NlosConst nc_l = a.nlos;
+            auto reload_nlos = [&]() {
+                nc_l = kernarg_copy<NlosConst>(offsetof(FusedArgs, nlos));
+                film_l = kernarg_copy<Film>(offsetof(FusedArgs, film)); rc_l = kernarg_copy<RenderConst>(offsetof(FusedArgs, rc));
+            };
             // (NOT the splat log and NOT the arguments of the end-of-path bookkeeping: re-read where they are used as well, 37 instead
             // of 65 spilled SGPRs but 59.0 -> 59.9 / 59.6 ms — short sections wait for their scalar loads)
             auto refresh = [&](Path &pp, auto &) {
@@ -413,19 +424,19 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
             } else if (FIXED) {
                 LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, a.nlos, a.film, a.rc, st, sink, bstat)
+                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }

@@ -166,15 +166,20 @@ template <bool EXT>
 MTR_HD bool nlos_bsdf_smooth(const mtr_material &m) { return m.type == MTR_BSDF_DIFFUSE || (EXT && bsdf_is_rough(m.type)); }
 
 // emitter_nee_sample (transientnlospath.py:432-509); `depth` is the reference's argument (not the loop depth)
-template <bool EXT, class Stack, class Sink>
+// `reload()` runs after every traversal: a caller that can re-read nc / film / rc (k_fused: from the kernarg segment, kernarg_copy)
+// does so there instead of holding ~100 uniform values in (spilled) scalar registers across the walks — path_bounce's `refresh`
+struct NoReload { MTR_HD void operator()() const {} };
+template <bool EXT, class Stack, class Sink, class Reload = NoReload>
 MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 beta, float distance, uint32_t depth,
                            bool focus_laser, uint32_t laser, const SceneView &sc, const NlosConst &nc, const Film &film,
-                           const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats)
+                           const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
 {
     // visibility of the emitter origin (:441)
     const Ray sr = spawn_ray_to(c.sp, c.gn, nc.l_origin);
     stats.shadow++;
-    if (traverse<true>(sc, sr.o, sr.d, sr.tmax, st).prim >= 0) return mk(0, 0, 0);
+    const bool blocked = traverse<true>(sc, sr.o, sr.d, sr.tmax, st).prim >= 0;
+    reload();
+    if (blocked) return mk(0, 0, 0);
     (void)rng_f32(p.rng); (void)rng_f32(p.rng);                      // sampler.next_2d(active_e): only visible lanes draw
     float ds_dist;
     f3 w;
@@ -202,20 +207,21 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
 }
 
 // emitter_laser_targets_sample (:511-564)
-template <bool EXT, class Stack, class Sink>
+template <bool EXT, class Stack, class Sink, class Reload = NoReload>
 MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 lt, uint32_t depth, uint32_t laser,
                              const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
-                             Stack &st, Sink &sink, BounceStats &stats)
+                             Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
 {
     f3 dd = lt - c.sp;
     const float dl = sqrtf(dot(dd, dd));
     dd = dd / dl;
     Ray rb = spawn_ray_to(c.sp, c.gn, lt);
     stats.shadow++;
-    if (traverse<true>(sc, rb.o, rb.d, rb.tmax, st).prim >= 0) return mk(0, 0, 0);             // :528
+    if (traverse<true>(sc, rb.o, rb.d, rb.tmax, st).prim >= 0) { reload(); return mk(0, 0, 0); }             // :528
     const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
     const f3 bs = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);                                  // :531-533
     const Hit h2 = traverse<false>(sc, rb.o, rb.d, kInf, st);                                  // :535-537
+    reload();
     stats.closest++;
     if (h2.prim < 0) return mk(0, 0, 0);
     if (!(bs.x > kDrEps || bs.y > kDrEps || bs.z > kDrEps)) return mk(0, 0, 0);               // :539-540
@@ -226,7 +232,7 @@ MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, 
     const float pdf_ls = (dl * dl) / wlz;                                                      // :546-551
     const f3 b2 = mk(p.beta.x * (bs.x / pdf_ls), p.beta.y * (bs.y / pdf_ls), p.beta.z * (bs.z / pdf_ls));
     return nlos_emitter_nee<EXT>(p, c2, sc.mats[c2.mat], material_albedo<EXT>(sc, sc.mats[c2.mat], h2), b2, p.dist + dl * p.eta, depth + 1, true,
-                                 laser, sc, nc, film, rc, st, sink, stats);
+                                 laser, sc, nc, film, rc, st, sink, stats, reload);
 }
 
 // hidden_geometry_sample (:637-670) incl. _sample_hidden_geometry_position (:385-430)
@@ -269,11 +275,12 @@ MTR_HD f3 nlos_laser_target(const NlosConst &nc, uint32_t px, uint32_t py)
 }
 
 // One iteration of TransientNLOSPath.sample (:740-918).  Returns active_next.
-template <bool EXT = false, class Stack, class Sink>
+template <bool EXT = false, class Stack, class Sink, class Reload = NoReload>
 MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
-                        Stack &st, Sink &sink, BounceStats &stats)
+                        Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
 {
     const Hit h = traverse<false>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);
+    reload();
     stats.closest++;
     const bool valid = h.prim >= 0;
     if ((nc.flags & MTR_NLOS_ACCOUNT_FIRST_LAST) || p.depth > 0) p.dist += h.t * p.eta;          // :751-752
@@ -292,15 +299,15 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
             const uint32_t nl = nc.laser_w * nc.laser_h, t0 = nc.film_w * nc.film_h + 1u;
             for (uint32_t i = 0; i < nl; ++i) {
                 const q4 t = nc.targets[t0 + i];
-                const f3 li = nlos_laser_targets<EXT>(p, c, mat, albedo, mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats);
+                const f3 li = nlos_laser_targets<EXT>(p, c, mat, albedo, mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats, reload);
                 Lr = mk(Lr.x + li.x, Lr.y + li.y, Lr.z + li.z);
             }
             const float nlf = (float)nl;
             Lr = mk(Lr.x / nlf, Lr.y / nlf, Lr.z / nlf);
         } else if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                            // emitter_laser_sample: depth + 1
-            Lr = nlos_laser_targets<EXT>(p, c, mat, albedo, nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats);
+            Lr = nlos_laser_targets<EXT>(p, c, mat, albedo, nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats, reload);
         else
-            Lr = nlos_emitter_nee<EXT>(p, c, mat, albedo, p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats);
+            Lr = nlos_emitter_nee<EXT>(p, c, mat, albedo, p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats, reload);
     }
     // hidden-geometry / BSDF sampling (:797-833)
     const bool hg = (nc.flags & MTR_NLOS_HG_SAMPLING) != 0;
