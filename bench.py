@@ -585,7 +585,7 @@ def main():
     renderer_collectives = renderer.last_collectives
     # N > 1: the same steps with the film reduction ALONE (reduce-scatter, every rank keeps the developed rows it owns —
     # north_star's "single RCCL reduce"); the headline keeps the all-gather that hands every rank the whole tensor
-    rs_only = rows_leg = None
+    rs_only = rows_leg = single_leg = None
     if world > 1:
         r2 = mdist.DistributedRenderer(scene, partition="spp", gather=False)
         e2, t2, *_ = timed_run(r2)
@@ -602,6 +602,17 @@ def main():
                                   "path": r3.last_path}
         del r3
         comm_full, comm_rs = comm_only_leg(True), comm_only_leg(False)
+        # opt-in (MTR_BENCH_SINGLE_LAUNCH=1): the headline's pipeline with ONE launch of the path kernel per step — band completion
+        # words + hipStreamWaitValue32 on the communication stream (DistributedRenderer(single_launch=True)) instead of a launch
+        # per band (+4.7 % on one GPU; tools/bands.py).  Not in the default line: RCCL beside a stream parked on a memory word has
+        # not run on more than one GPU anywhere.
+        if os.environ.get("MTR_BENCH_SINGLE_LAUNCH") == "1":
+            r4 = mdist.DistributedRenderer(scene, partition="spp", gather=True, single_launch=True)
+            e4, t4, *_ = timed_run(r4)
+            single_leg = {"ms_per_step": e4 / args.steps * 1e3, "value": (t4["rays_closest"] + t4["rays_shadow"]) / e4 / 1e6, "unit": "Mray/s",
+                          "band_launches_per_step": r4.last_band_launches, "path": r4.last_path,
+                          "what": "the headline's reduce_scatter + all_gather pipeline behind ONE launch with band completion words"}
+            del r4
 
     # ---- untimed extra leg (rank 0, N=1): the same render in wavefront mode, to time the stand-alone
     # time-bin scatter-add kernel (k_wf_scatter) with HIP events on its stream
@@ -735,6 +746,8 @@ def main():
             res["render_path"] = path_taken
             res["reduce_scatter_only"] = rs_only
             res["row_sharded"] = rows_leg
+            if single_leg:
+                res["single_launch_bands"] = single_leg
             res["comm_only"] = comm_full
             res["comm_only_reduce_scatter"] = comm_rs
             res["reserve_cus"] = reserve

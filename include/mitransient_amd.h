@@ -279,7 +279,16 @@ typedef struct mtr_render_params {
                                used).  The kernel otherwise owns every CU's LDS for the whole launch, so kernels of other
                                streams — RCCL's reduce-scatter of the previous row band — could only start between two
                                launches.  0 = use every CU (one GPU; the measured cost of 8 / 16 is in DESIGN.md section 7) */
-    uint32_t reserved[4];
+    /* BAND COMPLETION WORDS (round 5; the struct's former reserved words: no ABI change).  n_bands > 0, fused organisation only
+       (MTR_ERR_UNSUPPORTED otherwise: ask mtr_render_plan first): the pixel range is split into n_bands equal contiguous bands
+       (the last takes the remainder) and, when every pixel of band b has been flushed to the film, the kernel stores band_epoch to
+       band_done[b] with a system-scope release — rows and steady sums of the band are then visible to whatever waits for that
+       word (hipStreamWaitValue32 on another stream: a multi-GPU caller starts band b's film reduction while the SAME launch still
+       renders band b + 1, instead of issuing one launch per band).  The caller owns band_done (device memory, n_bands words) and
+       picks an epoch the words do not hold yet.                                                                        */
+    uint32_t n_bands;
+    uint32_t band_epoch;
+    uint64_t band_done;     /* device pointer (uint32_t *), or 0 */
 } mtr_render_params;
 
 /* in-kernel counters */

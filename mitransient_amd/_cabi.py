@@ -111,7 +111,7 @@ class mtr_render_params(C.Structure):
                 ("pixel_begin", C.c_uint32), ("pixel_end", C.c_uint32),
                 ("seed", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
                 ("flags", C.c_uint32), ("mode", C.c_uint32), ("spp_scale", C.c_uint32), ("reserve_cus", C.c_uint32),
-                ("reserved", C.c_uint32 * 4)]
+                ("n_bands", C.c_uint32), ("band_epoch", C.c_uint32), ("band_done", C.c_uint64)]
 
 
 class mtr_counters(C.Structure):

@@ -34,6 +34,7 @@ struct mtr_ctx {
     hipEvent_t ev2 = nullptr, ev3 = nullptr;               // mtr_splat_add: the partitioned passes, timed apart from the first pass (the workspace allocation in between is host time)
     float *d_freq = nullptr; uint32_t freq_cap = 0;      // phasor film frequencies of a ctx-level call (mtr_splat_add)
     void *d_runs = nullptr; size_t runs_cap = 0;         // mtr_splat_add variant 1: sortedness flag + run table
+    uint32_t *d_band_count = nullptr; uint32_t band_cap = 0;     // mtr_render_params.n_bands: flushed pixels per band of the launch in flight
     void *d_part = nullptr; size_t part_cap = 0;         // ... and the partition workspace of unsorted input (at most 256 MiB of it kept between calls, until mtr_ctx_trim / destroy)
 };
 
@@ -131,6 +132,7 @@ void mtr_ctx_destroy(mtr_ctx *c)
     if (c->d_freq) (void)hipFree(c->d_freq);
     if (c->d_runs) (void)hipFree(c->d_runs);
     if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_band_count) (void)hipFree(c->d_band_count);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -674,6 +676,8 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
         if (int r = resolve_mode(s, p, n_pixels, a.spp_chunk, &mode, &dev_ok)) return r;
         if ((p->flags & MTR_FLAG_DEVELOPED_ROWS) && !dev_ok)
             return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: MTR_FLAG_DEVELOPED_ROWS needs the fused organisation with time-bin rows in LDS (see mtr_render_plan)");
+        if (p->n_bands && (mode == MTR_MODE_WAVEFRONT || !p->band_done || p->n_bands > n_pixels))
+            return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: band completion words need the fused organisation, a band_done array and at most one band per pixel");
         if (mode == MTR_MODE_WAVEFRONT) {
             int r = wf_render(s, p, t4, s4, a.rc, &wf_trace_ms, &scatter_ms, &launches, &scatter_launches, times_out != nullptr, &wf_trace_n, want_stats, &wf_shade_ms);
             if (r) return r;
@@ -682,6 +686,21 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
             if (!fused_plan(s->dev, f, n_pixels, a.spp_chunk, usable_cus(c, p), a, cfg))
                 return fail(c, MTR_ERR_UNSUPPORTED, "mtr_render: no kernel configuration fits (BVH depth / LDS)");
             a.ticket = c->d_ticket + (c->fused_launches++ & 15u);
+            a.n_bands = 0u;
+            if (p->n_bands) {
+                // (one banded launch in flight per context: the counts are the context's; callers that overlap launches on two
+                // streams — the per-band pipeline — do not use band words)
+                if (c->band_cap < p->n_bands) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (c->d_band_count) (void)hipFree(c->d_band_count);
+                    c->d_band_count = nullptr; c->band_cap = 0;
+                    HIP_TRY(c, hipMalloc((void **)&c->d_band_count, (size_t)p->n_bands * sizeof(uint32_t)));
+                    c->band_cap = p->n_bands;
+                }
+                HIP_TRY(c, hipMemsetAsync(c->d_band_count, 0, (size_t)p->n_bands * sizeof(uint32_t), c->stream));
+                a.n_bands = p->n_bands; a.band_px = (n_pixels + p->n_bands - 1u) / p->n_bands; a.band_epoch = p->band_epoch;
+                a.band_count = c->d_band_count; a.band_done = (uint32_t *)(uintptr_t)p->band_done;
+            }
             HIP_TRY(c, launch_fused(a, cfg, c->stream));
             launches = 1;
         }

@@ -15,6 +15,8 @@ Two partitions:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 
@@ -91,6 +93,23 @@ def all_gather_rows(slab, height: int, group=None):
     return full[:height]
 
 
+_HIP = None
+
+
+def stream_wait_value(stream, word_ptr: int, value: int):
+    """park ``stream`` until the uint32 at device address ``word_ptr`` EQUALS ``value`` (hipStreamWaitValue32): what follows on
+    the stream — the film reduction of a band — starts when the path kernel has published that band's completion word"""
+    global _HIP
+    import ctypes as C
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")             # already mapped by torch
+        _HIP.hipStreamWaitValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]
+        _HIP.hipStreamWaitValue32.restype = C.c_int
+    rc = _HIP.hipStreamWaitValue32(C.c_void_p(stream.cuda_stream), C.c_void_p(word_ptr), C.c_uint32(value & 0xFFFFFFFF), 1, 0xFFFFFFFF)   # 1 = hipStreamWaitValueEq
+    if rc != 0:
+        raise RuntimeError(f"hipStreamWaitValue32 failed with {rc}")
+
+
 def _develop_rows(film, raw_rows, out=None):
     """develop() of a slab of raw film rows (rows, W, T, 4) -> (rows, W, T, 3), without a steady image"""
     import torch
@@ -125,11 +144,19 @@ class DistributedRenderer:
     so that RCCL's kernels of band b can run WHILE band b + 1 renders instead of waiting for a launch boundary; None keeps the
     integrator's own ``amd_reserve_cus``."""
 
-    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True, bands: int = 8, reserve_cus=None):
+    def __init__(self, scene, partition: str = "spp", group=None, gather: bool = True, bands: int = 8, reserve_cus=None,
+                 single_launch=None):
         if partition not in ("spp", "rows"):
             raise ValueError("partition must be 'spp' or 'rows'")
         self.scene, self.partition, self.group, self.gather, self.bands = scene, partition, group, gather, int(bands)
         self.reserve_cus = reserve_cus
+        # ONE launch of the fused kernel per render with band completion words (mtr_render_params.n_bands) instead of one launch
+        # per band: the communication stream is parked on band b's word (hipStreamWaitValue32) while the same launch renders
+        # band b + 1.  Opt-in (or MTR_SINGLE_LAUNCH_BANDS=1): it removes the +4 % of eight launches on one GPU, but RCCL next to a
+        # stream parked on a memory word has not run on more than one GPU anywhere — the per-band launches stay the default.
+        self.single_launch = (os.environ.get("MTR_SINGLE_LAUNCH_BANDS", "") == "1") if single_launch is None else bool(single_launch)
+        self.last_band_launches = 0
+        self._band_epoch = 0
         self.last_path = None            # "single" | "pipelined" | "spp" | "rows": which code path the last render took
         self.last_collectives = 0        # collectives the last render issued on the data path
         self.owned_rows = None
@@ -271,9 +298,14 @@ class DistributedRenderer:
         # ... but ONLY launches of the fused kernel may overlap (each takes its own work-ticket slot): the wavefront
         # organisation keeps one workspace per scene — path state, queues, records, segment tickets — so its bands stay
         # on ONE stream, in order
-        if integ.resolved_mode(scene, sens, total_spp, my_spp, (0, rows_b * W)) != "fused":
+        fused = integ.resolved_mode(scene, sens, total_spp, my_spp, (0, rows_b * W)) == "fused"
+        if not fused:
+            lanes = (lanes[0], lanes[0])
+        single = self.single_launch and fused and dev.type == "cuda" and H % nb == 0
+        if single:
             lanes = (lanes[0], lanes[0])
         self.last_band_streams = 1 if lanes[0] is lanes[1] else 2
+        self.last_band_launches = 1 if single else nb
         # the device counters are zeroed ONCE, before any band starts (a reset issued by band 0 on its own stream could
         # land after band 1, on the other stream, had begun to count)
         integ.reset_counters(film)
@@ -282,20 +314,43 @@ class DistributedRenderer:
         for st in set(lanes):
             st.wait_event(start)                    # the clear of prepare() and the counter reset ran on the main stream
         band_ev = []
+        band_words = None
+        if single:
+            # ONE launch over all rows; word b of band_words receives this render's epoch when band b is in the film
+            if getattr(self, "_band_words", None) is None or self._band_words.numel() < nb:
+                self._band_words = torch.zeros(nb, dtype=torch.int32, device=dev)
+                self._band_epoch = 0
+            band_words = self._band_words
+            self._band_epoch = (self._band_epoch % 0x7FFFFFFE) + 1
+            begin = torch.cuda.Event(enable_timing=True)
+            done = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(lanes[0]):
+                begin.record(lanes[0])
+                integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(0, H * W),
+                                 rows_are_zero=True, defer_stats="more", developed_partial=dev3,
+                                 bands=(nb, self._band_epoch, band_words.data_ptr()))
+                done.record(lanes[0])
+            band_ev.append((begin, done))
         for b in range(nb):
             r0, r1 = b * rows_b, (b + 1) * rows_b
             ready = torch.cuda.Event(enable_timing=True)
             begin = torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(lanes[b & 1]):
-                begin.record(lanes[b & 1])
-                # every band owns its rows: they are still zero from prepare()'s clear when the band's only pass flushes them;
-                # no read-back per band (the launches stay asynchronous): counters sum on the device
-                integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W),
-                                 rows_are_zero=True, defer_stats="more", developed_partial=dev3)
-                ready.record(lanes[b & 1])
-            band_ev.append((begin, ready))
+            if single:
+                with torch.cuda.stream(side):
+                    side.wait_event(start)
+                    stream_wait_value(side, band_words.data_ptr() + 4 * b, self._band_epoch)
+            else:
+                with torch.cuda.stream(lanes[b & 1]):
+                    begin.record(lanes[b & 1])
+                    # every band owns its rows: they are still zero from prepare()'s clear when the band's only pass flushes
+                    # them; no read-back per band (the launches stay asynchronous): counters sum on the device
+                    integ.accumulate(scene, sens, passes, total_spp, spp_range=my_spp, pixel_range=(r0 * W, r1 * W),
+                                     rows_are_zero=True, defer_stats="more", developed_partial=dev3)
+                    ready.record(lanes[b & 1])
+                band_ev.append((begin, ready))
             with torch.cuda.stream(side):
-                side.wait_event(ready)
+                if not single:
+                    side.wait_event(ready)
                 if gloo:
                     side.synchronize()              # gloo collectives are host-driven (CPU test path)
                 # ONE collective per band and direction: the steady accumulator (4 MB for the whole image) is reduced once, below
@@ -333,7 +388,7 @@ class DistributedRenderer:
                 st.synchronize()
             integ.fetch_counters(film)
             ms = [a.elapsed_time(b_) for a, b_ in band_ev]
-            integ.total_times = {"total_ms": sum(ms), "trace_ms": sum(ms), "scatter_ms": 0.0, "trace_launches": nb,
+            integ.total_times = {"total_ms": sum(ms), "trace_ms": sum(ms), "scatter_ms": 0.0, "trace_launches": len(band_ev),
                                  "scatter_launches": 0}
         if dev3:                                 # the film held this rank's PARTIAL sums: not a result anyone should develop
             film._developed = None

@@ -197,12 +197,14 @@ class TransientADIntegrator:
         return bool(ok.value)
 
     def accumulate(self, scene, sensor, samplers_spps, total_spp, spp_range=None, pixel_range=None,
-                   progress_callback=None, rows_are_zero=None, defer_stats=None, developed_partial=False):
+                   progress_callback=None, rows_are_zero=None, defer_stats=None, developed_partial=False, bands=None):
         """The pass loop of render() (common.py:157-210) without prepare/develop: ADDS into the film.
         ``rows_are_zero``: the caller vouches that the film rows of ``pixel_range`` are untouched since clear() (a render
         split into disjoint row bands: every band's FIRST pass may store its rows instead of read-modify-write).
         ``defer_stats``: "first" / "more" — the call stays asynchronous (no counters / timings are read back); the device
-        counters are reset by "first" and keep summing through "more"; read them with ``fetch_counters()``."""
+        counters are reset by "first" and keep summing through "more"; read them with ``fetch_counters()``.
+        ``bands``: (n, epoch, device pointer of n uint32 words) — band completion words of ONE fused launch over the whole pixel
+        range (mtr_render_params.n_bands): word b receives ``epoch`` when band b's rows are in the film."""
         film = sensor.film()
         ctx = get_context(film._device.index)
         ctx.bind_current_stream()
@@ -224,6 +226,10 @@ class TransientADIntegrator:
             # a pass of a split render indexes its lanes with ITS sample count (its own sampler) and scales by the total
             params = self.render_params(film, sampler_i.seed_value(), spp_i if multi else total_spp, s0, s1, p0, p1,
                                         spp_scale=total_spp if multi else 0)
+            if bands is not None:
+                if multi:
+                    raise NotImplementedError("band completion words of a multi-pass render")
+                params.n_bands, params.band_epoch, params.band_done = int(bands[0]), int(bands[1]) & 0xFFFFFFFF, int(bands[2])
             if direct is not None:
                 params.flags |= _cabi.MTR_FLAG_DEVELOPED_ROWS  # the row flush stores the developed (H,W,T,3) rows whole
             elif film.film_is_zero or (rows_are_zero and i == 0):

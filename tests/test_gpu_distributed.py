@@ -36,8 +36,9 @@ def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
     try:
         from mitransient_amd import distributed as md
         gather = kind != "cornell_nogather"
-        scene = _scene(kind if gather else "cornell", height)
-        r = md.DistributedRenderer(scene, partition=partition, gather=gather)
+        single = kind == "cornell_single"            # ONE fused launch with band completion words instead of a launch per band
+        scene = _scene("cornell" if (single or not gather) else kind, height)
+        r = md.DistributedRenderer(scene, partition=partition, gather=gather, single_launch=single)
         steady, transient = r.render(spp=10, seed=3)
         torch.cuda.synchronize()
         np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
@@ -46,6 +47,8 @@ def _worker(rank, world, port, tmp, partition, height=18, kind="cornell"):
             fh.write(str(getattr(r, "last_reduced_channels", 0)))
         with open(os.path.join(tmp, f"info{rank}.txt"), "w") as fh:
             fh.write(f"{r.last_path} {getattr(r, 'last_band_streams', 0)} {' '.join(map(str, getattr(r, 'owned_rows', None) or []))}")
+        with open(os.path.join(tmp, f"launches{rank}.txt"), "w") as fh:
+            fh.write(str(getattr(r, "last_band_launches", 0)))
         with open(os.path.join(tmp, f"coll{rank}.txt"), "w") as fh:
             fh.write(str(r.last_collectives))
     finally:
@@ -88,6 +91,60 @@ def test_two_rank_pipelined_band_reduction(tmp_path):
         assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
         # one reduce-scatter + one all-gather per band, one all-reduce of the steady sums per render (round 3: four per band)
         assert int((tmp_path / f"coll{r}.txt").read_text()) == 2 * 8 + 1
+
+
+def test_two_rank_pipelined_single_launch_with_band_words(tmp_path):
+    """the same pipeline with ONE launch of the fused kernel per render: the communication stream is parked on band b's
+    completion word (mtr_render_params.n_bands, hipStreamWaitValue32) while the launch renders the later bands"""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=24, height=32, bins=48)
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=10)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "spp", 32, "cornell_single"), nprocs=2, join=True)
+    for r in range(2):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+        assert int((tmp_path / f"launches{r}.txt").read_text()) == 1
+        assert int((tmp_path / f"coll{r}.txt").read_text()) == 2 * 8 + 1
+
+
+def test_band_completion_words_on_one_gpu():
+    """mtr_render_params.n_bands: one fused launch publishes a word per band; a stream parked on the LAST band's word runs
+    its work only after the whole film is there, the film equals an ordinary render's, a second render needs a new epoch,
+    and the wavefront organisation refuses band words"""
+    from conftest import make_cornell, rel_l2
+    from mitransient_amd import distributed as md
+    scene = make_cornell(width=40, height=32, bins=64)
+    integ, sens = scene.integrator(), scene.sensors()[0]
+    film = sens.film()
+    s_ref, t_ref = (np.array(x) for x in integ.render(scene, seed=5, spp=12))
+    integ.direct_develop = False
+    words = torch.zeros(8, dtype=torch.int32, device="cuda")
+    seen = torch.zeros(1, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    for epoch in (1, 2):
+        passes = integ.prepare(scene, sens, 5, 12, [])
+        integ.accumulate(scene, sens, passes, 12, bands=(8, epoch, words.data_ptr()))
+        raw = film.transient_storage.torch_tensor()
+        with torch.cuda.stream(side):
+            md.stream_wait_value(side, words.data_ptr() + 4 * 7, epoch)
+            seen.copy_(raw[-1].abs().sum().reshape(1))              # the last band's rows, read behind its word
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert words.cpu().tolist() == [epoch] * 8
+        s, t = (np.array(x) for x in film.develop())
+        assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+        assert abs(float(seen.item()) - float(raw[-1].abs().sum().item())) <= 1e-3 * max(1.0, float(seen.item()))
+    wf = make_cornell(width=40, height=32, bins=64, amd_mode="wavefront")
+    iw, sw = wf.integrator(), wf.sensors()[0]
+    passes = iw.prepare(wf, sw, 5, 12, [])
+    with pytest.raises(Exception, match="band completion words"):
+        iw.accumulate(wf, sw, passes, 12, bands=(8, 3, words.data_ptr()))
 
 
 def test_two_rank_pipelined_with_rough_materials(tmp_path):
@@ -191,8 +248,9 @@ BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--spp", "8", "--width", "128", 
 def test_bench_self_launches_its_ranks():
     """the driver's command form for N > 1 WITHOUT a launcher — `python bench.py --gpus 2 ...` — starts its two ranks
     itself and prints one JSON line (both ranks on this box's GPU, gloo instead of RCCL: MTR_BENCH_* dry-run hooks)"""
-    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0"}, ["--gpus", "2"] + BENCH_SMALL)
+    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0", "MTR_BENCH_SINGLE_LAUNCH": "1"}, ["--gpus", "2"] + BENCH_SMALL)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["comm_backend"] == "gloo" and res["rccl_ranks"] == 0
+    assert res["single_launch_bands"]["band_launches_per_step"] == 1 and res["single_launch_bands"]["value"] > 0      # the opt-in leg
     assert res["render_path"] == "pipelined" and res["scaling"] == "weak"
     assert res["counters_per_step"]["paths"] == 128 * 128 * 8 * 2            # weak scaling: 8 spp per rank
     assert res["reduce_scatter_only"]["path"] == "pipelined" and res["reduce_scatter_only"]["ms_per_step"] > 0
