@@ -411,6 +411,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     }
     if (const char *e = mtr::knob("MTR_WF_TILE_LOG2")) kTileSlots = 1u << atoi(e);      // experiments
     if (const char *e = mtr::knob("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
+    if (kSegSlots > 32768u) kSegSlots = 32768u;          // a segment holds at most 2^16 slots (seg < kSegSlots + S): k_wf_trace packs (list position, slot) into one word
     const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
     const uint32_t G = (kSegSlots + S - 1) / S;
     uint32_t P = kTileSlots / S; if (P < G) P = G; if (P > n_pixels) P = n_pixels;

@@ -1637,6 +1637,23 @@ MTR_HD void sh_frame_of(f3 n, f3 dp_du, f3 &s, f3 &t)
     t = cross(n, s);
 }
 
+// si.p of a hit from its shading record and barycentrics (h[2..4] of TriShade)
+MTR_HD f3 hit_point(q4 hc, q4 hd, q4 he, float b1, float b2)
+{
+    const float b0 = 1.0f - b1 - b2;
+    if (fbits(he.w) & kShadeQuadBit)          // rectangle: to_world.transform_affine((u, v, 0)) = fmadd(dv, v, fmadd(du, u, c))
+        return mk(fmaf(hd.x, b2, fmaf(hc.y, b1, hd.w)), fmaf(hd.y, b2, fmaf(hc.z, b1, he.x)), fmaf(hd.z, b2, fmaf(hc.w, b1, he.y)));
+    return mk(fmaf(hd.w, b0, fmaf(hc.y, b1, hd.x * b2)),
+              fmaf(he.x, b0, fmaf(hc.z, b1, hd.y * b2)),
+              fmaf(he.y, b0, fmaf(hc.w, b1, hd.z * b2)));
+}
+// ... of a hit record alone: the vertex a path came from, rebuilt where it is needed (k_wf_shade: an emitter was hit) instead of carried
+MTR_HD f3 hit_point(const SceneView &sc, const Hit &h)
+{
+    const TriShade &tsd = sc.tshade[h.prim];
+    return hit_point(tsd.h[2], tsd.h[3], tsd.h[4], h.u, h.v);
+}
+
 template <bool SMOOTH = true>
 MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
 {
@@ -1644,11 +1661,7 @@ MTR_HD HitCtx hit_ctx(const SceneView &sc, f3 ray_d, const Hit &h)
     const TriShade &tsd = sc.tshade[h.prim];
     const q4 ha = tsd.h[0], hb = tsd.h[1], hc = tsd.h[2], hd = tsd.h[3], he = tsd.h[4];
     const float b1 = h.u, b2 = h.v, b0 = 1.0f - b1 - b2;
-    c.sp = mk(fmaf(hd.w, b0, fmaf(hc.y, b1, hd.x * b2)),
-              fmaf(he.x, b0, fmaf(hc.z, b1, hd.y * b2)),
-              fmaf(he.y, b0, fmaf(hc.w, b1, hd.z * b2)));
-    if (fbits(he.w) & kShadeQuadBit)          // rectangle: to_world.transform_affine((u, v, 0)) = fmadd(dv, v, fmadd(du, u, c))
-        c.sp = mk(fmaf(hd.x, b2, fmaf(hc.y, b1, hd.w)), fmaf(hd.y, b2, fmaf(hc.z, b1, he.x)), fmaf(hd.z, b2, fmaf(hc.w, b1, he.y)));
+    c.sp = hit_point(hc, hd, he, b1, b2);
     c.sn = mk(ha.x, ha.y, ha.z); c.ss = mk(ha.w, hb.x, hb.y); c.stt = mk(hb.z, hb.w, hc.x);
     c.gn = c.sn;
     if (SMOOTH && (fbits(he.w) & kShadeSmoothBit)) {

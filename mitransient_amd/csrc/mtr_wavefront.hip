@@ -141,7 +141,15 @@ __device__ __forceinline__ void wf_segment_survivors(const WfArgs &a, uint32_t s
 // Q_RNG is the LAST plane and holds 8 bytes per slot: the PCG32 state.  The stream's increment is a function of (seed, lane)
 // (rng_seed) and is recomputed where the state is loaded — 8 bytes less to read and 8 less to write per vertex and bounce
 // in kernels that wait on HBM (round 4; the four TEA rounds are hidden by the loads)
-enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_HIT, Q_PEND, PL16_COUNT, Q_RNG = PL16_COUNT };
+// The PATH-TRACER tier keeps less (round 5): Q_BETA and Q_AUX = (PCG32 state lo, hi, prev_pdf, depth | pending << 30 | prev_delta << 31),
+// which lives in the plane the NLOS tier calls Q_RAD.  The direction (and eta) of a vertex's incoming ray are read from the ray list
+// the trace kernel has just walked (the material lists carry the list position next to the slot); the path's radiance is not carried
+// at all: every vertex deposits its own increment into its pixel's steady sum (wave_deposit); and the previous vertex's position
+// (read only where a path hits an emitter: the MIS weight of transientpath.py:166-176) is rebuilt from the previous bounce's HIT
+// RECORD, which survives because the hit plane alternates with the bounce's parity (Q_HIT / Q_HIT1, the latter in the plane the NLOS
+// tier calls Q_PREV).  152 instead of 216 B per vertex in k_wf_shade.
+enum Plane { Q_RAY0 = 0, Q_RAY1, Q_BETA, Q_RAD, Q_PREV, Q_HIT, Q_PEND, PL16_COUNT, Q_RNG = PL16_COUNT, Q_AUX = Q_RAD, Q_HIT1 = Q_PREV };
+__device__ __forceinline__ int hit_plane(uint32_t parity) { return parity ? (int)Q_HIT1 : (int)Q_HIT; }
 
 // NT: scenes walked in HBM.  Their path state, rays and hits stream through every kernel of a bounce exactly once —
 // NON-TEMPORAL accesses keep them from pushing the scene (BVH nodes, triangles) out of L2: staircase, 720 x 1280 x 64 spp,
@@ -156,6 +164,17 @@ struct PlanesT {
     __device__ __forceinline__ void st(int pl, uint32_t slot, float4 v) const
     {
         if (NT) nt_store(base + (size_t)pl * n + slot, v); else base[(size_t)pl * n + slot] = v;
+    }
+    // the fourth word of a 16-byte plane alone
+    __device__ __forceinline__ uint32_t ld_w(int pl, uint32_t slot) const
+    {
+        const uint32_t *w = (const uint32_t *)(base + (size_t)pl * n + slot) + 3;
+        return NT ? __builtin_nontemporal_load(w) : *w;
+    }
+    __device__ __forceinline__ void st_w(int pl, uint32_t slot, uint32_t v) const
+    {
+        uint32_t *w = (uint32_t *)(base + (size_t)pl * n + slot) + 3;
+        if (NT) __builtin_nontemporal_store(v, w); else *w = v;
     }
     // the 8-byte plane behind the 16-byte ones
     __device__ __forceinline__ uint64_t ld_rng(uint32_t slot) const
@@ -209,6 +228,29 @@ __device__ __forceinline__ void load_state(const Planes &P, uint32_t s, Path &p,
     p.rng.inc = 0u;                      // the caller knows the lane: p.rng.inc = rng_inc_of(...)
 }
 
+// path-tracer tier (k_wf_shade): what a vertex carries from one bounce to the next — see `enum Plane`.  The ray itself goes to the next
+// live list's ray list (origin for the trace kernel, direction and eta for the next k_wf_shade); p.L is the caller's business.
+template <class Planes>
+__device__ __forceinline__ void store_path(const Planes &P, uint32_t s, const Path &p, uint32_t pend)
+{
+    P.st(Q_BETA, s, make_float4(p.beta.x, p.beta.y, p.beta.z, p.dist));
+    P.st(Q_AUX, s, make_float4(__uint_as_float((uint32_t)p.rng.state), __uint_as_float((uint32_t)(p.rng.state >> 32)), p.prev_pdf,
+                               __uint_as_float(p.depth | (pend << 30) | (p.prev_delta << 31))));
+}
+template <class Planes>
+__device__ __forceinline__ void load_path(const Planes &P, uint32_t s, float4 dir_eta, Path &p, uint32_t &pend)
+{
+    const float4 b = P.ld(Q_BETA, s), x = P.ld(Q_AUX, s);
+    p.ray.o = mk(0, 0, 0); p.ray.tmax = 0.0f; p.ray.d = mk(dir_eta.x, dir_eta.y, dir_eta.z); p.eta = dir_eta.w;
+    p.beta = mk(b.x, b.y, b.z); p.dist = b.w;
+    p.rng.state = (uint64_t)__float_as_uint(x.x) | ((uint64_t)__float_as_uint(x.y) << 32); p.prev_pdf = x.z;
+    p.L = mk(0, 0, 0);
+    p.prev_p = mk(0, 0, 0);              // (rebuilt by the caller where it is read)
+    const uint32_t fl = __float_as_uint(x.w);
+    p.depth = fl & 0x3fffffffu; p.prev_delta = fl >> 31; pend = (fl >> 30) & 1u;
+    p.rng.inc = 0u;                      // the caller knows the lane: p.rng.inc = rng_inc_of(...)
+}
+
 // slot -> (pixel, sample) of the tile
 __device__ __forceinline__ void slot_to_lane(const WfArgs &a, uint32_t slot, uint32_t &pixel, uint32_t &s, uint32_t &p_local)
 {
@@ -232,6 +274,31 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want)
     if ((int)lane == leader) base = atomicAdd(counter, n);
     base = __shfl(base, leader);
     return base + rank;
+}
+
+// steady sums of the segment's pixels (LDS, [G][4]): the wave adds up what its lanes bring per distinct pixel (lists are in slot order:
+// mostly one pixel per wave) and one lane adds the sums — every vertex deposits its radiance increment, a path that ends its weight
+// of 1 (block.put(pos, [L.r, L.g, L.b, 1]), common.py:187-200).  Called by WHOLE waves.
+__device__ __forceinline__ void wave_deposit(float *s_steady, bool has, uint32_t p_seg, f3 L, float w)
+{
+    unsigned long long todo = __ballot(has);
+    const uint32_t lane_id = threadIdx.x & 63u;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t px = __shfl(p_seg, leader);
+        const bool mine = has & (p_seg == px);
+        float x = mine ? L.x : 0.0f, y = mine ? L.y : 0.0f, z = mine ? L.z : 0.0f, c = mine ? w : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); z += __shfl_xor(z, o); c += __shfl_xor(c, o); }
+        if ((int)lane_id == leader) {
+            float *sp = s_steady + 4 * px;
+            if (x != 0.0f) __hip_atomic_fetch_add(sp, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (y != 0.0f) __hip_atomic_fetch_add(sp + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (z != 0.0f) __hip_atomic_fetch_add(sp + 2, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (c != 0.0f) __hip_atomic_fetch_add(sp + 3, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        todo &= ~__ballot(mine);
+    }
 }
 
 // time-bin contribution -> 16-byte record appended to its pixel's list; list full -> f32 atomics to HBM.
@@ -404,7 +471,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
                 if (idle && pending) {
                     if (any_hit) a.occ[slot] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
                     else {
-                        P.st(Q_HIT, slot, make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim)));
+                        P.st(hit_plane(par), slot, make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim)));
                         // hit: the list key rides in the low bits of the tie-break word of the best hit (TriPair, mtr_core.h)
                         const uint32_t key = tr.h.prim >= 0 ? (tr.best_orig & 7u) : 4u;
                         s_key[pos] = (uint8_t)key;
@@ -463,7 +530,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
                 const bool mine = on & (key == k);
                 if (__ballot(mine) != 0ull) {
                     const uint32_t p2 = wave_append(&s_cnt[k], mine);
-                    if (mine) a.q_mat[(size_t)k * a.n_slots + (size_t)sg * a.seg + p2] = sl;
+                    if (mine) a.q_mat[(size_t)k * a.n_slots + (size_t)sg * a.seg + p2] = (i << 16) | (sl - sg * a.seg);     // (list position, slot within the segment): seg <= 2^16, wf_render
                 }
             }
         }
@@ -495,8 +562,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
 // shadow list and parks the term (Lr, optical path length) in the Q_PEND plane, shade_finish runs with the term withheld,
 // the occlusion kernel follows, and the NEXT bounce's k_wf_shade commits the parked term first thing.  The sums are bit for bit
 // the reference's: L = (L + Le) + Lr there, (L + Le) + 0 now and + Lr at the commit — before the next bounce's Le, as there.
-// A path that ENDS with a term parked becomes a "zombie" (its radiance and depth in Q_RAD, the term in Q_PEND, its slot on the
-// segment's zombie list); the next launch commits it and deposits its radiance.  No term can be left at the end of a render:
+// A path that ENDS with a term parked becomes a "zombie" (its depth in Q_AUX.w, the term in Q_PEND, its slot on the
+// segment's zombie list); the next launch commits it and counts the path in its pixel's steady sum.  No term can be left at the end of a render:
 // a vertex samples the emitter only if depth + 1 < max_depth, and the host's live count includes the zombies.
 // (commit_pending: mtr_core.h — shade_finish's own commit, shared with k_fused's deferred organisation)
 
@@ -538,6 +605,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
         __syncthreads();
         uint32_t *q_next = a.q_live + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg;
         float4 *r_next = a.q_ray + 2 * ((size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg);
+        const float4 *r_cur = a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);      // the rays k_wf_trace has just walked, in list order
         uint32_t *qz_next = DEFER ? a.q_zombie + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg : nullptr;
         uint32_t *q_sh = a.q_shadow + (size_t)sg * a.seg;
         float4 *r_sh = a.r_shadow + 2 * (size_t)sg * a.seg;
@@ -550,29 +618,25 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
             sink.n_splats = 0; sink.n_overflow = 0; sink.log = a.log;
             return sink;
         };
-        auto deposit = [&](uint32_t pl, f3 L) {
-            // steady splat: block.put(pos, [L.r, L.g, L.b, 1])  (common.py:187-200)
-            float *sp = s_steady + 4 * (pl - pl0);
-            __hip_atomic_fetch_add(sp, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sp + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sp + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sp + 3, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        if (DEFER && n_z) {      // zombies of the previous bounce: commit the parked term, deposit the path's radiance
+        if (DEFER && n_z) {      // zombies of the previous bounce: commit the parked term, count the path
             const uint32_t *qz = a.q_zombie + (size_t)par * a.n_slots + (size_t)sg * a.seg;
-            for (uint32_t i = tid; i < n_z; i += kBlock) {
-                const uint32_t slot = qz[i];
-                uint32_t pixel, s, pl;
-                slot_to_lane(a, slot, pixel, s, pl);
-                const float4 l = P.ld(Q_RAD, slot), pe = P.ld(Q_PEND, slot);
-                f3 L = mk(l.x, l.y, l.z);
-                if (a.occ[slot] == 0) {
-                    const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
-                    RecordSink sink = make_sink(pl, pixel * a.rc.spp_total + s);
-                    commit_pending(L, mk(pe.x, pe.y, pe.z), pe.w, __float_as_uint(l.w) - 1u, px + a.film.crop_x, py + a.film.crop_y, a.film, a.rc, sink);
-                    n_splats += sink.n_splats; n_over += sink.n_overflow;
+            for (uint32_t i = tid; i < ((n_z + 63u) & ~63u); i += kBlock) {
+                const bool on = i < n_z;
+                uint32_t pl = pl0;
+                f3 L = mk(0, 0, 0);
+                if (on) {
+                    const uint32_t slot = qz[i];
+                    uint32_t pixel, s;
+                    slot_to_lane(a, slot, pixel, s, pl);
+                    if (a.occ[slot] == 0) {
+                        const float4 pe = P.ld(Q_PEND, slot);
+                        const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
+                        RecordSink sink = make_sink(pl, pixel * a.rc.spp_total + s);
+                        commit_pending(L, mk(pe.x, pe.y, pe.z), pe.w, P.ld_w(Q_AUX, slot) - 1u, px + a.film.crop_x, py + a.film.crop_y, a.film, a.rc, sink);
+                        n_splats += sink.n_splats; n_over += sink.n_overflow;
+                    }
                 }
-                deposit(pl, L);
+                wave_deposit(s_steady, on, pl - pl0, L, 1.0f);
             }
         }
         for (uint32_t k = 0; k < kWfKeys; ++k) {                 // one material type after the other
@@ -582,23 +646,30 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
             for (uint32_t i = tid; i < n_round; i += kBlock) {
                 const bool on = i < n_k;
                 bool alive = false, zombie = false;
-                uint32_t slot = 0;
-                f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1); float ray_tmax = 0.0f;
+                uint32_t slot = 0, dep_px = 0;
+                f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1), dep_L = mk(0, 0, 0); float ray_tmax = 0.0f, ray_eta = 1.0f, dep_w = 0.0f;
                 if (on) {
-                    slot = q[i];
+                    const uint32_t e = q[i];                  // (position in the live list the trace kernel walked, slot within the segment)
+                    slot = sg * a.seg + (e & 0xffffu);
                     uint32_t pixel, s, pl;
                     slot_to_lane(a, slot, pixel, s, pl);
                     Path p;
                     uint32_t pend = 0u;
                     if (FIRST) path_begin(p, a.cam, a.film, a.rc, pixel, s);      // (see k_wf_raygen: bounce 0's state is recomputed, not read)
                     else {
-                        load_state(P, slot, p, &pend, false);
+                        load_path(P, slot, r_cur[2 * (size_t)(e >> 16) + 1], p, pend);
                         const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                         p.px = px + a.film.crop_x; p.py = py + a.film.crop_y; p.lane = pixel * a.rc.spp_total + s;
                         p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
                     }
                     Hit h;
-                    { const float4 hq = P.ld(Q_HIT, slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
+                    { const float4 hq = P.ld(hit_plane(par), slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
+                    if (!FIRST && h.prim >= 0 && (fbits(sv.tshade[h.prim].h[4].z) >> 16) != 0u) {
+                        // an emitter was hit: its MIS weight wants the vertex the path came from = the previous bounce's hit (a live path's is valid)
+                        const float4 hq = P.ld(hit_plane(par ^ 1u), slot);
+                        Hit hp; hp.t = hq.x; hp.u = hq.y; hp.v = hq.z; hp.prim = (int32_t)__float_as_uint(hq.w);
+                        p.prev_p = hit_point(sv, hp);
+                    }
                     ++n_closest;
                     RecordSink sink = make_sink(pl, p.lane);
                     if (DEFER && pend && a.occ[slot] == 0) {          // the previous bounce's emitter sample was visible: commit it now
@@ -629,22 +700,25 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
                     alive = shade_finish<EXT, TR>(p, h, occluded, pd, sv, a.film, a.rc, sink);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
-                    ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax;
+                    ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax; ray_eta = p.eta;
                     const uint32_t pend_now = (DEFER && pd.has_shadow) ? 1u : 0u;
-                    if (alive) { ++n_alive; store_state(P, slot, p, false, pend_now); }      // (a path that ended leaves nothing to read)
-                    else if (pend_now) {                      // ended with a term parked: the next launch commits it and deposits
+                    // p.L is what THIS vertex added (the term committed above, emission, the emitter sample): it goes to the pixel's sum now
+                    dep_px = pl - pl0; dep_L = p.L;
+                    if (alive) { ++n_alive; store_path(P, slot, p, pend_now); }      // (a path that ended leaves nothing to read)
+                    else if (pend_now) {                      // ended with a term parked: the next launch commits it and counts the path
                         zombie = true; ++n_alive;             // (the host's live count must keep the loop going for it)
-                        P.st(Q_RAD, slot, make_float4(p.L.x, p.L.y, p.L.z, __uint_as_float(p.depth)));
+                        P.st_w(Q_AUX, slot, p.depth);
                     }
-                    else deposit(pl, p.L);
+                    else dep_w = 1.0f;
                 }
+                wave_deposit(s_steady, on & ((dep_L.x != 0.0f) | (dep_L.y != 0.0f) | (dep_L.z != 0.0f) | (dep_w != 0.0f)), dep_px, dep_L, dep_w);
                 // wave64 stream compaction of the survivors into the segment's next live list
                 if (__ballot(alive) != 0ull) {
                     const uint32_t pos = wave_append(s_next_p, alive);
                     if (alive) {
                         q_next[pos] = slot;
                         r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, ray_tmax);
-                        r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, 0.0f);
+                        r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, ray_eta);
                     }
                 }
                 if (DEFER && __ballot(zombie) != 0ull) {
