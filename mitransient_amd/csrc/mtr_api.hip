@@ -396,8 +396,10 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     // empty: config 5 (2^29 slots) with tiles of 2^25 / 2^26 / 2^27 / 2^28 slots: 2.01 / 1.80 / 1.70 / 1.59 s per render
     // (config 2 in this organisation: 2^22 269 ms, 2^24 174 ms, 2^25 168 ms).
     // Segment: scenes walked in HBM 8192 slots (config 5: 2048 / 4096 / 8192 / 16384 slots: 338 / 288 / 275 / 273 ms at 256 spp
-    // with the 8-wide tree), scenes staged in LDS 4096 (config 2: 141 against 169 ms with 8192).
-    uint32_t kTileSlots = 1u << 28; uint32_t kSegSlots = cfg.scene_lds ? 4096u : 8192u;
+    // with the 8-wide tree); scenes staged in LDS the same since k_wf_shade's state diet (round 5; config 2 with 2048 / 4096 / 6144 /
+    // 8192 / 12288 / 16384 slots: 97.8 / 81.9 / 79.4 / 77.1 - 79.7 / 77.5 / 80.8 ms, 108 triangles 131.9 / 117.2 / 113.9 / 116.1 / 114.7 /
+    // 123.4 ms; rounds 2-4 had 4096: 141 against 169 ms with 8192 then).
+    uint32_t kTileSlots = 1u << 28; uint32_t kSegSlots = 8192u;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_slot = 344;                                   // planes 128 + queues 52 + rays 96 + records 64 + occlusion 1, rounded up
@@ -413,7 +415,9 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     if (const char *e = mtr::knob("MTR_WF_SEG")) kSegSlots = (uint32_t)atoi(e);
     if (kSegSlots > 32768u) kSegSlots = 32768u;          // a segment holds at most 2^16 slots (seg < kSegSlots + S): k_wf_trace packs (list position, slot) into one word
     const uint32_t S = spp_chunk < 4096u ? spp_chunk : 4096u;
-    const uint32_t G = (kSegSlots + S - 1) / S;
+    // (at most 1024 pixels per segment: k_wf_shade keeps 20 B of LDS per pixel of its segment — record-list tail, steady sums —
+    // and a render of very few samples per pixel would otherwise ask for more LDS than a CU has: 8192 pixels = 164 KB)
+    const uint32_t G = std::min<uint32_t>((kSegSlots + S - 1) / S, 1024u);
     uint32_t P = kTileSlots / S; if (P < G) P = G; if (P > n_pixels) P = n_pixels;
     const uint32_t n_slots_max = P * S;
     const uint32_t seg = G * S;

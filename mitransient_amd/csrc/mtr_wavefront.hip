@@ -374,20 +374,20 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     uint32_t n_closest = 0;
-    for (uint32_t slot = blockIdx.x * kBlock + tid; slot < a.n_slots; slot += gridDim.x * kBlock) {
+    // The path tier's bounce 0 is a function of (pixel, sample) alone: its live list is the identity and k_wf_trace<FIRST> /
+    // k_wf_shade<FIRST> REBUILD the camera ray and the path state instead of reading back what this kernel would have written
+    // (round 5: 72 + 36 B written here and read there per slot, 58 GB of config 2's 2^28 slots).  The NLOS bounce kernel reads
+    // the planes and the lists, so that tier still stores them.
+    // camera_unwarp (transientpath.py:133-138: distance = -t of the camera ray's own hit): that hit IS the closest hit of
+    // bounce 0, which k_wf_trace is about to find for this very ray — k_wf_shade takes it from there (depth 0) instead of
+    // tracing every camera ray twice (config 5: k_wf_raygen 31 -> 6 ms per tile); the ray is still counted
+    if (!a.nlos_on && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP) && blockIdx.x == 0 && tid == 0) n_closest = a.n_slots;
+    for (uint32_t slot = blockIdx.x * kBlock + tid; a.nlos_on && slot < a.n_slots; slot += gridDim.x * kBlock) {
         uint32_t pixel, s, pl;
         slot_to_lane(a, slot, pixel, s, pl);
         Path p;
-        if (a.nlos_on) nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
-        else path_begin(p, a.cam, a.film, a.rc, pixel, s);
-        // camera_unwarp (transientpath.py:133-138: distance = -t of the camera ray's own hit): that hit IS the closest hit of
-        // bounce 0, which k_wf_trace is about to find for this very ray — k_wf_shade takes it from there (depth 0) instead of
-        // tracing every camera ray twice (config 5: k_wf_raygen 31 -> 6 ms per tile); the ray is still counted
-        if (!a.nlos_on && (a.rc.flags & MTR_FLAG_CAMERA_UNWARP)) ++n_closest;
-        // The path state of bounce 0 is a function of (pixel, sample) alone: k_wf_shade REBUILDS it in its first launch (a.first_bounce)
-        // instead of reading back what this kernel would have written — 72 B written here and 72 B read there per slot, 38 GB of
-        // config 2's 2^28 slots (round 5; the NLOS bounce kernel reads the planes, so that tier still stores them)
-        if (a.nlos_on) store_state(P, slot, p, true);
+        nlos_begin(p, a.nlos, a.film, a.rc, pixel, s);
+        store_state(P, slot, p, true);
         a.q_live[slot] = slot;                                   // live queue of bounce 0 = identity
         a.q_ray[2 * (size_t)slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, p.ray.tmax);
         a.q_ray[2 * (size_t)slot + 1] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, p.eta);
@@ -426,7 +426,10 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 #endif
 // ANY: the occlusion pass of a bounce's shadow rays (a.trace_any) as its own instantiation — no hit record to keep, nothing to sort
 // into material lists: the compiler drops the closest-hit bookkeeping from the walk instead of carrying both behind a flag
-template <int STACK, bool SCENE_LDS, bool ANY>
+// FIRST: the closest hits of bounce 0 — the live list is the identity and a camera ray is a function of (pixel, sample): both are
+// computed here (path_begin, as k_wf_shade<FIRST> does for the rest of the state) instead of written by k_wf_raygen and read back,
+// 36 B per slot each way (config 2: 9.7 GB written + 9.7 GB read per render)
+template <int STACK, bool SCENE_LDS, bool ANY, bool FIRST = false>
 __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WAVES_ANY : MTR_WF_TRACE_WAVES)) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -484,9 +487,19 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
                 base = __shfl(base, leader);
                 const uint32_t idx = base + (uint32_t)__popcll(m_idle & ((1ull << lane_id) - 1ull));
                 if (idle && idx < n_live) {
-                    pos = idx; slot = q[idx];
-                    const float4 r0 = qr[2 * (size_t)idx], r1 = qr[2 * (size_t)idx + 1];
-                    trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, st);
+                    pos = idx;
+                    if (FIRST) {
+                        slot = sg * a.seg + idx;
+                        uint32_t pixel, s, pl;
+                        slot_to_lane(a, slot, pixel, s, pl);
+                        Path p;
+                        path_begin(p, a.cam, a.film, a.rc, pixel, s);
+                        trav_init(tr, sv, p.ray.o, p.ray.d, p.ray.tmax, st);
+                    } else {
+                        slot = q[idx];
+                        const float4 r0 = qr[2 * (size_t)idx], r1 = qr[2 * (size_t)idx + 1];
+                        trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, st);
+                    }
                     pending = true;
                 }
             }
@@ -524,7 +537,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
         for (uint32_t i = tid; i < n_round; i += kBlock) {
             const bool on = i < n_live;
             const uint32_t key = on ? (uint32_t)s_key[i] : kWfKeys;
-            const uint32_t sl = on ? q[i] : 0u;
+            const uint32_t sl = on ? (FIRST ? sg * a.seg + i : q[i]) : 0u;
 #pragma unroll
             for (uint32_t k = 0; k < kWfKeys; ++k) {
                 const bool mine = on & (key == k);
@@ -643,13 +656,18 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_
             const uint32_t n_k = a.seg_mat[(size_t)sg * kWfKeys + k];
             const uint32_t *q = a.q_mat + (size_t)k * a.n_slots + (size_t)sg * a.seg;
             const uint32_t n_round = (n_k + 63u) & ~63u;
+            // the list entry of the NEXT pass is requested a pass ahead: entry -> state is a dependent pair of loads, and three waves per
+            // SIMD do not hide two memory latencies per vertex
+            uint32_t e_next = (uint32_t)tid < n_k ? q[tid] : 0u;
             for (uint32_t i = tid; i < n_round; i += kBlock) {
                 const bool on = i < n_k;
+                const uint32_t e = e_next;
+                if (i + kBlock < n_k) e_next = q[i + kBlock];
                 bool alive = false, zombie = false;
                 uint32_t slot = 0, dep_px = 0;
                 f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1), dep_L = mk(0, 0, 0); float ray_tmax = 0.0f, ray_eta = 1.0f, dep_w = 0.0f;
                 if (on) {
-                    const uint32_t e = q[i];                  // (position in the live list the trace kernel walked, slot within the segment)
+                    // e: (position in the live list the trace kernel walked, slot within the segment)
                     slot = sg * a.seg + (e & 0xffffu);
                     uint32_t pixel, s, pl;
                     slot_to_lane(a, slot, pixel, s, pl);
@@ -1036,7 +1054,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
             return hipGetLastError();
         }
     }
-    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? (a.trace_any ? k_wf_trace<STACK, SL, true> : k_wf_trace<STACK, SL, false>)
+    void (*k)(const WfArgs) = which == 0 ? k_wf_raygen<STACK, SL> : which == 1 ? (a.trace_any ? k_wf_trace<STACK, SL, true> : a.first_bounce ? k_wf_trace<STACK, SL, false, true> : k_wf_trace<STACK, SL, false>)
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : a.first_bounce ? (ext ? k_wf_shade<STACK, SL, true, 0u, true> : k_wf_shade<STACK, SL, false, 0u, true>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
