@@ -492,6 +492,26 @@ def test_staircase_like_scene_in_hbm(oracle, mode):
         assert got[k] == cnt[k], k
 
 
+@pytest.mark.parametrize("which", ["lds", "hbm"])
+def test_one_sample_per_pixel_in_the_wavefront_organisation(oracle, which):
+    """1 spp over a film of more pixels than a segment holds: the segment is cut by its PIXEL count then (k_wf_shade keeps 20 B of
+    LDS per pixel of its segment; uncapped, 8192 one-sample pixels asked for 164 KB of LDS and the launch was refused)"""
+    import mitransient_amd.mi as mi
+    if which == "lds":
+        scene = make_cornell(width=128, height=96, bins=32, amd_mode="wavefront")
+    else:
+        from mitransient_amd.scenes import staircase_like
+        d = staircase_like(n_steps=12, balusters=2, tiles=6, width=128, height=96, temporal_bins=32, spp=1)
+        d["integrator"]["amd_mode"] = "wavefront"
+        scene = mi.load_dict(d)
+    s_gpu, t_gpu = gpu_render(scene, 1)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 1)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
+
+
 def test_large_procedural_scene_modes_agree():
     """~29k triangles (tiles=120): too slow for the oracle at useful sample counts, so the two independent
     kernel organisations are compared with each other (same lanes, same RNG) + the energy identity."""
