@@ -583,11 +583,14 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WA
 #ifndef MTR_WF_SHADE_WAVES
 #define MTR_WF_SHADE_WAVES 4
 #endif
+#ifndef MTR_WF_SHADE_WAVES_LDS
+#define MTR_WF_SHADE_WAVES_LDS 3
+#endif
 // TR: scene traits (mtr_core.h kTr*; scenes staged in LDS only): shading code the scene's tables cannot reach is not compiled in
 // FIRST: the launch that shades bounce 0 — the path state is rebuilt from (pixel, sample) instead of loaded (k_wf_raygen); its own
 // instantiation, so that the camera and path_begin's code stay out of the kernel every other bounce runs
 template <int STACK, bool SCENE_LDS, bool EXT, uint32_t TR = 0u, bool FIRST = false>
-__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 3 : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : MTR_WF_SHADE_WAVES) k_wf_shade(const WfArgs a)
 {
     constexpr bool DEFER = !SCENE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

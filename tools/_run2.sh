@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_rough.py tests/test_gpu_configs.py tests/test_gpu_nlos.py -x -q -m gpu 2>&1 | tail -5
-bash tools/ab_wf.sh ab/libs/lib_cur.so ab/libs/lib_xcd.so
-SPP=256 bash tools/ab_stair.sh ab/libs/lib_cur.so ab/libs/lib_xcd.so
-for n in 2 6 26; do python tools/sweep_point.py $n wavefront 2>/dev/null | tail -1; done
+bash tools/ab_wf.sh ab/libs/lib_cur.so ab/libs/lib_sw4.so
+for lib in cur sw4; do echo -n "$lib "; MITRANSIENT_AMD_LIB=$(pwd)/ab/libs/lib_$lib.so python tools/sweep_point.py 2 wavefront 2>/dev/null | tail -1; done
+SPP=256 bash tools/ab_stair.sh ab/libs/lib_cur.so ab/libs/lib_sw5h.so
