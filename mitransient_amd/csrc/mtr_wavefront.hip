@@ -421,6 +421,9 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 #ifndef MTR_WF_TRACE_WAVES_ANY
 #define MTR_WF_TRACE_WAVES_ANY 6      // the occlusion instantiation (80 registers, none spilled)
 #endif
+#ifndef MTR_WF_TRACE_WAVES_LDS
+#define MTR_WF_TRACE_WAVES_LDS 1      // scenes staged in LDS: no bound (93 registers, 5 waves per SIMD)
+#endif
 #ifndef MTR_WF_TRACE_WAVES
 #define MTR_WF_TRACE_WAVES 6          // scenes in HBM: the walk waits on loads, 6 waves per SIMD (80 registers, 6 spilled) beat 5 and 8 (measured)
 #endif
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_raygen(const WfArgs a)
 // computed here (path_begin, as k_wf_shade<FIRST> does for the rest of the state) instead of written by k_wf_raygen and read back,
 // 36 B per slot each way (config 2: 9.7 GB written + 9.7 GB read per render)
 template <int STACK, bool SCENE_LDS, bool ANY, bool FIRST = false>
-__global__ void __launch_bounds__(kBlock, SCENE_LDS ? 1 : (ANY ? MTR_WF_TRACE_WAVES_ANY : MTR_WF_TRACE_WAVES)) k_wf_trace(const WfArgs a)
+__global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (ANY ? MTR_WF_TRACE_WAVES_ANY : MTR_WF_TRACE_WAVES)) k_wf_trace(const WfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_cnt = (uint32_t *)smem;                         // [kWfKeys] list tails of the segment
