@@ -297,7 +297,10 @@ constexpr uint32_t kLeafQuadBit = 0x40000000u;      // in the leaf code ~ref = (
 // smooth-shaded triangles (interpolated vertex normals, mtr_scene_desc.tri_normals): h[0] = (ng.x, ng.y, ng.z, dp_du.x),
 // h[1] = (dp_du.y, dp_du.z, -, -) — the geometric normal and the tangent direction from which the frame is built at the hit
 // (hit_ctx) — orig |= kShadeSmoothBit; the three vertex normals live in SceneView::vnormals[3 * slot ..]
-struct alignas(16) TriShade { q4 h[5]; };
+#ifndef MTR_TSHADE_QUADS
+#define MTR_TSHADE_QUADS 5      // (experiments: 8 = one record per 128-byte line; profiles/r05_trace_experiments.txt)
+#endif
+struct alignas(16) TriShade { q4 h[MTR_TSHADE_QUADS]; };
 constexpr uint32_t kShadeQuadBit = 0x80000000u;
 constexpr uint32_t kShadeSmoothBit = 0x40000000u;
 struct alignas(16) Emitter {                       // 80 B
