@@ -332,6 +332,57 @@ def test_shared_edges_are_closed(oracle, host_harness):
     assert np.all(oracle.intersect(sd, o, d)[1] < 0) and np.all(_hh_intersect(host_harness, sd, o, d)[1] < 0)
 
 
+@pytest.mark.parametrize("wide", [0, 3], ids=["bvh2", "quantised-8"])
+def test_spatial_splits_equal_brute_force(oracle, host_harness, tmp_path, monkeypatch, wide):
+    """mtr_bvh.cpp's spatial splits (scenes of >= 1024 triangles): 1500 long thin triangles at random angles — the case in which
+    a triangle's box is mostly empty and the builder prefers a plane that cuts references in two.  The tree must return the
+    brute-force closest hit (t bits, primitive) and occlusion answer for random rays, duplicated references or not, and the
+    splits must actually have happened (more leaves than the build without them)."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    rng = np.random.default_rng(11)
+    fn = tmp_path / "sticks.obj"
+    with open(fn, "w") as fh:
+        for i in range(1500):
+            c = rng.uniform(-0.9, 0.9, 3)
+            axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+            side = np.cross(axis, rng.normal(size=3)); side /= np.linalg.norm(side)
+            half = rng.uniform(0.05, 0.9) if i % 3 else rng.uniform(0.01, 0.05)
+            for p in (c - half * axis, c + half * axis, c + 0.01 * side):
+                fh.write("v %.9g %.9g %.9g\n" % tuple(np.clip(p, -0.99, 0.99)))
+            fh.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=8, height=8, temporal_bins=8)
+    for name in ("small-box", "large-box"):
+        d.pop(name)
+    d["sticks"] = {"type": "obj", "filename": str(fn), "face_normals": True, "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
+    sd = mi.load_dict(d).data()
+    assert sd.tri_verts.shape[0] >= 1500
+    n = 6000
+    o = rng.uniform(-0.95, 0.95, (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3))
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    maxt = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.1, 2.0, n)).astype(np.float32)
+    t0, p0, occ0 = oracle.intersect(sd, o, dirs, maxt, use_bvh=False)
+    leaves = {}
+    host_harness.hh_set_wide(wide)
+    try:
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("MTR_BVH_NO_SBVH", "1")
+            t1, p1, occ1 = _hh_intersect(host_harness, sd, o, dirs, maxt)
+            assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+            assert np.array_equal(p0, p1) and np.array_equal(occ0, occ1)
+            nn, dd, ll = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+            desc = sd.desc()
+            assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dd), C.byref(ll)) == 0
+            leaves[off] = ll.value
+    finally:
+        host_harness.hh_set_wide(0)
+    assert leaves[False] > leaves[True] * 1.1, leaves
+
+
 def test_obj_loader(tmp_path):
     from mitransient_amd.scene import load_obj
     p = tmp_path / "q.obj"
