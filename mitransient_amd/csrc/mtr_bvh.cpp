@@ -127,6 +127,7 @@ struct Builder {
     // ... only where the object split's children overlap by more than this share of the scene's area (the paper's alpha; its 1e-5
     // duplicates 12 % of the staircase's triangles, 1e-6 52 %: config 5 at 256 spp k_wf_trace 117.2 / 113.5 ms, 3e-7 113.0, 0 (budget 2 n) 120)
     float kAlpha = 1e-6f;
+    bool kUnsplit = false;            // reference unsplitting (below): measured, k_wf_trace 112.1 with against 110.5 ms without — off
 
     explicit Builder(Shared &s) : S(s) {}
 
@@ -309,11 +310,29 @@ struct Builder {
             // (nothing has been changed yet: a plane that leaves one side empty falls back to the object split)
             if (left.size() + cuts.size() == 0u || right.size() + cuts.size() == 0u) { left.clear(); right.clear(); }
             else {
+                // REFERENCE UNSPLITTING (the paper's 4.4): a straddling reference is cut only if that is cheaper than handing it whole
+                // to one child — C_split = A(B1) N1 + A(B2) N2 against A(B1 + ref) N1 + A(B2) (N2 - 1) and its mirror image
+                Box B1, B2; B1.reset(); B2.reset();
+                for (uint32_t t : left) B1.grow(sbox[t]);
+                for (uint32_t t : right) B2.grow(sbox[t]);
+                for (const Cut &c : cuts) { B1.grow(c.lo_b); B2.grow(c.hi_b); }
+                float N1 = (float)(left.size() + cuts.size()), N2 = (float)(right.size() + cuts.size());
+                size_t n_cut = 0;
                 for (const Cut &c : cuts) {
-                    set_box(c.t, c.lo_b); left.push_back(c.t);
-                    right.push_back(add_reference(items[c.t].first_tri, c.hi_b));
+                    Box U1 = B1, U2 = B2; U1.grow(sbox[c.t]); U2.grow(sbox[c.t]);
+                    const float c_split = B1.area() * N1 + B2.area() * N2;
+                    const float c_left = U1.area() * N1 + B2.area() * (N2 - 1.0f);
+                    const float c_right = B1.area() * (N1 - 1.0f) + U2.area() * N2;
+                    if (kUnsplit && c_left < c_split && c_left <= c_right && N2 > 1.0f) { left.push_back(c.t); B1 = U1; N2 -= 1.0f; }
+                    else if (kUnsplit && c_right < c_split && N1 > 1.0f) { right.push_back(c.t); B2 = U2; N1 -= 1.0f; }
+                    else {
+                        const uint32_t tri = items[c.t].first_tri;
+                        set_box(c.t, c.lo_b); left.push_back(c.t);
+                        right.push_back(add_reference(tri, c.hi_b));
+                        ++n_cut;
+                    }
                 }
-                *dup_budget = left_budget;
+                *dup_budget -= n_cut;
             }
         }
         if (left.empty() || right.empty()) {
@@ -395,14 +414,17 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     if (n == 0) return;
     Shared S; S.verts = verts;
     Builder B(S); B.prims = prims;
-    // leaves: two triangles for scenes staged in LDS (k_fused: 1 / 3 / 4 measured worse), four for the large scenes walked in
-    // HBM (config 5 at 256 spp, 8-wide tree: 1 / 2 / 3 / 4 triangles per leaf: 335 / 288 / 283 / 275 ms — fewer, fuller leaves)
+    // leaves: two triangles for scenes staged in LDS (k_fused: 1 / 3 / 4 measured worse) and for the large scenes built with spatial
+    // splits, four for scenes walked in HBM without them
     // The two cases cannot overlap: a slot costs 120 B of LDS (TriShade + half a TriPair) and the staged scene is limited to 64 KB
     // (fused_plan / wf_plan), so no scene above 546 triangles is ever walked in LDS — the choice is made on exactly that bound.
     // (The quantised HBM trees are still built for small scenes — a handful of nodes — because k_nlos_prepare and the
     // HBM instantiations requested explicitly walk them.)
     const bool never_in_lds = (size_t)n * (sizeof(TriShade) + sizeof(TriPair) / 2) > 64u * 1024u;
-    if (never_in_lds) { B.kLeafTarget = 4; B.kBins = 32; }          // (SAH bins 8 / 16 / 32 / 64: 243 / 239 / 233 / 237 ms)
+    // (before the spatial splits four triangles per leaf were best for the large scenes — config 5 at 256 spp, 1 / 2 / 3 / 4: 335 / 288 /
+    // 283 / 275 ms; with them 2 / 3 / 4: k_wf_trace 110.0 / 116.1 / 113.9 ms)
+    const bool sbvh = n >= 1024 && !mtr::knob("MTR_BVH_NO_SBVH");
+    if (never_in_lds) { B.kLeafTarget = sbvh ? 2 : 4; B.kBins = 32; }          // (SAH bins 16 / 32 / 64: k_wf_trace 119.9 / 113.9 / 113.5 ms)
     if (const char *e = mtr::knob("MTR_BVH_BINS")) { B.kBins = atoi(e); if (B.kBins < 4) B.kBins = 4; if (B.kBins > Builder::kMaxBins) B.kBins = Builder::kMaxBins; }   // experiments
     if (const char *e = mtr::knob("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     S.tmp.reserve(3 * (size_t)n);
@@ -477,9 +499,10 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     // references are duplicated, the budget (as many duplicates as triangles) is a bound on memory, not a tuning knob.
     // Config 5 at 256 spp, k_wf_trace per render: no splits 161 ms, early split clipping (rounds 2-5) 131 ms, spatial splits 113.5 ms
     // (both together 121 ms: pieces cut before the build take the planes the builder would have chosen).
-    size_t dup_budget = n >= 1024 && !mtr::knob("MTR_BVH_NO_SBVH") ? (size_t)n : 0u;
+    size_t dup_budget = sbvh ? (size_t)n : 0u;
     if (const char *e = mtr::knob("MTR_BVH_SBVH_BUDGET")) dup_budget = (size_t)(atof(e) * (double)n);
     if (const char *e = mtr::knob("MTR_BVH_SBVH_ALPHA")) B.kAlpha = (float)atof(e);
+    if (mtr::knob("MTR_BVH_UNSPLIT")) B.kUnsplit = true;
     if (const char *e = mtr::knob("MTR_BVH_SBVH_BINS")) B.kSpatialBins = std::min(Builder::kMaxSpatialBins, std::max(4, atoi(e)));
     if (dup_budget) {
         Box scene; scene.reset();
