@@ -205,7 +205,7 @@ struct Builder {
         return true;
     }
 
-    int build(std::vector<uint32_t> refs)
+    int build(std::vector<uint32_t> refs, uint32_t depth = 0)
     {
         const uint32_t count = (uint32_t)refs.size();
         bool special = false;
@@ -250,7 +250,9 @@ struct Builder {
 
         // ---- spatial split candidate: only where the children of the object split overlap noticeably
         int sp_axis = -1; float sp_pos = 0.0f, sp_cost = FLT_MAX;
-        if (spatial && dup_budget && *dup_budget > 0 && best_axis >= 0 && count > kLeafTarget) {
+        // (not below level 40: the walkers' stacks end at 64 levels, and a chain of planes that each shave a sliver off the same
+        // references must not be what uses them up)
+        if (spatial && dup_budget && *dup_budget > 0 && best_axis >= 0 && count > kLeafTarget && depth < 40u) {
             Box lb, rb; lb.reset(); rb.reset();
             for (uint32_t t : refs) (object_side(t) ? lb : rb).grow(sbox[t]);
             const Box ov = intersect(lb, rb);
@@ -345,8 +347,8 @@ struct Builder {
             }
         }
         refs.clear(); refs.shrink_to_fit();
-        const int l = build(std::move(left));
-        const int r = build(std::move(right));
+        const int l = build(std::move(left), depth + 1u);
+        const int r = build(std::move(right), depth + 1u);
         Tmp t; t.box = S.tmp[l].box; t.box.grow(S.tmp[r].box); t.left = l; t.right = r;
         S.tmp.push_back(t);
         return (int)S.tmp.size() - 1;
