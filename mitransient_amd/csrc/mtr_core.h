@@ -1738,8 +1738,10 @@ struct Pending {
 // Part A of one loop iteration (transientpath.py:148-218): consumes the closest hit, splats the
 // emission term, samples the emitter and emits the shadow ray.  RNG: next_2d (:193).
 template <bool ROUGH = true, uint32_t TR = 0u, class Sink>
+// keep: (optional) the surface interaction for shade_finish — a caller that runs nothing between the two parts (k_wf_shade over scenes
+// in HBM: the shadow ray goes to a list) hands it over instead of having shade_finish fetch the shading record a second time
 MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &film, const RenderConst &rc,
-                      Sink &sink, Pending &pd, Ray &shadow)
+                      Sink &sink, Pending &pd, Ray &shadow, HitCtx *keep = nullptr)
 {
     constexpr bool kDiff = (TR & kTrDiffuse) != 0u, kOneRect = (TR & kTrOneRectEmitter) != 0u;
     const bool valid = h.prim >= 0;
@@ -1754,6 +1756,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
     float u1 = rng_f32(p.rng), u2 = rng_f32(p.rng);                  // :193, unconditional for a live lane
     if (!valid) return;
     const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
+    if (keep) *keep = c;
     const mtr_material &mat = sc.mats[c.mat];
 
     // direct emission (:166-176)
@@ -1851,7 +1854,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
 // RNG: next_1d, next_2d (:223-224), next_1d (:256).  Returns active_next.
 template <bool ROUGH = true, uint32_t TR = 0u, class Sink>
 MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd, const SceneView &sc,
-                         const Film &film, const RenderConst &rc, Sink &sink)
+                         const Film &film, const RenderConst &rc, Sink &sink, const HitCtx *kept = nullptr)
 {
     constexpr bool kDiff = (TR & kTrDiffuse) != 0u;
     const bool valid = h.prim >= 0;
@@ -1874,7 +1877,7 @@ MTR_HD bool shade_finish(Path &p, const Hit &h, bool occluded, const Pending &pd
     f3 sp = mk(0, 0, 0);
     p.L = mk((p.L.x + pd.Le.x) + Lr.x, (p.L.y + pd.Le.y) + Lr.y, (p.L.z + pd.Le.z) + Lr.z);    // :230
     if (valid) {
-        const HitCtx c = hit_ctx<ROUGH>(sc, p.ray.d, h);
+        const HitCtx c = kept ? *kept : hit_ctx<ROUGH>(sc, p.ray.d, h);
         sp = c.sp;
         if (active_next) {
             bs = bsdf_sample<ROUGH, TR>(sc.mats[c.mat], c.wi, s1, s2a, s2b, material_albedo<ROUGH>(sc, sc.mats[c.mat], h));     // :222-227

@@ -703,7 +703,12 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     Pending pd; Ray shadow;
                     shadow.o = mk(0, 0, 0); shadow.d = mk(0, 0, 1); shadow.tmax = 0.0f;
                     if ((a.rc.flags & MTR_FLAG_CAMERA_UNWARP) && p.depth == 0u && h.prim >= 0) p.dist = -h.t;      // camera_unwarp: see k_wf_raygen
-                    shade_hit<EXT, TR>(p, h, sv, a.film, a.rc, sink, pd, shadow);
+                    // scenes in HBM: nothing runs between shade_hit and shade_finish, the surface interaction is handed over instead of
+                    // rebuilt from a second fetch of the shading record (config 5 at 256 spp 153.3 -> 152.4 ms; not with the extended
+                    // shading code, whose registers are all taken: 170.1 -> 173.3 ms)
+                    constexpr bool kKeepCtx = DEFER && !EXT;
+                    HitCtx hc;
+                    shade_hit<EXT, TR>(p, h, sv, a.film, a.rc, sink, pd, shadow, kKeepCtx ? &hc : nullptr);
                     bool occluded = false;
                     if (pd.has_shadow) {
                         ++n_shadow;
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                             occluded = true;
                         }
                     }
-                    alive = shade_finish<EXT, TR>(p, h, occluded, pd, sv, a.film, a.rc, sink);
+                    alive = shade_finish<EXT, TR>(p, h, occluded, pd, sv, a.film, a.rc, sink, kKeepCtx ? &hc : nullptr);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
                     ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax; ray_eta = p.eta;
