@@ -208,6 +208,8 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         s.uvs.assign(2 * (size_t)n_slots, q4{ 0, 0, 0, 0 });
     }
     if (d.n_tris >= (1u << 29)) return "too many triangles (the tie-break word holds 29 bits of triangle index)";
+    // (a leaf's code is (first slot << 2 | count - 1) under kLeafQuadBit = bit 30; spatial splits duplicate references: up to 2 slots per triangle)
+    if (n_slots >= (1u << 28)) return "too many triangle slots (a leaf code holds 28 bits of slot index)";
     // the tie-break word of an intersection record: (original index << 3) | list key of the triangle's material (mtr_core.h hit_list_key)
     auto tie_word = [&](uint32_t orig) { return (orig << 3) | hit_list_key(d.materials[d.tri_material[orig]].type); };
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
