@@ -703,7 +703,7 @@ int mtr_render(mtr_scene *s, const mtr_render_params *p, float *t4, float *s4,
                     c->band_cap = p->n_bands;
                 }
                 HIP_TRY(c, hipMemsetAsync(c->d_band_count, 0, (size_t)p->n_bands * sizeof(uint32_t), c->stream));
-                a.n_bands = p->n_bands; a.band_px = (n_pixels + p->n_bands - 1u) / p->n_bands; a.band_epoch = p->band_epoch;
+                a.n_bands = p->n_bands; a.band_px = n_pixels / p->n_bands; a.band_epoch = p->band_epoch;      // (>= 1: n_bands <= n_pixels, checked above; the last band takes the remainder)
                 a.band_count = c->d_band_count; a.band_done = (uint32_t *)(uintptr_t)p->band_done;
             }
             HIP_TRY(c, launch_fused(a, cfg, c->stream));

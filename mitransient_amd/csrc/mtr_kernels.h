@@ -68,6 +68,7 @@ struct FusedArgs {
     DevCounters *counters;
     SplatLog log;
     uint32_t nlos_on;                    // 1: transient_nlos_path + nlos_capture_meter (nlos valid)
+    float fixed_lim; uint32_t fixed_dcap;    // MTR_FLAG_DETERMINISTIC rows: what is summed in fixed point (LdsFixedSink's RANGE GUARD; fused_plan)
     // band completion words (mtr_render_params.n_bands): band b = pixels [b * band_px, (b + 1) * band_px) of the launch's range;
     // band_count[b] counts its flushed pixels (zeroed before the launch), band_done[b] receives band_epoch when it is complete
     uint32_t n_bands, band_px, band_epoch;

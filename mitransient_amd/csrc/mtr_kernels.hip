@@ -119,6 +119,14 @@ __device__ __forceinline__ unsigned long long splat_to_fixed(float v)
     return (unsigned long long)q;
 }
 __device__ __forceinline__ float splat_from_fixed(unsigned long long q) { return __ll2float_rn((long long)q) * 2.2737367544323206e-13f; }
+// RANGE GUARD of the fixed-point rows (round 6; the reference's film is plain f32: transient_image_block.py:79-81).  n values are
+// summed in fixed point only while each is below 2^20 / n in magnitude — no sum then leaves +-2^20; a larger value, an Inf or a
+// NaN (they fail the same comparison) takes the f32 route of the kernel it is in (see mtr_wavefront.hip: to_fixed).
+__device__ __forceinline__ float splat_fixed_limit(uint64_t n) { return 1048576.0f / (float)(n ? n : 1ull); }
+__device__ __forceinline__ bool splat_fixed_unsafe(float r, float g, float b, float lim)
+{
+    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+}
 
 #ifndef MTR_FUSED_SEG_LANES
 #define MTR_FUSED_SEG_LANES 2048u      // samples in flight per workgroup the ring of row slots is sized for (1024 / 4096 measured worse)
@@ -142,15 +150,24 @@ struct LdsHistSink {
     }
 };
 
-// MTR_FLAG_DETERMINISTIC: the same ring in 64-bit fixed point
+// MTR_FLAG_DETERMINISTIC: the same ring in 64-bit fixed point.  RANGE GUARD: a path adds at most two contributions to any one bin
+// per depth, so the contributions of depth < dcap whose channels are all below lim = 2^20 / (2 spp dcap) cannot carry a bin
+// sum out of +-2^20; every other one (deeper, larger, Inf, NaN) goes to the f32 OVERFLOW ring beside the fixed-point one
+// (ovf: [3][G * T] f32) and the flush returns fixed + overflow — what the reference's f32 film holds, up to summation order.
 struct LdsFixedSink {
-    unsigned long long *hist; uint32_t plane, row, film_w, lane, n_splats;
+    unsigned long long *hist; float *ovf; uint32_t plane, row, film_w, lane, n_splats;
+    float lim; uint32_t dcap;
     SplatLog log;
     __device__ __forceinline__ void splat(uint32_t fx, uint32_t fy, uint32_t bin, float r, float g, float b,
                                           float opl, uint32_t depth, uint32_t kind)
     {
-        unsigned long long *p = hist + row + bin;
-        atomicAdd(p, splat_to_fixed(r)); atomicAdd(p + plane, splat_to_fixed(g)); atomicAdd(p + 2 * plane, splat_to_fixed(b));
+        if (depth < dcap && !splat_fixed_unsafe(r, g, b, lim)) {
+            unsigned long long *p = hist + row + bin;
+            atomicAdd(p, splat_to_fixed(r)); atomicAdd(p + plane, splat_to_fixed(g)); atomicAdd(p + 2 * plane, splat_to_fixed(b));
+        } else {
+            float *o = ovf + row + bin;
+            lds_add(o, r); lds_add(o + plane, g); lds_add(o + 2 * plane, b);
+        }
         ++n_splats;
         if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
     }
@@ -263,6 +280,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     const uint32_t K = a.G;
     float *s_steady = (float *)(smem + off); off += align16(K * 32);          // [K][4] f32, or u64 fixed point (FIXED)
     unsigned long long *s_steady64 = (unsigned long long *)s_steady;
+    float *s_steady_ovf = (float *)(smem + off); if (FIXED) off += align16(K * 16);      // (FIXED) [K][4] f32: RANGE GUARD overflow of the steady sums
     uint32_t *s_owner = (uint32_t *)(smem + off); off += align16(K * 4);      // pixel ordinal that may use the slot
     uint32_t *s_done = (uint32_t *)(smem + off); off += align16(K * 4);       // paths of that pixel that have ended
     float *s_hist = (float *)(smem + off);
@@ -273,7 +291,9 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     for (uint32_t k = tid; k < K; k += kBlock) s_done[k] = 0u;
     for (uint32_t k = tid; k < K * 8; k += kBlock) s_steady[k] = 0.0f;
     unsigned long long *s_hist64 = (unsigned long long *)s_hist;
-    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : (FIXED ? 6u : 3u)) * plane; k += kBlock) s_hist[k] = 0.0f;
+    float *s_ovf = s_hist + 6u * plane;                 // (FIXED) the f32 overflow ring behind the fixed-point one: [3][plane]
+    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : (FIXED ? 9u : 3u)) * plane; k += kBlock) s_hist[k] = 0.0f;
+    if (FIXED) for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady_ovf[k] = 0.0f;
 
     LdsStack st; st.base = s_stack + tid; st.sp = 0;
 #ifndef MTR_NO_PARK
@@ -311,9 +331,12 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
         uint32_t f = s_chunk[0];
         const uint32_t end = f + min(s_chunk[1], n_px_all - f);
         while (f < end) {
-            const uint32_t bnd = f / a.band_px;
-            const uint32_t lim = min(end, (bnd + 1u) * a.band_px), cnt = lim - f;
-            const uint32_t in_band = min(a.band_px, n_px_all - bnd * a.band_px);
+            // equal bands of band_px = floor(n / n_bands) pixels, the LAST takes the remainder (no band is ever empty: a word
+            // nobody would publish would park its waiter for ever)
+            const uint32_t bnd = min(f / a.band_px, a.n_bands - 1u);
+            const bool last = bnd == a.n_bands - 1u;
+            const uint32_t lim = last ? end : min(end, (bnd + 1u) * a.band_px), cnt = lim - f;
+            const uint32_t in_band = last ? n_px_all - bnd * a.band_px : a.band_px;
             const uint32_t old = __hip_atomic_fetch_add(a.band_count + bnd, cnt, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (old + cnt == in_band) __hip_atomic_store(a.band_done + bnd, a.band_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             f = lim;
@@ -441,7 +464,8 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 alive = path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 did_splats = sink.n_splats;
             } else if (FIXED) {
-                LdsFixedSink sink; sink.hist = s_hist64; sink.plane = plane; sink.row = slot * T;
+                LdsFixedSink sink; sink.hist = s_hist64; sink.ovf = s_ovf; sink.plane = plane; sink.row = slot * T;
+                sink.lim = a.fixed_lim; sink.dcap = a.fixed_dcap;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
@@ -475,8 +499,14 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 const uint32_t fx = p.px - a.film.crop_x, fy = p.py - a.film.crop_y;
                 if (fx < a.film.width && fy < a.film.height && !carry) {
                     if (FIXED) {
-                        unsigned long long *sp = s_steady64 + 4 * slot;
-                        atomicAdd(sp, splat_to_fixed(p.L.x)); atomicAdd(sp + 1, splat_to_fixed(p.L.y)); atomicAdd(sp + 2, splat_to_fixed(p.L.z));
+                        // (RANGE GUARD: spp_chunk radiances below 2^20 / spp_chunk cannot leave +-2^20; the others are summed in f32)
+                        if (!splat_fixed_unsafe(p.L.x, p.L.y, p.L.z, a.fixed_lim * (float)(2u * a.fixed_dcap))) {
+                            unsigned long long *sp = s_steady64 + 4 * slot;
+                            atomicAdd(sp, splat_to_fixed(p.L.x)); atomicAdd(sp + 1, splat_to_fixed(p.L.y)); atomicAdd(sp + 2, splat_to_fixed(p.L.z));
+                        } else {
+                            float *sp = s_steady_ovf + 4 * slot;
+                            lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z);
+                        }
                     } else {
                         float *sp = s_steady + 4 * slot;
                         lds_add(sp, p.L.x); lds_add(sp + 1, p.L.y); lds_add(sp + 2, p.L.z);
@@ -519,8 +549,10 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                         float r, gc, b;
                         if (FIXED) {
                             unsigned long long *h = s_hist64 + fs * T;
-                            r = splat_from_fixed(h[t]); gc = splat_from_fixed(h[t + plane]); b = splat_from_fixed(h[t + 2 * plane]);
+                            float *o = s_ovf + fs * T;
+                            r = splat_from_fixed(h[t]) + o[t]; gc = splat_from_fixed(h[t + plane]) + o[t + plane]; b = splat_from_fixed(h[t + 2 * plane]) + o[t + 2 * plane];
                             h[t] = 0ull; h[t + plane] = 0ull; h[t + 2 * plane] = 0ull;
+                            o[t] = 0.0f; o[t + plane] = 0.0f; o[t + 2 * plane] = 0.0f;
                         } else {
                             float *h = s_hist + fs * T;
                             r = h[t]; gc = h[t + plane]; b = h[t + 2 * plane];
@@ -532,14 +564,17 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 } else if (FIXED) {
                     float4 *row = (float4 *)(a.film_out + fpix * T * 4u);
                     unsigned long long *h = s_hist64 + fs * T;
+                    float *o = s_ovf + fs * T;
                     for (uint32_t t = wl; t < T; t += 64u) {
                         const unsigned long long qr = h[t], qg = h[t + plane], qb = h[t + 2 * plane];
-                        if ((qr | qg | qb) != 0ull) {
+                        const float er = o[t], eg = o[t + plane], eb = o[t + 2 * plane];       // (RANGE GUARD overflow; NaN != 0)
+                        if ((qr | qg | qb) != 0ull || er != 0.0f || eg != 0.0f || eb != 0.0f) {
                             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                             if (!(a.rc.flags & MTR_FLAG_FILM_ZERO)) v = row[t];
-                            v.x += splat_from_fixed(qr); v.y += splat_from_fixed(qg); v.z += splat_from_fixed(qb);
+                            v.x += splat_from_fixed(qr) + er; v.y += splat_from_fixed(qg) + eg; v.z += splat_from_fixed(qb) + eb;
                             row[t] = v;
                             h[t] = 0ull; h[t + plane] = 0ull; h[t + 2 * plane] = 0ull;
+                            o[t] = 0.0f; o[t + plane] = 0.0f; o[t + 2 * plane] = 0.0f;
                         }
                     }
                 } else if (HIST_LDS) {
@@ -582,7 +617,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 }
                 if (wl < 4) {
                     float v;
-                    if (FIXED) { v = splat_from_fixed(s_steady64[4 * fs + wl]); s_steady64[4 * fs + wl] = 0ull; }
+                    if (FIXED) { v = splat_from_fixed(s_steady64[4 * fs + wl]) + s_steady_ovf[4 * fs + wl]; s_steady64[4 * fs + wl] = 0ull; s_steady_ovf[4 * fs + wl] = 0.0f; }
                     else { v = s_steady[4 * fs + wl]; s_steady[4 * fs + wl] = 0.0f; }
                     if (wl == 3) v = (float)a.spp_chunk;          // every sample of the pixel of this launch has ended
                     if (v != 0.0f) a.steady_out[fpix * 4u + wl] += v;
@@ -669,9 +704,12 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (cfg.scene_lds) fixed_b += scene_b;
     // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
     const bool det = (args.rc.flags & MTR_FLAG_DETERMINISTIC) && !film.n_freq;
-    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * (det ? 24u : 12u);     // (Re, Im) per frequency | 3 planes of T bins (f32 | 64-bit fixed point)
+    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * (det ? 36u : 12u);     // (Re, Im) per frequency | 3 planes of T bins (f32 | 64-bit fixed point + its f32 overflow ring)
     cfg.fixed = false;
-    const uint32_t hist_budget = (det ? 72u : 48u) * 1024u;
+    const uint32_t hist_budget = (det ? 108u : 48u) * 1024u;
+    // RANGE GUARD of the fixed-point rows (LdsFixedSink): depth cap and per-channel limit of what is summed in fixed point
+    args.fixed_dcap = args.rc.max_depth < 64u ? (args.rc.max_depth ? args.rc.max_depth : 1u) : 64u;
+    args.fixed_lim = 1048576.0f / (2.0f * (float)(spp_chunk ? spp_chunk : 1u) * (float)args.fixed_dcap);
     uint32_t g_want = (MTR_FUSED_SEG_LANES + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
     if (g_want < 1) g_want = 1;
     uint32_t g_fit = row_bytes ? hist_budget / row_bytes : 1u;
@@ -688,7 +726,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     args.G = G;
     args.div_G = fastdiv_make(G); args.div_spp = fastdiv_make(spp_chunk);
     cfg.stack = stack;
-    cfg.lds_bytes = fixed_b + align16(G * 32) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
+    cfg.lds_bytes = fixed_b + align16(G * 32) + (cfg.fixed ? align16(G * 16) : 0u) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
     if (cfg.lds_bytes > kLdsMax) return false;
     // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), each with at least g_want pixels
     int per_cu = (int)(kLdsMax / cfg.lds_bytes);
@@ -846,10 +884,12 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
 {
     if (*unsorted) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_redo;                                      // (FIXED) RANGE GUARD: this pixel's row must be rebuilt in f32
     float *row = (float *)smem;                                      // [3][T] f32 ...
     unsigned long long *row64 = (unsigned long long *)smem;          // ... or [3][T] 2^-42 fixed point
     const uint32_t T = film.bins, npix = film.width * film.height;
     const int tid = threadIdx.x;
+    if (tid == 0) s_redo = 0u;
     for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
     __syncthreads();
     uint32_t mine = 0;
@@ -882,6 +922,8 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
         const uint64_t lo = lo_n, hi = hi_n;
         const uint32_t px_next = px + gridDim.x;
         if (px_next < npix) run_of(px_next, lo_n, hi_n);
+        const float lim = splat_fixed_limit(hi - lo);
+        bool unsafe = false;
         for (uint64_t base = lo; base < hi || base == lo; base += (uint64_t)kBatch * kBlock) {
             if (base != lo) fetch(base, hi);
 #pragma unroll
@@ -891,6 +933,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
                 if (bin < 0) continue;
                 if (FIXED) {
                     unsigned long long *p = row64 + bin;
+                    unsafe |= splat_fixed_unsafe(br[k], bg[k], bb[k], lim);
                     atomicAdd(p, splat_to_fixed(br[k])); atomicAdd(p + T, splat_to_fixed(bg[k])); atomicAdd(p + 2 * T, splat_to_fixed(bb[k]));
                 } else {
                     lds_add(row + bin, br[k]); lds_add(row + T + bin, bg[k]); lds_add(row + 2 * T + bin, bb[k]);
@@ -900,11 +943,27 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows(mtr_splat_soa s, Film fil
         }
         if (px_next < npix) fetch(lo_n, hi_n);            // in flight across the flush below
         if (lo == hi) continue;                           // no contributions (uniform across the workgroup)
+        if (FIXED && unsafe) s_redo = 1u;
         __syncthreads();
+        bool as_f32 = !FIXED;
+        if (FIXED && s_redo != 0u) {
+            // RANGE GUARD: a value of this run does not fit the fixed-point row — the row again, in f32 (the next run's first batch
+            // stays in the batch registers: this block has its own loads; `mine` was counted by the first pass)
+            as_f32 = true;
+            for (uint32_t t = tid; t < 6 * T; t += kBlock) row[t] = 0.0f;
+            __syncthreads();
+            if (tid == 0) s_redo = 0u;
+            for (uint64_t i = lo + tid; i < hi; i += kBlock) {
+                const int32_t bin = film_row_bin(film, s.opl[i], s.laser ? s.laser[i] : 0u);
+                if (bin < 0) continue;
+                lds_add(row + bin, s.r[i]); lds_add(row + T + bin, s.g[i]); lds_add(row + 2 * T + bin, s.b[i]);
+            }
+            __syncthreads();
+        }
         float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
         for (uint32_t t = tid; t < T; t += kBlock) {
             float r, g, b; bool nz;
-            if (FIXED) {
+            if (FIXED && !as_f32) {
                 const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
                 nz = (qr | qg | qb) != 0ull;
                 r = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; g = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;

@@ -39,6 +39,13 @@ __device__ __forceinline__ unsigned long long splat_fixed(float v)
     return (unsigned long long)q;
 }
 
+// RANGE GUARD of the fixed-point rows (see mtr_wavefront.hip: to_fixed; mtr_kernels.hip: splat_fixed_limit)
+__device__ __forceinline__ float part_fixed_limit(uint32_t n) { return 1048576.0f / (float)(n ? n : 1u); }
+__device__ __forceinline__ bool part_fixed_unsafe(float r, float g, float b, float lim)
+{
+    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+}
+
 struct PartArgs {
     mtr_splat_soa s;
     Film film;
@@ -342,10 +349,12 @@ template <bool FIXED>
 __global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, float *out, uint32_t film_zero, DevCounters *cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_redo;                            // (FIXED) RANGE GUARD: this pixel's row must be rebuilt in f32
     float *row = (float *)smem;
     unsigned long long *row64 = (unsigned long long *)smem;
     const uint32_t T = a.film.bins;
     const int tid = threadIdx.x;
+    if (tid == 0) s_redo = 0u;
     for (uint32_t t = tid; t < 3 * T; t += kBlock) { if (FIXED) row64[t] = 0ull; else row[t] = 0.0f; }
     __syncthreads();
     uint32_t mine = 0;
@@ -366,6 +375,8 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, flo
         const uint32_t lo = lo_n, hi = hi_n;
         const uint32_t px_next = px + gridDim.x;
         if (px_next < a.npix) { lo_n = a.starts[px_next]; hi_n = a.starts[px_next + 1]; }
+        const float lim = part_fixed_limit(hi - lo);
+        bool unsafe = false;
         for (uint32_t base = lo; base < hi || base == lo; base += kBatch * kBlock) {
             if (base != lo) fetch(base, hi);
 #pragma unroll
@@ -373,6 +384,7 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, flo
                 if (r[k].x == kDropped) continue;
                 if (FIXED) {
                     unsigned long long *p = row64 + r[k].x;
+                    unsafe |= part_fixed_unsafe(__uint_as_float(r[k].y), __uint_as_float(r[k].z), __uint_as_float(r[k].w), lim);
                     atomicAdd(p, splat_fixed(__uint_as_float(r[k].y))); atomicAdd(p + T, splat_fixed(__uint_as_float(r[k].z))); atomicAdd(p + 2 * T, splat_fixed(__uint_as_float(r[k].w)));
                 } else {
                     float *p = row + r[k].x;
@@ -385,11 +397,29 @@ __global__ void __launch_bounds__(kBlock) k_splat_rows_rec(const PartArgs a, flo
         }
         if (px_next < a.npix) fetch(lo_n, hi_n);          // in flight across the flush below
         if (lo == hi) continue;                           // nothing landed in this row (uniform across the workgroup)
+        if (FIXED && unsafe) s_redo = 1u;
         __syncthreads();
+        bool as_f32 = !FIXED;
+        if (FIXED && s_redo != 0u) {
+            // RANGE GUARD: a value of this pixel does not fit the fixed-point row — the row again, in f32, from the records
+            as_f32 = true;
+            for (uint32_t t = tid; t < 6 * T; t += kBlock) row[t] = 0.0f;
+            __syncthreads();
+            if (tid == 0) s_redo = 0u;
+            for (uint32_t i = lo + tid; i < hi; i += kBlock) {
+                const uint4 q = nt_load(a.rec_b + i);
+                if (q.x == kDropped) continue;
+                float *p = row + q.x;
+                __hip_atomic_fetch_add(p, __uint_as_float(q.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + T, __uint_as_float(q.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(q.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+        }
         float4 *dst = (float4 *)(out + (size_t)px * T * 4u);
         for (uint32_t t = tid; t < T; t += kBlock) {
             float vr, vg, vb; bool nz;
-            if (FIXED) {
+            if (FIXED && !as_f32) {
                 const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
                 nz = (qr | qg | qb) != 0ull;
                 vr = __ll2float_rn((long long)qr) * 2.2737367544323206e-13f; vg = __ll2float_rn((long long)qg) * 2.2737367544323206e-13f;

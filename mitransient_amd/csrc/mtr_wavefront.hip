@@ -896,7 +896,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
 // is therefore accumulated in signed 2^-42 fixed point with ds_add_u64 and converted back to
 // f32 once per (pixel, bin) at the flush: 13x faster, order-independent (deterministic) sums, and an
 // absolute rounding error of 2^-43 per contribution — below the f32 rounding of any bin sum > 1e-5.
-// resolution 2.3e-13, range +-2^21 per bin
+// resolution 2.3e-13, range +-2^21 per bin.
+// RANGE GUARD (round 6): the reference's film is plain f32 (transient_image_block.py:79-81: scatter_reduce(Add) — values of
+// any size, Inf and NaN propagate).  A pixel's n records are summed in fixed point only while every channel value is below
+// 2^20 / n in magnitude (then no bin sum can leave +-2^20); a value at or above that — or an Inf / a NaN, which fail the
+// same comparison — marks the PIXEL, whose row is then rebuilt from its record stream with f32 LDS atomics, i.e. by the code
+// of the f32-row instantiation (fixed_row_limit, the `redo` blocks of k_wf_scatter / k_splat_rows / k_splat_rows_rec).
+__device__ __forceinline__ float fixed_row_limit(uint32_t n) { return 1048576.0f / (float)(n ? n : 1u); }
+__device__ __forceinline__ bool fixed_row_unsafe(float r, float g, float b, float lim)
+{
+    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+}
 __device__ __forceinline__ unsigned long long to_fixed(float v)
 {
     long long q = __float2ll_rn(v * 4398046511104.0f);          // 2^42, exact scaling
@@ -917,6 +927,8 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
     const uint32_t T = a.film.bins;
     const int tid = threadIdx.x;
     const bool rows = a.rec_cap > 0;                    // false: T*12 B does not fit LDS, shade used HBM atomics
+    uint32_t *s_redo = (uint32_t *)smem;                // (FIXED) RANGE GUARD: this pixel's row must be rebuilt in f32
+    if (tid == 0) *s_redo = 0u;
     if (rows) {
         if (FIXED) for (uint32_t t = tid; t < 3 * T; t += kBlock) row64[t] = 0ull;
         else for (uint32_t t = tid; t < 3 * T; t += kBlock) row[t] = 0.0f;
@@ -948,6 +960,8 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
         const bool store_only = a.film_zero && n_all <= a.rec_cap;      // no overflow atomics landed on this row
         const uint32_t pl_next = pl + gridDim.x;
         if (pl_next < a.P) n_next_all = a.rec_count[pl_next];
+        const float lim = fixed_row_limit(n);           // (FIXED) see RANGE GUARD above
+        bool unsafe = false;
         for (uint32_t base = 0; base < n || base == 0u; base += kBatch * kBlock) {
             if (base != 0u) fetch(pl, n, base);
 #pragma unroll
@@ -955,6 +969,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
                 if (r[k].x != 0xffffffffu) {
                     if (FIXED) {
                         unsigned long long *p = row64 + r[k].x;
+                        unsafe |= fixed_row_unsafe(__uint_as_float(r[k].y), __uint_as_float(r[k].z), __uint_as_float(r[k].w), lim);
                         atomicAdd(p, to_fixed(__uint_as_float(r[k].y)));
                         atomicAdd(p + T, to_fixed(__uint_as_float(r[k].z)));
                         atomicAdd(p + 2 * T, to_fixed(__uint_as_float(r[k].w)));
@@ -968,13 +983,32 @@ __global__ void __launch_bounds__(kBlock) k_wf_scatter(const WfArgs a)
             }
         }
         if (pl_next < a.P) fetch(pl_next, rows ? min(n_next_all, a.rec_cap) : 0u, 0u);      // in flight across the flush below
+        if (FIXED && unsafe) *s_redo = 1u;
         __syncthreads();
+        bool as_f32 = !FIXED;
+        if (FIXED && rows && *s_redo != 0u) {
+            // RANGE GUARD: a value of this pixel does not fit the fixed-point row — the row again, in f32, from the record stream
+            // (the next pixel's first batch stays in r[]: this block has its own loads)
+            as_f32 = true;
+            for (uint32_t t = tid; t < 6 * T; t += kBlock) row[t] = 0.0f;
+            __syncthreads();
+            if (tid == 0) *s_redo = 0u;
+            const uint4 *rec_ = a.rec + (size_t)pl * a.rec_cap;
+            for (uint32_t i = tid; i < n; i += kBlock) {
+                const uint4 q = nt_load(rec_ + i);
+                float *p = row + q.x;
+                __hip_atomic_fetch_add(p, __uint_as_float(q.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + T, __uint_as_float(q.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p + 2 * T, __uint_as_float(q.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+        }
         if (rows) {
             float4 *dst = (float4 *)(a.film_out + fpix * T * 4u);
             for (uint32_t t = tid; t < T; t += kBlock) {
                 float r_, g, b;
                 bool nz;
-                if (FIXED) {
+                if (FIXED && !as_f32) {
                     const unsigned long long qr = row64[t], qg = row64[T + t], qb = row64[2 * T + t];
                     nz = (qr | qg | qb) != 0ull;
                     r_ = from_fixed(qr); g = from_fixed(qg); b = from_fixed(qb);

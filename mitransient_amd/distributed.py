@@ -301,7 +301,9 @@ class DistributedRenderer:
         fused = integ.resolved_mode(scene, sens, total_spp, my_spp, (0, rows_b * W)) == "fused"
         if not fused:
             lanes = (lanes[0], lanes[0])
-        single = self.single_launch and fused and dev.type == "cuda" and H % nb == 0
+        # (band completion words exist for a render that is ONE pass: accumulate() refuses them for a split one — and by then the
+        # streams of this pipeline are set up on every rank — so a split render keeps the per-band launches)
+        single = self.single_launch and fused and dev.type == "cuda" and H % nb == 0 and len(passes) == 1
         if single:
             lanes = (lanes[0], lanes[0])
         self.last_band_streams = 1 if lanes[0] is lanes[1] else 2

@@ -147,6 +147,25 @@ def test_band_completion_words_on_one_gpu():
         iw.accumulate(wf, sw, passes, 12, bands=(8, 3, words.data_ptr()))
 
 
+@pytest.mark.parametrize("w,h,nb", [(10, 10, 16), (3, 3, 4), (7, 5, 35), (9, 7, 2)])
+def test_band_words_when_the_bands_do_not_divide_the_pixels(w, h, nb):
+    """bands of floor(n / n_bands) pixels, the last takes the remainder (include/mitransient_amd.h): no band is empty, every
+    word is published — 100 pixels in 16 bands and 9 in 4 left trailing bands EMPTY under the former ceil rule, and a stream
+    parked on such a word would never have run"""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=w, height=h, bins=32)
+    integ, sens = scene.integrator(), scene.sensors()[0]
+    s_ref, t_ref = (np.array(x) for x in integ.render(scene, seed=2, spp=9))
+    integ.direct_develop = False
+    words = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    passes = integ.prepare(scene, sens, 2, 9, [])
+    integ.accumulate(scene, sens, passes, 9, bands=(nb, 5, words.data_ptr()))
+    torch.cuda.synchronize()
+    assert words.cpu().tolist() == [5] * nb
+    s, t = (np.array(x) for x in sens.film().develop())
+    assert rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+
+
 def test_two_rank_pipelined_with_rough_materials(tmp_path):
     """the band-pipelined path with a scene that runs the extended-shading kernels (GGX lobes on four shapes)"""
     from conftest import rel_l2
