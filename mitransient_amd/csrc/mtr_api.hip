@@ -239,6 +239,23 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
             }
         if (leaf_pairs) s->dev.traits |= kTrLeafPair;
     }
+    // kTrFlatTop (any materials): the root's children are rectangles and box nodes, the boxes' nodes follow the root in order
+    memset(&s->dev.flat, 0, sizeof s->dev.flat);
+    if (hs.has_wide && !hs.wnodes.empty() && hs.wide_levels <= 2 && !mtr::knob("MTR_NO_FLAT")) {
+        const WNode &root = hs.wnodes[0];
+        bool flat = root.flags == 0u && root.count >= 1u && root.count - root.n_quads <= kFlatMaxBoxes;
+        for (uint32_t k = 0; flat && k < root.count; ++k) {
+            const int32_t ref = root.ref[k];
+            if (k < root.n_quads) flat = ref < 0 && ((~(uint32_t)ref) & kLeafQuadBit) != 0u;
+            else flat = ref == (int32_t)(1u + (k - root.n_quads)) && (size_t)ref < hs.wnodes.size() && hs.wnodes[ref].flags == 3u && hs.wnodes[ref].count == 6u;
+        }
+        if (flat) {
+            FlatTop &ft = s->dev.flat;
+            ft.n_quads = root.n_quads; ft.n_boxes = root.count - root.n_quads; ft.node0 = 1u;
+            for (uint32_t b = 0; b < ft.n_boxes; ++b) memcpy(ft.xf[b], hs.wnodes[1u + b].xf, sizeof ft.xf[b]);
+            s->dev.traits |= kTrFlatTop;
+        }
+    }
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);

@@ -248,6 +248,18 @@ struct alignas(16) WNodeT {
 };
 constexpr uint32_t kWide = MTR_WIDE;
 typedef WNodeT<kWide> WNode;
+// FLAT TOP LEVEL (round 6; scene trait kTrFlatTop): the root's children are analytic rectangles and BOX nodes only — a room
+// with a few cubes in it, the Cornell box of configs 1-3.  Such a scene is not walked at all (flat_walk_device): no stack, no
+// group words, no votes between node and primitive steps.  The boxes' world -> object rows are handed to the kernels in
+// their ARGUMENT, so that the object-space transform and the face selection of a box run on scalar operands (s_load from the
+// kernarg segment) for every lane at once.  The box nodes are wnodes[node0 .. node0 + n_boxes).
+constexpr uint32_t kFlatMaxBoxes = 4;
+struct FlatTop {
+    uint32_t n_boxes, node0, n_quads, pad;
+    float xf[kFlatMaxBoxes][12];          // copies of WNode::xf
+};
+struct FlatHdr { uint32_t n_boxes, node0, n_quads, pad; };
+struct FlatXf { q4 A, B, C; };
 // Scenes walked in HBM: 4-wide nodes with the children's boxes quantised to 8 bits per plane on the node's own grid
 // (origin = the node's lower corner, one power-of-two step per axis) — 64 bytes, the size of a BVH2 packet, for twice the
 // fan-out.  The trace kernel is bound by the number of 16-byte-per-lane loads it issues (divergent addresses: 0.6 - 0.8
@@ -345,6 +357,7 @@ struct SceneView {
     // bitmap textures (HBM; null without textures): all texels as RGBA f32, per texture (first texel, width, height, -),
     // and the corner texture coordinates by slot: (u0, v0, u1, v1) (u2, v2, -, -)
     const q4 *texels; const q4 *tex_info; const q4 *uvs;
+    uint32_t flat_off;        // kTrFlatTop kernels: byte offset of the scene's FlatTop inside the kernel's argument (kernarg_copy)
 };
 
 // [mitsuba3: DiscreteDistribution::sample_reuse_pmf] on a normalised f32 table
@@ -961,15 +974,122 @@ __device__ __forceinline__ void wide_walk_device(Trav &tr, const SceneView &sc, 
 }
 #endif
 
+#if defined(__HIPCC__)
+// A field of the kernel's (single, by-value) argument read from the kernarg segment with scalar loads AT THE POINT OF USE: the
+// empty asm makes the address opaque, so the loads can neither be hoisted out of a persistent loop nor merged with the
+// compiler's own copy of the argument.  (Taking the address of the argument itself sends the whole struct through scratch.)
+template <class T>
+__device__ __forceinline__ T kernarg_copy(size_t offset)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized fields");
+    typedef const uint32_t __attribute__((address_space(4))) *WordPtr;
+    WordPtr w = (WordPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+    asm volatile("" : "+s"(w));
+    T out;
+    uint32_t *o = (uint32_t *)&out;
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) o[k] = w[k];
+    return out;
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The "walk" of a scene with a FLAT TOP LEVEL (FlatTop).  Nothing here decides a hit: rectangles are intersected by
+// trav_quad_test, cube faces by trav_leaf_test, ties go to the original index — the arithmetic of every other walker; what
+// is different is only WHICH primitives a ray is spared, and every rule that spares one is one the tree walk applies too:
+//   boxes      every lane runs box_select for box b in the SAME iteration, on scalar operands; the faces it returns (a
+//              superset of those that can hold the hit, see box_select) of all boxes are then tested in lock step — normally
+//              one face per lane that meets a box at all, i.e. one pass;
+//   rectangles the slab tests of the root node against the rectangles' padded boxes, with the closest hit so far as the far
+//              bound — the root step of the tree walk, taken AFTER the boxes instead of before them — while remembering the
+//              nearest entry distance t1 (child k1) and the second nearest t2; the nearest is intersected first, and when
+//              the hit so far lies in front of t2 every other candidate is culled exactly as a node step taken now would cull it.
+// Shadow rays leave at their first hit; the rectangle tests of a wave whose rays all ended on a box are skipped.
+template <bool ANY_HIT, class Stack>
+__device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, Stack &st)
+{
+    typedef WNode N;
+    const char *root = (const char *)sc.wnodes;
+    const FlatHdr fh = kernarg_copy<FlatHdr>(sc.flat_off);
+    bool live = true;
+    // ---- boxes: face selection per box, uniform over the wave
+    uint32_t fm = 0u;
+    for (uint32_t b = 0; b < fh.n_boxes; ++b) {
+        const FlatXf X = kernarg_copy<FlatXf>(sc.flat_off + sizeof(FlatHdr) + sizeof(FlatXf) * b);
+        const q4 A = X.A, B = X.B, C = X.C;
+        const f3 o = tr.o, d = tr.d;
+        const f3 ol = mk(fmaf(A.z, o.z, fmaf(A.y, o.y, fmaf(A.x, o.x, A.w))), fmaf(B.z, o.z, fmaf(B.y, o.y, fmaf(B.x, o.x, B.w))),
+                         fmaf(C.z, o.z, fmaf(C.y, o.y, fmaf(C.x, o.x, C.w))));
+        const f3 dl = mk(fmaf(A.z, d.z, fmaf(A.y, d.y, A.x * d.x)), fmaf(B.z, d.z, fmaf(B.y, d.y, B.x * d.x)),
+                         fmaf(C.z, d.z, fmaf(C.y, d.y, C.x * d.x)));
+        const f3 id = mk(safe_rcp(dl.x), safe_rcp(dl.y), safe_rcp(dl.z));
+        fm |= box_select(A, B, C, o, ol, dl, id, tr.tmax) << (6u * b);
+    }
+    // ---- the selected faces, in lock step (box = k / 6, face = k % 6; the face's leaf = child `face` of the box node)
+    while (__ballot(live && fm != 0u) != 0ull) {
+        if (live && fm != 0u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(fm);
+            fm &= fm - 1u;
+            const uint32_t box = (k * 43u) >> 8, face = k - 6u * box;
+            tr.cur = *(const int32_t *)(root + (size_t)(fh.node0 + box) * N::kBytes + N::kRefOff + 4u * face);
+            const bool found = trav_leaf_test<true>(tr, sc, st, ANY_HIT);
+            if (ANY_HIT && found) live = false;
+        }
+    }
+    // ---- rectangles
+    if (__ballot(live) != 0ull) {
+        const f3 id = tr.id, noid = tr.noid;
+        const float tb = fminf(tr.tmax, tr.h.t);
+        const uint32_t sel0 = tr.sel[0], sel1 = tr.sel[1], sel2 = tr.sel[2];
+        uint32_t qm = 0u, k1 = 0u;
+        float t1 = kInf, t2 = kInf;
+        for (uint32_t j = 0; 2u * j < fh.n_quads; ++j) {
+            const char *pb = root + 48u * j;
+            const f2 nx = fma2(*(const f2 *)(pb + sel0), id.x, noid.x), fx = fma2(*(const f2 *)(pb + (sel0 ^ 8u)), id.x, noid.x);
+            const f2 ny = fma2(*(const f2 *)(pb + sel1), id.y, noid.y), fy = fma2(*(const f2 *)(pb + (sel1 ^ 8u)), id.y, noid.y);
+            const f2 nz = fma2(*(const f2 *)(pb + sel2), id.z, noid.z), fz = fma2(*(const f2 *)(pb + (sel2 ^ 8u)), id.z, noid.z);
+            const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
+            const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
+            const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
+            const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
+            const bool h0 = tn0 <= tf0, h1 = (tn1 <= tf1) && (2u * j + 1u < fh.n_quads);
+            qm |= (h0 ? 1u : 0u) << (2u * j);
+            qm |= (h1 ? 2u : 0u) << (2u * j);
+            { const bool nearer = h0 && tn0 < t1; t2 = h0 ? (nearer ? t1 : fminf(t2, tn0)) : t2; t1 = nearer ? tn0 : t1; k1 = nearer ? 2u * j : k1; }
+            { const bool nearer = h1 && tn1 < t1; t2 = h1 ? (nearer ? t1 : fminf(t2, tn1)) : t2; t1 = nearer ? tn1 : t1; k1 = nearer ? 2u * j + 1u : k1; }
+        }
+        if (!live) qm = 0u;
+        for (uint32_t it = 0; __ballot(qm != 0u) != 0ull; ++it) {
+            if (qm != 0u) {
+                const uint32_t k = it == 0u ? k1 : (uint32_t)__builtin_ctz(qm);
+                qm &= ~(1u << k);
+                tr.cur = *(const int32_t *)(root + N::kRefOff + 4u * k);
+                const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                if (ANY_HIT ? found : (it == 0u && tr.h.t < t2)) qm = 0u;
+            }
+        }
+    }
+    tr.cur = kTravDone;
+}
+#endif
+
 // run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
 // intersects leaves together)
-template <bool ANY_HIT, bool ONE_PAIR = false, class Stack>
+// FLAT: the scene has a flat top level (kTrFlatTop, FlatTop) — the device does not walk its tree at all (flat_walk_device); a host
+// build walks the tree, whose result is the same by construction
+template <bool ANY_HIT, bool ONE_PAIR = false, bool FLAT = false, class Stack>
 MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
     Trav tr;
     trav_init(tr, sc, o, d, tmax, st);
 #ifdef MTR_PROFILE_SIMT
     uint32_t my_nodes = 0;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FLAT) {
+        if (tr.cur != kTravDone) flat_walk_device<ANY_HIT>(tr, sc, st);
+        return tr.h;
+    }
 #endif
     if (sc.wnodes) {
         // three kinds of steps, each run by the whole wave at once: inner nodes until no lane holds one, then one
@@ -1546,8 +1666,11 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 //     emitter pick and its sample reuse, no mesh tables, no 1 / n_emitters factors.
 //   kTrLeafPair: no triangle leaf of the 8-wide tree holds more than two triangles (the builder's target size; object-space
 //     leaves never do): the leaf test is one packed pass without a loop around it.
-constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u;
+//   kTrFlatTop: the 8-wide tree is a root whose children are analytic rectangles and at most kFlatMaxBoxes box nodes (FlatTop):
+//     the kernels do not walk it (flat_walk_device).
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u;
 constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0
+constexpr uint32_t kTrCornellFlat = kTrCornell | kTrFlatTop;                       // ... and with the flat top level
 
 template <bool ROUGH = true, uint32_t TR = 0u>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)
@@ -1923,7 +2046,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
                         Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh(), bool unwarp_here = false)
 {
     st.prof_mark(2);
-    Hit h = traverse<false, (TR & kTrLeafPair) != 0u>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
+    Hit h = traverse<false, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
     st.prof_mark(0);
     stats.closest++;
     Pending pd; Ray shadow;
@@ -1938,7 +2061,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     bool occluded = false;
     if (pd.has_shadow) {
         stats.shadow++;
-        Hit sh = traverse<true, (TR & kTrLeafPair) != 0u>(sc, shadow.o, shadow.d, shadow.tmax, st);
+        Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sc, shadow.o, shadow.d, shadow.tmax, st);
         occluded = sh.prim >= 0;
     }
     st.prof_mark(0);

@@ -30,6 +30,7 @@ struct SceneDev {
     uint32_t traits;                 // kTr* bits (mtr_core.h) that hold for the material / emitter tables: kernels specialised on them are chosen
     uint32_t has_rough;              // the scene needs the EXTENDED shading code (kernels instantiated with ROUGH = true): a material
                                      // is a GGX lobe (MTR_BSDF_ROUGH*), or a triangle is smooth-shaded (vnormals)
+    FlatTop flat;                    // traits & kTrFlatTop: the top level as scalar kernel arguments (mtr_core.h)
 };
 
 // streaming accesses (data touched once): non-temporal 16-byte load / store

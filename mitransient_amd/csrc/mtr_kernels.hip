@@ -77,23 +77,6 @@ struct LdsStack {
 #endif
 };
 
-// A field of the kernel's (single, by-value) argument read from the kernarg segment with scalar loads AT THE POINT OF USE: the
-// empty asm makes the address opaque, so the loads can neither be hoisted out of the persistent loop nor merged with the
-// compiler's own copy of the argument.  (Taking the address of the argument itself sends the whole struct through scratch.)
-template <class T>
-__device__ __forceinline__ T kernarg_copy(size_t offset)
-{
-    static_assert(sizeof(T) % 4 == 0, "dword-sized fields");
-    typedef const uint32_t __attribute__((address_space(4))) *WordPtr;
-    WordPtr w = (WordPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
-    asm volatile("" : "+s"(w));
-    T out;
-    uint32_t *o = (uint32_t *)&out;
-#pragma unroll
-    for (size_t k = 0; k < sizeof(T) / 4; ++k) o[k] = w[k];
-    return out;
-}
-
 __device__ __forceinline__ void lds_add(float *p, float v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -250,6 +233,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     sv.n_emitters = a.sc.n_ems; sv.n_slots = a.sc.n_slots;
     sv.samp_tris = a.sc.samp_tris; sv.samp_vn = a.sc.samp_vn; sv.face_pmf = a.sc.face_pmf; sv.face_cdf = a.sc.face_cdf; sv.vnormals = a.sc.vnormals;
     sv.texels = a.sc.texels; sv.tex_info = a.sc.tex_info; sv.uvs = a.sc.uvs;
+    sv.flat_off = (uint32_t)(offsetof(FusedArgs, sc) + offsetof(SceneDev, flat));
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (fused_plan); the BVH2 packets stay in HBM, unused
         const uint32_t tree_bytes = a.sc.n_wnodes * (uint32_t)sizeof(WNode);
@@ -757,14 +741,17 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     return true;
 }
 
+#ifndef MTR_C2_TRAITS
+#define MTR_C2_TRAITS kTrCornellFlat       // (-DMTR_ONLY_C2 builds) the instantiation config 2 runs; kTrCornell with MTR_NO_FLAT=1
+#endif
 template <bool NLOS>
 static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, hipStream_t stream)
 {
     void (*k)(const FusedArgs) = nullptr;
 #ifdef MTR_ONLY_C2            // tools/regs_c2.sh, tools/build_variant.sh -DMTR_ONLY_C2: compile ONLY the instantiation config 2 runs (experiments: one
                               // minute per variant instead of four); such a library renders config 2 and refuses everything else
-    if (NLOS || args.film.n_freq || cfg.rough || cfg.fixed || !cfg.scene_lds || !cfg.hist_lds || cfg.traits != kTrCornell || cfg.per_cu <= 3) return hipErrorInvalidValue;
-    k = k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
+    if (NLOS || args.film.n_freq || cfg.rough || cfg.fixed || !cfg.scene_lds || !cfg.hist_lds || cfg.traits != MTR_C2_TRAITS || cfg.per_cu <= 3) return hipErrorInvalidValue;
+    k = k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, MTR_C2_TRAITS>;
 #else
     if (!NLOS && args.film.n_freq) {
         if (!cfg.hist_lds || cfg.rough) return hipErrorInvalidValue;       // (2F floats per row always fit: fused_plan)
@@ -776,7 +763,9 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
                           : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
     }
     else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
-    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornell)          // diffuse materials, one rectangle emitter: the specialised shading code
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat)      // ... and a flat top level: no tree walk either (flat_walk_device)
+        k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornellFlat> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornellFlat>;
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrCornell) == kTrCornell)          // diffuse materials, one rectangle emitter: the specialised shading code
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornell> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
     else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;

@@ -75,6 +75,7 @@ __device__ __forceinline__ void wf_setup(const SceneDev &sc, unsigned char *smem
     sv.n_emitters = sc.n_ems; sv.n_slots = sc.n_slots;
     sv.samp_tris = sc.samp_tris; sv.samp_vn = sc.samp_vn; sv.face_pmf = sc.face_pmf; sv.face_cdf = sc.face_cdf; sv.vnormals = sc.vnormals;
     sv.texels = sc.texels; sv.tex_info = sc.tex_info; sv.uvs = sc.uvs;
+    sv.flat_off = (uint32_t)(offsetof(WfArgs, sc) + offsetof(SceneDev, flat));
     if (SCENE_LDS) {
         // a scene staged in LDS is walked through its 8-wide tree (wf_plan), as in k_fused
         WNode *n = (WNode *)(smem + off); off += al16(sc.n_wnodes * sizeof(WNode));
@@ -1090,7 +1091,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
 {
     const bool ext = a.sc.has_rough != 0u;
     if constexpr (SL) {          // scenes staged in LDS whose tables allow it: the specialised shading code (as k_fused)
-        if (which == 2 && !ext && a.sc.traits == kTrCornell) {
+        if (which == 2 && !ext && (a.sc.traits & kTrCornell) == kTrCornell) {
             void (*ks)(const WfArgs) = a.first_bounce ? k_wf_shade<STACK, true, false, kTrCornell, true> : k_wf_shade<STACK, true, false, kTrCornell>;
             lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);
             hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

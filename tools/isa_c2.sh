@@ -6,13 +6,13 @@ src="$(cd "$(dirname "$0")/../mitransient_amd/csrc" && pwd)/mtr_kernels.hip"
 d=/tmp/isa_$tag; mkdir -p $d; cd $d
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wno-unused-function -DMTR_ONLY_C2 "$@" \
   -Rpass-analysis=kernel-resource-usage --save-temps -c "$src" -o k.o 2> log.txt
-grep -A12 "k_fusedILb1ELb1ELb0ELi4ELb0ELb0ELb0ELj7E" log.txt | grep -E "VGPRs:|Spill|Scratch" | sed 's/.*remark: *//' | tr '\n' ' '; echo
+grep -A12 "k_fusedILb1ELb1ELb0ELi4ELb0ELb0ELb0ELj15E" log.txt | grep -E "VGPRs:|Spill|Scratch" | sed 's/.*remark: *//' | tr '\n' ' '; echo
 python3 - <<'PY'
 import re, collections
 S = open('mtr_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read().split('\n')
 on = False; ins = []; labels = {}
 for l in S:
-    if l.startswith('_ZN3mtr7k_fusedILb1ELb1ELb0ELi4ELb0ELb0ELb0ELj7EEEvNS_9FusedArgsE:'): on = True; continue
+    if l.startswith('_ZN3mtr7k_fusedILb1ELb1ELb0ELi4ELb0ELb0ELb0ELj15EEEvNS_9FusedArgsE:'): on = True; continue
     if not on: continue
     if 's_endpgm' in l: break
     m = re.match(r'^(\.LBB\d+_\d+):', l)
