@@ -252,7 +252,12 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
         if (flat) {
             FlatTop &ft = s->dev.flat;
             ft.n_quads = root.n_quads; ft.n_boxes = root.count - root.n_quads; ft.node0 = 1u;
-            for (uint32_t b = 0; b < ft.n_boxes; ++b) memcpy(ft.xf[b], hs.wnodes[1u + b].xf, sizeof ft.xf[b]);
+            for (uint32_t b = 0; b < ft.n_boxes; ++b) {
+                const float *x = hs.wnodes[1u + b].xf;
+                memcpy(ft.xf[b], x, 12 * sizeof(float));
+                for (int k = 0; k < 3; ++k) ft.xf[b][12 + k] = (fabsf(x[4 * k]) + fabsf(x[4 * k + 1]) + fabsf(x[4 * k + 2])) * 1.000001f;      // S: row sums of |R| (rounded up)
+                ft.xf[b][15] = 0.0f;
+            }
             s->dev.traits |= kTrFlatTop;
         }
     }

@@ -256,10 +256,10 @@ typedef WNodeT<kWide> WNode;
 constexpr uint32_t kFlatMaxBoxes = 4;
 struct FlatTop {
     uint32_t n_boxes, node0, n_quads, pad;
-    float xf[kFlatMaxBoxes][12];          // copies of WNode::xf
+    float xf[kFlatMaxBoxes][16];          // copies of WNode::xf (rows A, B, C), then S = (|A.x|+|A.y|+|A.z|, ... of B, ... of C, 0)
 };
 struct FlatHdr { uint32_t n_boxes, node0, n_quads, pad; };
-struct FlatXf { q4 A, B, C; };
+struct FlatXf { q4 A, B, C, S; };
 // Scenes walked in HBM: 4-wide nodes with the children's boxes quantised to 8 bits per plane on the node's own grid
 // (origin = the node's lower corner, one power-of-two step per axis) — 64 bytes, the size of a BVH2 packet, for twice the
 // fan-out.  The trace kernel is bound by the number of 16-byte-per-lane loads it issues (divergent addresses: 0.6 - 0.8
@@ -652,14 +652,24 @@ MTR_HD void trav_leaf_step(Trav &tr, const SceneView &sc, Stack &st, bool any_hi
 // pe (px) counts only when its distance is neither behind the origin nor beyond tb = min(tmax, closest hit so far) by more
 // than it — a ray leaving a face of the cube does not revisit that face.
 // Returns the mask of faces, bit f = face 2 * axis + (coordinate = +1).
-MTR_HD uint32_t box_select(q4 A, q4 B, q4 C, f3 o, f3 ol, f3 dl, f3 id, float tb)
+// box_mag: the magnitude of the terms of the object-space coordinates of a ray's origin, per axis ...
+MTR_HD f3 box_mag(q4 A, q4 B, q4 C, f3 o)
+{
+    return mk(fmaf(fabsf(A.z), fabsf(o.z), fmaf(fabsf(A.y), fabsf(o.y), fmaf(fabsf(A.x), fabsf(o.x), fabsf(A.w)))),
+              fmaf(fabsf(B.z), fabsf(o.z), fmaf(fabsf(B.y), fabsf(o.y), fmaf(fabsf(B.x), fabsf(o.x), fabsf(B.w)))),
+              fmaf(fabsf(C.z), fabsf(o.z), fmaf(fabsf(C.y), fabsf(o.y), fmaf(fabsf(C.x), fabsf(o.x), fabsf(C.w)))));
+}
+// ... or an upper bound of it from the row sums S of |A|, |B|, |C| and the largest coordinate of the origin (a larger `mag` only
+// widens the tolerances: more faces, never fewer) — three fmas where box_mag takes nine (flat_walk_device)
+MTR_HD f3 box_mag_bound(q4 A, q4 B, q4 C, q4 S, float omax)
+{
+    return mk(fmaf(S.x, omax, fabsf(A.w)), fmaf(S.y, omax, fabsf(B.w)), fmaf(S.z, omax, fabsf(C.w)));
+}
+MTR_HD uint32_t box_select(f3 mag, f3 ol, f3 dl, f3 id, float tb)
 {
     const f3 en = mk(dl.x < 0.0f ? 1.0f : -1.0f, dl.y < 0.0f ? 1.0f : -1.0f, dl.z < 0.0f ? 1.0f : -1.0f);   // entry planes; exit = -en
     const float tn = fmaxf(fmaxf((en.x - ol.x) * id.x, (en.y - ol.y) * id.y), (en.z - ol.z) * id.z);
     const float tf = fminf(fminf((-en.x - ol.x) * id.x, (-en.y - ol.y) * id.y), (-en.z - ol.z) * id.z);
-    const f3 mag = mk(fmaf(fabsf(A.z), fabsf(o.z), fmaf(fabsf(A.y), fabsf(o.y), fmaf(fabsf(A.x), fabsf(o.x), fabsf(A.w)))),
-                      fmaf(fabsf(B.z), fabsf(o.z), fmaf(fabsf(B.y), fabsf(o.y), fmaf(fabsf(B.x), fabsf(o.x), fabsf(B.w)))),
-                      fmaf(fabsf(C.z), fabsf(o.z), fmaf(fabsf(C.y), fabsf(o.y), fmaf(fabsf(C.x), fabsf(o.x), fabsf(C.w)))));
     const float slide = 8e-6f * fmaxf(fmaxf(mag.x * fabsf(id.x), mag.y * fabsf(id.y)), mag.z * fabsf(id.z));
     const f3 eps = mk(fmaf(slide, fabsf(dl.x), fmaf(8e-6f, mag.x, 2e-5f)), fmaf(slide, fabsf(dl.y), fmaf(8e-6f, mag.y, 2e-5f)),
                       fmaf(slide, fabsf(dl.z), fmaf(8e-6f, mag.z, 2e-5f)));
@@ -729,7 +739,7 @@ MTR_HD uint32_t wide_node_test(Trav &tr, const void *nodes, Stack &st)
         id = mk(safe_rcp(dl.x), safe_rcp(dl.y), safe_rcp(dl.z));
         noid = mk(-(ol.x * id.x), -(ol.y * id.y), -(ol.z * id.z));
         sel0 = id.x < 0.0f ? 8u : 0u; sel1 = 16u + (id.y < 0.0f ? 8u : 0u); sel2 = 32u + (id.z < 0.0f ? 8u : 0u);
-        if (flags & 2u) box_m = box_select(A, B, C, o, ol, dl, id, tb);
+        if (flags & 2u) box_m = box_select(box_mag(A, B, C, o), ol, dl, id, tb);
     }
     const bool sx = id.x < 0.0f, sy = id.y < 0.0f, sz = id.z < 0.0f;
     uint32_t m = 0u;
@@ -1014,17 +1024,20 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
     bool live = true;
     // ---- boxes: face selection per box, uniform over the wave
     uint32_t fm = 0u;
+    const float omax = fmaxf(fmaxf(fabsf(tr.o.x), fabsf(tr.o.y)), fabsf(tr.o.z));
     for (uint32_t b = 0; b < fh.n_boxes; ++b) {
+        // (requesting the next box's rows before this one's arithmetic costs 45 scalar moves per iteration: measured, not kept)
         const FlatXf X = kernarg_copy<FlatXf>(sc.flat_off + sizeof(FlatHdr) + sizeof(FlatXf) * b);
-        const q4 A = X.A, B = X.B, C = X.C;
+        const q4 A = X.A, B = X.B, C = X.C, S = X.S;
         const f3 o = tr.o, d = tr.d;
         const f3 ol = mk(fmaf(A.z, o.z, fmaf(A.y, o.y, fmaf(A.x, o.x, A.w))), fmaf(B.z, o.z, fmaf(B.y, o.y, fmaf(B.x, o.x, B.w))),
                          fmaf(C.z, o.z, fmaf(C.y, o.y, fmaf(C.x, o.x, C.w))));
         const f3 dl = mk(fmaf(A.z, d.z, fmaf(A.y, d.y, A.x * d.x)), fmaf(B.z, d.z, fmaf(B.y, d.y, B.x * d.x)),
                          fmaf(C.z, d.z, fmaf(C.y, d.y, C.x * d.x)));
         const f3 id = mk(safe_rcp(dl.x), safe_rcp(dl.y), safe_rcp(dl.z));
-        fm |= box_select(A, B, C, o, ol, dl, id, tr.tmax) << (6u * b);
+        fm |= box_select(box_mag_bound(A, B, C, S, omax), ol, dl, id, tr.tmax) << (6u * b);
     }
+    st.prof_flat(0);
     // ---- the selected faces, in lock step (box = k / 6, face = k % 6; the face's leaf = child `face` of the box node)
     while (__ballot(live && fm != 0u) != 0ull) {
         if (live && fm != 0u) {
@@ -1036,6 +1049,7 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             if (ANY_HIT && found) live = false;
         }
     }
+    st.prof_flat(5);
     // ---- rectangles
     if (__ballot(live) != 0ull) {
         const f3 id = tr.id, noid = tr.noid;
@@ -1043,7 +1057,9 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
         const uint32_t sel0 = tr.sel[0], sel1 = tr.sel[1], sel2 = tr.sel[2];
         uint32_t qm = 0u, k1 = 0u;
         float t1 = kInf, t2 = kInf;
-        for (uint32_t j = 0; 2u * j < fh.n_quads; ++j) {
+        // one pair of children of the root per step; the offsets are compile-time constants (the loop is unrolled: a pair whose
+        // children are absent has inverted boxes and fails by itself), a shadow ray keeps no entry distances
+        auto slab_pair = [&](uint32_t j) {
             const char *pb = root + 48u * j;
             const f2 nx = fma2(*(const f2 *)(pb + sel0), id.x, noid.x), fx = fma2(*(const f2 *)(pb + (sel0 ^ 8u)), id.x, noid.x);
             const f2 ny = fma2(*(const f2 *)(pb + sel1), id.y, noid.y), fy = fma2(*(const f2 *)(pb + (sel1 ^ 8u)), id.y, noid.y);
@@ -1052,16 +1068,21 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
             const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
             const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
-            const bool h0 = tn0 <= tf0, h1 = (tn1 <= tf1) && (2u * j + 1u < fh.n_quads);
+            const bool h0 = (tn0 <= tf0) && (2u * j < fh.n_quads), h1 = (tn1 <= tf1) && (2u * j + 1u < fh.n_quads);
             qm |= (h0 ? 1u : 0u) << (2u * j);
             qm |= (h1 ? 2u : 0u) << (2u * j);
-            { const bool nearer = h0 && tn0 < t1; t2 = h0 ? (nearer ? t1 : fminf(t2, tn0)) : t2; t1 = nearer ? tn0 : t1; k1 = nearer ? 2u * j : k1; }
-            { const bool nearer = h1 && tn1 < t1; t2 = h1 ? (nearer ? t1 : fminf(t2, tn1)) : t2; t1 = nearer ? tn1 : t1; k1 = nearer ? 2u * j + 1u : k1; }
-        }
+            if (!ANY_HIT) {
+                { const bool nearer = h0 && tn0 < t1; t2 = h0 ? (nearer ? t1 : fminf(t2, tn0)) : t2; t1 = nearer ? tn0 : t1; k1 = nearer ? 2u * j : k1; }
+                { const bool nearer = h1 && tn1 < t1; t2 = h1 ? (nearer ? t1 : fminf(t2, tn1)) : t2; t1 = nearer ? tn1 : t1; k1 = nearer ? 2u * j + 1u : k1; }
+            }
+        };
+        slab_pair(0u); slab_pair(1u); slab_pair(2u);
+        if (kWide > 6u && fh.n_quads > 6u) slab_pair(3u);
         if (!live) qm = 0u;
+        st.prof_flat(2);
         for (uint32_t it = 0; __ballot(qm != 0u) != 0ull; ++it) {
             if (qm != 0u) {
-                const uint32_t k = it == 0u ? k1 : (uint32_t)__builtin_ctz(qm);
+                const uint32_t k = (!ANY_HIT && it == 0u) ? k1 : (uint32_t)__builtin_ctz(qm);
                 qm &= ~(1u << k);
                 tr.cur = *(const int32_t *)(root + N::kRefOff + 4u * k);
                 const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
@@ -1069,6 +1090,7 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             }
         }
     }
+    st.prof_flat(4);
     tr.cur = kTravDone;
 }
 #endif

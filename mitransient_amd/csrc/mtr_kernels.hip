@@ -54,9 +54,16 @@ struct LdsStack {
 #endif
 #ifdef MTR_PROFILE_CYCLES      // experiment build: wave-clock per code section (time since the previous mark)
     unsigned long long t0, cyc[6];
+#if MTR_PROFILE_CYCLES == 2     // ... the flat walk's stages in sections 0 (box selection), 5 (box faces), 2 (rectangle slabs), 4 (rectangle tests); everything else but shading in 3
+    __device__ __forceinline__ void prof_mark(int sec) { unsigned long long t = __builtin_readcyclecounter(); cyc[sec == 1 ? 1 : 3] += t - t0; t0 = t; }
+    __device__ __forceinline__ void prof_flat(int sec) { unsigned long long t = __builtin_readcyclecounter(); cyc[sec] += t - t0; t0 = t; }
+#else
     __device__ __forceinline__ void prof_mark(int sec) { unsigned long long t = __builtin_readcyclecounter(); cyc[sec] += t - t0; t0 = t; }
+    __device__ __forceinline__ void prof_flat(int) {}
+#endif
 #else
     __device__ __forceinline__ void prof_mark(int) {}
+    __device__ __forceinline__ void prof_flat(int) {}
 #endif
 #ifdef MTR_PROFILE_SIMT        // experiment build: lane-steps vs wave-steps of node / triangle tests
     unsigned int ls[2], ws[2], wmax, wcalls;

@@ -46,6 +46,7 @@ struct WStack {
     __device__ __forceinline__ int32_t pop() { --sp; return base[sp * kBlock]; }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ void prof_mark(int) {}
+    __device__ __forceinline__ void prof_flat(int) {}
     __device__ __forceinline__ void count(int) {}
     __device__ __forceinline__ void tail(unsigned int) {}
 };
