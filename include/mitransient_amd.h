@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 11
+#define MTR_ABI_VERSION 12
 
 typedef enum mtr_status {
     MTR_OK = 0,
@@ -351,6 +351,13 @@ int  mtr_scene_set_film(mtr_scene *, const mtr_film_desc *);
 int  mtr_scene_set_nlos(mtr_scene *, const mtr_nlos_desc *);
 /* BVH statistics for tests: nodes, max depth, leaf count. */
 int  mtr_scene_bvh_info(const mtr_scene *, uint32_t *n_nodes, uint32_t *max_depth, uint32_t *n_leaves);
+/* Which specialised kernels the scene's tables select (for tests and tools; no counterpart in the reference, whose tracing
+ * JIT specialises on the scene implicitly): MTR_TRAIT_* bits. */
+#define MTR_TRAIT_DIFFUSE          1u   /* every material plain one-sided diffuse */
+#define MTR_TRAIT_ONE_RECT_EMITTER 2u   /* exactly one emitter, an analytic rectangle */
+#define MTR_TRAIT_LEAF_PAIR        4u   /* no leaf of the LDS-staged tree beyond one triangle pair */
+#define MTR_TRAIT_FLAT_TOP         8u   /* top level = rectangles + box nodes: the fused kernel does not walk a tree */
+int  mtr_scene_traits(const mtr_scene *, uint32_t *traits);
 
 /* TransientImageBlock.clear (transient_image_block.py:56-70): zero the
  * (H,W,T,4) f32 accumulator and the (H,W,4) steady accumulator. */

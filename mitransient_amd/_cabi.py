@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
-MTR_ABI_VERSION = 11
+MTR_ABI_VERSION = 12
+MTR_TRAIT_DIFFUSE, MTR_TRAIT_ONE_RECT_EMITTER, MTR_TRAIT_LEAF_PAIR, MTR_TRAIT_FLAT_TOP = 1, 2, 4, 8      # mtr_scene_traits
 MTR_SPLAT_FILM_ZERO = 0x100      # mtr_splat_add: OR into `variant` when the film is all-zero on entry
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3
@@ -148,7 +149,7 @@ class mtr_kernel_times(C.Structure):
 # Every symbol include/mitransient_amd.h declares (checked by tests/test_abi.py).
 EXPORTS = [
     "mtr_abi_version", "mtr_ctx_create", "mtr_ctx_destroy", "mtr_ctx_set_stream", "mtr_last_error",
-    "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_set_nlos", "mtr_scene_bvh_info",
+    "mtr_scene_create", "mtr_scene_destroy", "mtr_scene_set_film", "mtr_scene_set_nlos", "mtr_scene_bvh_info", "mtr_scene_traits",
     "mtr_ctx_trim", "mtr_film_clear", "mtr_render", "mtr_render_plan", "mtr_counters_reset", "mtr_counters_read", "mtr_film_develop", "mtr_splat_add", "mtr_debug_set_splat_log",
 ]
 
@@ -187,6 +188,7 @@ def load_library() -> C.CDLL:
     lib.mtr_scene_set_film.argtypes = [vp, C.POINTER(mtr_film_desc)]
     lib.mtr_scene_set_nlos.argtypes = [vp, C.POINTER(mtr_nlos_desc)]
     lib.mtr_scene_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mtr_scene_traits.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.mtr_counters_read.argtypes = [vp, C.POINTER(mtr_counters)]
     lib.mtr_counters_reset.argtypes = [vp]
     lib.mtr_ctx_trim.argtypes = [vp]

@@ -372,6 +372,15 @@ int mtr_scene_bvh_info(const mtr_scene *s, uint32_t *n_nodes, uint32_t *max_dept
     return MTR_OK;
 }
 
+int mtr_scene_traits(const mtr_scene *s, uint32_t *traits)
+{
+    if (!s || !traits) return MTR_ERR_INVALID;
+    static_assert(MTR_TRAIT_DIFFUSE == kTrDiffuse && MTR_TRAIT_ONE_RECT_EMITTER == kTrOneRectEmitter && MTR_TRAIT_LEAF_PAIR == kTrLeafPair &&
+                  MTR_TRAIT_FLAT_TOP == kTrFlatTop, "public trait bits");
+    *traits = s->dev.traits;
+    return MTR_OK;
+}
+
 } // extern "C"
 
 // ---- MTR_MODE_WAVEFRONT: host loop over tiles and bounces ------------------------------------
@@ -387,10 +396,10 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.q_ray, (size_t)2 * n_slots * 32));                       // rays of the live lists, in list order
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
-    HIP_TRY(c, hipMalloc(&w.q_shadow, (size_t)n_slots * 4));
+    w.q_shadow = nullptr;                                                           // (unused since round 6: occlusion results go to the shadow rays' list positions)
     HIP_TRY(c, hipMalloc(&w.q_zombie, (size_t)2 * n_slots * 4));                    // paths that ended with an emitter-sampling term parked, per parity
     HIP_TRY(c, hipMalloc(&w.r_shadow, (size_t)n_slots * 32));
-    HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots));
+    HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots + (size_t)n_seg * 16u + 16u));       // [n_seg][seg rounded up to 16] occlusion flags in shadow-list order
     HIP_TRY(c, hipMalloc(&w.counts, ((size_t)n_seg * (7 + kWfKeys) + 16) * 4));     // seg_live[2][n_seg], seg_mat[n_seg][5], seg_shadow[n_seg], live_total + seg_list_n[2] (16 words), seg_list[2][n_seg], seg_zombie[2][n_seg]
     HIP_TRY(c, hipMalloc(&w.rec, std::max<size_t>(16, (size_t)P * rec_cap * 16)));
     HIP_TRY(c, hipMalloc(&w.rec_count, (size_t)P * 4));
@@ -502,6 +511,7 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             a.n_slots = Pcur * Scur;
             a.film_zero = ((p->flags & MTR_FLAG_FILM_ZERO) && s0 == 0 && rec_cap > 0) ? 1u : 0u;
             a.seg = G * Scur;                                       // segments always cover whole pixels
+            a.occ_stride = (a.seg + 15u) & ~15u;
             a.n_seg = (Pcur + G - 1) / G;
             a.seg_live = (uint32_t *)w.counts;
             a.seg_mat = (uint32_t *)w.counts + (size_t)2 * a.n_seg;

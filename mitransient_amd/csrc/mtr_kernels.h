@@ -107,12 +107,13 @@ struct WfArgs {
     uint32_t *seg_list;                  // [2][n_seg]   the segments that HOLD live paths, per parity (the kernels of a bounce walk this list:
     uint32_t *seg_list_n;                // [2]          its length        a deep bounce of max_depth 65 touches a handful of 32768 segments)
     uint32_t *q_mat;                     // [kWfKeys][n_slots] material-sorted hit lists, same segmentation
-    uint32_t *q_shadow;                  // [n_slots] slots whose vertex emits a shadow ray this bounce, same segmentation
+    uint32_t *q_shadow;                  // (unused since round 6: the occlusion results go to the rays' list positions, no slot needed)
     float4 *r_shadow;                    // [n_slots][2] those shadow rays, in list order: (o, tmax) (d, -)
     uint32_t *seg_shadow;                // [n_seg] their counts
     uint32_t *q_zombie;                  // [2][n_slots] scenes in HBM: paths that ended with an emitter-sampling term parked (Q_PEND), per parity
     uint32_t *seg_zombie;                // [2][n_seg] their counts
-    uint8_t *occ;                        // [n_slots] shadow-ray result per slot: 1 = occluded
+    uint8_t *occ;                        // [n_seg][occ_stride] shadow-ray results in the order of the segment's shadow list: 1 = occluded
+    uint32_t occ_stride;                 // seg rounded up to 16 (the flags of a segment leave LDS as 16-byte stores)
     uint32_t trace_any;                  // k_wf_trace: 0 closest hits of the live lists, 1 occlusion of the shadow lists
     uint32_t first_bounce;               // k_wf_shade: this launch shades bounce 0 — the path state is rebuilt from (pixel, sample), not loaded
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths

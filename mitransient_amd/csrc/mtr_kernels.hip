@@ -115,7 +115,7 @@ __device__ __forceinline__ float splat_from_fixed(unsigned long long q) { return
 __device__ __forceinline__ float splat_fixed_limit(uint64_t n) { return 1048576.0f / (float)(n ? n : 1ull); }
 __device__ __forceinline__ bool splat_fixed_unsafe(float r, float g, float b, float lim)
 {
-    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+    return !(fabsf(r) < lim) || !(fabsf(g) < lim) || !(fabsf(b) < lim);
 }
 
 #ifndef MTR_FUSED_SEG_LANES

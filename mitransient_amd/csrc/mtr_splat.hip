@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long splat_fixed(float v)
 __device__ __forceinline__ float part_fixed_limit(uint32_t n) { return 1048576.0f / (float)(n ? n : 1u); }
 __device__ __forceinline__ bool part_fixed_unsafe(float r, float g, float b, float lim)
 {
-    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+    return !(fabsf(r) < lim) || !(fabsf(g) < lim) || !(fabsf(b) < lim);
 }
 
 struct PartArgs {

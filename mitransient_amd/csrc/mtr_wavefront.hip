@@ -461,12 +461,12 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
         if (tid < (int)kWfKeys) s_cnt[tid] = 0u;
         if (tid == 0) *s_fetch = 0u;
         __syncthreads();
-        const uint32_t *q = any_hit ? a.q_shadow + (size_t)sg * a.seg : a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;
+        const uint32_t *q = a.q_live + (size_t)par * a.n_slots + (size_t)sg * a.seg;      // (closest hits: the slots of the material lists)
 
         Trav tr;
         tr.cur = kTravDone; tr.h.t = kInf; tr.h.u = 0.0f; tr.h.v = 0.0f; tr.h.prim = -1; tr.best_orig = 0xffffffffu;
         tr.o = mk(0, 0, 0); tr.d = mk(0, 0, 1); tr.id = mk(0, 0, 0); tr.noid = mk(0, 0, 0); tr.tmax = 0.0f;
-        uint32_t slot = 0, pos = 0;
+        uint32_t pos = 0;
         bool pending = false;                                   // a finished ray whose result is not written yet
         const float4 *qr = any_hit ? a.r_shadow + 2 * (size_t)sg * a.seg
                                    : a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);   // rays in list order
@@ -477,9 +477,16 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
             const uint32_t n_idle = (uint32_t)__popcll(m_idle);
             if (n_idle >= MTR_WF_REFILL_MIN) {
                 if (idle && pending) {
-                    if (any_hit) a.occ[slot] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
+                    // RESULTS IN LIST ORDER (round 6).  Hit records and occlusion flags used to be stored by SLOT: 16 bytes / one byte
+                    // scattered over the segment's 8192 slots, i.e. partial cache lines that left L2 one by one (config 5: 177 GB written
+                    // for 61 GB of hit records, 90 GB for 3 GB of flags).  They are produced in ray-list order and k_wf_shade holds a
+                    // vertex's list position next to its slot (q_mat), so they now live at the list position: the records of the
+                    // rays a workgroup has in flight fill whole lines while these are still in L2; the flags are gathered in LDS
+                    // and leave in one coalesced pass per segment.
+                    if (any_hit) s_key[pos] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
                     else {
-                        P.st(hit_plane(par), slot, make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim)));
+                        // (an ordinary store, not the streaming one of the planes: the line is completed by the neighbouring rays)
+                        P.base[(size_t)hit_plane(par) * P.n + sg * a.seg + pos] = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
                         // hit: the list key rides in the low bits of the tie-break word of the best hit (TriPair, mtr_core.h)
                         const uint32_t key = tr.h.prim >= 0 ? (tr.best_orig & 7u) : 4u;
                         s_key[pos] = (uint8_t)key;
@@ -494,16 +501,16 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
                 if (idle && idx < n_live) {
                     pos = idx;
                     if (FIRST) {
-                        slot = sg * a.seg + idx;
                         uint32_t pixel, s, pl;
-                        slot_to_lane(a, slot, pixel, s, pl);
+                        slot_to_lane(a, sg * a.seg + idx, pixel, s, pl);
                         Path p;
                         path_begin(p, a.cam, a.film, a.rc, pixel, s);
                         trav_init(tr, sv, p.ray.o, p.ray.d, p.ray.tmax, st);
                     } else {
-                        slot = q[idx];
                         const float4 r0 = qr[2 * (size_t)idx], r1 = qr[2 * (size_t)idx + 1];
-                        trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, st);
+                        // (a bounce ray's tmax is infinite — shade_finish — and the word of the list that would hold it carries the list
+                        // position of the path's PREVIOUS vertex instead: k_wf_shade, `prev_pos`)
+                        trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any_hit ? r0.w : kInf, st);
                     }
                     pending = true;
                 }
@@ -537,12 +544,16 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
             }
         }
         __syncthreads();
+        if (any_hit) {       // the occlusion flags of the segment's shadow list, in list order: 16 bytes per lane
+            uint4 *dst = (uint4 *)(a.occ + (size_t)sg * a.occ_stride);
+            for (uint32_t i = tid; 16u * i < n_live; i += kBlock) dst[i] = ((const uint4 *)s_key)[i];
+        }
         // material lists in list order
         const uint32_t n_round = any_hit ? 0u : (n_live + 63u) & ~63u;     // whole waves stay in the loop (ballots)
         for (uint32_t i = tid; i < n_round; i += kBlock) {
             const bool on = i < n_live;
             const uint32_t key = on ? (uint32_t)s_key[i] : kWfKeys;
-            const uint32_t sl = on ? (FIRST ? sg * a.seg + i : q[i]) : 0u;
+            const uint32_t sl = on ? (FIRST ? sg * a.seg + i : sg * a.seg + (q[i] & 0xffffu)) : 0u;      // (a live-list entry: shadow-list position << 16 | slot within the segment)
 #pragma unroll
             for (uint32_t k = 0; k < kWfKeys; ++k) {
                 const bool mine = on & (key == k);
@@ -628,7 +639,6 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
         float4 *r_next = a.q_ray + 2 * ((size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg);
         const float4 *r_cur = a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);      // the rays k_wf_trace has just walked, in list order
         uint32_t *qz_next = DEFER ? a.q_zombie + (size_t)(par ^ 1u) * a.n_slots + (size_t)sg * a.seg : nullptr;
-        uint32_t *q_sh = a.q_shadow + (size_t)sg * a.seg;
         float4 *r_sh = a.r_shadow + 2 * (size_t)sg * a.seg;
         auto make_sink = [&](uint32_t pl, uint32_t lane) {
             RecordSink sink;
@@ -646,10 +656,10 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                 uint32_t pl = pl0;
                 f3 L = mk(0, 0, 0);
                 if (on) {
-                    const uint32_t slot = qz[i];
+                    const uint32_t zq = qz[i], slot = sg * a.seg + (zq & 0xffffu);       // (shadow-list position << 16 | slot within the segment)
                     uint32_t pixel, s;
                     slot_to_lane(a, slot, pixel, s, pl);
-                    if (a.occ[slot] == 0) {
+                    if (a.occ[(size_t)sg * a.occ_stride + (zq >> 16)] == 0) {
                         const float4 pe = P.ld(Q_PEND, slot);
                         const uint32_t py = pixel / a.film.crop_w, px = pixel - a.film.crop_w * py;
                         RecordSink sink = make_sink(pl, pixel * a.rc.spp_total + s);
@@ -672,8 +682,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                 const uint32_t e = e_next;
                 if (i + kBlock < n_k) e_next = q[i + kBlock];
                 bool alive = false, zombie = false;
-                uint32_t slot = 0, dep_px = 0;
-                f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1), dep_L = mk(0, 0, 0); float ray_tmax = 0.0f, ray_eta = 1.0f, dep_w = 0.0f;
+                uint32_t slot = 0, dep_px = 0, sh_pos = 0;
+                f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1), dep_L = mk(0, 0, 0); float ray_eta = 1.0f, dep_w = 0.0f;
                 if (on) {
                     // e: (position in the live list the trace kernel walked, slot within the segment)
                     slot = sg * a.seg + (e & 0xffffu);
@@ -689,16 +699,21 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                         p.rng.inc = rng_inc_of(a.rc.seed, p.lane, a.rc.flags);
                     }
                     Hit h;
-                    { const float4 hq = P.ld(hit_plane(par), slot); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
+                    const uint32_t lpos = e >> 16;                   // this vertex's position in the list the trace kernel walked = where its hit record lives
+                    { const float4 hq = P.ld(hit_plane(par), sg * a.seg + lpos); h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w); }
                     if (!FIRST && h.prim >= 0 && (fbits(sv.tshade[h.prim].h[4].z) >> 16) != 0u) {
-                        // an emitter was hit: its MIS weight wants the vertex the path came from = the previous bounce's hit (a live path's is valid)
-                        const float4 hq = P.ld(hit_plane(par ^ 1u), slot);
+                        // an emitter was hit: its MIS weight wants the vertex the path came from = the previous bounce's hit (a live path's is
+                        // valid), which lives at the path's position in the PREVIOUS list — the word of the ray list a tmax would take
+                        const uint32_t prev_pos = __float_as_uint(r_cur[2 * (size_t)lpos].w);
+                        const float4 hq = P.ld(hit_plane(par ^ 1u), sg * a.seg + prev_pos);
                         Hit hp; hp.t = hq.x; hp.u = hq.y; hp.v = hq.z; hp.prim = (int32_t)__float_as_uint(hq.w);
                         p.prev_p = hit_point(sv, hp);
                     }
                     ++n_closest;
                     RecordSink sink = make_sink(pl, p.lane);
-                    if (DEFER && pend && a.occ[slot] == 0) {          // the previous bounce's emitter sample was visible: commit it now
+                    // (the flag of the shadow ray this path emitted at its previous vertex: at that ray's position in the shadow list, which
+                    // the path's live-list entry carries in its high half)
+                    if (DEFER && pend && a.occ[(size_t)sg * a.occ_stride + (a.q_live[(size_t)par * a.n_slots + (size_t)sg * a.seg + lpos] >> 16)] == 0) {          // the previous bounce's emitter sample was visible: commit it now
                         const float4 pe = P.ld(Q_PEND, slot);
                         commit_pending(p.L, mk(pe.x, pe.y, pe.z), pe.w, p.depth - 1u, p.px, p.py, a.film, a.rc, sink);
                     }
@@ -721,7 +736,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                             // the ray goes to the segment's shadow list (k_wf_trace, any-hit, runs next), the term is parked and
                             // withheld from shade_finish: `occluded` only gates the commit there
                             const uint32_t pos = wave_append(s_shadow_p, true);
-                            q_sh[pos] = slot;
+                            sh_pos = pos;          // (the occlusion kernel needs no slot: its result goes to the ray's list position)
                             r_sh[2 * (size_t)pos] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.tmax);
                             r_sh[2 * (size_t)pos + 1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
                             P.st(Q_PEND, slot, make_float4(pd.Lr.x, pd.Lr.y, pd.Lr.z, pd.opl));
@@ -731,7 +746,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     alive = shade_finish<EXT, TR>(p, h, occluded, pd, sv, a.film, a.rc, sink, kKeepCtx ? &hc : nullptr);
                     ++n_bounce;
                     n_splats += sink.n_splats; n_over += sink.n_overflow;
-                    ray_o = p.ray.o; ray_d = p.ray.d; ray_tmax = p.ray.tmax; ray_eta = p.eta;
+                    ray_o = p.ray.o; ray_d = p.ray.d; ray_eta = p.eta;
                     const uint32_t pend_now = (DEFER && pd.has_shadow) ? 1u : 0u;
                     // p.L is what THIS vertex added (the term committed above, emission, the emitter sample): it goes to the pixel's sum now
                     dep_px = pl - pl0; dep_L = p.L;
@@ -747,14 +762,15 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                 if (__ballot(alive) != 0ull) {
                     const uint32_t pos = wave_append(s_next_p, alive);
                     if (alive) {
-                        q_next[pos] = slot;
-                        r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, ray_tmax);
+                        q_next[pos] = (sh_pos << 16) | (slot - sg * a.seg);
+                        // (.w: not the ray's tmax, which is infinite, but where this vertex's hit record lives — the next vertex's prev_pos)
+                        r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, __uint_as_float(e >> 16));
                         r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, ray_eta);
                     }
                 }
                 if (DEFER && __ballot(zombie) != 0ull) {
                     const uint32_t pos = wave_append(s_zombie_p, zombie);
-                    if (zombie) qz_next[pos] = slot;
+                    if (zombie) qz_next[pos] = (sh_pos << 16) | (slot - sg * a.seg);
                 }
             }
         }
@@ -907,7 +923,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_wf_nlos_bounce(const WfArgs a)
 __device__ __forceinline__ float fixed_row_limit(uint32_t n) { return 1048576.0f / (float)(n ? n : 1u); }
 __device__ __forceinline__ bool fixed_row_unsafe(float r, float g, float b, float lim)
 {
-    return !(fabsf(r) < lim) | !(fabsf(g) < lim) | !(fabsf(b) < lim);
+    return !(fabsf(r) < lim) || !(fabsf(g) < lim) || !(fabsf(b) < lim);
 }
 __device__ __forceinline__ unsigned long long to_fixed(float v)
 {

@@ -234,6 +234,14 @@ class Scene:
                 self._nlos_fp[key] = fp
         return h
 
+    def gpu_traits(self, sensor=0):
+        """MTR_TRAIT_* bits of the scene on the current device (which specialised kernels its tables select)"""
+        from .runtime import get_context
+        ctx = get_context()
+        t = C.c_uint32(0)
+        ctx.check(ctx.lib.mtr_scene_traits(self.gpu_handle(ctx, sensor), C.byref(t)), "mtr_scene_traits")
+        return int(t.value)
+
     def __del__(self):
         try:
             lib = _cabi.load_library()

@@ -956,3 +956,36 @@ def test_specialised_kernels_return_the_bits_of_the_general_ones(oracle):
         scene = mi.load_dict(d)
         outs.append(gpu_render(scene, 16)[1])
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_flat_top_level_returns_the_bits_of_the_tree_walk(oracle):
+    """scene trait kTrFlatTop (mtr_core.h flat_walk_device): the Cornell box — rectangles and box nodes under one root — is not
+    walked at all; the same box with one more shape, a small triangle BEHIND the closed back wall that no ray can reach, has a
+    triangle leaf at its top level and is walked through its tree.  Neither the primitive tests nor the tie rule differ, only what is
+    culled: with order-independent film rows (amd_deterministic) the two films are equal bit for bit, and so are the counters."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd import _cabi
+    mi.set_variant("llvm_ad_rgb")
+    outs, cnts, flat = [], [], []
+    for extra in (False, True):
+        d = mitr.cornell_box()
+        d["sensor"]["film"].update(width=40, height=40, temporal_bins=128, start_opl=3.5, bin_width_opl=6.0 / 128)
+        d["integrator"].update(amd_mode="fused", amd_deterministic=True)
+        if extra:
+            tri = os.path.join(ROOT, "tests", "_build", "far_triangle.obj")
+            os.makedirs(os.path.dirname(tri), exist_ok=True)
+            with open(tri, "w") as fh:
+                fh.write("v -0.1 -0.1 -30\nv 0.1 -0.1 -30\nv 0 0.1 -30\nf 1 2 3\n")
+            d["far-triangle"] = {"type": "obj", "filename": tri, "face_normals": True, "bsdf": {"type": "ref", "id": "white"}}
+        scene = mi.load_dict(d)
+        s, t = gpu_render(scene, 64, seed=7)
+        outs.append((s, t)); cnts.append(dict(scene.integrator().last_counters))
+        flat.append(bool(scene.gpu_traits() & _cabi.MTR_TRAIT_FLAT_TOP))
+    assert flat == [True, False]
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert cnts[0][k] == cnts[1][k], k
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 64, seed=7)
+    assert rel_l2(outs[0][1], t_ref) <= TOL and cnts[0]["rays_shadow"] == cnt["rays_shadow"]
