@@ -58,6 +58,7 @@ struct mtr_scene {
     NlosDev nlos;
     std::vector<float> tri_verts;            // host copy (NLOS tables are re-derived when the laser moves)
     std::vector<float> tri_normals;          // ... and the vertex normals (empty without): Mesh::sample_position on hidden meshes
+    float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };   // bounds of the triangles (the grid of the wavefront organisation's trace order)
     uint32_t n_emitters_area = 0;
     SceneDev dev{};
     Camera cam{};
@@ -264,6 +265,9 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
     s->dev.wide_levels = hs.wide_levels; s->dev.wide4_levels = hs.wide4_levels; s->dev.wide8q_levels = hs.wide8q_levels;
     s->tri_verts.assign(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
+    for (int k = 0; k < 3; ++k) { s->bb_lo[k] = d->n_tris ? INFINITY : 0.0f; s->bb_hi[k] = d->n_tris ? -INFINITY : 0.0f; }
+    for (size_t i = 0; i < 3 * (size_t)d->n_tris; ++i)
+        for (int k = 0; k < 3; ++k) { const float v = d->tri_verts[3 * i + k]; s->bb_lo[k] = std::min(s->bb_lo[k], v); s->bb_hi[k] = std::max(s->bb_hi[k], v); }
     if (d->tri_normals) s->tri_normals.assign(d->tri_normals, d->tri_normals + 9 * (size_t)d->n_tris);
     s->n_emitters_area = d->n_emitters;
     if (d->nlos) {
@@ -396,7 +400,7 @@ static int wf_alloc(mtr_scene *s, uint32_t n_slots, uint32_t P, uint32_t n_seg, 
     HIP_TRY(c, hipMalloc(&w.q_live, (size_t)2 * n_slots * 4));
     HIP_TRY(c, hipMalloc(&w.q_ray, (size_t)2 * n_slots * 32));                       // rays of the live lists, in list order
     HIP_TRY(c, hipMalloc(&w.q_mat, (size_t)kWfKeys * n_slots * 4));
-    w.q_shadow = nullptr;                                                           // (unused since round 6: occlusion results go to the shadow rays' list positions)
+    HIP_TRY(c, hipMalloc(&w.q_shadow, (size_t)2 * n_slots * 2 + 64));                // TRACE ORDER: q_order | q_order_sh, 16 bits per list position (the former shadow-slot list's buffer)
     HIP_TRY(c, hipMalloc(&w.q_zombie, (size_t)2 * n_slots * 4));                    // paths that ended with an emitter-sampling term parked, per parity
     HIP_TRY(c, hipMalloc(&w.r_shadow, (size_t)n_slots * 32));
     HIP_TRY(c, hipMalloc(&w.occ, (size_t)n_slots + (size_t)n_seg * 16u + 16u));       // [n_seg][seg rounded up to 16] occlusion flags in shadow-list order
@@ -470,7 +474,23 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
     WfArgs a{};
     a.sc = s->dev; a.cam = s->cam; a.film = f; a.rc = rc;
     a.planes = (float *)w.planes; a.q_live = (uint32_t *)w.q_live; a.q_ray = (float4 *)w.q_ray; a.q_mat = (uint32_t *)w.q_mat;
-    a.q_shadow = (uint32_t *)w.q_shadow; a.r_shadow = (float4 *)w.r_shadow; a.occ = (uint8_t *)w.occ;
+    a.q_shadow = nullptr; a.r_shadow = (float4 *)w.r_shadow; a.occ = (uint8_t *)w.occ;
+    // TRACE ORDER (mtr_kernels.h; an EXPERIMENT, off: MTR_WF_SORT=1 / MTR_WF_SORT_SH=1 in the experiments build): rays of the path
+    // tier traced sorted by (origin cell, direction octant); the grid's 5 bits go to the axes along which the scene is longest.
+    // Measured (round 6, config 5 at 256 spp): k_wf_trace 108.2 -> 110.3 ms, render 155.6 -> 160.1 ms; config 2 wavefront 81.4 -> 88.9 ms.
+    a.q_order = nullptr; a.q_order_sh = nullptr;
+    if (!s->nlos.on && mtr::knob("MTR_WF_SORT") && s->tri_verts.size() >= 9) {
+        a.q_order = (uint16_t *)w.q_shadow;
+        if (mtr::knob("MTR_WF_SORT_SH")) a.q_order_sh = (uint16_t *)w.q_shadow + w.n_slots;
+        float ext[3]; uint32_t bits[3] = { 0u, 0u, 0u };
+        for (int k = 0; k < 3; ++k) ext[k] = std::max(s->bb_hi[k] - s->bb_lo[k], 1e-20f);
+        for (int b = 0; b < 5; ++b) {
+            int m = 0;
+            for (int k = 1; k < 3; ++k) if (ext[k] / (float)(1u << bits[k]) > ext[m] / (float)(1u << bits[m])) m = k;
+            bits[m]++;
+        }
+        for (int k = 0; k < 3; ++k) { a.sort_lo[k] = s->bb_lo[k]; a.sort_scale[k] = (float)(1u << bits[k]) / ext[k]; a.sort_bits[k] = bits[k]; }
+    }
     a.q_zombie = (uint32_t *)w.q_zombie;
     a.rec = (uint4 *)w.rec; a.rec_count = (uint32_t *)w.rec_count; a.rec_cap = rec_cap;
     a.film_out = t4; a.steady_out = s4; a.counters = c->d_counters; a.log = s->log;

@@ -7,6 +7,9 @@
 // splits are chosen in the shape's OBJECT space (where the faces of a rotated cube are flat: coplanar triangles end up in
 // the same leaf) and which the 8-wide collapse turns into one object node with object-space boxes (mtr_core.h, WNodeT).
 #include "mtr_bvh.h"
+#include <thread>
+#include <chrono>
+#include <atomic>
 #include "mtr_knobs.h"
 
 #include <algorithm>
@@ -120,7 +123,10 @@ struct Builder {
     // cut by a PLANE; a triangle reference that straddles it is duplicated, each copy with the box of its part.  World-space builder over
     // large scenes only (build_bvh); `dup_budget` bounds the duplicates of the whole build.
     bool spatial = false;
-    size_t *dup_budget = nullptr;     // duplicates the whole build may still make (one budget, drawn on in build order)
+    long long *dup_budget = nullptr;  // duplicates this builder may still make (the root builder draws on the build's budget in build order;
+                                      // what is left when the subtrees are deferred is shared out among them by their reference counts —
+                                      // build_parallel_finish — so that the tree does not depend on the workers' timing; the staircase
+                                      // uses 0.56 n of its n)
     float root_area = 0.0f;
     static constexpr int kMaxSpatialBins = 64;
     int kSpatialBins = 16;
@@ -211,8 +217,103 @@ struct Builder {
         return true;
     }
 
+    // PARALLEL BUILD (round 6).  The root builder splits nodes until a subtree holds at most `defer_grain` references; such a subtree is
+    // DEFERRED — a placeholder node now, built later by a worker thread in a builder of its own (copies of its references, its own
+    // node and leaf arrays) and stitched in behind the placeholder.  Every split is a function of the node's references alone, so the
+    // tree is the one the sequential build makes, node for node (tests/test_scene_host.py), as long as the duplicate budget lasts.
+    struct Deferred { int tmp; std::vector<uint32_t> refs; uint32_t depth; };
+    std::vector<Deferred> deferred;
+    std::vector<int> top_inner;       // inner nodes made by the root builder, children first: their boxes are set once the placeholders are real
+    size_t defer_grain = 0;
+    unsigned n_threads = 1;
+
+    void build_parallel_finish()
+    {
+        std::vector<Shared> LS(deferred.size());
+        std::vector<int> roots(deferred.size(), -1);
+        // every subtree's share of the duplicates that are left
+        std::vector<long long> share(deferred.size(), 0);
+        if (dup_budget) {
+            size_t total = 0;
+            for (const Deferred &D : deferred) total += D.refs.size();
+            // (four times the even share: where the long thin triangles are, a subtree needs more duplicates than it has references — with
+            // even shares the staircase made 91 k duplicates instead of the 146 k of one budget drawn on in build order; the bound on
+            // memory becomes 4 n in the worst case, 0.56 n in this scene)
+            for (size_t i = 0; i < deferred.size(); ++i) share[i] = total ? (long long)(4.0 * (double)*dup_budget * (double)deferred[i].refs.size() / (double)total) : 0;
+        }
+        // largest subtrees first (they finish last otherwise)
+        std::vector<size_t> by_size(deferred.size());
+        for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return deferred[a].refs.size() > deferred[b].refs.size(); });
+        std::atomic<size_t> next{ 0 };
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= by_size.size()) break;
+                const size_t i = by_size[k];
+                const Deferred &D = deferred[i];
+                LS[i].verts = S.verts;
+                Builder LB(LS[i]);
+                LB.prims = prims; LB.kBins = kBins; LB.kLeafTarget = kLeafTarget; LB.kLeafMax = kLeafMax; LB.spatial = spatial;
+                LB.dup_budget = dup_budget ? &share[i] : nullptr; LB.root_area = root_area; LB.kSpatialBins = kSpatialBins; LB.kAlpha = kAlpha; LB.kUnsplit = kUnsplit;
+                LB.kPairCost = kPairCost;
+                const size_t m = D.refs.size();
+                LB.items.reserve(2 * m); LB.sbox.reserve(2 * m); LB.wbox.reserve(2 * m); LB.cent.reserve(6 * m); LB.order.reserve(2 * m);
+                for (uint32_t r : D.refs) {
+                    LB.items.push_back(items[r]); LB.sbox.push_back(sbox[r]); LB.wbox.push_back(wbox[r]);
+                    for (int c = 0; c < 3; ++c) LB.cent.push_back(cent[3 * (size_t)r + c]);
+                    LB.order.push_back((uint32_t)LB.items.size() - 1u);
+                }
+                roots[i] = LB.build(LB.order, D.depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+        // stitch, in the order the subtrees were deferred
+        for (size_t i = 0; i < deferred.size(); ++i) {
+            const int base = (int)S.tmp.size();
+            const uint32_t leaf_base = (uint32_t)S.leaf_tris.size();
+            for (Tmp t : LS[i].tmp) {
+                if (t.left >= 0) { t.left += base; t.right += base; } else t.first += leaf_base;
+                S.tmp.push_back(t);
+            }
+            S.leaf_tris.insert(S.leaf_tris.end(), LS[i].leaf_tris.begin(), LS[i].leaf_tris.end());
+            S.tmp[deferred[i].tmp] = S.tmp[base + roots[i]];
+            LS[i] = Shared();
+        }
+        if (dup_budget) {          // (for the build's statistics: the budget minus what the subtrees used)
+            size_t total = 0;
+            for (const Deferred &D : deferred) total += D.refs.size();
+            long long used = 0;
+            for (size_t i = 0; i < deferred.size(); ++i) used += (long long)(4.0 * (double)*dup_budget * (double)deferred[i].refs.size() / (double)total) - share[i];
+            *dup_budget -= used;
+        }
+        for (int k : top_inner) { Tmp &t = S.tmp[k]; t.box = S.tmp[t.left].box; t.box.grow(S.tmp[t.right].box); }
+        deferred.clear(); top_inner.clear();
+    }
+
+    // the loops over the references of a LARGE node (the root builder's: everything above the deferred subtrees) run in chunks on
+    // worker threads; f(chunk, begin, end); what the chunks produce — boxes, counts — is merged by min / max / integer sums, which
+    // do not care about the order
+    unsigned chunks_for(size_t n) const { return (n_threads > 1 && n >= 16384) ? n_threads : 1u; }
+    template <class F> void par_chunks(size_t n, unsigned nc, F f) const
+    {
+        if (nc <= 1u) { f(0u, (size_t)0, n); return; }
+        std::vector<std::thread> pool;
+        for (unsigned c = 1; c < nc; ++c) pool.emplace_back([&, c] { f(c, n * c / nc, n * (c + 1) / nc); });
+        f(0u, (size_t)0, n / nc);
+        for (std::thread &t : pool) t.join();
+    }
+
     int build(std::vector<uint32_t> refs, uint32_t depth = 0)
     {
+        if (defer_grain && refs.size() <= defer_grain) {
+            S.tmp.emplace_back();
+            deferred.push_back(Deferred{ (int)S.tmp.size() - 1, std::move(refs), depth });
+            return (int)S.tmp.size() - 1;
+        }
         const uint32_t count = (uint32_t)refs.size();
         bool special = false;
         uint32_t n_tris = 0;
@@ -230,10 +331,19 @@ struct Builder {
             Box bins[kMaxBins]; uint32_t cnt[kMaxBins];
             for (int k = 0; k < kBins; ++k) { bins[k].reset(); cnt[k] = 0; }
             float scale = (float)kBins / ext;
-            for (uint32_t t : refs) {
-                int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + ax] - cb.lo[ax]) * scale)));
-                bins[k].grow(sbox[t]); cnt[k] += items[t].n_tris;
-            }
+            const unsigned nc = chunks_for(refs.size());
+            struct ObjBins { Box bins[kMaxBins]; uint32_t cnt[kMaxBins]; };
+            std::vector<ObjBins> part(nc > 1u ? nc : 0u);
+            par_chunks(refs.size(), nc, [&](unsigned c, size_t lo_i, size_t hi_i) {
+                Box *pb = nc > 1u ? part[c].bins : bins; uint32_t *pc = nc > 1u ? part[c].cnt : cnt;
+                if (nc > 1u) for (int k = 0; k < kBins; ++k) { pb[k].reset(); pc[k] = 0; }
+                for (size_t i = lo_i; i < hi_i; ++i) {
+                    const uint32_t t = refs[i];
+                    int k = std::min(kBins - 1, std::max(0, (int)((cent[3 * (size_t)t + ax] - cb.lo[ax]) * scale)));
+                    pb[k].grow(sbox[t]); pc[k] += items[t].n_tris;
+                }
+            });
+            for (const ObjBins &P : part) for (int k = 0; k < kBins; ++k) { bins[k].grow(P.bins[k]); cnt[k] += P.cnt[k]; }
             float right_area[kMaxBins]; uint32_t right_cnt[kMaxBins];
             Box acc; acc.reset(); uint32_t c = 0;
             for (int k = kBins - 1; k > 0; --k) { acc.grow(bins[k]); c += cnt[k]; right_area[k] = acc.area(); right_cnt[k] = c; }
@@ -270,24 +380,33 @@ struct Builder {
                     for (int k = 0; k < kSpatialBins; ++k) { bins[k].reset(); n_in[k] = 0; n_out[k] = 0; }
                     const float scale = (float)kSpatialBins / ext;
                     auto bin_of = [&](float x) { return std::min(kSpatialBins - 1, std::max(0, (int)((x - lo) * scale))); };
-                    for (uint32_t t : refs) {
-                        const Box &rb_ = sbox[t];
-                        int k0 = bin_of(rb_.lo[ax]), k1 = bin_of(rb_.hi[ax]);
-                        if (!splittable(t)) { k0 = k1 = bin_of(cent[3 * (size_t)t + ax]); }
-                        n_in[k0] += items[t].n_tris; n_out[k1] += items[t].n_tris;
-                        if (k0 == k1) { bins[k0].grow(rb_); continue; }
-                        double poly[16][3], piece[16][3], rest[16][3];
-                        int n = tri_in_box(S.verts + 9 * (size_t)items[t].first_tri, rb_, poly);
-                        if (n < 3) { for (int k = k0; k <= k1; ++k) bins[k].grow(rb_); continue; }
-                        for (int k = k0; k <= k1 && n >= 3; ++k) {          // chop the polygon bin by bin
-                            if (k == k1) { bins[k].grow(intersect(poly_box(poly, n), rb_)); break; }
-                            const double edge = (double)lo + (double)(k + 1) * (double)ext / (double)kSpatialBins;
-                            const int np_ = clip_poly(poly, n, ax, edge, true, piece);
-                            if (np_ >= 3) bins[k].grow(intersect(poly_box(piece, np_), rb_));
-                            n = clip_poly(poly, n, ax, edge, false, rest);
-                            for (int q = 0; q < n; ++q) for (int r = 0; r < 3; ++r) poly[q][r] = rest[q][r];
+                    const unsigned nc = chunks_for(refs.size());
+                    struct SpBins { Box bins[kMaxSpatialBins]; uint32_t n_in[kMaxSpatialBins], n_out[kMaxSpatialBins]; };
+                    std::vector<SpBins> part(nc > 1u ? nc : 0u);
+                    par_chunks(refs.size(), nc, [&](unsigned c, size_t lo_i, size_t hi_i) {
+                        Box *pb = nc > 1u ? part[c].bins : bins; uint32_t *pi = nc > 1u ? part[c].n_in : n_in, *po = nc > 1u ? part[c].n_out : n_out;
+                        if (nc > 1u) for (int k = 0; k < kSpatialBins; ++k) { pb[k].reset(); pi[k] = 0; po[k] = 0; }
+                        for (size_t i = lo_i; i < hi_i; ++i) {
+                            const uint32_t t = refs[i];
+                            const Box &rb_ = sbox[t];
+                            int k0 = bin_of(rb_.lo[ax]), k1 = bin_of(rb_.hi[ax]);
+                            if (!splittable(t)) { k0 = k1 = bin_of(cent[3 * (size_t)t + ax]); }
+                            pi[k0] += items[t].n_tris; po[k1] += items[t].n_tris;
+                            if (k0 == k1) { pb[k0].grow(rb_); continue; }
+                            double poly[16][3], piece[16][3], rest[16][3];
+                            int n = tri_in_box(S.verts + 9 * (size_t)items[t].first_tri, rb_, poly);
+                            if (n < 3) { for (int k = k0; k <= k1; ++k) pb[k].grow(rb_); continue; }
+                            for (int k = k0; k <= k1 && n >= 3; ++k) {          // chop the polygon bin by bin
+                                if (k == k1) { pb[k].grow(intersect(poly_box(poly, n), rb_)); break; }
+                                const double edge = (double)lo + (double)(k + 1) * (double)ext / (double)kSpatialBins;
+                                const int np_ = clip_poly(poly, n, ax, edge, true, piece);
+                                if (np_ >= 3) pb[k].grow(intersect(poly_box(piece, np_), rb_));
+                                n = clip_poly(poly, n, ax, edge, false, rest);
+                                for (int q = 0; q < n; ++q) for (int r = 0; r < 3; ++r) poly[q][r] = rest[q][r];
+                            }
                         }
-                    }
+                    });
+                    for (const SpBins &P : part) for (int k = 0; k < kSpatialBins; ++k) { bins[k].grow(P.bins[k]); n_in[k] += P.n_in[k]; n_out[k] += P.n_out[k]; }
                     float right_area[kMaxSpatialBins]; uint32_t right_cnt[kMaxSpatialBins];
                     Box acc; acc.reset(); uint32_t c = 0;
                     for (int k = kSpatialBins - 1; k > 0; --k) { acc.grow(bins[k]); c += n_out[k]; right_area[k] = acc.area(); right_cnt[k] = c; }
@@ -306,7 +425,7 @@ struct Builder {
         if (sp_axis >= 0 && sp_cost < best_cost) {
             struct Cut { uint32_t t; Box lo_b, hi_b; };
             std::vector<Cut> cuts;
-            size_t left_budget = *dup_budget;
+            long long left_budget = *dup_budget;
             for (uint32_t t : refs) {
                 const Box &rb_ = sbox[t];
                 if (rb_.hi[sp_axis] <= sp_pos) { left.push_back(t); continue; }
@@ -340,7 +459,7 @@ struct Builder {
                         ++n_cut;
                     }
                 }
-                *dup_budget -= n_cut;
+                *dup_budget -= (long long)n_cut;
             }
         }
         if (left.empty() || right.empty()) {
@@ -357,6 +476,7 @@ struct Builder {
         const int r = build(std::move(right), depth + 1u);
         Tmp t; t.box = S.tmp[l].box; t.box.grow(S.tmp[r].box); t.left = l; t.right = r;
         S.tmp.push_back(t);
+        if (defer_grain) top_inner.push_back((int)S.tmp.size() - 1);
         return (int)S.tmp.size() - 1;
     }
 };
@@ -507,8 +627,8 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     // references are duplicated, the budget (as many duplicates as triangles) is a bound on memory, not a tuning knob.
     // Config 5 at 256 spp, k_wf_trace per render: no splits 161 ms, early split clipping (rounds 2-5) 131 ms, spatial splits 113.5 ms
     // (both together 121 ms: pieces cut before the build take the planes the builder would have chosen).
-    size_t dup_budget = sbvh ? (size_t)n : 0u;
-    if (const char *e = mtr::knob("MTR_BVH_SBVH_BUDGET")) dup_budget = (size_t)(atof(e) * (double)n);
+    long long dup_budget = sbvh ? (long long)n : 0;
+    if (const char *e = mtr::knob("MTR_BVH_SBVH_BUDGET")) dup_budget = (long long)(atof(e) * (double)n);
     if (const char *e = mtr::knob("MTR_BVH_SBVH_ALPHA")) B.kAlpha = (float)atof(e);
     if (mtr::knob("MTR_BVH_UNSPLIT")) B.kUnsplit = true;
     B.kPairCost = sbvh && !mtr::knob("MTR_BVH_NO_PAIR_COST");
@@ -518,11 +638,21 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
         for (const Box &bx : B.wbox) scene.grow(bx);
         B.spatial = true; B.dup_budget = &dup_budget; B.root_area = scene.area();
     }
-    const size_t dup_budget0 = dup_budget, n_refs0 = B.items.size();
+    const long long dup_budget0 = dup_budget; const size_t n_refs0 = B.items.size();
+    // large scenes: subtrees of <= n / 64 references are built by worker threads (Builder::build_parallel_finish)
+    B.n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = mtr::knob("MTR_BVH_THREADS")) B.n_threads = (unsigned)std::max(1, atoi(e));       // experiments / tests
+    if (n >= 16384) B.defer_grain = std::max<size_t>(2048, B.items.size() / 32);      // (whatever the number of threads: ONE algorithm, one tree)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_b0 = now();
     const int root = B.build(B.order);
+    const double t_b1 = now();
+    if (B.defer_grain) B.build_parallel_finish();
+    const double t_b2 = now();
+    if (mtr::knob("MTR_BVH_VERBOSE")) fprintf(stderr, "build_bvh: top of the tree %.3f s, subtrees + stitching %.3f s\n", t_b1 - t_b0, t_b2 - t_b1);
     if (mtr::knob("MTR_BVH_VERBOSE"))
-        fprintf(stderr, "build_bvh: %u triangles, %zu references before the build (early split clipping), %zu duplicated by spatial splits (budget %zu)\n",
-                n, n_refs0, dup_budget0 - dup_budget, dup_budget0);
+        fprintf(stderr, "build_bvh: %u triangles, %zu references before the build (early split clipping), %lld duplicated by spatial splits (budget %lld), %u threads\n",
+                n, n_refs0, dup_budget0 - dup_budget, dup_budget0, B.n_threads);
 
     // flatten: one packet per inner Tmp node
     // leaves are laid out in slot space: each starts on an even slot, odd leaves get a pad slot

@@ -114,6 +114,13 @@ struct WfArgs {
     uint32_t *seg_zombie;                // [2][n_seg] their counts
     uint8_t *occ;                        // [n_seg][occ_stride] shadow-ray results in the order of the segment's shadow list: 1 = occluded
     uint32_t occ_stride;                 // seg rounded up to 16 (the flags of a segment leave LDS as 16-byte stores)
+    // TRACE ORDER (round 6; an experiment that lost and is off by default — mtr_api.hip wf_render): k_wf_shade sorts the positions of a segment's next live list by (cell of the ray's origin, octant of its
+    // direction) — a counting sort in LDS — and k_wf_trace fetches its rays in that order: the 64 rays of a wave start in one part
+    // of the scene and walk it the same way round.  The list itself, and everything keyed by the list position, stays in arrival order.
+    uint16_t *q_order;                   // [n_slots] j-th ray to trace -> its position in the live list (per segment); null: list order
+    uint16_t *q_order_sh;                // [n_slots] the same for the shadow list
+    float sort_lo[3], sort_scale[3];     // origin -> cell: floor((o - lo) * scale), clamped to the grid
+    uint32_t sort_bits[3];               // log2 of the grid's extent per axis (5 bits in all)
     uint32_t trace_any;                  // k_wf_trace: 0 closest hits of the live lists, 1 occlusion of the shadow lists
     uint32_t first_bounce;               // k_wf_shade: this launch shades bounce 0 — the path state is rebuilt from (pixel, sample), not loaded
     uint32_t *seg_mat;                   // [n_seg][kWfKeys] their lengths

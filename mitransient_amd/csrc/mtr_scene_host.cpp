@@ -1,4 +1,6 @@
 #include "mtr_scene_host.h"
+#include <chrono>
+#include <cstdio>
 #include "mtr_knobs.h"
 #include <cstring>
 #include <cmath>
@@ -178,15 +180,22 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
 
     // BVH2 over the primitives; triangles are stored in leaf order
     BvhBuild bvh;
+    const bool verbose = mtr::knob("MTR_BVH_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_phase = now();
+    auto phase = [&](const char *what) { if (verbose) { const double t = now(); fprintf(stderr, "derive_scene: %-28s %.3f s\n", what, t - t_phase); t_phase = t; } };
     build_bvh(d.tri_verts, d.n_tris, &prims, bvh);
+    phase("build_bvh");
     s.nodes = bvh.nodes; s.bvh_depth = bvh.max_depth; s.n_leaves = bvh.n_leaves;
     s.wnodes.clear();
     s.has_wide = bvh.nodes.size() <= 2048;
     s.wide_levels = s.has_wide ? build_wide(bvh, &prims, d.tri_verts, s.wnodes) : 0;
     s.wnodes4.clear();
     s.wide4_levels = build_wide4(bvh, s.wnodes4);
+    phase("build_wide + build_wide4");
     s.wnodes8q.clear(); s.wide8q_levels = 0;
     if (!mtr::knob("MTR_NO_WIDE8Q")) s.wide8q_levels = build_wide8q(bvh, s.wnodes8q);      // (experiments: without it the HBM walk uses the 4-wide tree)
+    phase("build_wide8q");
     const uint32_t n_slots = (uint32_t)bvh.order.size();
     s.tpairs.assign(n_slots / 2, TriPair{}); s.tshade.assign(n_slots, TriShade{}); s.slot_orig.assign(n_slots, 0u);
     s.vnormals.clear(); s.samp_vn.clear();
@@ -315,6 +324,7 @@ const char *derive_scene(const mtr_scene_desc &d, HostScene &s)
         E.inv_area = 1.0f / (4.0f * len);      // rectangle area = |(2 du) x (2 dv)|
     }
     s.mats.assign(d.materials, d.materials + d.n_materials);
+    phase("slots, materials, emitters");
     return nullptr;
 }
 

@@ -303,6 +303,40 @@ __device__ __forceinline__ void wave_deposit(float *s_steady, bool has, uint32_t
     }
 }
 
+// TRACE ORDER (WfArgs::q_order): sort key of a ray = (cell of its origin on a 32-cell grid over the scene) << 3 | octant of its direction
+__device__ __forceinline__ uint32_t trace_sort_key(const WfArgs &a, f3 o, f3 d)
+{
+    const uint32_t bx = a.sort_bits[0], by = a.sort_bits[1], bz = a.sort_bits[2];
+    const float cx = fminf(fmaxf((o.x - a.sort_lo[0]) * a.sort_scale[0], 0.0f), (float)((1u << bx) - 1u));
+    const float cy = fminf(fmaxf((o.y - a.sort_lo[1]) * a.sort_scale[1], 0.0f), (float)((1u << by) - 1u));
+    const float cz = fminf(fmaxf((o.z - a.sort_lo[2]) * a.sort_scale[2], 0.0f), (float)((1u << bz) - 1u));
+    const uint32_t cell = (((uint32_t)cx << by) | (uint32_t)cy) << bz | (uint32_t)cz;
+    return (cell << 3) | (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+}
+// counting sort of the n keys (one byte each, LDS) of a segment's list: order[j] = list position of the j-th ray in key order.
+// Called by the whole workgroup; s_hist: 260 words of LDS.  (Within one key the order is that of the atomics: it only decides which
+// lane traces which ray.)
+__device__ __forceinline__ void trace_sort(const uint8_t *s_keys, uint32_t n, uint32_t *s_hist, uint16_t *order, int tid)
+{
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kBlock) atomicAdd(&s_hist[s_keys[i]], 1u);
+    __syncthreads();
+    const uint32_t c = s_hist[tid];
+    uint32_t incl = c;
+    const uint32_t lane = (uint32_t)tid & 63u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += v; }
+    if (lane == 63u) s_hist[256 + (tid >> 6)] = incl;
+    __syncthreads();
+    uint32_t base = 0u;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_hist[256 + w];
+    __syncthreads();
+    s_hist[tid] = base + incl - c;                       // exclusive prefix = the key's cursor
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kBlock) order[atomicAdd(&s_hist[s_keys[i]], 1u)] = (uint16_t)i;
+}
+
 // time-bin contribution -> 16-byte record appended to its pixel's list; list full -> f32 atomics to HBM.
 // The list tails of the segment's pixels live in LDS for the duration of the launch.
 struct RecordSink {
@@ -470,6 +504,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
         bool pending = false;                                   // a finished ray whose result is not written yet
         const float4 *qr = any_hit ? a.r_shadow + 2 * (size_t)sg * a.seg
                                    : a.q_ray + 2 * ((size_t)par * a.n_slots + (size_t)sg * a.seg);   // rays in list order
+        const uint16_t *ord = any_hit ? (a.q_order_sh ? a.q_order_sh + (size_t)sg * a.seg : nullptr) : (a.q_order ? a.q_order + (size_t)sg * a.seg : nullptr);
         st.reset();
         for (;;) {
             const bool idle = tr.cur == kTravDone;
@@ -499,7 +534,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
                 base = __shfl(base, leader);
                 const uint32_t idx = base + (uint32_t)__popcll(m_idle & ((1ull << lane_id) - 1ull));
                 if (idle && idx < n_live) {
-                    pos = idx;
+                    // TRACE ORDER: the idx-th ray to trace sits at list position ord[idx] (bounce 0's camera rays are coherent as they are)
+                    pos = (!FIRST && ord) ? (uint32_t)ord[idx] : idx;
                     if (FIRST) {
                         uint32_t pixel, s, pl;
                         slot_to_lane(a, sg * a.seg + idx, pixel, s, pl);
@@ -507,7 +543,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
                         path_begin(p, a.cam, a.film, a.rc, pixel, s);
                         trav_init(tr, sv, p.ray.o, p.ray.d, p.ray.tmax, st);
                     } else {
-                        const float4 r0 = qr[2 * (size_t)idx], r1 = qr[2 * (size_t)idx + 1];
+                        const float4 r0 = qr[2 * (size_t)pos], r1 = qr[2 * (size_t)pos + 1];
                         // (a bounce ray's tmax is infinite — shade_finish — and the word of the list that would hold it carries the list
                         // position of the path's PREVIOUS vertex instead: k_wf_shade, `prev_pos`)
                         trav_init(tr, sv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any_hit ? r0.w : kInf, st);
@@ -618,6 +654,9 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
     wf_setup<STACK, SCENE_LDS>(a.sc, smem, tid, sv, st, off);
     uint32_t *s_rec = (uint32_t *)(smem + off);                 // [G] record-list tails of the segment's pixels
     float *s_steady = (float *)(smem + off + al16(a.G * 4u));   // [G][4] radiance sums of the paths that end here
+    uint8_t *s_sortkey = (uint8_t *)(smem + off + al16(a.G * 4u) + al16(a.G * 16u));      // [seg] TRACE ORDER: keys of the next live list
+    uint8_t *s_sortkey_sh = s_sortkey + al16(a.seg);            // [seg] ... of the shadow list (DEFER)
+    uint32_t *s_hist = (uint32_t *)(s_sortkey_sh + (DEFER ? al16(a.seg) : 0u));           // [260]
     const PlanesT<!SCENE_LDS> P{ (float4 *)a.planes, a.n_slots };
     const uint32_t par = a.parity;
     uint32_t n_closest = 0, n_shadow = 0, n_bounce = 0, n_splats = 0, n_over = 0, n_alive = 0;
@@ -737,6 +776,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                             // withheld from shade_finish: `occluded` only gates the commit there
                             const uint32_t pos = wave_append(s_shadow_p, true);
                             sh_pos = pos;          // (the occlusion kernel needs no slot: its result goes to the ray's list position)
+                            if (a.q_order_sh) s_sortkey_sh[pos] = (uint8_t)trace_sort_key(a, shadow.o, shadow.d);
                             r_sh[2 * (size_t)pos] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.tmax);
                             r_sh[2 * (size_t)pos + 1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
                             P.st(Q_PEND, slot, make_float4(pd.Lr.x, pd.Lr.y, pd.Lr.z, pd.opl));
@@ -763,6 +803,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     const uint32_t pos = wave_append(s_next_p, alive);
                     if (alive) {
                         q_next[pos] = (sh_pos << 16) | (slot - sg * a.seg);
+                        if (a.q_order) s_sortkey[pos] = (uint8_t)trace_sort_key(a, ray_o, ray_d);
                         // (.w: not the ray's tmax, which is infinite, but where this vertex's hit record lives — the next vertex's prev_pos)
                         r_next[2 * (size_t)pos] = make_float4(ray_o.x, ray_o.y, ray_o.z, __uint_as_float(e >> 16));
                         r_next[2 * (size_t)pos + 1] = make_float4(ray_d.x, ray_d.y, ray_d.z, ray_eta);
@@ -775,6 +816,8 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
             }
         }
         __syncthreads();
+        if (a.q_order) trace_sort(s_sortkey, *s_next_p, s_hist, a.q_order + (size_t)sg * a.seg, tid);
+        if (DEFER && a.q_order_sh) { __syncthreads(); trace_sort(s_sortkey_sh, *s_shadow_p, s_hist, a.q_order_sh + (size_t)sg * a.seg, tid); }
         if (tid == 0) { wf_segment_survivors(a, sg, *s_next_p, DEFER ? *s_zombie_p : 0u); if (DEFER) a.seg_shadow[sg] = *s_shadow_p; }
         for (uint32_t t = tid; t < npx; t += kBlock) a.rec_count[pl0 + t] = s_rec[t];
         for (uint32_t t = tid; t < 4 * npx; t += kBlock) {        // this workgroup owns the segment's pixels in this launch
@@ -1110,7 +1153,7 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
     if constexpr (SL) {          // scenes staged in LDS whose tables allow it: the specialised shading code (as k_fused)
         if (which == 2 && !ext && (a.sc.traits & kTrCornell) == kTrCornell) {
             void (*ks)(const WfArgs) = a.first_bounce ? k_wf_shade<STACK, true, false, kTrCornell, true> : k_wf_shade<STACK, true, false, kTrCornell>;
-            lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);
+            lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg) + (a.q_order ? 1056u : 0u);       // (+ 260 words: trace_sort's histogram)
             hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(ks, dim3(grid), dim3(kBlock), lds, stream, a);
@@ -1121,7 +1164,8 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
                             : which == 5 ? (ext ? k_wf_nlos_bounce<STACK, SL, true> : k_wf_nlos_bounce<STACK, SL, false>)
                             : a.first_bounce ? (ext ? k_wf_shade<STACK, SL, true, 0u, true> : k_wf_shade<STACK, SL, false, 0u, true>)
                             : (ext ? k_wf_shade<STACK, SL, true> : k_wf_shade<STACK, SL, false>);
-    lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums; k_wf_trace: hit material types
+    lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg);        // k_wf_shade: record-list tails, steady sums, sort keys of the next live list; k_wf_trace: hit material types
+    if (which == 2 && a.q_order) lds += (SL ? 0u : al16(a.seg)) + 1056u;      // k_wf_shade, TRACE ORDER experiment: + sort keys of the shadow list (scenes in HBM), trace_sort's histogram
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, stream, a);

@@ -159,6 +159,23 @@ extern "C" int hh_bvh_info(const mtr_scene_desc *d, uint32_t *n_nodes, uint32_t 
     return 0;
 }
 
+// FNV-1a over everything the builders produce (BVH2 packets, the quantised trees, the slot order): two builds of one scene
+// with different thread counts must agree on it
+extern "C" int hh_tree_hash(const mtr_scene_desc *d, uint64_t *hash)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(hs.nodes.data(), hs.nodes.size() * sizeof(Node));
+    mix(hs.wnodes4.data(), hs.wnodes4.size() * sizeof(QNode4));
+    mix(hs.wnodes8q.data(), hs.wnodes8q.size() * sizeof(QNode8));
+    mix(hs.slot_orig.data(), hs.slot_orig.size() * sizeof(uint32_t));
+    mix(hs.tpairs.data(), hs.tpairs.size() * sizeof(TriPair));
+    *hash = h;
+    return 0;
+}
+
 // closest hit / occlusion through the product's BVH, for BVH-vs-brute-force tests
 extern "C" int hh_intersect(const mtr_scene_desc *d, uint32_t n, const float *o3, const float *d3, const float *maxt,
                             float *t_out, int32_t *prim_out, uint8_t *occ_out)

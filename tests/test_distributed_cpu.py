@@ -62,7 +62,7 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])      # 8: the node the scaling curve is measured on — 10 rows in 8 padded slabs, 6 samples over 8 ranks (two render nothing)
 def test_gloo_spp_shard_reduce(tmp_path, world):
     import socket
     s = socket.socket()

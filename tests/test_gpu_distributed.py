@@ -248,6 +248,68 @@ def test_two_rank_reduce_scatter_only(tmp_path):
     assert seen.all()
 
 
+def _worker8(rank, world, port, tmp, partition, gather, single, bands):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_cornell
+        from mitransient_amd import distributed as md
+        scene = make_cornell(width=64, height=64, bins=64)
+        r = md.DistributedRenderer(scene, partition=partition, gather=gather, bands=bands, single_launch=single)
+        steady, transient = r.render(spp=20, seed=3)          # 20 samples over 8 ranks: shards of 3 and 2
+        torch.cuda.synchronize()
+        np.save(os.path.join(tmp, f"t{rank}.npy"), np.array(transient))
+        np.save(os.path.join(tmp, f"s{rank}.npy"), np.array(steady))
+        with open(os.path.join(tmp, f"info{rank}.txt"), "w") as fh:
+            fh.write(f"{r.last_path} {getattr(r, 'last_band_launches', 0)} {r.last_collectives} {' '.join(map(str, getattr(r, 'owned_rows', None) or []))}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partition,gather,single", [("spp", True, False), ("spp", False, True), ("spp", True, True), ("spp", False, False),
+                                                     ("rows", True, False), ("rows", False, False)])
+def test_eight_ranks_on_one_gpu(tmp_path, partition, gather, single):
+    """WORLD SIZE 8 (the node the 1/2/4/8 curve is measured on) through DistributedRenderer on this box's one GPU, gloo instead of
+    RCCL: 64 rows = 8 bands x 8 ranks x 1 row, 20 samples in shards of 3 and 2, both partitions, with and without the final
+    all-gather, per-band launches and the single launch with band completion words — the first 8-rank execution of this code
+    should not be the driver's"""
+    from conftest import make_cornell, rel_l2
+    scene = make_cornell(width=64, height=64, bins=64)
+    s_ref, t_ref = scene.integrator().render(scene, seed=3, spp=20)
+    s_ref, t_ref = np.array(s_ref), np.array(t_ref)
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path), partition, gather, single, 8), nprocs=8, join=True)
+    seen = np.zeros(64, bool)
+    for r in range(8):
+        t = np.load(tmp_path / f"t{r}.npy")
+        s = np.load(tmp_path / f"s{r}.npy")
+        info = (tmp_path / f"info{r}.txt").read_text().split()
+        if partition == "spp":
+            assert info[0] == "pipelined" and int(info[1]) == (1 if single else 8)
+            assert int(info[2]) == 8 * (2 if gather else 1) + 1
+        if gather:
+            assert t.shape == t_ref.shape and rel_l2(t, t_ref) <= 1e-6 and rel_l2(s, s_ref) <= 1e-6
+        else:
+            rows = np.array([int(x) for x in info[3:]])
+            assert len(rows) == 8 == t.shape[0] and not seen[rows].any()
+            seen[rows] = True
+            assert rel_l2(t, t_ref[rows]) <= 1e-6 and rel_l2(s, s_ref[rows]) <= 1e-6
+    assert gather or seen.all()
+
+
+def test_bench_with_eight_ranks_dry_run():
+    """`python bench.py --gpus 8` in the dry-run form (every rank on this GPU, gloo): one JSON line, weak scaling, 17 collectives"""
+    res = _bench_line({"MTR_BENCH_BACKEND": "gloo", "MTR_BENCH_DEVICE": "0", "OMP_NUM_THREADS": "1"},
+                      ["--gpus", "8", "--steps", "2", "--warmup", "1", "--spp", "8", "--width", "128", "--height", "128", "--bins", "128", "--no-cpu-baseline"], timeout=900)
+    assert res["n_gpus"] == 8 and res["comm_backend"] == "gloo" and res["scaling"] == "weak"
+    assert res["counters_per_step"]["paths"] == 128 * 128 * 8 * 8
+    assert res["render_path"] == "pipelined" and res["collectives_per_step"] == 17
+    assert res["row_sharded"]["path"] == "rows" and res["value"] > 0
+
+
 def _bench_line(env_extra, args, timeout=600):
     import json
     import subprocess
