@@ -730,6 +730,9 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     slot_to_lane(a, slot, pixel, s, pl);
                     Path p;
                     uint32_t pend = 0u;
+                    // (the path's live-list entry — its high half is where the shadow ray of the previous vertex sits in the shadow list —
+                    // is requested with the state, not behind it)
+                    const uint32_t live_entry = (DEFER && !FIRST) ? a.q_live[(size_t)par * a.n_slots + (size_t)sg * a.seg + (e >> 16)] : 0u;
                     if (FIRST) path_begin(p, a.cam, a.film, a.rc, pixel, s);      // (see k_wf_raygen: bounce 0's state is recomputed, not read)
                     else {
                         load_path(P, slot, r_cur[2 * (size_t)(e >> 16) + 1], p, pend);
@@ -752,7 +755,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     RecordSink sink = make_sink(pl, p.lane);
                     // (the flag of the shadow ray this path emitted at its previous vertex: at that ray's position in the shadow list, which
                     // the path's live-list entry carries in its high half)
-                    if (DEFER && pend && a.occ[(size_t)sg * a.occ_stride + (a.q_live[(size_t)par * a.n_slots + (size_t)sg * a.seg + lpos] >> 16)] == 0) {          // the previous bounce's emitter sample was visible: commit it now
+                    if (DEFER && pend && a.occ[(size_t)sg * a.occ_stride + (live_entry >> 16)] == 0) {          // the previous bounce's emitter sample was visible: commit it now
                         const float4 pe = P.ld(Q_PEND, slot);
                         commit_pending(p.L, mk(pe.x, pe.y, pe.z), pe.w, p.depth - 1u, p.px, p.py, a.film, a.rc, sink);
                     }
@@ -769,7 +772,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     if (pd.has_shadow) {
                         ++n_shadow;
                         if (SCENE_LDS) {                  // short rays out of LDS: tracing them right here is cheaper (config 2: 168 vs 243 ms)
-                            Hit sh = traverse<true, (TR & kTrLeafPair) != 0u>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                            Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sv, shadow.o, shadow.d, shadow.tmax, st);
                             occluded = sh.prim >= 0;
                         } else {
                             // the ray goes to the segment's shadow list (k_wf_trace, any-hit, runs next), the term is parked and
@@ -1152,6 +1155,9 @@ hipError_t launch_set(const WfArgs &a, int which, int grid, size_t lds, hipStrea
     const bool ext = a.sc.has_rough != 0u;
     if constexpr (SL) {          // scenes staged in LDS whose tables allow it: the specialised shading code (as k_fused)
         if (which == 2 && !ext && (a.sc.traits & kTrCornell) == kTrCornell) {
+            // (NOT the flat top level of k_fused: this kernel's lanes are the samples of neighbouring pixels at the SAME bounce — their shadow
+            // rays walk the tree together — and flat_walk_device's uniform stages cost them more than the walk: config 2 in this
+            // organisation 82.4 -> 87.4 ms with it, measured in round 6; a flat k_wf_trace changed nothing, 82.4 against 81 - 83)
             void (*ks)(const WfArgs) = a.first_bounce ? k_wf_shade<STACK, true, false, kTrCornell, true> : k_wf_shade<STACK, true, false, kTrCornell>;
             lds += al16(a.G * 4u) + al16(a.G * 16u) + al16(a.seg) + (a.q_order ? 1056u : 0u);       // (+ 260 words: trace_sort's histogram)
             hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -514,7 +514,8 @@ static hit_t intersect(const orc_scene *sc, const ray3 *r, int use_bvh)
     int stack[128], sp = 0; stack[sp++] = 0;
     while (sp) {
         const orc_node *N = &sc->nodes[stack[--sp]];
-        if (!box_hit(N, r, inv_d, ORC_MIN(h.t, r->maxt))) continue;
+        /* (x (1 + 2^-10): the computed distance of a grazing sliver can lie in front of its own box — the product's kCullSlack, mtr_core.h) */
+        if (!box_hit(N, r, inv_d, ORC_MIN(h.t, r->maxt) * 1.0009765625f)) continue;
         if (N->left < 0) {
             for (int i = N->first; i < N->first + N->count; ++i) {
                 int p = sc->tri_order[i];
@@ -538,7 +539,7 @@ static int ray_test(const orc_scene *sc, const ray3 *r, int use_bvh)
     int stack[128], sp = 0; stack[sp++] = 0;
     while (sp) {
         const orc_node *N = &sc->nodes[stack[--sp]];
-        if (!box_hit(N, r, inv_d, r->maxt)) continue;
+        if (!box_hit(N, r, inv_d, r->maxt * 1.0009765625f)) continue;
         if (N->left < 0) {
             for (int i = N->first; i < N->first + N->count; ++i)
                 if (prim_test(&sc->tris[sc->tri_order[i]], r, &t, &u, &v)) return 1;

@@ -353,10 +353,11 @@ def test_config5_full_size_properties_and_strips(oracle):
     """BASELINE config 5 at its stated size — the staircase's 262,663 triangles, 512 x 512 px, 2048 bins over OPL 0 .. 40,
     2048 spp, max_depth 65, camera_unwarp — rendered once (the full-size render had no check of any kind).
     Properties of the whole film (sample count, finiteness, energy: the time window only cuts, it never adds; counters
-    repeat from render to render), and two pixel strips against the CPU oracle.  The strips are held to 1e-5 and to
-    counters within 1e-5 RELATIVE, not to the last ray: on grazing sliver triangles the f32 Moller-Trumbore distance can
-    leave the triangle's own box by more than its padding, and then which of two near-coincident slivers is 'closest'
-    depends on what was culled — brute force and ANY tree differ on about one ray in 1e8 (tools/find_tree_diff.py)."""
+    repeat from render to render), and two pixel strips against the CPU oracle, held to 1e-5 and to EQUAL counters.  (Rounds 3-5
+    allowed the counters 1e-5 relative: on grazing sliver triangles the f32 Moller-Trumbore distance can leave the triangle's own
+    box by more than its padding, and brute force and every tree then differed on about one ray in 1e8.  Since round 6 the far
+    bound of every slab test is widened by 2^-10 — mtr_core.h kCullSlack, the oracle's box_hit — and tools/find_tree_diff.py
+    finds no such ray.)"""
     import torch
     from mitransient_amd.scenes import staircase
     W = H = 512
@@ -392,7 +393,7 @@ def test_config5_full_size_properties_and_strips(oracle):
         assert rel_l2(t_gpu, t4[y, x:x + 4, :, :3]) <= TOL
         del t4, s4
         for k in COUNTERS:
-            assert abs(got[k] - cnt[k]) <= max(2, 1e-5 * cnt[k]), (k, got[k], cnt[k])
+            assert got[k] == cnt[k], (k, got[k], cnt[k])
     # counters repeat exactly from render to render
     integ.render(scene, seed=0, spp=SPP)
     torch.cuda.synchronize()
