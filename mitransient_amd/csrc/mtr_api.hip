@@ -556,6 +556,9 @@ static int wf_render(mtr_scene *s, const mtr_render_params *p, float *t4, float 
             // live path (launches over an empty segment list: 4 us each) and the stream never idles while the host decides; rounds
             // 1-4 synchronised the stream here, a bubble per chunk and a stall for a caller overlapping bands with collectives.
             uint32_t n_polls = 0;
+            // (the count a poll reads is the one the PREVIOUS chunk of 8 bounces left: an unbounded render issues 8 - 16 bounce launches
+            // over empty segment lists after its last path has died — about 4 us each; n_trace / trace_launches and the kernel times of
+            // mtr_kernel_times include that speculative tail)
             auto poll_live = [&](bool &done) -> int {
                 const uint32_t cur = n_polls & 1u;
                 HIP_TRY(c, hipMemcpyAsync(w.host_count + cur, live_total, 4, hipMemcpyDeviceToHost, c->stream));

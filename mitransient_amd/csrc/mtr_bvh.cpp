@@ -133,6 +133,7 @@ struct Builder {
     // ... only where the object split's children overlap by more than this share of the scene's area (the paper's alpha; its 1e-5
     // duplicates 12 % of the staircase's triangles, 1e-6 52 %: config 5 at 256 spp k_wf_trace 117.2 / 113.5 ms, 3e-7 113.0, 0 (budget 2 n) 120)
     float kAlpha = 1e-6f;
+    uint32_t kDepthBudget = 61;       // (build(): DEPTH BUDGET; MTR_BVH_DEPTH_BUDGET in test / experiment builds)
     bool kUnsplit = false;            // reference unsplitting (below): measured, k_wf_trace 112.1 with against 110.5 ms without — off
 
     explicit Builder(Shared &s) : S(s) {}
@@ -188,6 +189,7 @@ struct Builder {
         const float *xf = prims->object_xf + 12 * (size_t)it.object;
         Builder B(S);
         B.kLeafTarget = kLeafTarget; B.kLeafMax = 2;           // object-space leaves: at most one coplanar pair
+        B.kDepthBudget = kDepthBudget;
         for (uint32_t t = 0; t < it.n_tris; ++t) B.add_item(Item{ it.first_tri + t, 1u, kItemTri, -1 }, xf);
         const int root = B.build(B.order);
         S.tmp[root].object = it.object;
@@ -256,7 +258,7 @@ struct Builder {
                 Builder LB(LS[i]);
                 LB.prims = prims; LB.kBins = kBins; LB.kLeafTarget = kLeafTarget; LB.kLeafMax = kLeafMax; LB.spatial = spatial;
                 LB.dup_budget = dup_budget ? &share[i] : nullptr; LB.root_area = root_area; LB.kSpatialBins = kSpatialBins; LB.kAlpha = kAlpha; LB.kUnsplit = kUnsplit;
-                LB.kPairCost = kPairCost;
+                LB.kPairCost = kPairCost; LB.kDepthBudget = kDepthBudget;
                 const size_t m = D.refs.size();
                 LB.items.reserve(2 * m); LB.sbox.reserve(2 * m); LB.wbox.reserve(2 * m); LB.cent.reserve(6 * m); LB.order.reserve(2 * m);
                 for (uint32_t r : D.refs) {
@@ -422,6 +424,18 @@ struct Builder {
         }
 
         std::vector<uint32_t> left, right;
+        // DEPTH BUDGET: the walkers' stacks end at 64 levels and a scene whose tree is deeper has no kernel at all.  When what
+        // is left of the budget only just holds a BALANCED tree over this node's references, the node is split at the median of
+        // the centroids on its longest axis, whatever the SAH says: depth + ceil(log2 count) stays below 62.
+        uint32_t lg = 0; while ((1u << lg) < count) ++lg;
+        if (depth + lg >= kDepthBudget && !special) {
+            int ax = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+            std::vector<uint32_t> sorted(refs);
+            std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b_) { return cent[3 * (size_t)a + ax] < cent[3 * (size_t)b_ + ax]; });
+            left.assign(sorted.begin(), sorted.begin() + count / 2);
+            right.assign(sorted.begin() + count / 2, sorted.end());
+        } else
         if (sp_axis >= 0 && sp_cost < best_cost) {
             struct Cut { uint32_t t; Box lo_b, hi_b; };
             std::vector<Cut> cuts;
@@ -631,6 +645,7 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     if (const char *e = mtr::knob("MTR_BVH_SBVH_BUDGET")) dup_budget = (long long)(atof(e) * (double)n);
     if (const char *e = mtr::knob("MTR_BVH_SBVH_ALPHA")) B.kAlpha = (float)atof(e);
     if (mtr::knob("MTR_BVH_UNSPLIT")) B.kUnsplit = true;
+    if (const char *e = mtr::knob("MTR_BVH_DEPTH_BUDGET")) B.kDepthBudget = (uint32_t)std::max(4, atoi(e));
     B.kPairCost = sbvh && !mtr::knob("MTR_BVH_NO_PAIR_COST");
     if (const char *e = mtr::knob("MTR_BVH_SBVH_BINS")) B.kSpatialBins = std::min(Builder::kMaxSpatialBins, std::max(4, atoi(e)));
     if (dup_budget) {

@@ -625,8 +625,11 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
 // 160 B per vertex and a second random fetch of the 80-byte shading record just to learn the ray.  Nothing in shade_finish but
 // the commit depends on the shadow ray, so the iteration is now run ONCE: shade_hit writes the shadow ray to the segment's
 // shadow list and parks the term (Lr, optical path length) in the Q_PEND plane, shade_finish runs with the term withheld,
-// the occlusion kernel follows, and the NEXT bounce's k_wf_shade commits the parked term first thing.  The sums are bit for bit
-// the reference's: L = (L + Le) + Lr there, (L + Le) + 0 now and + Lr at the commit — before the next bounce's Le, as there.
+// the occlusion kernel follows, and the NEXT bounce's k_wf_shade commits the parked term first thing.  Every TRANSIENT record —
+// value, optical path length, bin — is bit for bit the reference's.  The STEADY image is not summed in the reference's order
+// since round 5: a path no longer carries its radiance L = (L + Le) + Lr from vertex to vertex; every vertex deposits its own
+// increment into its pixel's sum (wave_deposit: a wave reduction per distinct pixel, then LDS float atomics), so the steady image
+// of this organisation agrees with k_fused's and the oracle's to f32 summation order (1e-6 of its norm at 1024 spp), not to the bit.
 // A path that ENDS with a term parked becomes a "zombie" (its depth in Q_AUX.w, the term in Q_PEND, its slot on the
 // segment's zombie list); the next launch commits it and counts the path in its pixel's steady sum.  No term can be left at the end of a render:
 // a vertex samples the emitter only if depth + 1 < max_depth, and the host's live count includes the zombies.

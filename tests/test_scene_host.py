@@ -516,3 +516,51 @@ def test_parallel_build_makes_the_sequential_tree(host_harness, tmp_path, monkey
         hashes[threads] = h.value; infos[threads] = (nn.value, dep.value, lv.value)
     assert len(set(hashes.values())) == 1, hashes
     assert len(set(infos.values())) == 1 and infos[1][2] > n // 2, infos           # (spatial splits happened: more leaves than triangle pairs)
+
+
+def test_depth_budget_keeps_the_tree_walkable(oracle, host_harness, tmp_path, monkeypatch):
+    """the walkers' stacks end at 64 levels, and a scene whose tree is deeper has no kernel at all.  Near the limit the builder
+    splits at the median instead of where the SAH says (mtr_bvh.cpp, DEPTH BUDGET): depth + ceil(log2 references) stays below
+    the budget.  No geometry that fits f32 drives a binned SAH 64 levels deep, so the test lowers the budget to 14 on a scene
+    whose tree is 17 levels deep without it — 400 triangles falling off geometrically — and checks depth and brute-force hits."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    mi.set_variant("llvm_ad_rgb")
+    fn = tmp_path / "chain.obj"
+    n = 400
+    with open(fn, "w") as fh:
+        for i in range(n):
+            s = 0.9 * 0.93 ** i
+            x = -0.95 + 1.9 * (1.0 - 0.93 ** i)
+            for p in ((x, -s, -s), (x, s, -s), (x, 0.0, s)):
+                fh.write("v %.9g %.9g %.9g\n" % p)
+            fh.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=8, height=8, temporal_bins=8)
+    for name in ("small-box", "large-box"):
+        d.pop(name)
+    d["chain"] = {"type": "obj", "filename": str(fn), "face_normals": True, "bsdf": {"type": "ref", "id": "white"}}
+    sd = mi.load_dict(d).data()
+    desc = sd.desc()
+    rng = np.random.default_rng(3)
+    m = 4000
+    o = rng.uniform(-0.95, 0.95, (m, 3)).astype(np.float32)
+    dirs = rng.normal(size=(m, 3)); dirs[:, 0] *= 3.0
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    maxt = np.full(m, np.inf, np.float32)
+    t0, p0, occ0 = oracle.intersect(sd, o, dirs, maxt, use_bvh=False)
+    depths = {}
+    for budget in (None, 14):
+        if budget:
+            monkeypatch.setenv("MTR_BVH_DEPTH_BUDGET", str(budget))
+        nn, dep, lv = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dep), C.byref(lv)) == 0
+        depths[budget] = dep.value
+        for wide in (0, 3):
+            host_harness.hh_set_wide(wide)
+            try:
+                t1, p1, occ1 = _hh_intersect(host_harness, sd, o, dirs, maxt)
+            finally:
+                host_harness.hh_set_wide(0)
+            assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(p0, p1) and np.array_equal(occ0, occ1)
+    assert depths[None] > 15 and depths[14] <= 15, depths

@@ -1,10 +1,10 @@
 """tools/isa_loops.py <dir of tools/isa_c2.sh output> [kernel symbol substring] — every loop of a kernel: first / last instruction, size, VALU / SALU / LDS / scalar-load / division / lane-copy / scratch counts"""
 import re, collections, sys
 d = sys.argv[1]; sym = sys.argv[2] if len(sys.argv) > 2 else 'k_fusedILb1ELb1ELb0ELi4ELb0ELb0ELb0ELj15E'
-S = open(d + '/mtr_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read().split('\n')
+S = open(d + '/' + (sys.argv[4] if len(sys.argv) > 4 else 'mtr_kernels') + '-hip-amdgcn-amd-amdhsa-gfx950.s').read().split('\n')
 on = False; ins = []; labels = {}
 for l in S:
-    if not on and l.startswith('_ZN3mtr7') and sym in l and (':' in l): on = True; continue
+    if not on and l.startswith('_ZN3mtr') and sym in l and (':' in l): on = True; continue
     if not on: continue
     if 's_endpgm' in l: break
     m = re.match(r'^(\.LBB\d+_\d+):', l)
