@@ -205,7 +205,7 @@ WF_STATE_BYTES_PER_BOUNCE = 216.0      # un-fused wavefront s
 WF_SHADOW_RAY_BYTES = 48.0             # ... + 48 B per shadow ray
 
 
-def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
+def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok, section="staircase"):
     """Roofline blocks of a render in the wavefront organisation (config 5): the dominant kernel k_wf_trace (VALU issue x active
     lanes: instructions of the committed PMC pass of the SAME workload and sources over its own live HIP-event time), the
     HBM-bound k_wf_shade (SURVEY section 8d's algorithmic bytes over its live time) and the time-bin
@@ -214,7 +214,7 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
     trace_ms = times.get("wf_trace_ms", 0.0) / n_renders
     shade_ms = times.get("wf_shade_ms", 0.0) / n_renders
     scat_ms = times.get("scatter_ms", 0.0) / n_renders
-    c5 = pmc_from_profiles("k_wf_trace", "staircase")
+    c5 = pmc_from_profiles("k_wf_trace", section)
     if trace_ms > 0:
         blk = {"kernel": "k_wf_trace", "bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "kernel_ms_per_render": trace_ms,
                "launches_per_render": times.get("wf_trace_kernel_launches", 0) / n_renders, "share_of_render": trace_ms / ms_per_render}
@@ -228,10 +228,10 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
                         "profile_source_hash": source_hash(),
                         "note": "k_wf_trace waits on divergent 16-byte loads from L1/L2 (wait_any_frac), so its issue fraction is the "
                                 "honest utilisation figure; HBM traffic is a small fraction of the roof (scene resident in L2)",
-                        "source": "profiles/traffic.json[staircase] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"})
+                        "source": "profiles/traffic.json[" + section + "] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"})
         else:
             blk.update({"achieved": None, "frac": None, "roofline_stale": True,
-                        "note": "instruction counts need the PMC pass of THESE sources (tools/profile.sh ... --scene staircase); the live kernel time stands"})
+                        "note": "instruction counts need the PMC pass of THESE sources (tools/profile_all.sh); the live kernel time stands"})
         out["roofline_valu"] = blk
         # the contract form for the same kernel: the bytes a trace launch must move (a 32-byte ray read and a 16-byte
         # hit written per closest-hit ray, 32 + 1 per shadow ray) over its live time; `traffic` = L2-miss bytes of the PMC pass
@@ -249,7 +249,7 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
         ach = alg / (shade_ms * 1e-3) / 1e9
         traffic = None
         if profile_ok:
-            traffic = pmc_from_profiles("k_wf_shade", "staircase").get("hbm_bytes_per_render")
+            traffic = pmc_from_profiles("k_wf_shade", section).get("hbm_bytes_per_render")
         out["roofline_shade"] = {"kernel": "k_wf_shade", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms_per_render": shade_ms,
                                  "algorithmic_bytes_per_render": alg, "share_of_render": shade_ms / ms_per_render,
@@ -259,7 +259,7 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok):
         alg = SPLAT_BYTES * counters["splats_issued"] / n_renders
         ach = alg / (scat_ms * 1e-3) / 1e9
         out["scatter_add"] = {"kernel": "k_wf_scatter", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": (pmc_from_profiles("k_wf_scatter", "staircase").get("hbm_bytes_per_render") if profile_ok else None),
+                              "traffic": (pmc_from_profiles("k_wf_scatter", section).get("hbm_bytes_per_render") if profile_ok else None),
                               "kernel_ms_per_render": scat_ms, "algorithmic_bytes_per_render": alg,
                               "launches_per_render": times.get("scatter_launches", 0) / n_renders}
     return out
@@ -335,7 +335,7 @@ def extra_config_legs(spp4, spp5):
     r5r, c5r, t5r = run(sc5r, spp5, 2)
     r5r["workload"] = (f"staircase scene.xml as written (262,663 triangles, GGX roughplastic / roughconductor lobes, vertex normals, bitmap "
                        f"textures), 512x512 px, 2048 time bins (start_opl 0, width 40/2048), {spp5} of 2048 spp, max_depth 65, camera_unwarp")
-    r5r.update(wavefront_rooflines(c5r, t5r, 2, r5r["ms"], False))       # (live times and algorithmic bytes; the PMC passes are of the smooth workload)
+    r5r.update(wavefront_rooflines(c5r, t5r, 2, r5r["ms"], spp5 == 2048 and profile_is_current("staircase_rough"), section="staircase_rough"))
     out["config5_rough" if spp5 == 2048 else "config5_rough_reduced"] = r5r
     del sc5r
     torch.cuda.empty_cache()

@@ -483,14 +483,14 @@ def test_c_abi_rejects_bad_materials(host_harness):
 def test_parallel_build_makes_the_sequential_tree(host_harness, tmp_path, monkeypatch):
     """mtr_bvh.cpp builds the subtrees of a large scene on worker threads (Builder::build_parallel_finish).  Every split is a function
     of its node's references alone and the pieces are stitched in the order they were deferred, so the tree — BVH2 packets, both
-    quantised collapses, slot order, pair records — is the one a single thread builds, byte for byte: 20 000 random triangles with
-    spatial splits on, 1 / 2 / 5 / 8 threads."""
+    quantised collapses, slot order, pair records — is the one a single thread builds, byte for byte: 17 000 random triangles with
+    spatial splits on, 1 / 3 / 8 threads."""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     mi.set_variant("llvm_ad_rgb")
     rng = np.random.default_rng(5)
     fn = tmp_path / "soup.obj"
-    n = 20000
+    n = 17000
     with open(fn, "w") as fh:
         for i in range(n):
             c = rng.uniform(-0.9, 0.9, 3)
@@ -506,16 +506,16 @@ def test_parallel_build_makes_the_sequential_tree(host_harness, tmp_path, monkey
     sd = mi.load_dict(d).data()
     desc = sd.desc()
     host_harness.hh_tree_hash.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    hashes, infos = {}, {}
-    for threads in (1, 2, 5, 8):
+    hashes = {}
+    for threads in (1, 3, 8):
         monkeypatch.setenv("MTR_BVH_THREADS", str(threads))
         h = C.c_uint64(0)
         assert host_harness.hh_tree_hash(C.byref(desc), C.byref(h)) == 0
-        nn, dep, lv = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dep), C.byref(lv)) == 0
-        hashes[threads] = h.value; infos[threads] = (nn.value, dep.value, lv.value)
+        hashes[threads] = h.value
     assert len(set(hashes.values())) == 1, hashes
-    assert len(set(infos.values())) == 1 and infos[1][2] > n // 2, infos           # (spatial splits happened: more leaves than triangle pairs)
+    nn, dep, lv = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert host_harness.hh_bvh_info(C.byref(desc), C.byref(nn), C.byref(dep), C.byref(lv)) == 0
+    assert lv.value > n // 2, lv.value           # (spatial splits happened: more leaves than triangle pairs)
 
 
 def test_depth_budget_keeps_the_tree_walkable(oracle, host_harness, tmp_path, monkeypatch):

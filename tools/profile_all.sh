@@ -8,4 +8,7 @@ TAG=$1
 tools/profile.sh ${TAG}_c2 > gpurun_out/prof_${TAG}_c2.log 2>&1
 STEPS=1 WARMUP=0 RENDERS=1 tools/profile.sh ${TAG}_c5 --scene staircase --no-scatter-leg > gpurun_out/prof_${TAG}_c5.log 2>&1
 tools/profile.sh ${TAG}_c4 --scene nlos --no-scatter-leg > gpurun_out/prof_${TAG}_c4.log 2>&1
+# ... and config 5 as its file describes it (GGX lobes, vertex normals, bitmaps): the "staircase_rough" section
+STEPS=1 WARMUP=0 RENDERS=1 tools/profile.sh ${TAG}_c5r --scene staircase --materials rough --no-scatter-leg > gpurun_out/prof_${TAG}_c5r.log 2>&1
+tail -n 3 gpurun_out/prof_${TAG}_c5r.log
 tail -n 3 gpurun_out/prof_${TAG}_c2.log; tail -n 3 gpurun_out/prof_${TAG}_c5.log; tail -n 3 gpurun_out/prof_${TAG}_c4.log
