@@ -6,7 +6,10 @@
 
 namespace mtr {
 
-constexpr int kBlock = 256;          // 4 wave64 per workgroup
+#ifndef MTR_BLOCK
+#define MTR_BLOCK 256
+#endif
+constexpr int kBlock = MTR_BLOCK;    // 4 wave64 per workgroup (experiments: -DMTR_BLOCK=320 with -DMTR_FUSED_MIN_WAVES=5)
 
 struct DevCounters {                 // device mirror of mtr_counters (u64 atomics)
     unsigned long long paths, rays_closest, rays_shadow, splats_issued, bounces, splats_overflow, r0, r1;

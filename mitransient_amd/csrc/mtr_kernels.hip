@@ -712,6 +712,11 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     cfg.fixed = det && cfg.hist_lds;
     cfg.rough = sc.has_rough != 0u;
     cfg.traits = cfg.rough ? 0u : sc.traits;
+    // the kernel with the flat top level (launch_fused_s picks it under exactly this condition) walks no tree: no stack rows
+    if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat) {
+        fixed_b -= rows * kBlock * 4;
+        args.stack_rows = 0u;
+    }
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
