@@ -1064,8 +1064,12 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
         const f3 id = tr.id, noid = tr.noid;
         const float tb = fminf(tr.tmax, tr.h.t);          // (no kCullSlack: rectangles and cube faces are no slivers — and the two multiplies cost config 2 1.6 %)
         const uint32_t sel0 = tr.sel[0], sel1 = tr.sel[1], sel2 = tr.sel[2];
-        uint32_t qm = 0u, k1 = 0u;
-        float t1 = kInf, t2 = kInf;
+        uint32_t qm = 0u;
+        // nearest / second nearest entry distance as ORDERED KEYS: the bits of a non-negative float order like the float, so
+        // key = (bits(tn) & ~7) | child orders the candidates by entry distance with the child index along for the ride — one
+        // v_min_u32 / v_max_u32 pair per child instead of compares and selects on (distance, index).  Clearing the low bits moves a
+        // distance DOWN by at most 7 ulps: the comparison with the hit distance below only gets more careful.
+        uint32_t key1 = 0xffffffffu, key2 = 0xffffffffu;
         // one pair of children of the root per step; the offsets are compile-time constants (the loop is unrolled: a pair whose
         // children are absent has inverted boxes and fails by itself), a shadow ray keeps no entry distances
         auto slab_pair = [&](uint32_t j) {
@@ -1081,8 +1085,9 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             qm |= (h0 ? 1u : 0u) << (2u * j);
             qm |= (h1 ? 2u : 0u) << (2u * j);
             if (!ANY_HIT) {
-                { const bool nearer = h0 && tn0 < t1; t2 = h0 ? (nearer ? t1 : fminf(t2, tn0)) : t2; t1 = nearer ? tn0 : t1; k1 = nearer ? 2u * j : k1; }
-                { const bool nearer = h1 && tn1 < t1; t2 = h1 ? (nearer ? t1 : fminf(t2, tn1)) : t2; t1 = nearer ? tn1 : t1; k1 = nearer ? 2u * j + 1u : k1; }
+                const uint32_t ka = h0 ? ((fbits(tn0) & ~7u) | (2u * j)) : 0xffffffffu, kb = h1 ? ((fbits(tn1) & ~7u) | (2u * j + 1u)) : 0xffffffffu;
+                key2 = min(key2, max(key1, ka)); key1 = min(key1, ka);
+                key2 = min(key2, max(key1, kb)); key1 = min(key1, kb);
             }
         };
         slab_pair(0u); slab_pair(1u); slab_pair(2u);
@@ -1091,11 +1096,11 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
         st.prof_flat(2);
         for (uint32_t it = 0; __ballot(qm != 0u) != 0ull; ++it) {
             if (qm != 0u) {
-                const uint32_t k = (!ANY_HIT && it == 0u) ? k1 : (uint32_t)__builtin_ctz(qm);
+                const uint32_t k = (!ANY_HIT && it == 0u) ? (key1 & 7u) : (uint32_t)__builtin_ctz(qm);
                 qm &= ~(1u << k);
                 tr.cur = *(const int32_t *)(root + N::kRefOff + 4u * k);
                 const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
-                if (ANY_HIT ? found : (it == 0u && tr.h.t < t2)) qm = 0u;
+                if (ANY_HIT ? found : (it == 0u && tr.h.t < bitsf(key2 & ~7u))) qm = 0u;
             }
         }
     }

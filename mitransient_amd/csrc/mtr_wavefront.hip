@@ -515,13 +515,15 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_TRACE_WAVES_LDS : (
                     // RESULTS IN LIST ORDER (round 6).  Hit records and occlusion flags used to be stored by SLOT: 16 bytes / one byte
                     // scattered over the segment's 8192 slots, i.e. partial cache lines that left L2 one by one (config 5: 177 GB written
                     // for 61 GB of hit records, 90 GB for 3 GB of flags).  They are produced in ray-list order and k_wf_shade holds a
-                    // vertex's list position next to its slot (q_mat), so they now live at the list position: the records of the
-                    // rays a workgroup has in flight fill whole lines while these are still in L2; the flags are gathered in LDS
-                    // and leave in one coalesced pass per segment.
+                    // vertex's list position next to its slot (q_mat), so they now live at the list position; the flags are gathered in
+                    // LDS and leave in one coalesced pass per segment (90 -> 48 GB written by the occlusion pass, the rest of it spilled
+                    // registers).  The 16-byte records still reach HBM one by one — rays finish out of order, and there is no LDS left
+                    // to gather them in at six workgroups per CU — 184 GB for 61 GB of records, as before.
                     if (any_hit) s_key[pos] = tr.h.prim >= 0 ? (uint8_t)1 : (uint8_t)0;
                     else {
-                        // (an ordinary store, not the streaming one of the planes: the line is completed by the neighbouring rays)
-                        P.base[(size_t)hit_plane(par) * P.n + sg * a.seg + pos] = make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim));
+                        // (the planes' streaming store: with an ordinary store the records do NOT meet in L2 either — 245 against 184 GB written
+                        // per config-5 render and 0.7 % more time, measured; only the flags, gathered in LDS, leave as whole lines)
+                        P.st(hit_plane(par), sg * a.seg + pos, make_float4(tr.h.t, tr.h.u, tr.h.v, __uint_as_float((uint32_t)tr.h.prim)));
                         // hit: the list key rides in the low bits of the tie-break word of the best hit (TriPair, mtr_core.h)
                         const uint32_t key = tr.h.prim >= 0 ? (tr.best_orig & 7u) : 4u;
                         s_key[pos] = (uint8_t)key;
