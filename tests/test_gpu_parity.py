@@ -989,3 +989,54 @@ def test_flat_top_level_returns_the_bits_of_the_tree_walk(oracle):
         assert cnts[0][k] == cnts[1][k], k
     s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 64, seed=7)
     assert rel_l2(outs[0][1], t_ref) <= TOL and cnts[0]["rays_shadow"] == cnt["rays_shadow"]
+
+
+@pytest.mark.parametrize("case", ["seven-rects-one-cube", "four-rects-four-cubes", "touching-and-nested-cubes", "camera-inside-a-cube", "one-cube-one-rect", "five-cubes"])
+def test_flat_top_level_variants(oracle, case):
+    """flat_walk_device beyond the Cornell box: an odd number of rectangles (7 + 1 cube: the fourth slab pair and its masked second
+    half), the most boxes the flat top level takes (4, under 4 rectangles: the root holds 8 children), cubes that touch along a face and one nested in another (two boxes' faces
+    at one distance: the tie rule), the camera INSIDE a cube (box_select's 'origin inside' branch for every camera ray), the
+    smallest flat scene, and one box too many (the tree walk again).  Film to 1e-5, counters equal, against the oracle."""
+    import mitransient_amd as mitr
+    import mitransient_amd.mi as mi
+    from mitransient_amd import _cabi
+    from mitransient_amd.transform import ScalarTransform4f as T
+    mi.set_variant("llvm_ad_rgb")
+    d = mitr.cornell_box()
+    d["sensor"]["film"].update(width=32, height=32, temporal_bins=96, start_opl=0.0, bin_width_opl=12.0 / 96)
+    d["integrator"].update(amd_mode="fused", max_depth=6)
+    white = {"type": "ref", "id": "white"}
+
+    def cube(at, deg, scale):
+        return {"type": "cube", "to_world": T().translate(at).rotate([0, 1, 0], deg).scale(scale), "bsdf": white}
+    flat = True
+    if case == "seven-rects-one-cube":
+        d.pop("large-box")
+        d["shelf"] = {"type": "rectangle", "to_world": T().translate([0.0, 0.1, -0.6]).rotate([1, 0, 0], -70.0).scale([0.5, 0.2, 1.0]), "bsdf": {"type": "ref", "id": "green"}}
+    elif case == "four-rects-four-cubes":
+        d.pop("green-wall"); d.pop("red-wall")
+        d["third-box"] = cube([0.5, 0.3, -0.5], 31.0, [0.15, 0.2, 0.1])
+        d["fourth-box"] = cube([-0.6, -0.8, 0.5], -40.0, 0.18)
+    elif case == "touching-and-nested-cubes":
+        d.pop("green-wall"); d.pop("red-wall")
+        d["small-box"] = cube([0.3, -0.7, 0.3], 0.0, 0.3)
+        d["large-box"] = cube([-0.3, -0.7, 0.3], 0.0, 0.3)                  # shares the plane x = 0 with the other
+        d["inner-box"] = cube([0.3, -0.7, 0.3], 0.0, 0.15)                   # wholly inside the first
+        d["flush-box"] = cube([0.3, -0.25, 0.3], 0.0, [0.3, 0.15, 0.3])      # stands on the first: two coincident faces
+    elif case == "camera-inside-a-cube":
+        d["large-box"] = cube([0.0, 0.0, 3.9], 10.0, [0.5, 0.5, 0.5])        # around the camera; its inside faces face away: rays leave through them
+    elif case == "one-cube-one-rect":
+        for k in ("floor", "ceiling", "back", "green-wall", "red-wall", "small-box"):
+            d.pop(k)
+    else:
+        for i in range(3):
+            d[f"extra-box-{i}"] = cube([-0.6 + 0.6 * i, 0.5, -0.6], 15.0 * i, 0.12)
+        flat = False
+    scene = mi.load_dict(d)
+    assert bool(scene.gpu_traits() & _cabi.MTR_TRAIT_FLAT_TOP) == flat
+    s_gpu, t_gpu = gpu_render(scene, 24, seed=11)
+    s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 24, seed=11)
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
