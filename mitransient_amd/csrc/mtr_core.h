@@ -1707,6 +1707,7 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u;
 constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0
 constexpr uint32_t kTrCornellFlat = kTrCornell | kTrFlatTop;                       // ... and with the flat top level
+constexpr uint32_t kTrFlatFlags = kTrFlatTop | kTrLeafPair;                        // ... the flat top level alone (its box faces are pairs), any materials and emitters
 
 template <bool ROUGH = true, uint32_t TR = 0u>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)

@@ -713,7 +713,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     cfg.rough = sc.has_rough != 0u;
     cfg.traits = cfg.rough ? 0u : sc.traits;
     // the kernel with the flat top level (launch_fused_s picks it under exactly this condition) walks no tree: no stack rows
-    if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat) {
+    if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags) {
         fixed_b -= rows * kBlock * 4;
         args.stack_rows = 0u;
     }
@@ -777,6 +777,8 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat)      // ... and a flat top level: no tree walk either (flat_walk_device)
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornellFlat> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornellFlat>;
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags)      // the flat top level under the general shading code (a mirror box, two lights ...)
+        k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrFlatFlags> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrFlatFlags>;
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrCornell) == kTrCornell)          // diffuse materials, one rectangle emitter: the specialised shading code
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornell> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
     else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
