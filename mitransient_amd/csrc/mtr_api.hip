@@ -244,15 +244,21 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
     memset(&s->dev.flat, 0, sizeof s->dev.flat);
     if (hs.has_wide && !hs.wnodes.empty() && hs.wide_levels <= 2 && !mtr::knob("MTR_NO_FLAT")) {
         const WNode &root = hs.wnodes[0];
-        bool flat = root.flags == 0u && root.count >= 1u && root.count - root.n_quads <= kFlatMaxBoxes;
+        bool flat = root.flags == 0u && root.count >= 1u;
+        uint32_t n_inner = 0u, prim_mask = 0u;
         for (uint32_t k = 0; flat && k < root.count; ++k) {
             const int32_t ref = root.ref[k];
-            if (k < root.n_quads) flat = ref < 0 && ((~(uint32_t)ref) & kLeafQuadBit) != 0u;
-            else flat = ref == (int32_t)(1u + (k - root.n_quads)) && (size_t)ref < hs.wnodes.size() && hs.wnodes[ref].flags == 3u && hs.wnodes[ref].count == 6u;
+            if (k < root.n_quads) { flat = ref < 0 && ((~(uint32_t)ref) & kLeafQuadBit) != 0u; prim_mask |= 1u << k; }
+            else if (ref < 0) { flat = ((~(uint32_t)ref) & kLeafQuadBit) == 0u; prim_mask |= 1u << k; }             // a triangle leaf
+            else {            // an inner child: a box node, and the n-th of them is node n + 1
+                flat = ref == (int32_t)(1u + n_inner) && (size_t)ref < hs.wnodes.size() && hs.wnodes[ref].flags == 3u && hs.wnodes[ref].count == 6u;
+                ++n_inner;
+            }
         }
+        flat = flat && n_inner <= kFlatMaxBoxes;
         if (flat) {
             FlatTop &ft = s->dev.flat;
-            ft.n_quads = root.n_quads; ft.n_boxes = root.count - root.n_quads; ft.node0 = 1u;
+            ft.n_quads = root.n_quads; ft.n_boxes = n_inner; ft.node0 = 1u; ft.prim_mask = prim_mask;
             for (uint32_t b = 0; b < ft.n_boxes; ++b) {
                 const float *x = hs.wnodes[1u + b].xf;
                 memcpy(ft.xf[b], x, 12 * sizeof(float));

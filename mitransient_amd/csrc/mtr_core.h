@@ -248,17 +248,17 @@ struct alignas(16) WNodeT {
 };
 constexpr uint32_t kWide = MTR_WIDE;
 typedef WNodeT<kWide> WNode;
-// FLAT TOP LEVEL (round 6; scene trait kTrFlatTop): the root's children are analytic rectangles and BOX nodes only — a room
-// with a few cubes in it, the Cornell box of configs 1-3.  Such a scene is not walked at all (flat_walk_device): no stack, no
+// FLAT TOP LEVEL (round 6; scene trait kTrFlatTop): the root's children are primitives — analytic rectangles, triangle leaves — and
+// BOX nodes only: a room with a few cubes in it (the Cornell box of configs 1-3), a relay wall and a handful of triangles (config 4).  Such a scene is not walked at all (flat_walk_device): no stack, no
 // group words, no votes between node and primitive steps.  The boxes' world -> object rows are handed to the kernels in
 // their ARGUMENT, so that the object-space transform and the face selection of a box run on scalar operands (s_load from the
 // kernarg segment) for every lane at once.  The box nodes are wnodes[node0 .. node0 + n_boxes).
 constexpr uint32_t kFlatMaxBoxes = 4;
 struct FlatTop {
-    uint32_t n_boxes, node0, n_quads, pad;
+    uint32_t n_boxes, node0, n_quads, prim_mask;      // prim_mask: the root's children that are PRIMITIVES (rectangles: bits 0 .. n_quads-1; triangle leaves)
     float xf[kFlatMaxBoxes][16];          // copies of WNode::xf (rows A, B, C), then S = (|A.x|+|A.y|+|A.z|, ... of B, ... of C, 0)
 };
-struct FlatHdr { uint32_t n_boxes, node0, n_quads, pad; };
+struct FlatHdr { uint32_t n_boxes, node0, n_quads, prim_mask; };
 struct FlatXf { q4 A, B, C, S; };
 // Scenes walked in HBM: 4-wide nodes with the children's boxes quantised to 8 bits per plane on the node's own grid
 // (origin = the node's lower corner, one power-of-two step per axis) — 64 bytes, the size of a BVH2 packet, for twice the
@@ -1022,7 +1022,7 @@ __device__ __forceinline__ T kernarg_copy(size_t offset)
 //              nearest entry distance t1 (child k1) and the second nearest t2; the nearest is intersected first, and when
 //              the hit so far lies in front of t2 every other candidate is culled exactly as a node step taken now would cull it.
 // Shadow rays leave at their first hit; the rectangle tests of a wave whose rays all ended on a box are skipped.
-template <bool ANY_HIT, class Stack>
+template <bool ANY_HIT, bool ONE_PAIR, class Stack>
 __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, Stack &st)
 {
     typedef WNode N;
@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
             const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
             const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
-            const bool h0 = (tn0 <= tf0) && (2u * j < fh.n_quads), h1 = (tn1 <= tf1) && (2u * j + 1u < fh.n_quads);
+            const bool h0 = (tn0 <= tf0) && ((fh.prim_mask >> (2u * j)) & 1u), h1 = (tn1 <= tf1) && ((fh.prim_mask >> (2u * j + 1u)) & 1u);
             qm |= (h0 ? 1u : 0u) << (2u * j);
             qm |= (h1 ? 2u : 0u) << (2u * j);
             if (!ANY_HIT) {
@@ -1090,8 +1090,10 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
                 key2 = min(key2, max(key1, kb)); key1 = min(key1, kb);
             }
         };
-        slab_pair(0u); slab_pair(1u); slab_pair(2u);
-        if (kWide > 6u && fh.n_quads > 6u) slab_pair(3u);
+        slab_pair(0u);
+        if (fh.prim_mask > 3u) slab_pair(1u);
+        if (fh.prim_mask > 15u) slab_pair(2u);
+        if (kWide > 6u && fh.prim_mask > 63u) slab_pair(3u);
         if (!live) qm = 0u;
         st.prof_flat(2);
         for (uint32_t it = 0; __ballot(qm != 0u) != 0ull; ++it) {
@@ -1099,7 +1101,8 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
                 const uint32_t k = (!ANY_HIT && it == 0u) ? (key1 & 7u) : (uint32_t)__builtin_ctz(qm);
                 qm &= ~(1u << k);
                 tr.cur = *(const int32_t *)(root + N::kRefOff + 4u * k);
-                const bool found = trav_quad_test(tr, sc, st, ANY_HIT);
+                // (a rectangle or — only where the top level holds triangle leaves — a leaf of one or two pairs)
+                const bool found = (fh.prim_mask >> fh.n_quads) == 0u || is_quad_leaf(tr.cur) ? trav_quad_test(tr, sc, st, ANY_HIT) : trav_leaf_test<ONE_PAIR>(tr, sc, st, ANY_HIT);
                 if (ANY_HIT ? found : (it == 0u && tr.h.t < bitsf(key2 & ~7u))) qm = 0u;
             }
         }
@@ -1123,7 +1126,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     if (FLAT) {
-        if (tr.cur != kTravDone) flat_walk_device<ANY_HIT>(tr, sc, st);
+        if (tr.cur != kTravDone) flat_walk_device<ANY_HIT, ONE_PAIR>(tr, sc, st);
         return tr.h;
     }
 #endif

@@ -991,12 +991,14 @@ def test_flat_top_level_returns_the_bits_of_the_tree_walk(oracle):
     assert rel_l2(outs[0][1], t_ref) <= TOL and cnts[0]["rays_shadow"] == cnt["rays_shadow"]
 
 
-@pytest.mark.parametrize("case", ["seven-rects-one-cube", "four-rects-four-cubes", "touching-and-nested-cubes", "camera-inside-a-cube", "one-cube-one-rect", "five-cubes"])
+@pytest.mark.parametrize("case", ["seven-rects-one-cube", "four-rects-four-cubes", "touching-and-nested-cubes", "camera-inside-a-cube", "one-cube-one-rect", "five-cubes",
+                                  "rects-cube-and-loose-triangles"])
 def test_flat_top_level_variants(oracle, case):
     """flat_walk_device beyond the Cornell box: an odd number of rectangles (7 + 1 cube: the fourth slab pair and its masked second
     half), the most boxes the flat top level takes (4, under 4 rectangles: the root holds 8 children), cubes that touch along a face and one nested in another (two boxes' faces
     at one distance: the tie rule), the camera INSIDE a cube (box_select's 'origin inside' branch for every camera ray), the
-    smallest flat scene, and one box too many (the tree walk again).  Film to 1e-5, counters equal, against the oracle."""
+    smallest flat scene, one box too many (the tree walk again), and triangle leaves at the top level (a two-triangle mesh: the rectangle
+    stage tests rectangles and pair leaves alike, under the general shading code).  Film to 1e-5, counters equal, against the oracle."""
     import mitransient_amd as mitr
     import mitransient_amd.mi as mi
     from mitransient_amd import _cabi
@@ -1028,6 +1030,13 @@ def test_flat_top_level_variants(oracle, case):
     elif case == "one-cube-one-rect":
         for k in ("floor", "ceiling", "back", "green-wall", "red-wall", "small-box"):
             d.pop(k)
+    elif case == "rects-cube-and-loose-triangles":          # triangle leaves at the top level, beside rectangles and a box node
+        d.pop("small-box")
+        tri = os.path.join(ROOT, "tests", "_build", "kite.obj")
+        os.makedirs(os.path.dirname(tri), exist_ok=True)
+        with open(tri, "w") as fh:
+            fh.write("v 0.2 -0.9 0.6\nv 0.7 -0.9 0.2\nv 0.5 -0.2 0.4\nv 0.1 -0.3 0.1\nf 1 2 3\nf 1 3 4\n")
+        d["kite"] = {"type": "obj", "filename": tri, "face_normals": True, "bsdf": {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.4, 0.5, 0.6]}}}}
     else:
         for i in range(3):
             d[f"extra-box-{i}"] = cube([-0.6 + 0.6 * i, 0.5, -0.6], 15.0 * i, 0.12)
