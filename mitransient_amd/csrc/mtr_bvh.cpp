@@ -737,9 +737,81 @@ void subtree_leaves(const BvhBuild &bvh, int32_t packet, std::vector<int32_t> &o
     for (const WChild &w : ch) { if (w.ref < 0) out.push_back(w.ref); else subtree_leaves(bvh, w.ref, out); }
 }
 
+// COLLAPSE PLAN (round 6; VERDICT r5 #3c: "the SAH that scores the 8-wide collapse"; Ylitie, Karras, Laine 2017, section 3.1).  The
+// greedy collapse below opens the child of largest area until a node is full.  The plan instead MINIMISES the SAH cost of the wide
+// tree over all ways of cutting the binary tree into 8-wide nodes, by dynamic programming over the binary tree's subtrees:
+//   cost[S][1]     = S as ONE slot of its parent: a leaf as it is, or a wide node of its own = area(S) c_node + distribute(S, 8)
+//   cost[S][i > 1] = S dissolved into at most i slots = min(cost[S][i - 1], distribute(S, i))
+//   distribute(S, j) = min over k of cost[left(S)][k] + cost[right(S)][j - k]
+// with c_node the price of a node step and c_leaf that of a pair of triangles tested (a subtree = a child slot of a BVH2 packet: 2 p + side).
+struct CollapsePlan {
+    static constexpr int kW = 8;
+    std::vector<float> cost;                 // [slot][kW]: cost[s * kW + (i - 1)]
+    std::vector<uint8_t> opaque;             // [packet]: an object subtree that becomes ONE object node of its own — never dissolved into its parent
+    float c_node = 1.0f, c_leaf = 0.6f;
+    float at(size_t s, int i) const { return cost[s * kW + (size_t)(i - 1)]; }
+};
+void plan_collapse(const BvhBuild &bvh, CollapsePlan &P)
+{
+    const size_t np = bvh.nodes.size();
+    P.cost.assign(2 * np * CollapsePlan::kW, INFINITY);
+    auto distribute = [&](size_t q, int j) {            // the children of packet q in at most j slots
+        float best = INFINITY;
+        for (int k = 1; k < j; ++k) best = std::min(best, P.at(2 * q, k) + P.at(2 * q + 1, j - k));
+        return best;
+    };
+    for (size_t p = np; p-- > 0;) {                      // children have larger indices than their parents (build_bvh's flattening)
+        const float *f = &bvh.nodes[p].q[0].x;
+        for (int c = 0; c < 2; ++c) {
+            const size_t s = 2 * p + (size_t)c;
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) { lo[k] = f[4 * k + c]; hi[k] = f[4 * k + 2 + c]; }
+            if (!(lo[0] <= hi[0])) { for (int i = 1; i <= CollapsePlan::kW; ++i) P.cost[s * CollapsePlan::kW + (size_t)(i - 1)] = 0.0f; continue; }      // an absent child costs nothing
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2], area = dx * dy + dy * dz + dz * dx;
+            const int32_t ref = (int32_t)fbits(f[12 + c]);
+            if (ref < 0) {
+                const uint32_t code = ~(uint32_t)ref, cnt = (code & kLeafQuadBit) ? 2u : (code & 3u) + 1u;
+                const float v = area * P.c_leaf * (float)((cnt + 1u) / 2u);
+                for (int i = 1; i <= CollapsePlan::kW; ++i) P.cost[s * CollapsePlan::kW + (size_t)(i - 1)] = v;
+                continue;
+            }
+            const size_t q = (size_t)ref;
+            if (!P.opaque.empty() && P.opaque[q]) { for (int i = 1; i <= CollapsePlan::kW; ++i) P.cost[s * CollapsePlan::kW + (size_t)(i - 1)] = area * P.c_node; continue; }
+            P.cost[s * CollapsePlan::kW] = area * P.c_node + distribute(q, CollapsePlan::kW);
+            for (int i = 2; i <= CollapsePlan::kW; ++i) P.cost[s * CollapsePlan::kW + (size_t)(i - 1)] = std::min(P.at(s, i - 1), distribute(q, i));
+        }
+    }
+}
+// the slots the plan gives the children of packet q when they may take at most j: appended to `out`
+void plan_children(const BvhBuild &bvh, const CollapsePlan &P, size_t q, int j, std::vector<WChild> &out)
+{
+    int best_k = 1; float best = INFINITY;
+    for (int k = 1; k < j; ++k) { const float v = P.at(2 * q, k) + P.at(2 * q + 1, j - k); if (v < best) { best = v; best_k = k; } }
+    std::vector<WChild> two;
+    {
+        const float *f = &bvh.nodes[q].q[0].x;
+        for (int c = 0; c < 2; ++c) {
+            WChild w;
+            for (int k = 0; k < 3; ++k) { w.lo[k] = f[4 * k + c]; w.hi[k] = f[4 * k + 2 + c]; }
+            w.ref = (int32_t)fbits(f[12 + c]);
+            two.push_back(w);
+        }
+    }
+    const int share[2] = { best_k, j - best_k };
+    for (int c = 0; c < 2; ++c) {
+        const WChild &w = two[c];
+        if (!(w.lo[0] <= w.hi[0])) continue;                 // absent
+        const size_t s = 2 * q + (size_t)c;
+        int i = share[c];
+        while (i > 1 && P.at(s, i - 1) <= P.at(s, i)) --i;   // the fewest slots that reach the same cost
+        if (w.ref < 0 || i == 1 || (!P.opaque.empty() && P.opaque[(size_t)w.ref])) out.push_back(w);           // one slot: a leaf, or a wide node of its own
+        else plan_children(bvh, P, (size_t)w.ref, i, out);   // dissolved into its parent
+    }
+}
+
 template <uint32_t W>
 uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts, int32_t packet, std::vector<WNodeT<W>> &wide,
-                  uint32_t level, uint32_t &levels, size_t width)
+                  uint32_t level, uint32_t &levels, size_t width, const CollapsePlan *plan = nullptr)
 {
     levels = std::max(levels, level);
     const uint32_t me = (uint32_t)wide.size();
@@ -785,7 +857,8 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
             }
         }
     }
-    if (!xf) {
+    if (!xf && plan) plan_children(bvh, *plan, (size_t)packet, (int)W, ch);
+    else if (!xf) {
         packet_children(bvh.nodes[packet], ch);
         // (an object subtree that will become an object node of its own is never dissolved into its parent)
         auto opaque = [&](int32_t ref) {
@@ -829,7 +902,7 @@ uint32_t wide_rec(const BvhBuild &bvh, const BvhPrims *prims, const float *verts
     nd.axis = (uint32_t)axis; nd.count = (uint32_t)ch.size(); nd.n_quads = (uint32_t)nq; nd.flags = (xf ? 1u : 0u) | (is_box ? 2u : 0u);
     for (int k = 0; k < 12; ++k) nd.xf[k] = xf ? xf[k] : 0.0f;
     for (size_t c = 0; c < ch.size(); ++c)
-        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, prims, verts, ch[c].ref, wide, level + 1, levels, width) : ch[c].ref;
+        nd.ref[c] = ch[c].ref >= 0 ? (int32_t)wide_rec<W>(bvh, prims, verts, ch[c].ref, wide, level + 1, levels, width, plan) : ch[c].ref;
     wide[me] = nd;
     return me;
 }
@@ -843,7 +916,20 @@ uint32_t build_wide(const BvhBuild &bvh, const BvhPrims *prims, const float *ver
     size_t width = kWide;
     if (const char *e = mtr::knob("MTR_WIDE_WIDTH")) { int w = atoi(e); width = w < 2 ? 2 : (w > (int)kWide ? (int)kWide : w); }   // experiments
     uint32_t levels = 0;
-    wide_rec<kWide>(bvh, prims, verts, 0, wide, 1, levels, width);
+    // the collapse plan for the 8-wide tree of the scenes staged in LDS too; object subtrees stay whole (MTR_BVH_GREEDY_LDS in the experiments
+    // build = the greedy collapse of rounds 2 - 5).  Config 2's film over the Cornell box with 48-triangle boxes (108 triangles): wavefront
+    // organisation 122.3 -> 113.3 ms, fused (forced) 208.9 -> 147.4 ms; the Cornell box itself (one root, two box nodes) and config 4: unchanged.
+    CollapsePlan plan;
+    const bool planned = kWide == 8 && width == 8 && mtr::knob("MTR_BVH_GREEDY_LDS") == nullptr;
+    if (planned) {
+        plan.opaque.assign(bvh.nodes.size(), 0);
+        const bool objects_on = prims && prims->object_xf && verts && !mtr::knob("MTR_NO_OBJECT_NODES");
+        for (size_t q = 0; objects_on && q < bvh.nodes.size(); ++q)
+            if (bvh.packet_object[q] >= 0) { std::vector<int32_t> lv; subtree_leaves(bvh, (int32_t)q, lv); plan.opaque[q] = lv.size() <= width; }
+        plan_collapse(bvh, plan);
+    }
+    wide_rec<kWide>(bvh, prims, verts, 0, wide, 1, levels, width, planned && !plan.opaque[0] ? &plan : nullptr);
+    if (mtr::knob("MTR_BVH_VERBOSE")) fprintf(stderr, "build_wide: %zu nodes, %u levels%s\n", wide.size(), levels, planned ? " (planned collapse)" : "");
     return levels;
 }
 namespace {
@@ -857,7 +943,26 @@ uint32_t build_quantised(const BvhBuild &bvh, size_t &n_out, Emit emit)
 {
     uint32_t levels = 0;
     std::vector<WNodeT<W>> full;
-    wide_rec<W>(bvh, nullptr, nullptr, 0, full, 1, levels, W);
+    CollapsePlan plan;
+    // (the quantised 8-wide tree of the scenes walked in HBM; MTR_BVH_GREEDY8 in the experiments build = the greedy collapse of rounds 3 - 5.
+    // Staircase: 65 957 nodes of 4.15 children -> 42 081 of 5.94, sum of node areas 2982 -> 2713; config 5 at 256 spp k_wf_trace 109.3 -> 104.1 ms,
+    // the same with a leaf price of 0.3 / 0.6 / 1.0 node steps)
+    const bool planned = W == 8 && mtr::knob("MTR_BVH_GREEDY8") == nullptr;
+    if (planned) {
+        if (const char *e = mtr::knob("MTR_BVH_PLAN8_LEAF")) plan.c_leaf = (float)atof(e);
+        plan_collapse(bvh, plan);
+    }
+    wide_rec<W>(bvh, nullptr, nullptr, 0, full, 1, levels, W, planned ? &plan : nullptr);
+    if (mtr::knob("MTR_BVH_VERBOSE")) {
+        double sah = 0.0; size_t n_children = 0;
+        for (const WNodeT<W> &w : full) {
+            const float *f = &w.box[0].x;
+            Box b; b.reset();
+            for (uint32_t c = 0; c < w.count; ++c) { float lo[3], hi[3]; for (int k = 0; k < 3; ++k) { lo[k] = f[4 * (3 * (c >> 1) + k) + (c & 1)]; hi[k] = f[4 * (3 * (c >> 1) + k) + 2 + (c & 1)]; } b.grow(lo); b.grow(hi); }
+            sah += (double)b.area(); n_children += w.count;
+        }
+        fprintf(stderr, "build_quantised<%u>: %zu nodes, %.2f children per node, %u levels, sum of node areas %.4g%s\n", W, full.size(), (double)n_children / (double)full.size(), levels, sah, planned ? " (planned collapse)" : "");
+    }
     {
         std::vector<uint32_t> order{ 0u }, pos(full.size(), 0u);
         for (size_t i = 0; i < order.size(); ++i)
