@@ -566,7 +566,9 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     // (before the spatial splits four triangles per leaf were best for the large scenes — config 5 at 256 spp, 1 / 2 / 3 / 4: 335 / 288 /
     // 283 / 275 ms; with them 2 / 3 / 4: k_wf_trace 110.0 / 116.1 / 113.9 ms)
     const bool sbvh = n >= 1024 && !mtr::knob("MTR_BVH_NO_SBVH");
-    if (never_in_lds) { B.kLeafTarget = sbvh ? 2 : 4; B.kBins = 32; }          // (SAH bins 16 / 32 / 64: k_wf_trace 119.9 / 113.9 / 113.5 ms)
+    // (round 6, with the planned 8-wide collapse: leaf target 1 / 2 / 3 k_wf_trace 101.8 / 103.7 / 111.1 ms at 256 spp — the planner fills the nodes,
+    // so single-triangle leaves where the SAH wants them cost no node steps any more)
+    if (never_in_lds) { B.kLeafTarget = sbvh ? 1 : 4; B.kBins = 32; }          // (SAH bins 16 / 32 / 64: k_wf_trace 119.9 / 113.9 / 113.5 ms)
     if (const char *e = mtr::knob("MTR_BVH_BINS")) { B.kBins = atoi(e); if (B.kBins < 4) B.kBins = 4; if (B.kBins > Builder::kMaxBins) B.kBins = Builder::kMaxBins; }   // experiments
     if (const char *e = mtr::knob("MTR_BVH_LEAF")) { B.kLeafTarget = (uint32_t)atoi(e); if (B.kLeafTarget < 1) B.kLeafTarget = 1; if (B.kLeafTarget > 4) B.kLeafTarget = 4; }   // experiments
     S.tmp.reserve(3 * (size_t)n);
@@ -641,7 +643,10 @@ void build_bvh(const float *verts, uint32_t n, const BvhPrims *prims, BvhBuild &
     // references are duplicated, the budget (as many duplicates as triangles) is a bound on memory, not a tuning knob.
     // Config 5 at 256 spp, k_wf_trace per render: no splits 161 ms, early split clipping (rounds 2-5) 131 ms, spatial splits 113.5 ms
     // (both together 121 ms: pieces cut before the build take the planes the builder would have chosen).
-    long long dup_budget = sbvh ? (long long)n : 0;
+    // (round 6: alpha 3e-7 with room for 2 n duplicates — the parallel build pays for them: staircase build_bvh 0.98 s, 276 k leaves instead of 208 k;
+    // alpha 1e-6 / 3e-7 / 1e-7 with leaf target 1: k_wf_trace 101.8 / 100.8 / 99.5 ms at 256 spp, the last at 342 k leaves and 1.2 s)
+    long long dup_budget = sbvh ? 2ll * (long long)n : 0;
+    if (sbvh) B.kAlpha = 3e-7f;
     if (const char *e = mtr::knob("MTR_BVH_SBVH_BUDGET")) dup_budget = (long long)(atof(e) * (double)n);
     if (const char *e = mtr::knob("MTR_BVH_SBVH_ALPHA")) B.kAlpha = (float)atof(e);
     if (mtr::knob("MTR_BVH_UNSPLIT")) B.kUnsplit = true;
