@@ -266,6 +266,7 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
                 ft.xf[b][15] = 0.0f;
             }
             s->dev.traits |= kTrFlatTop;
+            if (prim_mask >> root.n_quads) s->dev.traits |= kTrFlatLeaves;
         }
     }
     s->dev.bvh_depth = hs.bvh_depth; s->n_leaves = hs.n_leaves;
@@ -386,7 +387,7 @@ int mtr_scene_traits(const mtr_scene *s, uint32_t *traits)
 {
     if (!s || !traits) return MTR_ERR_INVALID;
     static_assert(MTR_TRAIT_DIFFUSE == kTrDiffuse && MTR_TRAIT_ONE_RECT_EMITTER == kTrOneRectEmitter && MTR_TRAIT_LEAF_PAIR == kTrLeafPair &&
-                  MTR_TRAIT_FLAT_TOP == kTrFlatTop, "public trait bits");
+                  MTR_TRAIT_FLAT_TOP == kTrFlatTop && MTR_TRAIT_FLAT_LEAVES == kTrFlatLeaves, "public trait bits");
     *traits = s->dev.traits;
     return MTR_OK;
 }

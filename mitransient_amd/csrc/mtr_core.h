@@ -1022,7 +1022,9 @@ __device__ __forceinline__ T kernarg_copy(size_t offset)
 //              nearest entry distance t1 (child k1) and the second nearest t2; the nearest is intersected first, and when
 //              the hit so far lies in front of t2 every other candidate is culled exactly as a node step taken now would cull it.
 // Shadow rays leave at their first hit; the rectangle tests of a wave whose rays all ended on a box are skipped.
-template <bool ANY_HIT, bool ONE_PAIR, class Stack>
+// TOP_LEAVES: the top level may hold triangle leaves beside rectangles and boxes (kTrFlatLeaves).  A compile-time fact, not a test of
+// FlatTop::prim_mask at run time: with the general form in the Cornell box's kernel config 2 took 54.1 instead of 52.8 ms (round 6).
+template <bool ANY_HIT, bool ONE_PAIR, bool TOP_LEAVES, class Stack>
 __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, Stack &st)
 {
     typedef WNode N;
@@ -1081,7 +1083,8 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
             const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tb));
             const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
             const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tb));
-            const bool h0 = (tn0 <= tf0) && ((fh.prim_mask >> (2u * j)) & 1u), h1 = (tn1 <= tf1) && ((fh.prim_mask >> (2u * j + 1u)) & 1u);
+            const bool h0 = (tn0 <= tf0) && (TOP_LEAVES ? ((fh.prim_mask >> (2u * j)) & 1u) != 0u : 2u * j < fh.n_quads);
+            const bool h1 = (tn1 <= tf1) && (TOP_LEAVES ? ((fh.prim_mask >> (2u * j + 1u)) & 1u) != 0u : 2u * j + 1u < fh.n_quads);
             qm |= (h0 ? 1u : 0u) << (2u * j);
             qm |= (h1 ? 2u : 0u) << (2u * j);
             if (!ANY_HIT) {
@@ -1090,10 +1093,15 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
                 key2 = min(key2, max(key1, kb)); key1 = min(key1, kb);
             }
         };
-        slab_pair(0u);
-        if (fh.prim_mask > 3u) slab_pair(1u);
-        if (fh.prim_mask > 15u) slab_pair(2u);
-        if (kWide > 6u && fh.prim_mask > 63u) slab_pair(3u);
+        if (TOP_LEAVES) {
+            slab_pair(0u);
+            if (fh.prim_mask > 3u) slab_pair(1u);
+            if (fh.prim_mask > 15u) slab_pair(2u);
+            if (kWide > 6u && fh.prim_mask > 63u) slab_pair(3u);
+        } else {
+            slab_pair(0u); slab_pair(1u); slab_pair(2u);
+            if (kWide > 6u && fh.n_quads > 6u) slab_pair(3u);
+        }
         if (!live) qm = 0u;
         st.prof_flat(2);
         for (uint32_t it = 0; __ballot(qm != 0u) != 0ull; ++it) {
@@ -1102,7 +1110,7 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
                 qm &= ~(1u << k);
                 tr.cur = *(const int32_t *)(root + N::kRefOff + 4u * k);
                 // (a rectangle or — only where the top level holds triangle leaves — a leaf of one or two pairs)
-                const bool found = (fh.prim_mask >> fh.n_quads) == 0u || is_quad_leaf(tr.cur) ? trav_quad_test(tr, sc, st, ANY_HIT) : trav_leaf_test<ONE_PAIR>(tr, sc, st, ANY_HIT);
+                const bool found = (!TOP_LEAVES || is_quad_leaf(tr.cur)) ? trav_quad_test(tr, sc, st, ANY_HIT) : trav_leaf_test<ONE_PAIR>(tr, sc, st, ANY_HIT);
                 if (ANY_HIT ? found : (it == 0u && tr.h.t < bitsf(key2 & ~7u))) qm = 0u;
             }
         }
@@ -1114,9 +1122,9 @@ __device__ __forceinline__ void flat_walk_device(Trav &tr, const SceneView &sc, 
 
 // run-to-completion ("while-while": the wave walks inner nodes until every lane holds a leaf, then
 // intersects leaves together)
-// FLAT: the scene has a flat top level (kTrFlatTop, FlatTop) — the device does not walk its tree at all (flat_walk_device); a host
-// build walks the tree, whose result is the same by construction
-template <bool ANY_HIT, bool ONE_PAIR = false, bool FLAT = false, class Stack>
+// FLAT: the scene has a flat top level (kTrFlatTop, FlatTop; 2: one that may hold triangle leaves, kTrFlatLeaves) — the device does not walk its
+// tree at all (flat_walk_device); a host build walks the tree, whose result is the same by construction
+template <bool ANY_HIT, bool ONE_PAIR = false, int FLAT = 0, class Stack>
 MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 {
     Trav tr;
@@ -1126,7 +1134,7 @@ MTR_HD Hit traverse(const SceneView &sc, f3 o, f3 d, float tmax, Stack &st)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     if (FLAT) {
-        if (tr.cur != kTravDone) flat_walk_device<ANY_HIT, ONE_PAIR>(tr, sc, st);
+        if (tr.cur != kTravDone) flat_walk_device<ANY_HIT, ONE_PAIR, FLAT == 2>(tr, sc, st);
         return tr.h;
     }
 #endif
@@ -1707,10 +1715,13 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 //     leaves never do): the leaf test is one packed pass without a loop around it.
 //   kTrFlatTop: the 8-wide tree is a root whose children are analytic rectangles and at most kFlatMaxBoxes box nodes (FlatTop):
 //     the kernels do not walk it (flat_walk_device).
-constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u;
+//   kTrFlatLeaves: ... and triangle leaves among them.
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u, kTrFlatLeaves = 16u;
+constexpr int flat_kind(uint32_t tr) { return (tr & kTrFlatTop) ? ((tr & kTrFlatLeaves) ? 2 : 1) : 0; }
 constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0
 constexpr uint32_t kTrCornellFlat = kTrCornell | kTrFlatTop;                       // ... and with the flat top level
 constexpr uint32_t kTrFlatFlags = kTrFlatTop | kTrLeafPair;                        // ... the flat top level alone (its box faces are pairs), any materials and emitters
+constexpr uint32_t kTrFlatGeneral = kTrFlatFlags | kTrFlatLeaves;                  // ... the instantiation for it: takes top levels with and without triangle leaves
 
 template <bool ROUGH = true, uint32_t TR = 0u>
 MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, float ub, f3 albedo)
@@ -2093,7 +2104,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
                         Stack &st, Sink &sink, BounceStats &stats, const Refresh &refresh = Refresh(), bool unwarp_here = false)
 {
     st.prof_mark(2);
-    Hit h = traverse<false, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
+    Hit h = traverse<false, (TR & kTrLeafPair) != 0u, flat_kind(TR)>(sc, p.ray.o, p.ray.d, p.ray.tmax, st);       // :148-151
     st.prof_mark(0);
     stats.closest++;
     Pending pd; Ray shadow;
@@ -2110,7 +2121,7 @@ MTR_HD bool path_bounce(Path &p, const SceneView &sc, const Film &film, const Re
     bool occluded = false;
     if (pd.has_shadow) {
         stats.shadow++;
-        Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sc, shadow.o, shadow.d, shadow.tmax, st);
+        Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, flat_kind(TR)>(sc, shadow.o, shadow.d, shadow.tmax, st);
         occluded = sh.prim >= 0;
     }
     st.prof_mark(0);

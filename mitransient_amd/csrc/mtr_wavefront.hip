@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(kBlock, SCENE_LDS ? MTR_WF_SHADE_WAVES_LDS : M
                     if (pd.has_shadow) {
                         ++n_shadow;
                         if (SCENE_LDS) {                  // short rays out of LDS: tracing them right here is cheaper (config 2: 168 vs 243 ms)
-                            Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, (TR & kTrFlatTop) != 0u>(sv, shadow.o, shadow.d, shadow.tmax, st);
+                            Hit sh = traverse<true, (TR & kTrLeafPair) != 0u, flat_kind(TR)>(sv, shadow.o, shadow.d, shadow.tmax, st);
                             occluded = sh.prim >= 0;
                         } else {
                             // the ray goes to the segment's shadow list (k_wf_trace, any-hit, runs next), the term is parked and
