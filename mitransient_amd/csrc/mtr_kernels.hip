@@ -777,7 +777,9 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat)      // ... and a flat top level: no tree walk either (flat_walk_device)
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornellFlat> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornellFlat>;
-    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags)      // the flat top level under the general shading code (a mirror box, two lights ...)
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatGeneral) == kTrFlatFlags)    // the flat top level under the general shading code (a mirror box, two lights ...)
+        k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrFlatFlags> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrFlatFlags>;
+    else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatGeneral) == kTrFlatGeneral)  // ... with triangle leaves among the top level's children
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrFlatGeneral> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrFlatGeneral>;
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrCornell) == kTrCornell)          // diffuse materials, one rectangle emitter: the specialised shading code
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornell> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
