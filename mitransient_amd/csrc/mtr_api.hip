@@ -240,6 +240,12 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
             }
         if (leaf_pairs) s->dev.traits |= kTrLeafPair;
     }
+    if (s->dev.has_rough) {          // kTrNoLobes: the extended shading code is needed for normals / bitmaps only
+        bool lobes = false;
+        for (uint32_t i = 0; i < d->n_materials; ++i)
+            if (bsdf_is_rough(d->materials[i].type) || d->materials[i].type == MTR_BSDF_THINDIELECTRIC) lobes = true;
+        if (!lobes) s->dev.traits |= kTrNoLobes;
+    }
     // kTrFlatTop (any materials): the root's children are rectangles and box nodes, the boxes' nodes follow the root in order
     memset(&s->dev.flat, 0, sizeof s->dev.flat);
     if (hs.has_wide && !hs.wnodes.empty() && hs.wide_levels <= 2 && !mtr::knob("MTR_NO_FLAT")) {
@@ -387,7 +393,7 @@ int mtr_scene_traits(const mtr_scene *s, uint32_t *traits)
 {
     if (!s || !traits) return MTR_ERR_INVALID;
     static_assert(MTR_TRAIT_DIFFUSE == kTrDiffuse && MTR_TRAIT_ONE_RECT_EMITTER == kTrOneRectEmitter && MTR_TRAIT_LEAF_PAIR == kTrLeafPair &&
-                  MTR_TRAIT_FLAT_TOP == kTrFlatTop && MTR_TRAIT_FLAT_LEAVES == kTrFlatLeaves, "public trait bits");
+                  MTR_TRAIT_FLAT_TOP == kTrFlatTop && MTR_TRAIT_FLAT_LEAVES == kTrFlatLeaves && MTR_TRAIT_NO_LOBES == kTrNoLobes, "public trait bits");
     *traits = s->dev.traits;
     return MTR_OK;
 }

@@ -1716,7 +1716,11 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 //   kTrFlatTop: the 8-wide tree is a root whose children are analytic rectangles and at most kFlatMaxBoxes box nodes (FlatTop):
 //     the kernels do not walk it (flat_walk_device).
 //   kTrFlatLeaves: ... and triangle leaves among them.
-constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u, kTrFlatLeaves = 16u;
+//   kTrNoLobes: the scene needs the EXTENDED shading code for interpolated normals or bitmaps only — no material is a GGX / Beckmann lobe,
+//     a plastic or a thin dielectric: an extended kernel specialised on it carries none of their code (config 4: the hidden Z's vertex normals;
+//     its share 6.77 -> 6.32 ms).
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u, kTrFlatLeaves = 16u, kTrNoLobes = 32u;
+template <bool ROUGH, uint32_t TR> constexpr bool lobes_on() { return ROUGH && (TR & kTrNoLobes) == 0u; }
 constexpr int flat_kind(uint32_t tr) { return (tr & kTrFlatTop) ? ((tr & kTrFlatLeaves) ? 2 : 1) : 0; }
 constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0
 constexpr uint32_t kTrCornellFlat = kTrCornell | kTrFlatTop;                       // ... and with the flat top level
@@ -1759,8 +1763,8 @@ MTR_HD BsdfSample bsdf_sample(const mtr_material &m, f3 wi, float u1, float ua, 
             float f2 = eti * eti;
             bs.w = mk(m.c2[0] * f2, m.c2[1] * f2, m.c2[2] * f2);
         }
-    } else if (ROUGH && bsdf_is_rough(m.type)) rough_sample(m, albedo, wi, u1, ua, ub, bs);
-    else if (ROUGH && m.type == MTR_BSDF_THINDIELECTRIC) thin_dielectric_sample(m, wi, u1, bs);
+    } else if (lobes_on<ROUGH, TR>() && bsdf_is_rough(m.type)) rough_sample(m, albedo, wi, u1, ua, ub, bs);
+    else if (lobes_on<ROUGH, TR>() && m.type == MTR_BSDF_THINDIELECTRIC) thin_dielectric_sample(m, wi, u1, bs);
     if (flip) bs.wo.z = -bs.wo.z;
     return bs;
 }
@@ -1965,7 +1969,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
     }
 
     // emitter sampling (:188-213); only smooth BSDFs (diffuse, the rough lobes) take part
-    if (pd.active_next && (kDiff || mat.type == MTR_BSDF_DIFFUSE || (ROUGH && bsdf_is_rough(mat.type))) && n_emitters > 0 ) {
+    if (pd.active_next && (kDiff || mat.type == MTR_BSDF_DIFFUSE || (lobes_on<ROUGH, TR>() && bsdf_is_rough(mat.type))) && n_emitters > 0 ) {
         uint32_t ei = 0;
         if (n_emitters > 1) {
             float su = u1 * rc.n_emitters_f;
@@ -2005,7 +2009,7 @@ MTR_HD void shade_hit(Path &p, const Hit &h, const SceneView &sc, const Film &fi
                 float sdist = sqrtf(dot(sd, sd));
                 shadow.o = so; shadow.d = sd / sdist; shadow.tmax = sdist * (1.0f - kShadowEps);
                 pd.has_shadow = 1u;
-                if (ROUGH && bsdf_is_rough(mat.type)) {
+                if (lobes_on<ROUGH, TR>() && bsdf_is_rough(mat.type)) {
                     f3 bval; float bpdf;
                     pd.alb = material_albedo<ROUGH>(sc, mat, h); pd.has_alb = 1u;
                     rough_eval_pdf(mat, pd.alb, wi_e, wo, bval, bpdf);

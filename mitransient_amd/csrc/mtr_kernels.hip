@@ -458,19 +458,19 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                 LdsFixedSink sink; sink.hist = s_hist64; sink.ovf = s_ovf; sink.plane = plane; sink.row = slot * T;
                 sink.lim = a.fixed_lim; sink.dcap = a.fixed_dcap;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
+                alive = NLOS ? nlos_bounce<ROUGH, TR>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
                 LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
+                alive = NLOS ? nlos_bounce<ROUGH, TR>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else {
                 GlobalAtomicSink sink; sink.film = a.film_out; sink.film_w = a.film.width; sink.bins = T;
                 sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
-                alive = NLOS ? nlos_bounce<ROUGH>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
+                alive = NLOS ? nlos_bounce<ROUGH, TR>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             }
@@ -711,7 +711,7 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     else { G = g_want; cfg.hist_lds = false; }                          // row > LDS: f32 atomics to HBM
     cfg.fixed = det && cfg.hist_lds;
     cfg.rough = sc.has_rough != 0u;
-    cfg.traits = cfg.rough ? 0u : sc.traits;
+    cfg.traits = cfg.rough ? (sc.traits & kTrNoLobes) : (sc.traits & ~kTrNoLobes);
     // the kernel with the flat top level (launch_fused_s picks it under exactly this condition) walks no tree: no stack rows
     if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags) {
         fixed_b -= rows * kBlock * 4;
@@ -771,6 +771,8 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     }
     else if (cfg.rough) {                  // scenes with GGX lobes / smooth normals / bitmaps: the f32 organisations only, 168 registers for the larger shading
         if (cfg.fixed) return hipErrorInvalidValue;
+        if (cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrNoLobes)) k = k_fused<true, true, NLOS, 3, false, false, true, kTrNoLobes>;      // ... for normals / bitmaps only: no lobe code
+        else
         k = cfg.scene_lds ? (cfg.hist_lds ? k_fused<true, true, NLOS, 3, false, false, true> : k_fused<true, false, NLOS, 3, false, false, true>)
                           : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
     }

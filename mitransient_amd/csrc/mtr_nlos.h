@@ -152,24 +152,25 @@ MTR_HD Ray spawn_ray_to(f3 sp, f3 sn, f3 t)
 
 // bsdf.eval (value * cos) of the smooth BSDFs: diffuse, and with EXT the GGX lobes; `albedo` = the reflectance at the hit
 // (the material's constant, or its bitmap: material_albedo)
-template <bool EXT>
+template <bool EXT, uint32_t TR = 0u>
 MTR_HD f3 bsdf_eval_cos(const mtr_material &m, f3 albedo, f3 wi, f3 wo)
 {
-    const bool rough = EXT && bsdf_is_rough(m.type);
+    const bool rough = lobes_on<EXT, TR>() && bsdf_is_rough(m.type);
     if (m.type != MTR_BSDF_DIFFUSE && !rough) return mk(0, 0, 0);
     if ((m.flags & MTR_MAT_TWOSIDED) && wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
     if (rough) { f3 val; float pdf; rough_eval_pdf(m, albedo, wi, wo, val, pdf); return val; }
     if (!(wi.z > 0.0f && wo.z > 0.0f)) return mk(0, 0, 0);
     return mk((albedo.x * kInvPi) * wo.z, (albedo.y * kInvPi) * wo.z, (albedo.z * kInvPi) * wo.z);
 }
-template <bool EXT>
-MTR_HD bool nlos_bsdf_smooth(const mtr_material &m) { return m.type == MTR_BSDF_DIFFUSE || (EXT && bsdf_is_rough(m.type)); }
+template <bool EXT, uint32_t TR = 0u>
+MTR_HD bool nlos_bsdf_smooth(const mtr_material &m) { return m.type == MTR_BSDF_DIFFUSE || (lobes_on<EXT, TR>() && bsdf_is_rough(m.type)); }
 
 // emitter_nee_sample (transientnlospath.py:432-509); `depth` is the reference's argument (not the loop depth)
 // `reload()` runs after every traversal: a caller that can re-read nc / film / rc (k_fused: from the kernarg segment, kernarg_copy)
 // does so there instead of holding ~100 uniform values in (spilled) scalar registers across the walks — path_bounce's `refresh`
 struct NoReload { MTR_HD void operator()() const {} };
-template <bool EXT, class Stack, class Sink, class Reload = NoReload>
+// TR (here and below): scene traits (mtr_core.h) — kTrNoLobes takes the rough lobes' code out of the extended instantiations
+template <bool EXT, uint32_t TR = 0u, class Stack, class Sink, class Reload = NoReload>
 MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 beta, float distance, uint32_t depth,
                            bool focus_laser, uint32_t laser, const SceneView &sc, const NlosConst &nc, const Film &film,
                            const RenderConst &rc, Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
@@ -192,7 +193,7 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
     }
     const f3 dirn = normalize(nc.l_origin - c.sp);                   // :483
     const f3 wo = mk(dot(dirn, c.ss), dot(dirn, c.stt), dot(dirn, c.sn));
-    const f3 bv = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);
+    const f3 bv = bsdf_eval_cos<EXT, TR>(mat, albedo, c.wi, wo);
     if (nc.filter_depth != -1 && depth != (uint32_t)nc.filter_depth) return mk(0, 0, 0);      // :489-490
     if ((nc.flags & MTR_NLOS_DISCARD_DIRECT) && !(depth > 2)) return mk(0, 0, 0);             // :491-492
     const f3 Lr = mk((beta.x * bv.x) * w.x, (beta.y * bv.y) * w.y, (beta.z * bv.z) * w.z);    // :493
@@ -207,7 +208,7 @@ MTR_HD f3 nlos_emitter_nee(Path &p, const HitCtx &c, const mtr_material &mat, f3
 }
 
 // emitter_laser_targets_sample (:511-564)
-template <bool EXT, class Stack, class Sink, class Reload = NoReload>
+template <bool EXT, uint32_t TR = 0u, class Stack, class Sink, class Reload = NoReload>
 MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, f3 albedo, f3 lt, uint32_t depth, uint32_t laser,
                              const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
                              Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
@@ -219,7 +220,7 @@ MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, 
     stats.shadow++;
     if (traverse<true>(sc, rb.o, rb.d, rb.tmax, st).prim >= 0) { reload(); return mk(0, 0, 0); }             // :528
     const f3 wo = mk(dot(dd, c.ss), dot(dd, c.stt), dot(dd, c.sn));
-    const f3 bs = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);                                  // :531-533
+    const f3 bs = bsdf_eval_cos<EXT, TR>(mat, albedo, c.wi, wo);                              // :531-533
     const Hit h2 = traverse<false>(sc, rb.o, rb.d, kInf, st);                                  // :535-537
     reload();
     stats.closest++;
@@ -231,12 +232,12 @@ MTR_HD f3 nlos_laser_targets(Path &p, const HitCtx &c, const mtr_material &mat, 
     if (!(wlz > 0.0f)) return mk(0, 0, 0);                                                     // :543
     const float pdf_ls = (dl * dl) / wlz;                                                      // :546-551
     const f3 b2 = mk(p.beta.x * (bs.x / pdf_ls), p.beta.y * (bs.y / pdf_ls), p.beta.z * (bs.z / pdf_ls));
-    return nlos_emitter_nee<EXT>(p, c2, sc.mats[c2.mat], material_albedo<EXT>(sc, sc.mats[c2.mat], h2), b2, p.dist + dl * p.eta, depth + 1, true,
+    return nlos_emitter_nee<EXT, TR>(p, c2, sc.mats[c2.mat], material_albedo<EXT>(sc, sc.mats[c2.mat], h2), b2, p.dist + dl * p.eta, depth + 1, true,
                                  laser, sc, nc, film, rc, st, sink, stats, reload);
 }
 
 // hidden_geometry_sample (:637-670) incl. _sample_hidden_geometry_position (:385-430)
-template <bool EXT>
+template <bool EXT, uint32_t TR = 0u>
 MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat, f3 albedo, float ua, float ub, const NlosConst &nc)
 {
     BsdfSample bs;
@@ -261,7 +262,7 @@ MTR_HD BsdfSample nlos_hidden_geometry(const HitCtx &c, const mtr_material &mat,
     bs.pdf = ppdf * (dist * dist) / fabsf(cos_g);
     if (!(cos_i > kDrEps && cos_g > kDrEps)) return bs;
     if (!(bs.pdf > kDrEps)) return bs;
-    const f3 val = bsdf_eval_cos<EXT>(mat, albedo, c.wi, wo);
+    const f3 val = bsdf_eval_cos<EXT, TR>(mat, albedo, c.wi, wo);
     bs.w = mk(val.x / bs.pdf, val.y / bs.pdf, val.z / bs.pdf);
     return bs;
 }
@@ -275,7 +276,7 @@ MTR_HD f3 nlos_laser_target(const NlosConst &nc, uint32_t px, uint32_t py)
 }
 
 // One iteration of TransientNLOSPath.sample (:740-918).  Returns active_next.
-template <bool EXT = false, class Stack, class Sink, class Reload = NoReload>
+template <bool EXT = false, uint32_t TR = 0u, class Stack, class Sink, class Reload = NoReload>
 MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const Film &film, const RenderConst &rc,
                         Stack &st, Sink &sink, BounceStats &stats, const Reload &reload = Reload())
 {
@@ -292,22 +293,22 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     const mtr_material &mat = sc.mats[c.mat];
     const f3 albedo = valid ? material_albedo<EXT>(sc, mat, h) : mk(0, 0, 0);
     // the only emitter is the projector (not a surface): Le = 0 (:757-777)
-    if (active_next && nlos_bsdf_smooth<EXT>(mat)) {                                 // active_em :785-786
+    if (active_next && nlos_bsdf_smooth<EXT, TR>(mat)) {                                 // active_em :785-786
         if ((nc.flags & MTR_NLOS_LASER_SAMPLING) && nc.capture_type == MTR_CAPTURE_EXHAUSTIVE) {
             // every illuminated point in turn (:597-621); target i lands in film cell laser_x = i / Ly, laser_y = i % Ly,
             // i.e. row offset i * T; the steady estimate is the mean over the grid
             const uint32_t nl = nc.laser_w * nc.laser_h, t0 = nc.film_w * nc.film_h + 1u;
             for (uint32_t i = 0; i < nl; ++i) {
                 const q4 t = nc.targets[t0 + i];
-                const f3 li = nlos_laser_targets<EXT>(p, c, mat, albedo, mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats, reload);
+                const f3 li = nlos_laser_targets<EXT, TR>(p, c, mat, albedo, mk(t.x, t.y, t.z), p.depth + 1u, i, sc, nc, film, rc, st, sink, stats, reload);
                 Lr = mk(Lr.x + li.x, Lr.y + li.y, Lr.z + li.z);
             }
             const float nlf = (float)nl;
             Lr = mk(Lr.x / nlf, Lr.y / nlf, Lr.z / nlf);
         } else if (nc.flags & MTR_NLOS_LASER_SAMPLING)                                            // emitter_laser_sample: depth + 1
-            Lr = nlos_laser_targets<EXT>(p, c, mat, albedo, nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats, reload);
+            Lr = nlos_laser_targets<EXT, TR>(p, c, mat, albedo, nlos_laser_target(nc, p.px, p.py), p.depth + 1u, 0u, sc, nc, film, rc, st, sink, stats, reload);
         else
-            Lr = nlos_emitter_nee<EXT>(p, c, mat, albedo, p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats, reload);
+            Lr = nlos_emitter_nee<EXT, TR>(p, c, mat, albedo, p.beta, p.dist, p.depth, false, 0u, sc, nc, film, rc, st, sink, stats, reload);
     }
     // hidden-geometry / BSDF sampling (:797-833)
     const bool hg = (nc.flags & MTR_NLOS_HG_SAMPLING) != 0;
@@ -321,8 +322,8 @@ MTR_HD bool nlos_bounce(Path &p, const SceneView &sc, const NlosConst &nc, const
     BsdfSample bs;
     bs.wo = mk(0, 0, 0); bs.pdf = 0.0f; bs.eta = 1.0f; bs.delta = false; bs.w = mk(0, 0, 0);
     if (active_next) {
-        if (do_hg) bs = nlos_hidden_geometry<EXT>(c, mat, albedo, a2a, a2b, nc);
-        else bs = bsdf_sample<EXT>(mat, c.wi, b1, b2a, b2b, albedo);
+        if (do_hg) bs = nlos_hidden_geometry<EXT, TR>(c, mat, albedo, a2a, a2b, nc);
+        else bs = bsdf_sample<EXT, TR & kTrNoLobes>(mat, c.wi, b1, b2a, b2b, albedo);
         const f3 wo_w = mk(fmaf(c.sn.x, bs.wo.z, fmaf(c.stt.x, bs.wo.y, c.ss.x * bs.wo.x)),
                            fmaf(c.sn.y, bs.wo.z, fmaf(c.stt.y, bs.wo.y, c.ss.y * bs.wo.x)),
                            fmaf(c.sn.z, bs.wo.z, fmaf(c.stt.z, bs.wo.y, c.ss.z * bs.wo.x)));

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from conftest import make_nlos, rel_l2
+from mitransient_amd import _cabi
 from test_nlos import CONFIGS
 
 pytestmark = pytest.mark.gpu
@@ -222,6 +223,8 @@ def test_hidden_mesh_with_vertex_normals_and_rough_lobes_gpu(oracle, tmp_path, b
     else:
         s_ref, t_ref, cnt = _oracle(oracle, scene, 64)
     assert np.count_nonzero(t_ref) > 20 and rel_l2(t_gpu, t_ref) <= TOL
+    # normals without lobes: the extended kernel built without the lobe code (k_fused<..., kTrNoLobes>) — the same numbers
+    assert bool(scene.gpu_traits() & _cabi.MTR_TRAIT_NO_LOBES) == (bsdf == "diffuse")
     if capture != "exhaustive":              # (an exhaustive film's steady image is the mean over time: test_exhaustive_matches_oracle)
         assert np.linalg.norm(s_ref) == 0 or rel_l2(s_gpu, s_ref) <= TOL
     got = scene.integrator().last_counters
@@ -240,6 +243,7 @@ def test_textured_hidden_geometry_gpu(oracle, tmp_path, mode):
     s_gpu, t_gpu = _gpu(scene, 64)
     s_ref, t_ref, cnt = _oracle(oracle, scene, 64)
     assert np.count_nonzero(t_ref) > 50 and rel_l2(t_gpu, t_ref) <= TOL
+    assert scene.gpu_traits() & _cabi.MTR_TRAIT_NO_LOBES
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
