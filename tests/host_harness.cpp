@@ -15,6 +15,10 @@
 
 using namespace mtr;
 
+#ifdef HH_WALK_STATS          // tools/walk_stats.py: node steps / primitive passes of the host walk (one thread)
+static uint64_t g_walk_steps[2];
+extern "C" void hh_walk_steps(uint64_t *out, int reset) { out[0] = g_walk_steps[0]; out[1] = g_walk_steps[1]; if (reset) g_walk_steps[0] = g_walk_steps[1] = 0; }
+#endif
 namespace {
 struct ArrStack {
     static constexpr bool kPark = false;      // (k_fused's stack can park path state in LDS: mtr_kernels.hip)
@@ -30,7 +34,11 @@ struct ArrStack {
     int32_t pop() { return v[--sp]; }
     bool empty() const { return sp == 0; }
     void prof_mark(int) {}
+#ifdef HH_WALK_STATS
+    void count(int k) { ++g_walk_steps[k]; }
+#else
     void count(int) {}
+#endif
 };
 struct HostSink {
     float *film; uint32_t W, T; uint64_t n;
@@ -156,6 +164,25 @@ extern "C" int hh_bvh_info(const mtr_scene_desc *d, uint32_t *n_nodes, uint32_t 
     HostScene hs;
     if (derive_scene(*d, hs)) return -1;
     *n_nodes = (uint32_t)hs.nodes.size(); *depth = hs.bvh_depth; *leaves = hs.n_leaves;
+    return 0;
+}
+
+// leaves of the quantised 8-wide tree by triangle count (1 .. 4), rectangles in [0]; nodes and children in [5], [6]
+extern "C" int hh_leaf_sizes(const mtr_scene_desc *d, uint64_t *out7)
+{
+    HostScene hs;
+    if (derive_scene(*d, hs)) return -1;
+    for (int k = 0; k < 7; ++k) out7[k] = 0;
+    for (const QNode8 &n : hs.wnodes8q) {
+        const uint32_t cnt = (fbits(n.q[0].w) >> 26) & 0xfu;
+        ++out7[5]; out7[6] += cnt;
+        for (uint32_t c = 0; c < cnt; ++c) {
+            const int32_t ref = *((const int32_t *)&n.q[4] + c);
+            if (ref >= 0) continue;
+            const uint32_t code = ~(uint32_t)ref;
+            ++out7[(code & kLeafQuadBit) ? 0u : (code & 3u) + 1u];
+        }
+    }
     return 0;
 }
 

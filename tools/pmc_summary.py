@@ -76,11 +76,14 @@ def summarise(out, tag, renders):
             e.update({"valu_insts_per_launch": v["SQ_INSTS_VALU"] / nv,
                       "valu_lanes_per_inst": v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"],
                       "lds_insts_per_launch": v.get("SQ_INSTS_LDS", 0.0) / nv, "salu_insts_per_launch": v.get("SQ_INSTS_SALU", 0.0) / nv,
+                      "vmem_insts_per_launch": v.get("SQ_INSTS_VMEM", 0.0) / nv,
                       "wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / max(1.0, v.get("SQ_WAVE_CYCLES", 1.0)),
                       "wait_inst_any_frac": v.get("SQ_WAIT_INST_ANY", 0.0) / max(1.0, v.get("SQ_WAVE_CYCLES", 1.0)),
                       "profile": tag})
             if renders:
                 e["valu_insts_per_render"] = v["SQ_INSTS_VALU"] / renders
+                e["vmem_insts_per_render"] = v.get("SQ_INSTS_VMEM", 0.0) / renders
+                e["l2_requests_per_render"] = (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)) / renders
                 e["launches_per_render"] = nv / renders
         traffic[m.group(0)] = e
     json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
