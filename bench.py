@@ -230,11 +230,13 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok, s
                                 "honest utilisation figure; HBM traffic is a small fraction of the roof (scene resident in L2)",
                         "source": "profiles/traffic.json[" + section + "] (rocprofv3 --pmc, same sources) over k_wf_trace's own HIP-event time, live"})
             if c5.get("vmem_insts_per_render"):
-                # what bounds the kernel: divergent loads.  Vector-memory wave-instructions x active lanes = lane addresses the CU's
-                # texture addresser takes (a node step costs a lane 4 loads, a visited child 1 — its reference —, a triangle pair 5:
-                # tools/walk_stats.py), and the lines they miss in L1 go to L2 one request each; the round-1 microbenchmark of exactly
-                # this access pattern (profiles/r01_divergent_load_microbench.txt) reaches 0.10 - 0.16 L2 lines per clock and CU on a
-                # 32 - 8 MB set (the staircase: 5.5 MB of nodes + 22 MB of triangle pairs)
+                # the kernel's divergent loads as rates.  Vector-memory wave-instructions x active lanes = lane addresses (a node step
+                # costs a lane 4 loads, a visited child 1 — its reference —, a triangle pair 5: tools/walk_stats.py); the lines they miss
+                # in L1 go to L2 one request each; the round-1 microbenchmark of this access pattern
+                # (profiles/r01_divergent_load_microbench.txt) reaches 0.10 - 0.16 L2 lines per clock and CU on a 32 - 8 MB set (the
+                # staircase: 5.5 MB of nodes + 22 MB of triangle pairs).  NOT a roof the kernel leans on: fetching a quad's four nodes
+                # with quad-coalesced loads (a quarter of the node steps' lane addresses, transposed through LDS) made it 23 % slower
+                # (HISTORY.md: "quad fetch") — what it waits for is the latency of DEPENDENT loads (wait_any_frac)
                 lane_loads = c5["vmem_insts_per_render"] * c5["valu_lanes_per_inst"]
                 clk_cu = trace_ms * 1e-3 * 2.4e9 * 256.0
                 blk["divergent_loads"] = {"vmem_insts_per_render": c5["vmem_insts_per_render"], "lane_loads_per_render": lane_loads,
@@ -243,7 +245,8 @@ def wavefront_rooflines(counters, times, n_renders, ms_per_render, profile_ok, s
                                           "l2_requests_per_clk_per_cu": (c5["l2_requests_per_render"] / clk_cu) if c5.get("l2_requests_per_render") else None,
                                           "microbench_l2_lines_per_clk_per_cu": [0.10, 0.16],
                                           "note": "lane addresses = vector-memory wave-instructions x active lanes (the VALU average); L2 requests = "
-                                                  "TCC_HIT + TCC_MISS of the PMC pass; both over the kernel's live time, 256 CUs at 2.4 GHz"}
+                                                  "TCC_HIT + TCC_MISS of the PMC pass; both over the kernel's live time, 256 CUs at 2.4 GHz; "
+                                                  "diagnostic rates, not roofs: the kernel waits on dependent-load latency"}
         else:
             blk.update({"achieved": None, "frac": None, "roofline_stale": True,
                         "note": "instruction counts need the PMC pass of THESE sources (tools/profile_all.sh); the live kernel time stands"})
