@@ -125,6 +125,9 @@ def test_textured_scene_matches_oracle(oracle, tmp_path, mode, bsdf_type):
     s_gpu, t_gpu = gpu_render(scene, 16, seed=4)
     s_ref, t_ref, s4, t4, cnt = oracle_render(oracle, scene, 16, seed=4)
     assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    # bitmaps without lobes: the extended kernel built without the lobe code (scene trait kTrNoLobes) — the same numbers
+    from mitransient_amd import _cabi
+    assert bool(scene.gpu_traits() & _cabi.MTR_TRAIT_NO_LOBES) == (bsdf_type == "diffuse")
     got = scene.integrator().last_counters
     for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
         assert got[k] == cnt[k], k
