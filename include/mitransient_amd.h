@@ -359,6 +359,7 @@ int  mtr_scene_bvh_info(const mtr_scene *, uint32_t *n_nodes, uint32_t *max_dept
 #define MTR_TRAIT_FLAT_TOP         8u   /* top level = rectangles, triangle leaves and box nodes: the fused kernel does not walk a tree */
 #define MTR_TRAIT_FLAT_LEAVES     16u   /* ... and there are triangle leaves among them */
 #define MTR_TRAIT_NO_LOBES        32u   /* extended shading (interpolated normals, bitmaps) without any microfacet lobe / plastic / thin dielectric */
+#define MTR_TRAIT_GREY            64u   /* every colour (materials, emitters, the NLOS laser) has three equal channels, no bitmaps: r == g == b in every contribution */
 int  mtr_scene_traits(const mtr_scene *, uint32_t *traits);
 
 /* TransientImageBlock.clear (transient_image_block.py:56-70): zero the

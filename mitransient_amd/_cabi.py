@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MITRANSIENT_AMD_LIB") or os.path.join(_HERE, "csrc", "libmitransient_amd.so")   # env override: kernel A/B experiments
 
 MTR_ABI_VERSION = 12
-MTR_TRAIT_DIFFUSE, MTR_TRAIT_ONE_RECT_EMITTER, MTR_TRAIT_LEAF_PAIR, MTR_TRAIT_FLAT_TOP, MTR_TRAIT_FLAT_LEAVES, MTR_TRAIT_NO_LOBES = 1, 2, 4, 8, 16, 32      # mtr_scene_traits
+MTR_TRAIT_DIFFUSE, MTR_TRAIT_ONE_RECT_EMITTER, MTR_TRAIT_LEAF_PAIR, MTR_TRAIT_FLAT_TOP, MTR_TRAIT_FLAT_LEAVES, MTR_TRAIT_NO_LOBES, MTR_TRAIT_GREY = 1, 2, 4, 8, 16, 32, 64      # mtr_scene_traits
 MTR_SPLAT_FILM_ZERO = 0x100      # mtr_splat_add: OR into `variant` when the film is all-zero on entry
 
 MTR_BSDF_DIFFUSE, MTR_BSDF_CONDUCTOR, MTR_BSDF_DIELECTRIC, MTR_BSDF_NULL = 0, 1, 2, 3

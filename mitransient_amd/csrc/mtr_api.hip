@@ -60,6 +60,7 @@ struct mtr_scene {
     std::vector<float> tri_normals;          // ... and the vertex normals (empty without): Mesh::sample_position on hidden meshes
     float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };   // bounds of the triangles (the grid of the wavefront organisation's trace order)
     uint32_t n_emitters_area = 0;
+    bool grey_scene = false;                                 // kTrGrey without the NLOS laser (mtr_scene_set_nlos decides with it)
     SceneDev dev{};
     Camera cam{};
     Film film{};
@@ -246,6 +247,19 @@ int mtr_scene_create(mtr_ctx *c, const mtr_scene_desc *d, mtr_scene **out)
             if (bsdf_is_rough(d->materials[i].type) || d->materials[i].type == MTR_BSDF_THINDIELECTRIC) lobes = true;
         if (!lobes) s->dev.traits |= kTrNoLobes;
     }
+    {   // kTrGrey (the scene's part; mtr_scene_set_nlos adds the laser's): three equal channels in every colour, no bitmap
+        auto eq3 = [](const float *v) { return memcmp(v, v + 1, sizeof(float)) == 0 && memcmp(v, v + 2, sizeof(float)) == 0; };
+        bool grey = hs.texels.empty();
+        for (uint32_t i = 0; grey && i < d->n_materials; ++i) {
+            const mtr_material &m = d->materials[i];
+            const bool aniso = (m.flags & MTR_MAT_ANISOTROPIC) != 0u;
+            grey = m.albedo_texture == 0u && eq3(m.a) && eq3(m.c) &&
+                   ((aniso && m.type == MTR_BSDF_ROUGHDIELECTRIC) || eq3(m.b)) && ((aniso && m.type == MTR_BSDF_ROUGHCONDUCTOR) || eq3(m.c2));
+        }
+        for (uint32_t i = 0; grey && i < d->n_emitters; ++i) grey = eq3(d->emitters[i].radiance);
+        s->grey_scene = grey;
+        if (grey) s->dev.traits |= kTrGrey;
+    }
     // kTrFlatTop (any materials): the root's children are rectangles and box nodes, the boxes' nodes follow the root in order
     memset(&s->dev.flat, 0, sizeof s->dev.flat);
     if (hs.has_wide && !hs.wnodes.empty() && hs.wide_levels <= 2 && !mtr::knob("MTR_NO_FLAT")) {
@@ -334,6 +348,9 @@ int mtr_scene_set_nlos(mtr_scene *s, const mtr_nlos_desc *n)
     D.k.hg_tris = (const q4 *)D.hg_tris; D.k.hg_vn = (const q4 *)D.hg_vn; D.k.targets = (const q4 *)D.targets;
     HIP_TRY(c, launch_nlos_prepare(s->dev, D.k, (q4 *)D.targets, c->stream));    // scanned points + laser axis hit
     D.on = true;
+    // kTrGrey: ... and the laser's irradiance
+    const bool laser_grey = memcmp(n->laser_irradiance, n->laser_irradiance + 1, sizeof(float)) == 0 && memcmp(n->laser_irradiance, n->laser_irradiance + 2, sizeof(float)) == 0;
+    if (s->grey_scene && laser_grey) s->dev.traits |= kTrGrey; else s->dev.traits &= ~kTrGrey;
     return MTR_OK;
 }
 
@@ -393,7 +410,8 @@ int mtr_scene_traits(const mtr_scene *s, uint32_t *traits)
 {
     if (!s || !traits) return MTR_ERR_INVALID;
     static_assert(MTR_TRAIT_DIFFUSE == kTrDiffuse && MTR_TRAIT_ONE_RECT_EMITTER == kTrOneRectEmitter && MTR_TRAIT_LEAF_PAIR == kTrLeafPair &&
-                  MTR_TRAIT_FLAT_TOP == kTrFlatTop && MTR_TRAIT_FLAT_LEAVES == kTrFlatLeaves && MTR_TRAIT_NO_LOBES == kTrNoLobes, "public trait bits");
+                  MTR_TRAIT_FLAT_TOP == kTrFlatTop && MTR_TRAIT_FLAT_LEAVES == kTrFlatLeaves && MTR_TRAIT_NO_LOBES == kTrNoLobes &&
+                  MTR_TRAIT_GREY == kTrGrey, "public trait bits");
     *traits = s->dev.traits;
     return MTR_OK;
 }

@@ -1718,8 +1718,12 @@ MTR_HD void rough_sample(const mtr_material &m, f3 albedo, f3 wi, float u1, floa
 //   kTrFlatLeaves: ... and triangle leaves among them.
 //   kTrNoLobes: the scene needs the EXTENDED shading code for interpolated normals or bitmaps only — no material is a GGX / Beckmann lobe,
 //     a plastic or a thin dielectric: an extended kernel specialised on it carries none of their code (config 4: the hidden Z's vertex normals;
-//     its share 6.77 -> 6.32 ms).
-constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u, kTrFlatLeaves = 16u, kTrNoLobes = 32u;
+//     its share 6.82 -> 6.66 ms).
+//   kTrGrey: every colour of the scene has three equal channels — reflectances, conductor constants, radiances, the NLOS laser's irradiance —
+//     and no bitmap: the three channels of every path run the same instructions on the same operands, so every contribution has r == g == b
+//     to the bit.  k_fused<NLOS> then keeps ONE plane of a pixel's row in LDS instead of three (the flush writes it to all three channels):
+//     an rgb row of 4096 bins is 48 KB — one row slot per workgroup, no overlap between pixels — a grey one 16 KB: three slots (config 4).
+constexpr uint32_t kTrDiffuse = 1u, kTrOneRectEmitter = 2u, kTrLeafPair = 4u, kTrFlatTop = 8u, kTrFlatLeaves = 16u, kTrNoLobes = 32u, kTrGrey = 64u;
 template <bool ROUGH, uint32_t TR> constexpr bool lobes_on() { return ROUGH && (TR & kTrNoLobes) == 0u; }
 constexpr int flat_kind(uint32_t tr) { return (tr & kTrFlatTop) ? ((tr & kTrFlatLeaves) ? 2 : 1) : 0; }
 constexpr uint32_t kTrCornell = kTrDiffuse | kTrOneRectEmitter | kTrLeafPair;      // what the kernels are instantiated for besides 0

@@ -123,6 +123,7 @@ __device__ __forceinline__ bool splat_fixed_unsafe(float r, float g, float b, fl
 #endif
 
 // the workgroup's ring of row histograms in LDS: planes [3][G*T]
+template <bool GREY = false>          // GREY (scene trait kTrGrey): r == g == b in every contribution, the row holds ONE plane
 struct LdsHistSink {
     float *hist; uint32_t plane;       // plane = G * T
     uint32_t row;                      // (local pixel) * T, set per path
@@ -134,7 +135,8 @@ struct LdsHistSink {
                                           float opl, uint32_t depth, uint32_t kind)
     {
         float *p = hist + row + bin;
-        lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b);
+        if (GREY) lds_add(p, r);
+        else { lds_add(p, r); lds_add(p + plane, g); lds_add(p + 2 * plane, b); }
         ++n_splats;
         if (log.rec) log_splat(log, lane, depth, kind, fy * film_w + fx, bin, r, g, b, opl);
     }
@@ -276,14 +278,16 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
     uint32_t *s_done = (uint32_t *)(smem + off); off += align16(K * 4);       // paths of that pixel that have ended
     float *s_hist = (float *)(smem + off);
     const uint32_t T = PHASOR ? 2u * a.film.n_freq : a.film.bins;       // floats of one plane of a row
-    const uint32_t plane = K * T;
+    // (kTrGrey: one plane per row — the "three" planes of the flush below are the same one, read three times)
+    constexpr bool kGrey = (TR & kTrGrey) != 0u;
+    const uint32_t plane = kGrey ? 0u : K * T;
 
     if (tid < 6) s_cnt[tid] = 0ull;
     for (uint32_t k = tid; k < K; k += kBlock) s_done[k] = 0u;
     for (uint32_t k = tid; k < K * 8; k += kBlock) s_steady[k] = 0.0f;
     unsigned long long *s_hist64 = (unsigned long long *)s_hist;
     float *s_ovf = s_hist + 6u * plane;                 // (FIXED) the f32 overflow ring behind the fixed-point one: [3][plane]
-    if (HIST_LDS) for (uint32_t k = tid; k < (PHASOR ? 1u : (FIXED ? 9u : 3u)) * plane; k += kBlock) s_hist[k] = 0.0f;
+    if (HIST_LDS) for (uint32_t k = tid; k < (kGrey ? K * T : (PHASOR ? 1u : (FIXED ? 9u : 3u)) * plane); k += kBlock) s_hist[k] = 0.0f;
     if (FIXED) for (uint32_t k = tid; k < K * 4; k += kBlock) s_steady_ovf[k] = 0.0f;
 
     LdsStack st; st.base = s_stack + tid; st.sp = 0;
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_fused(const FusedArgs a)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
                 if (NLOS) n_splats += sink.n_splats; else did_splats = sink.n_splats;
             } else if (HIST_LDS) {
-                LdsHistSink sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
+                LdsHistSink<(TR & kTrGrey) != 0u> sink; sink.hist = s_hist; sink.plane = plane; sink.row = slot * T;
                 sink.film_w = a.film.width; sink.lane = p.lane; sink.n_splats = 0; sink.log = a.log;
                 alive = NLOS ? nlos_bounce<ROUGH, TR>(p, sv, nc_l, film_l, rc_l, st, sink, bstat, reload_nlos)
                              : path_bounce<ROUGH, TR>(p, sv, film_l, rc_l, st, sink, bstat, refresh, unwarp);
@@ -695,7 +699,11 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (cfg.scene_lds) fixed_b += scene_b;
     // row slots: enough lanes in flight to keep 256 persistent threads busy, rows must fit in LDS
     const bool det = (args.rc.flags & MTR_FLAG_DETERMINISTIC) && !film.n_freq;
-    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * (det ? 36u : 12u);     // (Re, Im) per frequency | 3 planes of T bins (f32 | 64-bit fixed point + its f32 overflow ring)
+    // kTrGrey (NLOS loop, scene in LDS, f32 rows, the shading code without lobes — the instantiations launch_fused_s holds): ONE plane per row
+    cfg.rough = sc.has_rough != 0u;
+    const bool grey = args.nlos_on && !film.n_freq && !det && cfg.scene_lds && (sc.traits & kTrGrey) && (!cfg.rough || (sc.traits & kTrNoLobes)) &&
+                      film.bins * 4u <= 48u * 1024u && !mtr::knob("MTR_NO_GREY");
+    const uint32_t row_bytes = film.n_freq ? film.n_freq * 8u : film.bins * (det ? 36u : grey ? 4u : 12u);     // (Re, Im) per frequency | 3 planes of T bins (f32 | 64-bit fixed point + its f32 overflow ring) | one plane
     cfg.fixed = false;
     const uint32_t hist_budget = (det ? 108u : 48u) * 1024u;
     // RANGE GUARD of the fixed-point rows (LdsFixedSink): depth cap and per-channel limit of what is summed in fixed point
@@ -710,26 +718,41 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     else if (fixed_b + row_bytes + 64 <= kLdsMax) G = 1;                  // one long row still fits the CU
     else { G = g_want; cfg.hist_lds = false; }                          // row > LDS: f32 atomics to HBM
     cfg.fixed = det && cfg.hist_lds;
-    cfg.rough = sc.has_rough != 0u;
-    cfg.traits = cfg.rough ? (sc.traits & kTrNoLobes) : (sc.traits & ~kTrNoLobes);
+    cfg.traits = (cfg.rough ? (sc.traits & kTrNoLobes) : (sc.traits & ~kTrNoLobes)) & ~kTrGrey;
+    if (grey) cfg.traits |= kTrGrey;                 // (g_fit >= 1 by the bound on the bins above: hist_lds holds)
     // the kernel with the flat top level (launch_fused_s picks it under exactly this condition) walks no tree: no stack rows
     if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags) {
         fixed_b -= rows * kBlock * 4;
         args.stack_rows = 0u;
     }
+    // ROW SLOTS AGAINST WORKGROUPS PER CU (round 6).  A workgroup is one wave per SIMD; how many are resident is bounded by LDS (rows) and by
+    // registers: the kernels launch_fused_s picks hold 168 registers (three workgroups per CU: the extended shading, the fixed-point rows, the
+    // NLOS loop — whose 128-register form is 18 % SLOWER at four per CU than the 168-register one at three, measured) or 128 (four).  Residency is
+    // worth more than the ring: config 4's share with (slots, workgroups per CU) = (1, 3) 6.23 ms, (2, 3) 5.94, (3, 3) 5.96, (2, 2) 7.89;
+    // deterministic config 2 at 256 spp (3, 1) 47.3 ms against (1, 3) 27.9; 2048 bins (2, 2) 23.8 against (1, 4) 20.8 ms.  So: the slot count
+    // that fits the most workgroups a CU can hold, and among those the largest (rounds 1 - 5 took as many slots as the row budget held).
+    const int reg_cap = (cfg.rough || cfg.fixed || args.nlos_on) ? 3 : (int)MTR_FUSED_MIN_WAVES;
+    auto lds_of = [&](uint32_t g) { return (size_t)fixed_b + align16(g * 32) + (cfg.fixed ? align16(g * 16) : 0u) + 2 * align16(g * 4) + (cfg.hist_lds ? (size_t)g * row_bytes : 0) + 16; };
+    auto per_cu_of = [&](uint32_t g) { const int p = (int)(kLdsMax / lds_of(g)); return p > reg_cap ? reg_cap : p; };
+    if (cfg.hist_lds && !mtr::knob("MTR_FUSED_OLD_PLAN")) {
+        uint32_t best = G;
+        for (uint32_t g = G; g-- > 1u;) if (per_cu_of(g) > per_cu_of(best)) best = g;
+        G = best;
+    }
+    if (const char *e = mtr::knob("MTR_FUSED_G")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1u && v < G && cfg.hist_lds) G = v; }     // experiments
     if (G > n_pixels) G = n_pixels ? n_pixels : 1;
     if (G > 4096) G = 4096;
     args.G = G;
     args.div_G = fastdiv_make(G); args.div_spp = fastdiv_make(spp_chunk);
     cfg.stack = stack;
-    cfg.lds_bytes = fixed_b + align16(G * 32) + (cfg.fixed ? align16(G * 16) : 0u) + 2 * align16(G * 4) + (cfg.hist_lds ? (size_t)G * row_bytes : 0) + 16;
+    cfg.lds_bytes = lds_of(G);
     if (cfg.lds_bytes > kLdsMax) return false;
-    // persistent grid: as many workgroups as can be resident (LDS / 8 per CU), each with at least g_want pixels
-    int per_cu = (int)(kLdsMax / cfg.lds_bytes);
-    if (per_cu > 8) per_cu = 8;
+    // persistent grid: as many workgroups as can be resident, each with at least g_want pixels
+    int per_cu = per_cu_of(G);
     if (per_cu < 1) per_cu = 1;
-    if (cfg.rough && per_cu > 3) per_cu = 3;          // the extended-shading kernels hold 168 registers: three workgroups per CU are resident
+    if (mtr::knob("MTR_FUSED_OLD_PLAN")) { per_cu = (int)(kLdsMax / cfg.lds_bytes); if (per_cu > 8) per_cu = 8; if (cfg.rough && per_cu > 3) per_cu = 3; }
     if (const char *e = mtr::knob("MTR_FUSED_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }     // experiments
+    if (mtr::knob("MTR_FUSED_VERBOSE")) fprintf(stderr, "fused_plan: G %u, row %u B, lds %zu B, per_cu %d, traits %u, rough %d, fixed %d\n", G, row_bytes, (size_t)cfg.lds_bytes, per_cu, cfg.traits, (int)cfg.rough, (int)cfg.fixed);
     cfg.per_cu = per_cu;
     long grid = (long)n_cu * per_cu;
     uint32_t g_blk = g_want;                       // small renders: rather more workgroups than long pixel queues
@@ -771,7 +794,8 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
     }
     else if (cfg.rough) {                  // scenes with GGX lobes / smooth normals / bitmaps: the f32 organisations only, 168 registers for the larger shading
         if (cfg.fixed) return hipErrorInvalidValue;
-        if (cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrNoLobes)) k = k_fused<true, true, NLOS, 3, false, false, true, kTrNoLobes>;      // ... for normals / bitmaps only: no lobe code
+        if (NLOS && (cfg.traits & kTrGrey)) { if constexpr (NLOS) k = k_fused<true, true, true, 3, false, false, true, kTrNoLobes | kTrGrey>; }      // ... and one plane per row (fused_plan)
+        else if (cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrNoLobes)) k = k_fused<true, true, NLOS, 3, false, false, true, kTrNoLobes>;      // ... for normals / bitmaps only: no lobe code
         else
         k = cfg.scene_lds ? (cfg.hist_lds ? k_fused<true, true, NLOS, 3, false, false, true> : k_fused<true, false, NLOS, 3, false, false, true>)
                           : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
@@ -787,7 +811,13 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornell> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornell>;
     // (NOT for the NLOS loop, whose scene — a relay wall and three triangle pairs — is one flat node: its rays are coherent, camera ->
     // wall -> hidden geometry, and walk together; with the flat walk config 4's share took 10.5 instead of 8.8 ms, measured in round 6)
-    else if (cfg.scene_lds && cfg.hist_lds) k = cfg.per_cu <= 3 ? k_fused<true, true, NLOS, 3> : k_fused<true, true, NLOS>;
+    else if (NLOS && (cfg.traits & kTrGrey)) {      // a grey NLOS scene: one plane per row (fused_plan)
+        if constexpr (NLOS) k = k_fused<true, true, true, 3, false, false, false, kTrGrey>;
+    }
+    else if (cfg.scene_lds && cfg.hist_lds) {       // (the NLOS loop: at most three workgroups per CU — fused_plan — hence the 168-register form only)
+        if constexpr (NLOS) k = k_fused<true, true, true, 3>;
+        else k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3> : k_fused<true, true, false>;
+    }
     else if (cfg.scene_lds && !cfg.hist_lds) k = k_fused<true, false, NLOS>;
     else if (!cfg.scene_lds && cfg.hist_lds) k = k_fused<false, true, NLOS>;
     else k = k_fused<false, false, NLOS>;

@@ -70,7 +70,7 @@ def hh_render(lib, sd, params):
 
 
 def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.85, hidden="quad", spp=4, film=None,
-              laser_fov=0.2, sensor_extra=None, focus=None, hidden_bsdf=None, **integ):
+              laser_fov=0.2, sensor_extra=None, focus=None, hidden_bsdf=None, scene_extra=None, laser_rgb=(1.0, 1.0, 1.0), **integ):
     """NLOS scene in the style of tests/integration/test_nlos.py:1-78 and examples/transient-nlos/nlos_Z.xml:
     2x2 relay wall at the origin with a nlos_capture_meter, projector laser and sensor at (-0.5, 0, 0.25),
     hidden geometry at z = 1 (a 0.8 x 0.8 quad, or a procedural 'Z' of 6 triangles / 3 quads)."""
@@ -88,7 +88,7 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
         "type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}},
         "nlos_sensor": meter})
     laser = mi.load_dict({"type": "projector", "to_world": T().translate([-0.5, 0.0, 0.25]),
-                          "irradiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}, "fov": laser_fov})
+                          "irradiance": {"type": "rgb", "value": list(laser_rgb)}, "fov": laser_fov})
     idict = {"type": "transient_nlos_path", "max_depth": -1, "nlos_laser_sampling": True,
              "nlos_hidden_geometry_sampling": True, "capture_type": capture, "temporal_filter": "box"}
     idict.update(integ)
@@ -103,6 +103,7 @@ def make_nlos(sx=8, sy=8, capture="confocal", bins=64, bin_width=0.03, start=1.8
         d["z_top"] = {"type": "cube", "to_world": T().translate([0.0, 0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}
         d["z_bot"] = {"type": "cube", "to_world": T().translate([0.0, -0.35, 1.0]).scale([0.4, 0.05, 0.004]), "bsdf": white}
         d["z_diag"] = {"type": "cube", "to_world": T().translate([0.0, 0.0, 1.0]).rotate([0, 0, 1], 40.0).scale([0.5, 0.05, 0.004]), "bsdf": white}
+    d.update(scene_extra or {})
     scene = mi.load_dict(d)
     mitr.nlos.focus_emitter_at_relay_wall_pixel(focus if focus is not None else (sx / 2, sy / 2), relay, laser)
     return scene

@@ -114,7 +114,7 @@ def test_release_library_reads_no_experiment_knobs():
     from mitransient_amd import _cabi
     blob = open(os.path.join(os.path.dirname(_cabi.__file__), "csrc", "libmitransient_amd.so"), "rb").read()
     for name in (b"MTR_FUSED_PER_CU", b"MTR_FUSED_CHUNK", b"MTR_NO_WIDE8Q", b"MTR_NO_BOX_NODES", b"MTR_WF_SEG", b"MTR_WF_TILE_LOG2",
-                 b"MTR_BVH_LEAF", b"MTR_WIDE_WIDTH", b"MTR_NO_FLAT", b"MTR_WF_SORT", b"MTR_BVH_THREADS", b"MTR_BVH_DEPTH_BUDGET"):
+                 b"MTR_BVH_LEAF", b"MTR_WIDE_WIDTH", b"MTR_NO_FLAT", b"MTR_NO_GREY", b"MTR_FUSED_G", b"MTR_FUSED_OLD_PLAN", b"MTR_FUSED_VERBOSE", b"MTR_WF_SORT", b"MTR_BVH_THREADS", b"MTR_BVH_DEPTH_BUDGET"):
         assert name not in blob, name
     src = os.path.join(os.path.dirname(_cabi.__file__), "csrc")
     for f in os.listdir(src):

@@ -263,3 +263,53 @@ def test_extended_nlos_deterministic_rows_take_the_wavefront_pipeline(tmp_path):
     c = build(amd_deterministic=True, amd_mode="fused")
     with pytest.raises(MitransientAMDError, match="wavefront"):
         _gpu(c, 8)
+
+
+# ---- scene trait kTrGrey: a grey NLOS scene keeps ONE plane per row in k_fused<NLOS> (config 4: three row slots instead of one) --------
+COLOURED = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.9, 0.5, 0.2]}}
+
+
+@pytest.mark.parametrize("hidden", ["quad", "z", "sphere"])
+def test_grey_scene_one_plane_per_row(oracle, tmp_path, hidden):
+    """the premise — every contribution of a grey scene has r == g == b to the bit — holds in the organisation that keeps three channels
+    (wavefront) and in the oracle; the fused kernel's one-plane rows give the oracle's film and counters"""
+    from test_nlos import ROUGH_HIDDEN, _hidden_sphere
+    h = _hidden_sphere(tmp_path, ROUGH_HIDDEN["diffuse"]) if hidden == "sphere" else hidden        # (vertex normals: the extended kernel without lobes)
+    films = {}
+    for mode in (1, 2):
+        scene = make_nlos(sx=8, sy=6, capture="confocal", hidden=h, bins=96, bin_width=0.03, start=1.8)
+        assert scene.gpu_traits() & _cabi.MTR_TRAIT_GREY
+        scene.integrator().mode = mode
+        s_gpu, t_gpu = _gpu(scene, 128)
+        assert np.array_equal(t_gpu[..., 0], t_gpu[..., 1]) and np.array_equal(t_gpu[..., 0], t_gpu[..., 2]) and np.count_nonzero(t_gpu) > 50
+        films[mode] = t_gpu
+        s_ref, t_ref, cnt = _oracle(oracle, scene, 128)
+        assert np.array_equal(t_ref[..., 0], t_ref[..., 1]) and np.array_equal(t_ref[..., 0], t_ref[..., 2])
+        assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+        got = scene.integrator().last_counters
+        for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+            assert got[k] == cnt[k], k
+    assert rel_l2(films[1], films[2]) <= 1e-6
+
+
+@pytest.mark.parametrize("what", ["hidden", "laser", "wall-texture"])
+def test_coloured_scene_keeps_three_planes(oracle, tmp_path, what):
+    """one colour anywhere — a reflectance, the laser, a bitmap — and the trait is off: k_fused<NLOS> with rgb rows, the oracle's film"""
+    kw = dict(sx=8, sy=6, capture="confocal", hidden="quad", bins=96, bin_width=0.03, start=1.8)
+    if what == "hidden":
+        scene = make_nlos(hidden_bsdf=COLOURED, **kw)
+    elif what == "laser":
+        scene = make_nlos(laser_rgb=(1.0, 0.6, 0.3), **kw)
+    else:
+        from test_textures import make_texture
+        make_texture(str(tmp_path / "tex.png"))
+        scene = make_nlos(hidden_bsdf={"type": "diffuse", "reflectance": {"type": "bitmap", "filename": str(tmp_path / "tex.png")}}, **kw)
+    scene.integrator().mode = 1
+    s_gpu, t_gpu = _gpu(scene, 128)
+    assert not (scene.gpu_traits() & _cabi.MTR_TRAIT_GREY)
+    s_ref, t_ref, cnt = _oracle(oracle, scene, 128)
+    assert not np.array_equal(t_ref[..., 0], t_ref[..., 2]) and np.count_nonzero(t_ref) > 50
+    assert rel_l2(t_gpu, t_ref) <= TOL and rel_l2(s_gpu, s_ref) <= TOL
+    got = scene.integrator().last_counters
+    for k in ("paths", "rays_closest", "rays_shadow", "splats_issued", "bounces"):
+        assert got[k] == cnt[k], k
