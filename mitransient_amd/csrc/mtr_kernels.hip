@@ -721,7 +721,8 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     cfg.traits = (cfg.rough ? (sc.traits & kTrNoLobes) : (sc.traits & ~kTrNoLobes)) & ~kTrGrey;
     if (grey) cfg.traits |= kTrGrey;                 // (g_fit >= 1 by the bound on the bins above: hist_lds holds)
     // the kernel with the flat top level (launch_fused_s picks it under exactly this condition) walks no tree: no stack rows
-    if (!args.nlos_on && !film.n_freq && !cfg.rough && !cfg.fixed && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatFlags) == kTrFlatFlags) {
+    if (!args.nlos_on && !film.n_freq && !cfg.rough && cfg.scene_lds && cfg.hist_lds &&
+        (cfg.fixed ? cfg.traits == kTrCornellFlat : (cfg.traits & kTrFlatFlags) == kTrFlatFlags)) {
         fixed_b -= rows * kBlock * 4;
         args.stack_rows = 0u;
     }
@@ -800,7 +801,11 @@ static hipError_t launch_fused_s(const FusedArgs &args, const FusedConfig &cfg, 
         k = cfg.scene_lds ? (cfg.hist_lds ? k_fused<true, true, NLOS, 3, false, false, true> : k_fused<true, false, NLOS, 3, false, false, true>)
                           : (cfg.hist_lds ? k_fused<false, true, NLOS, 3, false, false, true> : k_fused<false, false, NLOS, 3, false, false, true>);
     }
-    else if (cfg.fixed) k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
+    else if (cfg.fixed) {
+        k = cfg.scene_lds ? k_fused<true, true, NLOS, 3, false, true> : k_fused<false, true, NLOS, 3, false, true>;
+        // deterministic rows over a Cornell-class scene: the specialised shading code and the flat top level as well
+        if constexpr (!NLOS) if (cfg.scene_lds && cfg.traits == kTrCornellFlat) k = k_fused<true, true, false, 3, false, true, false, kTrCornellFlat>;
+    }
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && cfg.traits == kTrCornellFlat)      // ... and a flat top level: no tree walk either (flat_walk_device)
         k = cfg.per_cu <= 3 ? k_fused<true, true, false, 3, false, false, false, kTrCornellFlat> : k_fused<true, true, false, MTR_FUSED_MIN_WAVES, false, false, false, kTrCornellFlat>;
     else if (!NLOS && cfg.scene_lds && cfg.hist_lds && (cfg.traits & kTrFlatGeneral) == kTrFlatFlags)    // the flat top level under the general shading code (a mirror box, two lights ...)
