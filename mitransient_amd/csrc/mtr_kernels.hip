@@ -762,10 +762,12 @@ bool fused_plan(const SceneDev &sc, const Film &film, uint32_t n_pixels, uint32_
     if (grid > max_blocks) grid = max_blocks;
     if (grid < 1) grid = 1;
     // chunk of consecutive pixels per ticket: about 32768 samples (amortises the drain at the chunk's end: config 2 with
-    // 4 / 8 / 16 / 32 / 64 pixels per ticket 72.8 / 71.7 / 71.2 / 70.9 / 70.9 ms), but at least 8 chunks per workgroup (so that the
-    // last chunks level the workgroups out)
+    // 4 / 8 / 16 / 32 / 64 pixels per ticket 72.8 / 71.7 / 71.2 / 70.9 / 70.9 ms), but at least 2 chunks per workgroup (the guided tickets
+    // of the kernel — fewer pixels as the launch runs out — level the workgroups out; rounds 1 - 5 asked for 8 chunks per workgroup, which cut
+    // the tickets of a 64-row band of config 2 to 4 pixels: eight band launches 55.9 ms, with 16-pixel tickets 54.9; config 4's share
+    // 5.955 -> 5.92 ms with 42 instead of 10 pixels per ticket)
     uint32_t chunk = (32768u + spp_chunk - 1u) / (spp_chunk ? spp_chunk : 1u);
-    const uint32_t c_bal = (uint32_t)((unsigned long long)n_pixels / (8ull * (unsigned long long)grid));
+    const uint32_t c_bal = (uint32_t)((unsigned long long)n_pixels / (2ull * (unsigned long long)grid));
     if (chunk > c_bal) chunk = c_bal;
     if (chunk < 1u) chunk = 1u;
     if (const char *e = mtr::knob("MTR_FUSED_CHUNK")) { const int v = atoi(e); if (v >= 1) chunk = (uint32_t)v; }     // experiments
